@@ -1,0 +1,154 @@
+/* rsys.h -- C ABI of the MI355X-native training hot path (librsys_hip.so).
+ *
+ * Drop-in boundary for the data-parallel training step of Fro116/RecommenderSystem
+ * (reference files: notebooks/Training/transformer.model.py = "model.py",
+ * notebooks/Training/transformer.py = "train.py").  The reference has no FFI of its
+ * own; each entry point below names the reference
+ * interface it replaces.  A Julia host binds these with `ccall`, a Python host with
+ * ctypes (recommendersystem_amd/_lib.py); INTEGRATION.md shows both stubs.
+ *
+ * Conventions: every function returns 0 on success, <0 on error
+ * (rsys_last_error gives the thread-local message).  Handles are opaque.  The caller
+ * owns every host buffer; the library owns all device memory.  Calls on one handle
+ * must be serialised by the caller; one handle set per GPU (one process per GPU as
+ * in train.py:582-587).  No callbacks, no exceptions cross the boundary.
+ */
+#ifndef RSYS_H
+#define RSYS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsys_model rsys_model;
+typedef struct rsys_optimizer rsys_optimizer;
+typedef struct rsys_comm rsys_comm;
+
+enum { RSYS_DTYPE_FP32 = 0, RSYS_DTYPE_BF16 = 1 };
+
+/* mirrors the config dict of train.py:535-560 (+ finetune keys of :520-524) */
+typedef struct rsys_config {
+  int32_t num_layers, num_heads, num_kv_heads, embed_dim, intermediate_dim;
+  int32_t max_sequence_length;          /* S interactions per row -> 2S tokens */
+  int32_t vocab_0, vocab_1;             /* vocab_sizes["0_matchedid"], ["1_matchedid"] */
+  int32_t vocab_status, vocab_gender, vocab_source;
+  int32_t metadata_dim;                 /* metadata_emb_size */
+  double min_ts, max_ts;
+  float rating_mean, rating_std;
+  float mask_rate;
+  int32_t mask_topk;
+  int32_t finetune;                     /* 0/1 */
+  int32_t finetune_metric;              /* 0 = watch, 1 = rating */
+  int32_t dtype;                        /* RSYS_DTYPE_* : arithmetic type of the dense contractions */
+  int32_t max_rows;                     /* rows (of S interactions) per forward call = local batch size */
+} rsys_config;
+
+/* the batch record of train.py:75-98 / transformer.jl:79-142: 27 parallel arrays of
+ * rows*S interactions.  Index of label/weight/position: medium*3 + {0 watch,1 rating,2 status}. */
+typedef struct rsys_batch {
+  int32_t rows;
+  const int32_t *userid, *token_mask_ids, *gender, *source, *matchedid, *status;
+  const double* time;
+  const float *rating, *progress;
+  const float* label[6];
+  const float* weight[6];
+  const int32_t* position[6];
+  const uint8_t* watch_mask;   /* optional (parity mode): replaces the random draw of model.py:437-440 */
+  const uint8_t* rating_mask;  /* optional, with watch_mask */
+  const int32_t* rope_input_pos; /* optional (inference, model.py:470-476) */
+} rsys_batch;
+
+const char* rsys_version(void);
+size_t rsys_last_error(char* buf, size_t n);
+int32_t rsys_device_count(int32_t* n);
+int32_t rsys_device_synchronize(void);
+
+/* RecommenderModel(config) -- model.py:346-377.  Parameters are zero until set or
+ * rsys_model_init_random (init_weights, model.py:5-12) is called. */
+int32_t rsys_model_create(const rsys_config* cfg, int32_t device, rsys_model** out);
+int32_t rsys_model_destroy(rsys_model* m);
+int32_t rsys_model_init_random(rsys_model* m, uint64_t seed);
+/* load_pretrained_embeddings -- model.py:379-389; table is (V, M) row-major f32 */
+int32_t rsys_model_load_metadata(rsys_model* m, const float* table, int64_t V, int64_t M);
+/* synthetic frozen table generated on the device: N(0,1)/sqrt(M) */
+int32_t rsys_model_random_metadata(rsys_model* m, uint64_t seed);
+/* RoPE tables precompute_freqs_cis -- model.py:173-179; (n_pos, head_dim/2) f32 each */
+int32_t rsys_model_set_rope(rsys_model* m, const float* cos, const float* sin, int64_t n_pos);
+
+/* state_dict interchange -- names are the reference's state_dict keys */
+int32_t rsys_param_count(rsys_model* m, int32_t* n);
+int32_t rsys_param_info(rsys_model* m, int32_t i, char* name, size_t name_cap, int64_t shape[2], int32_t* ndim,
+                        int32_t* trainable);
+int32_t rsys_param_get(rsys_model* m, const char* name, float* out, int64_t n);
+int32_t rsys_param_set(rsys_model* m, const char* name, const float* in, int64_t n);
+int32_t rsys_grad_get(rsys_model* m, const char* name, float* out, int64_t n);
+int32_t rsys_zero_grad(rsys_model* m);
+
+/* to_device -- train.py:178-184: copies the batch into device-resident buffers */
+int32_t rsys_batch_upload(rsys_model* m, const rsys_batch* b);
+/* device-side synthetic batch (bench): fills the resident batch from a counter RNG */
+
+/* model(d, evaluate) + loss.backward() -- model.py:493-529, train.py:259-272.
+ * task_w[4] in the order (0,watch),(0,rating),(1,watch),(1,rating); the gradient of
+ * sum_i task_w[i]*loss_i*grad_scale is ACCUMULATED into the gradient buffer (skipped
+ * when evaluate != 0).  mask_seed/step drive the Philox mask draw when the batch
+ * carries no explicit masks.  Asynchronous: results are read with rsys_losses_get. */
+int32_t rsys_forward_backward(rsys_model* m, int32_t evaluate, const float task_w[4], float grad_scale,
+                              uint64_t mask_seed, uint64_t step);
+/* losses_out[12]: per task 3 slots (train: [loss,0,0]; evaluate rating tasks: 3 moments of model.py:395-401);
+ * weight_sums_out[4]: d[name.weight].sum() after masking (train.py:261).  Synchronises. */
+int32_t rsys_losses_get(rsys_model* m, float losses_out[12], float weight_sums_out[4]);
+/* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
+int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
+/* debug/parity: trunk output of the last forward (rows*2S*D floats) */
+int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) -- train.py:273; norm_out may be NULL */
+int32_t rsys_clip_grad_norm(rsys_model* m, float max_norm, float* norm_out);
+
+/* create_optimizer -- train.py:285-298 (AdamW, betas 0.9/0.95, wd on dim>=2) */
+int32_t rsys_adamw_create(rsys_model* m, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          rsys_optimizer** out);
+int32_t rsys_adamw_destroy(rsys_optimizer* o);
+/* optimizer.step(); optimizer.zero_grad() with lr = lr0*lr_factor (LambdaLR, train.py:684-689).
+ * fused_clip_max_norm > 0 fuses clip_grad_norm_ (global norm over the flat gradient buffer) and the
+ * data-parallel mean (grads / grad_div) into the update -- one pass over the parameters. */
+int32_t rsys_adamw_step(rsys_optimizer* o, float lr_factor, float fused_clip_max_norm, float grad_div);
+int32_t rsys_adamw_state_get(rsys_optimizer* o, const char* name, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step);
+int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* exp_avg, const float* exp_avg_sq, int64_t n, int32_t step);
+
+/* init_process_group("nccl") + DDP gradient all-reduce -- train.py:582, 678-682, 268-272;
+ * RCCL over xGMI, one communicator per process.  id_buf: 128 bytes made on rank 0 and
+ * distributed by the host (the reference uses torchrun's store). */
+int32_t rsys_comm_unique_id(uint8_t id_buf[128]);
+int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, int32_t device, rsys_comm** out);
+int32_t rsys_comm_destroy(rsys_comm* c);
+/* sum-all-reduce of the flat gradient buffer in buckets (the mean is folded into rsys_adamw_step's grad_div) */
+int32_t rsys_allreduce_grads(rsys_model* m, rsys_comm* c);
+int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n);   /* reduce_mean, train.py:199-204 */
+int32_t rsys_self_test(rsys_comm* c);                              /* hardware_check.py:6-12 */
+
+/* raw views for hosts that run collectives themselves (e.g. torch.distributed on aliased memory) */
+int32_t rsys_grad_buffer(rsys_model* m, void** dev_ptr, int64_t* n_floats);
+int32_t rsys_param_buffer(rsys_model* m, void** dev_ptr, int64_t* n_floats);
+int32_t rsys_refresh_shadow(rsys_model* m);   /* re-derive the bf16 compute copies after external parameter writes */
+
+/* per-kernel access for unit tests (device pointers from rsys_dev_alloc) */
+int32_t rsys_dev_alloc(void** p, size_t bytes);
+int32_t rsys_dev_free(void* p);
+int32_t rsys_dev_h2d(void* dst, const void* src, size_t bytes);
+int32_t rsys_dev_d2h(void* dst, const void* src, size_t bytes);
+int32_t rsys_dev_memset(void* dst, int value, size_t bytes);
+/* C[M,N] = sum_k A(m,k)B(n,k); dtype RSYS_DTYPE_*; a_km/b_km: operand stored K-major; a_f32: A is f32 in memory */
+int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
+                     int64_t lda, int64_t ldb, int64_t ldc, int32_t a_km, int32_t b_km, int32_t a_f32, int32_t c_f32,
+                     int32_t splitk);
+int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-phase HIP-event timings */
+int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,372 @@
+// extern "C" surface of librsys_hip.so (declared in include/rsys.h).
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+
+#include <sstream>
+
+#include "model.hpp"
+
+namespace rsys {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace rsys
+
+using namespace rsys;
+
+struct rsys_model { Model* m; };
+struct rsys_optimizer { Optimizer o; };
+
+// ---------------------------------------------------------------- RCCL, bound at run time (librccl.so.1)
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef void* ncclComm_t_;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueId_t*) = nullptr;
+  int (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_t, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t_) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+  if (g_rccl.lib) return RSYS_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+  if (!g_rccl.lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return RSYS_ERR_COMM; }
+  g_rccl.GetUniqueId = (int (*)(ncclUniqueId_t*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(ncclComm_t_*, int, ncclUniqueId_t, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+    set_error("librccl is missing a required symbol"); return RSYS_ERR_COMM;
+  }
+  return RSYS_OK;
+}
+#define NCCL_CHECK(expr)                                                                          \
+  do {                                                                                            \
+    int _r = (expr);                                                                              \
+    if (_r != 0) {                                                                                \
+      set_error(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
+      return RSYS_ERR_COMM;                                                                       \
+    }                                                                                             \
+  } while (0)
+enum { NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+struct rsys_comm {
+  ncclComm_t_ comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  double* scratch = nullptr;
+};
+
+#define CHECK_HANDLE(h) do { if ((h) == nullptr) { set_error("null handle"); return RSYS_ERR_ARG; } } while (0)
+
+extern "C" {
+
+const char* rsys_version(void) { return "recommendersystem_amd 0.1 (gfx950)"; }
+
+size_t rsys_last_error(char* buf, size_t n) {
+  if (buf && n) { strncpy(buf, g_err.c_str(), n - 1); buf[n - 1] = 0; }
+  return g_err.size();
+}
+
+int32_t rsys_device_count(int32_t* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) c = 0;
+  if (n) *n = c;
+  return RSYS_OK;
+}
+int32_t rsys_device_synchronize(void) { HIP_CHECK(hipDeviceSynchronize()); return RSYS_OK; }
+
+int32_t rsys_model_create(const rsys_config* cfg, int32_t device, rsys_model** out) {
+  Model* m = nullptr;
+  int rc = model_create(cfg, device, &m);
+  if (rc) return rc;
+  *out = new rsys_model{m};
+  return RSYS_OK;
+}
+int32_t rsys_model_destroy(rsys_model* h) { if (!h) return RSYS_OK; model_destroy(h->m); delete h; return RSYS_OK; }
+int32_t rsys_model_init_random(rsys_model* h, uint64_t seed) { CHECK_HANDLE(h); return model_init_random(h->m, seed); }
+int32_t rsys_model_load_metadata(rsys_model* h, const float* t, int64_t V, int64_t M) { CHECK_HANDLE(h); ARG_CHECK(t, "null table"); return model_load_metadata(h->m, t, V, M); }
+int32_t rsys_model_random_metadata(rsys_model* h, uint64_t seed) { CHECK_HANDLE(h); return model_random_metadata(h->m, seed); }
+int32_t rsys_model_set_rope(rsys_model* h, const float* c, const float* s, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(c && s, "null table"); return model_set_rope(h->m, c, s, n); }
+
+int32_t rsys_param_count(rsys_model* h, int32_t* n) { CHECK_HANDLE(h); *n = (int32_t)h->m->tensors.size(); return RSYS_OK; }
+int32_t rsys_param_info(rsys_model* h, int32_t i, char* name, size_t cap, int64_t shape[2], int32_t* ndim, int32_t* trainable) {
+  CHECK_HANDLE(h);
+  ARG_CHECK(i >= 0 && i < (int)h->m->tensors.size(), "parameter index");
+  const TensorInfo& t = h->m->tensors[i];
+  if (name && cap) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (shape) { if (t.ndim == 1) { shape[0] = t.cols; shape[1] = 0; } else { shape[0] = t.rows; shape[1] = t.cols; } }
+  if (ndim) *ndim = t.ndim;
+  if (trainable) *trainable = t.trainable ? 1 : 0;
+  return RSYS_OK;
+}
+int32_t rsys_param_get(rsys_model* h, const char* name, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(name && out, "null"); return model_param_io(h->m, name, out, nullptr, n, 0); }
+int32_t rsys_param_set(rsys_model* h, const char* name, const float* in, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(name && in, "null"); return model_param_io(h->m, name, nullptr, in, n, 0); }
+int32_t rsys_grad_get(rsys_model* h, const char* name, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(name && out, "null"); return model_param_io(h->m, name, out, nullptr, n, 1); }
+int32_t rsys_zero_grad(rsys_model* h) {
+  CHECK_HANDLE(h);
+  HIP_CHECK(hipSetDevice(h->m->device));
+  HIP_CHECK(hipMemsetAsync(h->m->G, 0, h->m->n_total * 4, h->m->stream));
+  h->m->table_grads_pending = false;
+  return RSYS_OK;
+}
+
+int32_t rsys_batch_upload(rsys_model* h, const rsys_batch* b) { CHECK_HANDLE(h); return model_batch_upload(h->m, b); }
+
+int32_t rsys_forward_backward(rsys_model* h, int32_t evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step) {
+  CHECK_HANDLE(h);
+  return model_forward_backward(h->m, evaluate, task_w, grad_scale, seed, step);
+}
+
+int32_t rsys_losses_get(rsys_model* h, float losses_out[12], float wsum_out[4]) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  float acc[16], st[8];
+  HIP_CHECK(hipMemcpyAsync(acc, m->loss_acc, 16 * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_CHECK(hipMemcpyAsync(st, m->stats, 8 * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  for (int ti = 0; ti < 4; ++ti) {
+    float ws = fmaxf(st[2 * ti], 1e-8f);  // w_sum over the selected positions, clamp(min=1e-8) (model.py:392,515)
+    for (int k = 0; k < 3; ++k) losses_out[3 * ti + k] = acc[3 * ti + k] / ws;
+    if (wsum_out) wsum_out[ti] = st[2 * ti + 1];
+  }
+  return RSYS_OK;
+}
+
+int32_t rsys_infer(rsys_model* h, int32_t task, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_infer(h->m, task, out, n); }
+
+int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  const int64_t cnt = (int64_t)2 * m->cur_rows * m->S * m->D;
+  ARG_CHECK(n == cnt, "trunk output has rows*2S*D floats");
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (!m->bf16_mode) { HIP_CHECK(hipMemcpy(out, m->out, cnt * 4, hipMemcpyDeviceToHost)); return RSYS_OK; }
+  std::vector<unsigned short> host(cnt);
+  HIP_CHECK(hipMemcpy(host.data(), m->out, cnt * 2, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < cnt; ++i) { uint32_t u = (uint32_t)host[i] << 16; memcpy(&out[i], &u, 4); }
+  return RSYS_OK;
+}
+
+int32_t rsys_clip_grad_norm(rsys_model* h, float max_norm, float* norm_out) { CHECK_HANDLE(h); return model_clip(h->m, max_norm, norm_out); }
+
+int32_t rsys_adamw_create(rsys_model* h, float lr, float b1, float b2, float eps, float wd, rsys_optimizer** out) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  rsys_optimizer* o = new rsys_optimizer();
+  o->o.m = m; o->o.lr = lr; o->o.b1 = b1; o->o.b2 = b2; o->o.eps = eps; o->o.wd = wd;
+  HIP_CHECK(hipMalloc((void**)&o->o.mom, m->n_total * 4));
+  HIP_CHECK(hipMalloc((void**)&o->o.var, m->n_total * 4));
+  HIP_CHECK(hipMemset(o->o.mom, 0, m->n_total * 4));
+  HIP_CHECK(hipMemset(o->o.var, 0, m->n_total * 4));
+  *out = o;
+  return RSYS_OK;
+}
+int32_t rsys_adamw_destroy(rsys_optimizer* o) {
+  if (!o) return RSYS_OK;
+  hipSetDevice(o->o.m->device);
+  hipStreamSynchronize(o->o.m->stream);
+  hipFree(o->o.mom); hipFree(o->o.var);
+  delete o;
+  return RSYS_OK;
+}
+int32_t rsys_adamw_step(rsys_optimizer* o, float lr_factor, float clip, float grad_div) { CHECK_HANDLE(o); return optimizer_step(&o->o, lr_factor, clip, grad_div); }
+
+static int adam_state_io(rsys_optimizer* o, const char* name, float* m_out, float* v_out, const float* m_in, const float* v_in, int64_t n) {
+  Model* m = o->o.m;
+  auto it = m->by_name.find(name);
+  if (it == m->by_name.end()) { set_error(std::string("unknown parameter: ") + name); return RSYS_ERR_ARG; }
+  const TensorInfo& t = m->tensors[it->second];
+  ARG_CHECK(!t.frozen_table, "frozen table has no optimizer state");
+  ARG_CHECK(n == t.rows * t.cols, "element count");
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  const int64_t int_rows = (t.map == MAP_DIRECT) ? t.rows : 2 * m->Ip;
+  std::vector<float> host((size_t)int_rows * t.ld);
+  for (int which = 0; which < 2; ++which) {
+    float* base = (which == 0 ? o->o.mom : o->o.var) + t.off;
+    float* out = which == 0 ? m_out : v_out;
+    const float* in = which == 0 ? m_in : v_in;
+    HIP_CHECK(hipMemcpy(host.data(), base, host.size() * 4, hipMemcpyDeviceToHost));
+    auto irow = [&](int64_t r) { return t.map == MAP_W1 ? (r / 16) * 32 + r % 16 : t.map == MAP_W3 ? (r / 16) * 32 + 16 + r % 16 : r; };
+    if (out) for (int64_t r = 0; r < t.rows; ++r) memcpy(out + r * t.cols, host.data() + irow(r) * t.ld, t.cols * 4);
+    if (in) {
+      for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + irow(r) * t.ld, in + r * t.cols, t.cols * 4);
+      HIP_CHECK(hipMemcpy(base, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  return RSYS_OK;
+}
+int32_t rsys_adamw_state_get(rsys_optimizer* o, const char* name, float* m_out, float* v_out, int64_t n, int32_t* step) {
+  CHECK_HANDLE(o);
+  if (step) *step = o->o.step;
+  if (name == nullptr) return RSYS_OK;
+  return adam_state_io(o, name, m_out, v_out, nullptr, nullptr, n);
+}
+int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* m_in, const float* v_in, int64_t n, int32_t step) {
+  CHECK_HANDLE(o);
+  if (step >= 0) o->o.step = step;
+  if (name == nullptr) return RSYS_OK;
+  return adam_state_io(o, name, nullptr, nullptr, m_in, v_in, n);
+}
+
+// ---------------------------------------------------------------- communicator
+int32_t rsys_comm_unique_id(uint8_t id_buf[128]) {
+  int rc = load_rccl();
+  if (rc) return rc;
+  ncclUniqueId_t id;
+  NCCL_CHECK(g_rccl.GetUniqueId(&id));
+  memcpy(id_buf, id.internal, 128);
+  return RSYS_OK;
+}
+int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, int32_t device, rsys_comm** out) {
+  ARG_CHECK(world >= 1 && rank >= 0 && rank < world, "rank/world");
+  int rc = load_rccl();
+  if (rc) return rc;
+  HIP_CHECK(hipSetDevice(device));
+  rsys_comm* c = new rsys_comm();
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId_t id;
+  memcpy(id.internal, id_buf, 128);
+  NCCL_CHECK(g_rccl.CommInitRank(&c->comm, world, id, rank));
+  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  HIP_CHECK(hipMalloc((void**)&c->scratch, 64 * sizeof(double)));
+  *out = c;
+  return RSYS_OK;
+}
+int32_t rsys_comm_destroy(rsys_comm* c) {
+  if (!c) return RSYS_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->comm) g_rccl.CommDestroy(c->comm);
+  hipFree(c->scratch);
+  hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return RSYS_OK;
+}
+
+// DDP's bucketed gradient all-reduce (train.py:678-682, 272): the flat gradient buffer is reduced in
+// 64 MiB buckets on the communicator's own stream, ordered after the backward kernels by an event; the
+// compute stream waits for the last bucket before the optimizer reads the gradients.
+int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
+  CHECK_HANDLE(h); CHECK_HANDLE(c);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  int rc = model_finalize_grads(m);
+  if (rc) return rc;
+  if (c->world == 1) return RSYS_OK;
+  HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+  const int64_t bucket = 16 * 1024 * 1024;  // floats
+  for (int64_t o = 0; o < m->n_total; o += bucket) {
+    int64_t n = std::min(bucket, m->n_total - o);
+    NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+  }
+  HIP_CHECK(hipEventRecord(c->ev_done, c->stream));
+  HIP_CHECK(hipStreamWaitEvent(m->stream, c->ev_done, 0));
+  return RSYS_OK;
+}
+int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n) {
+  CHECK_HANDLE(c);
+  ARG_CHECK(n >= 1 && n <= 64 && x, "n in [1,64]");
+  if (c->world == 1) return RSYS_OK;
+  HIP_CHECK(hipSetDevice(c->device));
+  HIP_CHECK(hipMemcpyAsync(c->scratch, x, n * 8, hipMemcpyHostToDevice, c->stream));
+  NCCL_CHECK(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
+  HIP_CHECK(hipMemcpyAsync(x, c->scratch, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  return RSYS_OK;
+}
+int32_t rsys_self_test(rsys_comm* c) {  // hardware_check.py:8-12
+  CHECK_HANDLE(c);
+  double one = 1.0;
+  int rc = rsys_allreduce_f64(c, &one, 1);
+  if (rc) return rc;
+  if (one != (double)c->world) { set_error("all-reduce self test: sum of ones != world size"); return RSYS_ERR_COMM; }
+  return RSYS_OK;
+}
+
+int32_t rsys_grad_buffer(rsys_model* h, void** p, int64_t* n) {
+  CHECK_HANDLE(h);
+  int rc = model_finalize_grads(h->m);
+  if (rc) return rc;
+  *p = h->m->G; *n = h->m->n_total;
+  return RSYS_OK;
+}
+int32_t rsys_param_buffer(rsys_model* h, void** p, int64_t* n) { CHECK_HANDLE(h); *p = h->m->P; *n = h->m->n_total; return RSYS_OK; }
+int32_t rsys_refresh_shadow(rsys_model* h) { CHECK_HANDLE(h); return model_refresh_shadow(h->m); }
+
+// ---------------------------------------------------------------- raw device helpers + per-op entry points (tests)
+int32_t rsys_dev_alloc(void** p, size_t bytes) { HIP_CHECK(hipMalloc(p, bytes ? bytes : 16)); HIP_CHECK(hipMemset(*p, 0, bytes ? bytes : 16)); return RSYS_OK; }
+int32_t rsys_dev_free(void* p) { HIP_CHECK(hipFree(p)); return RSYS_OK; }
+int32_t rsys_dev_h2d(void* d, const void* s, size_t n) { HIP_CHECK(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return RSYS_OK; }
+int32_t rsys_dev_d2h(void* d, const void* s, size_t n) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return RSYS_OK; }
+int32_t rsys_dev_memset(void* d, int v, size_t n) { HIP_CHECK(hipMemset(d, v, n)); return RSYS_OK; }
+
+int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                     int64_t ldb, int64_t ldc, int32_t a_km, int32_t b_km, int32_t a_f32, int32_t c_f32, int32_t splitk) {
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.c_f32 = c_f32; p.splitk = splitk < 1 ? 1 : splitk; p.alpha = 1.f;
+  p.epi = p.splitk > 1 ? EPI_ATOMIC : EPI_STORE;
+  int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, a_f32 != 0, false, a_km != 0, b_km != 0, nullptr)
+                                    : launch_gemm<float>(p, false, false, a_km != 0, b_km != 0, nullptr);
+  if (rc) return rc;
+  HIP_CHECK(hipDeviceSynchronize());
+  return RSYS_OK;
+}
+
+int32_t rsys_op_timing(rsys_model* h, int32_t enable) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  m->timer.enabled = enable != 0;
+  m->timer.marks.clear(); m->timer.acc_ms.clear(); m->timer.used = 0;
+  return RSYS_OK;
+}
+
+// "name ms count flops\n" per timed span since rsys_op_timing(1); nested spans are supported
+int32_t rsys_timing_get(rsys_model* h, char* buf, size_t cap) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  PhaseTimer& t = m->timer;
+  std::map<std::string, std::pair<double, long>> agg;
+  std::vector<size_t> stack;
+  for (size_t i = 0; i < t.marks.size(); ++i) {
+    if (!t.marks[i].first.empty()) { stack.push_back(i); continue; }
+    if (stack.empty()) continue;
+    size_t b = stack.back(); stack.pop_back();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t.marks[b].second, t.marks[i].second);
+    auto& a = agg[t.marks[b].first];
+    a.first += ms; a.second += 1;
+  }
+  std::ostringstream os;
+  for (auto& kv : agg) {
+    double fl = 0.0;
+    auto it = t.acc_ms.find(std::string("#flops:") + kv.first);
+    if (it != t.acc_ms.end()) fl = it->second;
+    os << kv.first << " " << kv.second.first << " " << kv.second.second << " " << fl << "\n";
+  }
+  std::string s = os.str();
+  if (buf && cap) { strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
+  t.marks.clear(); t.acc_ms.clear(); t.used = 0;
+  return (int32_t)RSYS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,577 @@
+// HBM-bound row kernels of the training step (gfx950).  One wave (64 lanes) per
+// row with 16-byte accesses wherever a row is contiguous; per-column reductions
+// keep partial sums in registers across a grid-stride row loop, combine through
+// LDS and finish with one float atomic per column per workgroup.
+#include "kernels.hpp"
+
+namespace rsys {
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// --------------------------------------------------------------------- mask_tokens
+// transformer.model.py:417-462
+__global__ void mask_tokens_kernel(BatchDev b, int finetune, int ft_metric, float rate,
+                                   unsigned long long seed, unsigned long long step) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.N) return;
+  bool wm, rm;
+  if (finetune) {
+    bool w = b.weight[0 * 3 + ft_metric][i] > 0.f || b.weight[1 * 3 + ft_metric][i] > 0.f;
+    wm = (ft_metric == 0) && w;
+    rm = (ft_metric == 1) && w;
+  } else if (b.watch_mask != nullptr) {
+    wm = b.watch_mask[i] != 0;
+    rm = b.rating_mask[i] != 0;
+  } else {
+    Philox ph(seed);
+    uint32_t r[4];
+    ph.gen((unsigned long long)i, (uint32_t)step, r);
+    float u = u01(r[0]);
+    wm = u < rate;
+    rm = (u >= rate) && (u < 2.f * rate);
+  }
+  const bool any = wm || rm;
+  b.m_tmid[i] = rm ? b.tmid[i] : 0;
+  b.m_matchedid[i] = wm ? -1 : b.matchedid[i];
+  b.m_status[i] = any ? -1 : b.status[i];
+  b.m_rating[i] = any ? 0.f : b.rating[i];
+  b.m_progress[i] = any ? 0.f : b.progress[i];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    b.m_label[m * 2 + 0][i] = wm ? b.label[m * 3 + 0][i] : 0.f;
+    b.m_weight[m * 2 + 0][i] = wm ? b.weight[m * 3 + 0][i] : 0.f;
+    b.m_position[m * 2 + 0][i] = wm ? b.position[m * 3 + 0][i] : 0;
+    b.m_label[m * 2 + 1][i] = rm ? b.label[m * 3 + 1][i] : 0.f;
+    b.m_weight[m * 2 + 1][i] = rm ? b.weight[m * 3 + 1][i] : 0.f;
+    b.m_position[m * 2 + 1][i] = rm ? b.position[m * 3 + 1][i] : 0;
+  }
+}
+
+int launch_mask_tokens(BatchDev b, int finetune, int finetune_metric, float mask_rate,
+                       unsigned long long seed, unsigned long long step, hipStream_t s) {
+  hipLaunchKernelGGL(mask_tokens_kernel, dim3(div_up(b.N, 256)), dim3(256), 0, s, b, finetune, finetune_metric,
+                     mask_rate, seed, step);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// --------------------------------------------------------------------- action features
+// transformer.model.py:51-93.  The periodic argument is formed in fp64, cast to
+// fp32, and the learned phase is added IN fp32 (|arg| ~ 1e5): that rounding is
+// part of the reference's arithmetic and is reproduced here.
+__device__ __forceinline__ void periodic_args(double t, double min_ts, float& p0, float& p1, double& ts_out) {
+  double ts = t < min_ts ? min_ts : t;
+  p0 = (float)((6.283185307179586 * ts) / 86400.0);
+  p1 = (float)((6.283185307179586 * ts) / 604800.0);
+  ts_out = ts;
+}
+
+template <typename T>
+__global__ void action_features_kernel(BatchDev b, SmallParams sp, T* feat) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.N) return;
+  float f[32];
+  float p0, p1; double ts;
+  periodic_args(b.time[i], sp.min_ts, p0, p1, ts);
+  f[0] = (float)((ts - sp.min_ts) / (sp.max_ts - sp.min_ts));
+  f[1] = cosf(p0 + sp.per_cos[0]);
+  f[2] = cosf(p1 + sp.per_cos[1]);
+  f[3] = sinf(p0 + sp.per_sin[0]);
+  f[4] = sinf(p1 + sp.per_sin[1]);
+  int gi = b.gender[i]; gi = gi == -1 ? sp.n_gender : gi;
+  int si = b.source[i]; si = si == -1 ? sp.n_source : si;
+  int st = b.m_status[i]; st = st == -1 ? sp.n_status : st;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f[5 + k] = sp.gender_emb[gi * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f[9 + k] = sp.source_emb[si * 4 + k];
+  float rating = b.m_rating[i];
+  float has = rating != 0.f ? 1.f : 0.f;
+  f[13] = has;
+  f[14] = has * ((rating - sp.rating_mean) / sp.rating_std);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) f[15 + k] = sp.status_emb[st * 16 + k];
+  f[31] = b.m_progress[i];
+  T* o = feat + (long long)i * 32;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) o[k] = from_f32<T>(f[k]);
+}
+
+template <typename T>
+int launch_action_features(const BatchDev& b, const SmallParams& sp, T* feat, hipStream_t s) {
+  hipLaunchKernelGGL((action_features_kernel<T>), dim3(div_up(b.N, 128)), dim3(128), 0, s, b, sp, feat);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_action_features<bf16>(const BatchDev&, const SmallParams&, bf16*, hipStream_t);
+template int launch_action_features<float>(const BatchDev&, const SmallParams&, float*, hipStream_t);
+
+// --------------------------------------------------------------------- item gather (K1/K3, fused table)
+// transformer.model.py:23-24,139-145 with the fused table of :120-133; one wave per row, 16 B per lane.
+__global__ void gather_items_kernel(BatchDev b, const float* __restrict__ F32, int V, int D, float* x0, int* uid_t, int* tm_t) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (wave >= b.N) return;
+  int id = b.m_matchedid[wave];
+  id = id == -1 ? V : id;
+  const float4* src = (const float4*)(F32 + (long long)id * D);
+  float4* dst = (float4*)(x0 + (long long)(2 * wave) * D);
+  for (int c = l; c < (D >> 2); c += 64) dst[c] = src[c];
+  if (l == 0) {
+    int u = b.userid[wave], tmv = b.m_tmid[wave];
+    uid_t[2 * wave] = u; uid_t[2 * wave + 1] = u;
+    tm_t[2 * wave] = tmv; tm_t[2 * wave + 1] = tmv;
+  }
+}
+
+int launch_gather_items(const BatchDev& b, const float* F32, int V, int D, float* x0, int* uid_t, int* tm_t, hipStream_t s) {
+  hipLaunchKernelGGL(gather_items_kernel, dim3(div_up(b.N, 4)), dim3(256), 0, s, b, F32, V, D, x0, uid_t, tm_t);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// --------------------------------------------------------------------- RMSNorm (K6), transformer.model.py:193-202
+template <typename T>
+__global__ void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
+                                   long long rows, int D) {
+  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int l = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + row * D);
+  float ss = 0.f;
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 v = xr[c];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)D + 1e-5f);
+  if (l == 0 && rstd) rstd[row] = r;
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 v = xr[c];
+    float4 sc = ((const float4*)scale)[c];
+    T* o = y + row * D + 4 * c;
+    o[0] = from_f32<T>(v.x * r * sc.x); o[1] = from_f32<T>(v.y * r * sc.y);
+    o[2] = from_f32<T>(v.z * r * sc.z); o[3] = from_f32<T>(v.w * r * sc.w);
+  }
+}
+
+template <typename T>
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s) {
+  ARG_CHECK(D % 4 == 0, "rmsnorm: D % 4");
+  hipLaunchKernelGGL((rmsnorm_fwd_kernel<T>), dim3(div_up(rows, 4)), dim3(256), 0, s, x, scale, y, rstd, rows, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t);
+
+// backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
+constexpr int NORM_MAXJ = 8;  // D <= 64 lanes * 4 * 8 = 2048
+
+template <typename TG>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
+                                                          const float* __restrict__ scale, const float* __restrict__ rstd,
+                                                          const float* resid, float* dx_out, float* dscale,
+                                                          long long rows, int D) {
+  extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
+  float4 acc[NORM_MAXJ];
+#pragma unroll
+  for (int j = 0; j < NORM_MAXJ; ++j) acc[j] = make_float4(0, 0, 0, 0);
+  for (int c = threadIdx.x; c < D; c += 256) sds[c] = 0.f;
+  __syncthreads();
+  const int nj = D >> 8;  // full groups of 256 columns; tail handled by guard
+  for (long long row = wave0; row < rows; row += nwaves) {
+    const float r = rstd[row];
+    float4 gv[NORM_MAXJ], xv[NORM_MAXJ];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXJ; ++j) {
+      const int c = (j * 64 + l) * 4;
+      if (c < D) {
+        const TG* gp = g + row * D + c;
+        float4 sc = *(const float4*)(scale + c);
+        gv[j] = make_float4(to_f32(gp[0]) * sc.x, to_f32(gp[1]) * sc.y, to_f32(gp[2]) * sc.z, to_f32(gp[3]) * sc.w);
+        xv[j] = *(const float4*)(x + row * D + c);
+        dot += gv[j].x * xv[j].x + gv[j].y * xv[j].y + gv[j].z * xv[j].z + gv[j].w * xv[j].w;
+        // dscale uses the un-scaled g: g*x*r = (g*s)*x*r/s is avoided by recomputing from gp
+        acc[j].x += to_f32(gp[0]) * xv[j].x * r; acc[j].y += to_f32(gp[1]) * xv[j].y * r;
+        acc[j].z += to_f32(gp[2]) * xv[j].z * r; acc[j].w += to_f32(gp[3]) * xv[j].w * r;
+      }
+    }
+    dot = wave_sum(dot);
+    const float k = r * r * r * dot / (float)D;
+#pragma unroll
+    for (int j = 0; j < NORM_MAXJ; ++j) {
+      const int c = (j * 64 + l) * 4;
+      if (c < D) {
+        float4 o;
+        o.x = r * gv[j].x - xv[j].x * k; o.y = r * gv[j].y - xv[j].y * k;
+        o.z = r * gv[j].z - xv[j].z * k; o.w = r * gv[j].w - xv[j].w * k;
+        if (resid) {
+          float4 rv = *(const float4*)(resid + row * D + c);
+          o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        *(float4*)(dx_out + row * D + c) = o;
+      }
+    }
+  }
+  (void)nj;
+#pragma unroll
+  for (int j = 0; j < NORM_MAXJ; ++j) {
+    const int c = (j * 64 + l) * 4;
+    if (c < D) {
+      atomicAdd(&sds[c], acc[j].x); atomicAdd(&sds[c + 1], acc[j].y);
+      atomicAdd(&sds[c + 2], acc[j].z); atomicAdd(&sds[c + 3], acc[j].w);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) atomicAdd(&dscale[c], sds[c]);
+}
+
+template <typename TG>
+static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
+                           float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
+  ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
+  int grid = (int)std::min<long long>((rows + 3) / 4, 1024);
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG>), dim3(grid), dim3(256), D * sizeof(float), s, g, x, scale, rstd, resid,
+                     dx_out, dscale, rows, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
+                       float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
+  return rmsnorm_bwd_any<T>(g, x, scale, rstd, resid_grad, dx_out, dscale, rows, D, s);
+}
+template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, long long, int, hipStream_t);
+int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
+                           float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
+  return rmsnorm_bwd_any<float>(g, x, scale, rstd, resid_grad, dx_out, dscale, rows, D, s);
+}
+
+// --------------------------------------------------------------------- SwiGLU backward (K10), model.py:205-213
+// ab is stored interleaved in 16-column blocks [a0..a15 | b0..b15 | a16.. ] (the W1/W3 rows are interleaved the same way)
+template <typename T>
+__global__ void swiglu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ ab, T* dab, long long total, int I) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; e < total; e += (long long)gridDim.x * blockDim.x) {
+    long long row = e / I; int i = (int)(e % I);
+    long long base = row * (2LL * I) + (i >> 4) * 32 + (i & 15);
+    float a = to_f32(ab[base]), b = to_f32(ab[base + 16]), d = to_f32(dg[e]);
+    float sg = 1.f / (1.f + __expf(-a));
+    dab[base] = from_f32<T>(d * b * sg * (1.f + a * (1.f - sg)));
+    dab[base + 16] = from_f32<T>(d * a * sg);
+  }
+}
+template <typename T>
+int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s) {
+  long long total = rows * I;
+  int grid = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL((swiglu_bwd_kernel<T>), dim3(grid), dim3(256), 0, s, dg, ab, dab, total, I);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_swiglu_bwd<bf16>(const bf16*, const bf16*, bf16*, long long, int, hipStream_t);
+template int launch_swiglu_bwd<float>(const float*, const float*, float*, long long, int, hipStream_t);
+
+// --------------------------------------------------------------------- position selection (K11), model.py:501-513
+// Deterministic replacement of torch.topk on 0/1 weights: positive-weight positions in
+// ascending flat index, then zero-weight positions ascending.  One
+// 1024-thread workgroup per task; two-level exclusive scan.
+__global__ __launch_bounds__(1024) void select_positions_kernel(const float* __restrict__ w, int N, int topk, int* idx, float* stats) {
+  __shared__ int wave_tot[16];
+  __shared__ float red[16];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int per = (N + 1023) / 1024;
+  const int i0 = t * per, i1 = min(N, i0 + per);
+  int cnt = 0; float wall = 0.f;
+  for (int i = i0; i < i1; ++i) { float x = w[i]; cnt += x > 0.f; wall += x; }
+  // exclusive scan of cnt over 1024 threads
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+  if (l == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0, npos = 0;
+  for (int k = 0; k < 16; ++k) { int v = wave_tot[k]; if (k < wv) base += v; npos += v; }
+  int rank = base + inc - cnt;  // positives before i0
+  float wsel = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    float x = w[i];
+    int slot = x > 0.f ? rank : npos + (i - rank);
+    if (slot < topk) { idx[slot] = i; wsel += x; }
+    rank += x > 0.f;
+  }
+  wsel = block_sum(wsel, red);
+  wall = block_sum(wall, red);
+  if (t == 0) { stats[0] = wsel; stats[1] = wall; }
+}
+int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats, hipStream_t s) {
+  ARG_CHECK(topk <= N, "select_positions: topk > N");
+  hipLaunchKernelGGL(select_positions_kernel, dim3(1), dim3(1024), 0, s, w, N, topk, idx, stats);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// --------------------------------------------------------------------- row gather / scatter for the heads
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, long long ld, const int* __restrict__ idx, int parity, T* dst, int n, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n) return;
+  constexpr int E = 16 / sizeof(T);
+  const uint4* s4 = (const uint4*)(src + (2LL * idx[row] + parity) * ld);
+  uint4* d4 = (uint4*)(dst + (long long)row * D);
+  for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+}
+template <typename T>
+int launch_gather_rows(const T* src, long long ld, const int* idx, int parity, T* dst, int n, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "gather_rows: rows must be 16-byte multiples");
+  hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(div_up(n, 4)), dim3(256), 0, s, src, ld, idx, parity, dst, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_gather_rows<bf16>(const bf16*, long long, const int*, int, bf16*, int, int, hipStream_t);
+template int launch_gather_rows<float>(const float*, long long, const int*, int, float*, int, int, hipStream_t);
+
+__global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int* __restrict__ idx, int parity, float* dst, long long ld, int n, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n) return;
+  const float4* s4 = (const float4*)(src + (long long)row * D);
+  float4* d4 = (float4*)(dst + (2LL * idx[row] + parity) * ld);
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 a = d4[c], b = s4[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[c] = a;
+  }
+}
+int launch_scatter_rows_add(const float* src, const int* idx, int parity, float* dst, long long ld, int n, int D, hipStream_t s) {
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, idx, parity, dst, ld, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// --------------------------------------------------------------------- cross entropy (K13), model.py:514-519
+// One workgroup per selected position.  Rows with zero coefficient only clear their dlogits.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(T* logits, long long ldl, int V, const int* __restrict__ idx,
+                                                 const float* __restrict__ label, const float* __restrict__ weight,
+                                                 const int* __restrict__ position, const float* __restrict__ stats,
+                                                 float task_w, float* loss_out) {
+  __shared__ float red[16];
+  constexpr int E = 16 / sizeof(T);
+  const int row = blockIdx.x, t = threadIdx.x;
+  T* lr = logits + (long long)row * ldl;
+  const int i = idx[row];
+  const float w = weight[i], lab = label[i];
+  const int nchunks = (int)(ldl / E);
+  const float lw = lab * w;
+  if (lw == 0.f) {
+    for (int c = t; c < nchunks; c += 256) ((uint4*)lr)[c] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  // online max / sum-exp
+  float m = -3.0e38f, ssum = 0.f;
+  for (int c = t; c < nchunks; c += 256) {
+    uint4 raw = ((const uint4*)lr)[c];
+    const T* e = (const T*)&raw;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if (c * E + k < V) {
+        float x = to_f32(e[k]);
+        if (x > m) { ssum = ssum * __expf(m - x) + 1.f; m = x; }
+        else ssum += __expf(x - m);
+      }
+    }
+  }
+  const float gm = block_max(m, red);
+  ssum = block_sum(ssum * __expf(m - gm), red);
+  const float lse = gm + logf(ssum);
+  const int tgt = position[i];
+  const float xt = to_f32(lr[tgt]);
+  __syncthreads();
+  if (t == 0) atomicAdd(loss_out, (lse - xt) * lw);
+  const float coef = task_w * lw / fmaxf(stats[0], 1e-8f);
+  for (int c = t; c < nchunks; c += 256) {
+    uint4 raw = ((const uint4*)lr)[c];
+    T* e = (T*)&raw;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      int col = c * E + k;
+      float x = to_f32(e[k]);
+      float gl = col < V ? coef * (__expf(x - lse) - (col == tgt ? 1.f : 0.f)) : 0.f;
+      e[k] = from_f32<T>(gl);
+    }
+    ((uint4*)lr)[c] = raw;
+  }
+}
+template <typename T>
+int launch_ce_fwd_bwd(T* logits, long long ldl, int n, int V, const int* idx, const float* label, const float* weight,
+                      const int* position, const float* stats, float task_w, float* loss_out, hipStream_t s) {
+  ARG_CHECK((ldl * sizeof(T)) % 16 == 0 && ldl >= V, "ce: ldl");
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(n), dim3(256), 0, s, logits, ldl, V, idx, label, weight, position, stats, task_w, loss_out);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_ce_fwd_bwd<bf16>(bf16*, long long, int, int, const int*, const float*, const float*, const int*, const float*, float, float*, hipStream_t);
+template int launch_ce_fwd_bwd<float>(float*, long long, int, int, const int*, const float*, const float*, const int*, const float*, float, float*, hipStream_t);
+
+// --------------------------------------------------------------------- rating head tail (K14), model.py:355-359,391-401,520-526
+template <typename T>
+__global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restrict__ hact, int n, int D,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          const int* __restrict__ idx, const float* __restrict__ label,
+                                                          const float* __restrict__ weight, const float* __restrict__ stats,
+                                                          float rating_mean, float task_w, int evaluate, float* loss_out,
+                                                          float* dw2, float* db2, float* db0) {
+  extern __shared__ __attribute__((aligned(16))) float sds[];  // 2*D floats: dw2 | db0
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < 2 * D; c += 256) sds[c] = 0.f;
+  __syncthreads();
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f, gb2 = 0.f;
+  const float inv_ws = 1.f / fmaxf(stats[0], 1e-8f);
+  for (int row = blockIdx.x * 4 + w; row < n; row += gridDim.x * 4) {
+    const int i = idx[row];
+    const float wt = weight[i], tgt = label[i] - rating_mean;
+    const T* hr = hact + (long long)row * D;
+    T* zr = z + (long long)row * D;
+    float acc = 0.f;
+    for (int c = l; c < D; c += 64) acc += to_f32(hr[c]) * w2[c];
+    acc = wave_sum(acc);
+    const float pred = acc + b2[0];
+    const float e1 = pred - tgt;
+    l0 += e1 * e1 * wt; l1 += tgt * tgt * wt; l2 += (-pred - tgt) * (-pred - tgt) * wt;
+    const float dpred = evaluate ? 0.f : task_w * 2.f * e1 * wt * inv_ws;
+    gb2 += dpred;
+    for (int c = l; c < D; c += 64) {
+      float zz = to_f32(zr[c]);
+      float gp = 0.5f * (1.f + erff(zz * 0.70710678118654752f)) + zz * __expf(-0.5f * zz * zz) * 0.3989422804014327f;
+      float dz = dpred * w2[c] * gp;
+      zr[c] = from_f32<T>(dz);
+      if (dpred != 0.f) {
+        atomicAdd(&sds[c], dpred * to_f32(hr[c]));
+        atomicAdd(&sds[D + c], dz);
+      }
+    }
+  }
+  __syncthreads();
+  if (!evaluate) {
+    for (int c = threadIdx.x; c < D; c += 256) {
+      if (sds[c] != 0.f) atomicAdd(&dw2[c], sds[c]);
+      if (sds[D + c] != 0.f) atomicAdd(&db0[c], sds[D + c]);
+    }
+    if (l == 0 && gb2 != 0.f) atomicAdd(db2, gb2);
+  }
+  if (l == 0) {
+    if (l0 != 0.f) atomicAdd(&loss_out[0], l0);
+    if (l1 != 0.f) atomicAdd(&loss_out[1], l1);
+    if (l2 != 0.f) atomicAdd(&loss_out[2], l2);
+  }
+}
+template <typename T>
+int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const float* b2, const int* idx,
+                       const float* label, const float* weight, const float* stats, float rating_mean, float task_w,
+                       int evaluate, float* loss_out, float* dw2, float* db2, float* db0, hipStream_t s) {
+  int grid = std::min(div_up(n, 4), 512);
+  hipLaunchKernelGGL((rating_tail_kernel<T>), dim3(grid), dim3(256), 2 * D * sizeof(float), s, z, hact, n, D, w2, b2, idx,
+                     label, weight, stats, rating_mean, task_w, evaluate, loss_out, dw2, db2, db0);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_rating_tail<bf16>(bf16*, const bf16*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
+template int launch_rating_tail<float>(float*, const float*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
+
+// --------------------------------------------------------------------- column sums
+template <typename TS>
+__global__ void colsum_kernel(const TS* __restrict__ src, long long ld, long long rows, int cols, float* dst, int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc = 0.f;
+  for (long long r = r0; r < r1; ++r) acc += to_f32(src[r * ld + c]);
+  if (acc != 0.f) atomicAdd(&dst[c], acc);
+}
+template <typename TS>
+static int colsum_any(const TS* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
+  int rpb = (int)std::max<long long>(64, (rows + 511) / 512);
+  dim3 grid(div_up(cols, 256), div_up(rows, rpb));
+  hipLaunchKernelGGL((colsum_kernel<TS>), grid, dim3(256), 0, s, src, ld, rows, cols, dst, rpb);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
+  return colsum_any<float>(src, ld, rows, cols, dst, s);
+}
+template <typename T>
+int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
+  return colsum_any<T>(src, ld, rows, cols, dst, s);
+}
+template int launch_colsum_add_t<bf16>(const bf16*, long long, long long, int, float*, hipStream_t);
+template int launch_colsum_add_t<float>(const float*, long long, long long, int, float*, hipStream_t);
+
+// --------------------------------------------------------------------- embedding scatter-add (K16)
+// gE[id'] += gx0[2n]; one wave per interaction, 256 contiguous bytes per atomic wave-instruction
+// (MI355X_MICROARCH.md "Global float atomics": full rate for this shape).
+__global__ void embedding_scatter_kernel(const float* __restrict__ gx0, BatchDev b, int V, int D, float* gE) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (n >= b.N) return;
+  int id = b.m_matchedid[n];
+  id = id == -1 ? V : id;
+  const float* src = gx0 + (long long)(2 * n) * D;
+  float* dst = gE + (long long)id * D;
+  for (int c = l; c < D; c += 64) atomicAdd(&dst[c], src[c]);
+}
+int launch_embedding_scatter_add(const float* gx0, const BatchDev& b, int V, int D, float* gE, hipStream_t s) {
+  hipLaunchKernelGGL(embedding_scatter_kernel, dim3(div_up(b.N, 4)), dim3(256), 0, s, gx0, b, V, D, gE);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// --------------------------------------------------------------------- action embedding: small-table gradients
+__global__ __launch_bounds__(256) void action_small_bwd_kernel(const float* __restrict__ gf, BatchDev b, SmallParams sp,
+                                                               float* g_cos, float* g_sin, float* g_status, float* g_gender,
+                                                               float* g_source) {
+  // LDS accumulators: cos(2) sin(2) gender(5*4) source(5*4) status(10*16) -> sized for vocab <= 15 each
+  __shared__ float acc[4 + 16 * 4 + 16 * 4 + 16 * 16];
+  const int NG = (sp.n_gender + 1) * 4, NS = (sp.n_source + 1) * 4, NST = (sp.n_status + 1) * 16;
+  float* a_g = acc + 4; float* a_s = a_g + 64; float* a_st = a_s + 64;
+  for (int c = threadIdx.x; c < 4 + 64 + 64 + 256; c += 256) acc[c] = 0.f;
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.N; i += gridDim.x * blockDim.x) {
+    const float* g = gf + (long long)i * 32;
+    float p0, p1; double ts;
+    periodic_args(b.time[i], sp.min_ts, p0, p1, ts);
+    atomicAdd(&acc[0], -sinf(p0 + sp.per_cos[0]) * g[1]);
+    atomicAdd(&acc[1], -sinf(p1 + sp.per_cos[1]) * g[2]);
+    atomicAdd(&acc[2], cosf(p0 + sp.per_sin[0]) * g[3]);
+    atomicAdd(&acc[3], cosf(p1 + sp.per_sin[1]) * g[4]);
+    int gi = b.gender[i]; gi = gi == -1 ? sp.n_gender : gi;
+    int si = b.source[i]; si = si == -1 ? sp.n_source : si;
+    int st = b.m_status[i]; st = st == -1 ? sp.n_status : st;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&a_g[gi * 4 + k], g[5 + k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&a_s[si * 4 + k], g[9 + k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) atomicAdd(&a_st[st * 16 + k], g[15 + k]);
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < 2) atomicAdd(&g_cos[t], acc[t]);
+  else if (t < 4) atomicAdd(&g_sin[t - 2], acc[t]);
+  for (int c = t; c < NG; c += 256) atomicAdd(&g_gender[c], a_g[c]);
+  for (int c = t; c < NS; c += 256) atomicAdd(&g_source[c], a_s[c]);
+  for (int c = t; c < NST; c += 256) atomicAdd(&g_status[c], a_st[c]);
+}
+int launch_action_small_bwd(const float* gf, const BatchDev& b, const SmallParams& sp, float* g_per_cos, float* g_per_sin,
+                            float* g_status, float* g_gender, float* g_source, hipStream_t s) {
+  ARG_CHECK(sp.n_gender < 16 && sp.n_source < 16 && sp.n_status < 16, "action_small_bwd: small vocab sizes must be < 16");
+  int grid = std::min(div_up(b.N, 256), 256);
+  hipLaunchKernelGGL(action_small_bwd_kernel, dim3(grid), dim3(256), 0, s, gf, b, sp, g_per_cos, g_per_sin, g_status,
+                     g_gender, g_source);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+}  // namespace rsys

@@ -1,0 +1,50 @@
+// MFMA GEMM for gfx950: C[M,N] = sum_k A(m,k) * B(n,k) with fused epilogues.
+// One kernel family serves every dense contraction of the training step
+// (SURVEY.md 2.3 K3/K7/K10/K12/K14/K16): operands may be row-major
+// (K contiguous) or K-major (the reduction index is the slow one, as in every
+// weight-gradient product); K-major bf16 tiles are consumed with
+// ds_read_b64_tr_b16 so no transposed copies are ever written to HBM.
+#pragma once
+#include "common.hpp"
+
+namespace rsys {
+
+enum GemmEpi : int {
+  EPI_STORE = 0,        // C = alpha*acc                      (C: T or f32)
+  EPI_ACCUM = 1,        // Cf32 += acc
+  EPI_ATOMIC = 2,       // atomicAdd(Cf32, acc)               (split-K weight grads)
+  EPI_BIAS = 3,         // C = acc + bias[col]                (C: T or f32)
+  EPI_RESIDUAL = 4,     // Cf32 = resid + acc
+  EPI_QKV_ROPE = 5,     // rotate q,k pairs; write C (T) and per-head transposed copies
+  EPI_SWIGLU = 6,       // cols interleaved [16 a | 16 b]: C = ab (T), C2 = silu(a)*b (T)
+  EPI_TABLE = 7,        // f = acc + E + bias: Cf32 = f, C2 = T(f)
+  EPI_GELU = 8,         // z = acc + bias: C = T(z), C2 = T(gelu(z))
+  EPI_STORE_HEADS_T = 9 // C = T(acc) and C2[b][head][d][t] = T(acc)   (dO and dO^T)
+};
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int epi;
+  int c_f32;        // 1: C is float, 0: C is T
+  int splitk;       // >=1; >1 requires EPI_ATOMIC
+  float alpha;
+  const float* bias;
+  const float* resid; long long ldr;
+  void* C2; long long ldc2;
+  // EPI_QKV_ROPE / EPI_STORE_HEADS_T
+  const float* rope_cos; const float* rope_sin;   // [pos][hd/2]
+  const int* rope_pos;                             // optional per-row position, else row % T
+  int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
+  void* qT; void* kT; void* vT;                    // [b][head][hd][T]
+  // EPI_TABLE
+  const float* E;
+};
+
+// CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).
+// a_f32/b_f32: operand is float in memory although CT is bf16 (converted while staging).
+template <typename CT>
+int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s);
+
+}  // namespace rsys

@@ -1,0 +1,854 @@
+// Training-step orchestration: RecommenderModel.train_forward + backward
+// (transformer.model.py:493-529 and its autograd), restructured for MI355X:
+//  * the item table is fused once per step, F = E + Meta Wp^T + bp (model.py:120-133
+//    does the same at inference), and shared by the token gather and both watch heads;
+//    its gradient dF IS the gradient of E, and dWp = dF^T Meta is one GEMM per optimizer step;
+//  * q/k/v and w1/w3 projections are single GEMMs (weights stored concatenated /
+//    16-row interleaved in the flat parameter buffer) with RoPE and SwiGLU epilogues;
+//  * residual stream fp32, GEMM operands T (bf16 or fp32), fp32 accumulation;
+//  * every kernel of a step is enqueued on one HIP stream, no host sync inside a step.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "model.hpp"
+
+namespace rsys {
+
+#define RC(expr)                  \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != RSYS_OK) return _rc; \
+  } while (0)
+
+static inline int64_t pad8(int64_t n) { return (n + 7) / 8 * 8; }
+
+static int dalloc(Model* m, void** p, size_t bytes) {
+  bytes = (bytes + 255) / 256 * 256;
+  HIP_CHECK(hipMalloc(p, bytes));
+  HIP_CHECK(hipMemset(*p, 0, bytes));
+  m->allocs.push_back(*p);
+  return RSYS_OK;
+}
+#define DALLOC(ptr, bytes) RC(dalloc(m, (void**)&(ptr), (size_t)(bytes)))
+
+// ------------------------------------------------------------------ timing
+static void tic(Model* m, const char* name, double flops = 0.0) {
+  PhaseTimer& t = m->timer;
+  if (!t.enabled) return;
+  if (t.used + 2 > t.pool.size()) {
+    for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); t.pool.push_back(e); }
+  }
+  hipEvent_t e = t.pool[t.used++];
+  hipEventRecord(e, m->stream);
+  t.marks.push_back({std::string(name), e});
+  t.acc_ms[std::string("#flops:") + name] += flops;
+}
+static void toc(Model* m) {
+  PhaseTimer& t = m->timer;
+  if (!t.enabled) return;
+  hipEvent_t e = t.pool[t.used++];
+  hipEventRecord(e, m->stream);
+  t.marks.push_back({std::string(""), e});
+}
+
+// ------------------------------------------------------------------ layout
+static void add_tensor(Model* m, const std::string& name, int64_t rows, int64_t cols, int ndim, int64_t off, int64_t ld,
+                       int map, bool trainable = true, bool frozen = false) {
+  TensorInfo t{name, rows, cols, ndim, off, ld, map, trainable, frozen};
+  m->by_name[name] = (int)m->tensors.size();
+  m->tensors.push_back(t);
+}
+
+static void build_layout(Model* m) {
+  const int D = m->D, Ip = m->Ip, I = m->I, L = m->L, hd = m->hd, H = m->H, KV = m->KV;
+  const bool ft = m->cfg.finetune != 0;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += pad8(n); return o; };
+  // ---- decay group (tensors with dim >= 2, train.py:288)
+  m->o_status = take((m->cfg.vocab_status + 1) * 16);
+  m->o_gender = take((m->cfg.vocab_gender + 1) * 4);
+  m->o_source = take((m->cfg.vocab_source + 1) * 4);
+  m->o_lin_w = take((int64_t)D * 32);
+  m->o_E = take((int64_t)(m->V + 1) * D);
+  m->o_Wp = take((int64_t)D * m->Mp);
+  m->lo.resize(L);
+  for (int l = 0; l < L; ++l) {
+    m->lo[l].wqkv = take((int64_t)m->Nqkv * D);
+    m->lo[l].wo = take((int64_t)D * D);
+    m->lo[l].w13 = take((int64_t)2 * Ip * D);
+    m->lo[l].w2 = take((int64_t)D * Ip);
+  }
+  m->o_r0w = take((int64_t)D * D);
+  m->o_r2w = take(D);
+  m->n_decay = off;
+  // ---- no-decay group
+  m->o_pcos = take(2); m->o_psin = take(2);
+  m->o_lin_b = take(D); m->o_bp = take(D);
+  for (int l = 0; l < L; ++l) { m->lo[l].sa = take(D); m->lo[l].mlp = take(D); }
+  m->o_norm = take(D); m->o_r0b = take(D); m->o_r2b = take(1);
+  m->n_total = off;
+
+  const bool tr = !ft;  // finetune freezes everything but LoRA (not built yet): base tensors are non-trainable
+  add_tensor(m, "action_embedding.periodic_time_cos", 1, 2, 1, m->o_pcos, 2, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.periodic_time_sin", 1, 2, 1, m->o_psin, 2, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.status_embedding.embedding.weight", m->cfg.vocab_status + 1, 16, 2, m->o_status, 16, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.gender_embedding.embedding.weight", m->cfg.vocab_gender + 1, 4, 2, m->o_gender, 4, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.source_embedding.embedding.weight", m->cfg.vocab_source + 1, 4, 2, m->o_source, 4, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.linear.weight", D, 32, 2, m->o_lin_w, 32, MAP_DIRECT, tr);
+  add_tensor(m, "action_embedding.linear.bias", 1, D, 1, m->o_lin_b, D, MAP_DIRECT, tr);
+  add_tensor(m, "item_embedding.matchedid_embedding.embedding.weight", m->V + 1, D, 2, m->o_E, D, MAP_DIRECT, tr);
+  add_tensor(m, "item_embedding.metadata_embedding.embedding.weight", m->V + 1, m->M, 2, 0, m->Mp, MAP_DIRECT, false, true);
+  add_tensor(m, "item_embedding.projection_layer.weight", D, m->M, 2, m->o_Wp, m->Mp, MAP_DIRECT, tr);
+  add_tensor(m, "item_embedding.projection_layer.bias", 1, D, 1, m->o_bp, D, MAP_DIRECT, tr);
+  for (int l = 0; l < L; ++l) {
+    std::string p = "transformers.layers." + std::to_string(l) + ".";
+    add_tensor(m, p + "attn.q_proj.weight", H * hd, D, 2, m->lo[l].wqkv, D, MAP_DIRECT, tr);
+    add_tensor(m, p + "attn.k_proj.weight", KV * hd, D, 2, m->lo[l].wqkv + (int64_t)H * hd * D, D, MAP_DIRECT, tr);
+    add_tensor(m, p + "attn.v_proj.weight", KV * hd, D, 2, m->lo[l].wqkv + (int64_t)(H + KV) * hd * D, D, MAP_DIRECT, tr);
+    add_tensor(m, p + "attn.output_proj.weight", D, H * hd, 2, m->lo[l].wo, D, MAP_DIRECT, tr);
+    add_tensor(m, p + "mlp.w1.weight", I, D, 2, m->lo[l].w13, D, MAP_W1, tr);
+    add_tensor(m, p + "mlp.w2.weight", D, I, 2, m->lo[l].w2, Ip, MAP_DIRECT, tr);
+    add_tensor(m, p + "mlp.w3.weight", I, D, 2, m->lo[l].w13, D, MAP_W3, tr);
+    add_tensor(m, p + "sa_norm.scale", 1, D, 1, m->lo[l].sa, D, MAP_DIRECT, tr);
+    add_tensor(m, p + "mlp_norm.scale", 1, D, 1, m->lo[l].mlp, D, MAP_DIRECT, tr);
+  }
+  add_tensor(m, "transformers.norm.scale", 1, D, 1, m->o_norm, D, MAP_DIRECT, tr);
+  add_tensor(m, "rating_head.0.weight", D, D, 2, m->o_r0w, D, MAP_DIRECT, tr);
+  add_tensor(m, "rating_head.0.bias", 1, D, 1, m->o_r0b, D, MAP_DIRECT, tr);
+  add_tensor(m, "rating_head.2.weight", 1, D, 2, m->o_r2w, D, MAP_DIRECT, tr);
+  add_tensor(m, "rating_head.2.bias", 1, 1, 1, m->o_r2b, 1, MAP_DIRECT, tr);
+}
+
+static inline int64_t internal_row(const TensorInfo& t, int64_t r) {
+  if (t.map == MAP_W1) return (r / 16) * 32 + (r % 16);
+  if (t.map == MAP_W3) return (r / 16) * 32 + 16 + (r % 16);
+  return r;
+}
+
+int model_create(const rsys_config* cfg, int device, Model** out) {
+  ARG_CHECK(cfg != nullptr && out != nullptr, "null argument");
+  ARG_CHECK(cfg->embed_dim % cfg->num_heads == 0, "embed_dim % num_heads");
+  ARG_CHECK(cfg->num_heads % cfg->num_kv_heads == 0, "num_heads % num_kv_heads");
+  const int hd = cfg->embed_dim / cfg->num_heads;
+  ARG_CHECK(hd == 16 || hd == 32 || hd == 64 || hd == 128, "head_dim must be 16/32/64/128");
+  ARG_CHECK(cfg->embed_dim % 16 == 0 && cfg->embed_dim <= 2048, "embed_dim must be a multiple of 16 and <= 2048");
+  ARG_CHECK((2 * cfg->max_sequence_length) % 64 == 0 && 2 * cfg->max_sequence_length <= 2048,
+            "2*max_sequence_length must be a multiple of 64 and <= 2048");
+  ARG_CHECK(cfg->max_rows >= 1, "max_rows");
+  ARG_CHECK(cfg->mask_topk >= 1 && cfg->mask_topk <= cfg->max_sequence_length, "mask_topk");
+  ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16, "dtype");
+  ARG_CHECK(cfg->finetune == 0, "finetune/LoRA training is not built in this round (SURVEY 8(f) N1)");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) { set_error("no HIP device visible: the HIP path has no CPU fallback"); return RSYS_ERR_HIP; }
+  ARG_CHECK(device >= 0 && device < ndev, "device index");
+  HIP_CHECK(hipSetDevice(device));
+  Model* m = new Model();
+  m->cfg = *cfg; m->device = device;
+  m->bf16_mode = cfg->dtype == RSYS_DTYPE_BF16;
+  m->esz = m->bf16_mode ? 2 : 4;
+  m->L = cfg->num_layers; m->H = cfg->num_heads; m->KV = cfg->num_kv_heads; m->D = cfg->embed_dim;
+  m->I = cfg->intermediate_dim; m->Ip = (m->I + 15) / 16 * 16; m->S = cfg->max_sequence_length; m->T = 2 * m->S;
+  m->V0 = cfg->vocab_0; m->V1 = cfg->vocab_1; m->V = m->V0 + m->V1; m->M = cfg->metadata_dim;
+  m->Mp = (m->M + 63) / 64 * 64; m->K = cfg->mask_topk; m->hd = hd;
+  m->Nqkv = (m->H + 2 * m->KV) * hd; m->rows_max = cfg->max_rows;
+  HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  build_layout(m);
+  const int64_t D = m->D, N = (int64_t)m->rows_max * m->S, NT = 2 * N, KB = (int64_t)m->K * m->rows_max;
+  const size_t e = m->esz;
+  DALLOC(m->P, m->n_total * 4); DALLOC(m->G, m->n_total * 4);
+  if (m->bf16_mode) { DALLOC(m->Sh, m->n_total * 2); } else { m->Sh = m->P; }
+  DALLOC(m->Meta, (int64_t)(m->V + 1) * m->Mp * e);
+  DALLOC(m->F32, (int64_t)(m->V + 1) * D * 4); DALLOC(m->FT, (int64_t)(m->V + 1) * D * e);
+  // RoPE tables (model.py:173-179), fp32 like torch; the host may overwrite them (rsys_model_set_rope)
+  {
+    const int half = hd / 2;
+    std::vector<float> c((size_t)m->T * half), s((size_t)m->T * half);
+    for (int k = 0; k < half; ++k) {
+      float freq = 1.0f / powf(500000.0f, (float)(2 * k) / (float)hd);
+      for (int t = 0; t < m->T; ++t) { float a = (float)t * freq; c[(size_t)t * half + k] = cosf(a); s[(size_t)t * half + k] = sinf(a); }
+    }
+    DALLOC(m->rope_cos, c.size() * 4); DALLOC(m->rope_sin, s.size() * 4);
+    HIP_CHECK(hipMemcpy(m->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    m->rope_npos = m->T;
+  }
+  // batch blob: 27 raw arrays + masked copies
+  {
+    size_t per_i = 4 * 6 + 8 + 4 * 2 + 18 * 4 /*raw*/ + 4 * 3 + 4 * 2 + 12 * 4 /*masked*/;
+    DALLOC(m->batch_blob, (size_t)N * per_i + 4096);
+    unsigned char* p = (unsigned char*)m->batch_blob;
+    auto carve = [&](size_t bytes) { void* r = p; p += (bytes + 15) / 16 * 16; return r; };
+    BatchDev& b = m->bd;
+    b.time = (const double*)carve(N * 8);
+    b.userid = (const int*)carve(N * 4); b.tmid = (const int*)carve(N * 4); b.gender = (const int*)carve(N * 4);
+    b.source = (const int*)carve(N * 4); b.matchedid = (const int*)carve(N * 4); b.status = (const int*)carve(N * 4);
+    b.rating = (const float*)carve(N * 4); b.progress = (const float*)carve(N * 4);
+    for (int k = 0; k < 6; ++k) { b.label[k] = (const float*)carve(N * 4); b.weight[k] = (const float*)carve(N * 4); b.position[k] = (const int*)carve(N * 4); }
+    b.m_tmid = (int*)carve(N * 4); b.m_matchedid = (int*)carve(N * 4); b.m_status = (int*)carve(N * 4);
+    b.m_rating = (float*)carve(N * 4); b.m_progress = (float*)carve(N * 4);
+    for (int k = 0; k < 4; ++k) { b.m_label[k] = (float*)carve(N * 4); b.m_weight[k] = (float*)carve(N * 4); b.m_position[k] = (int*)carve(N * 4); }
+    b.watch_mask = nullptr; b.rating_mask = nullptr; b.rope_pos = nullptr;
+    DALLOC(m->d_wm, N); DALLOC(m->d_rm, N); DALLOC(m->d_rope_pos, NT * 4);
+  }
+  DALLOC(m->feat, N * 32 * e); DALLOC(m->x0, NT * D * 4);
+  DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
+  DALLOC(m->qmap, (int64_t)m->rows_max * (m->T / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * (m->T / 64) * 4);
+  m->la.resize(m->L);
+  for (int l = 0; l < m->L; ++l) {
+    Model::LayerAct& a = m->la[l];
+    if (l == 0) a.x = m->x0; else DALLOC(a.x, NT * D * 4);
+    DALLOC(a.xn, NT * D * e); DALLOC(a.qkv, NT * m->Nqkv * e);
+    DALLOC(a.qT, NT * m->H * hd * e); DALLOC(a.kT, NT * m->KV * hd * e); DALLOC(a.vT, NT * m->KV * hd * e);
+    DALLOC(a.O, NT * D * e); DALLOC(a.lse, (int64_t)m->rows_max * m->H * m->T * 4);
+    DALLOC(a.rstd1, NT * 4); DALLOC(a.h, NT * D * 4); DALLOC(a.hn, NT * D * e); DALLOC(a.rstd2, NT * 4);
+    DALLOC(a.ab, NT * 2 * m->Ip * e); DALLOC(a.g, NT * m->Ip * e);
+  }
+  DALLOC(m->xL, NT * D * 4); DALLOC(m->rstdf, NT * 4); DALLOC(m->out, NT * D * e);
+  for (int k = 0; k < 4; ++k) DALLOC(m->idx[k], KB * 4);
+  DALLOC(m->stats, 8 * 4); DALLOC(m->Ew, KB * D * e);
+  m->ldl = pad8(std::max(m->V0, m->V1));
+  DALLOC(m->logits, KB * m->ldl * e); DALLOC(m->dE, KB * D * 4);
+  DALLOC(m->z, KB * D * e); DALLOC(m->hact, KB * D * e); DALLOC(m->loss_acc, 16 * 4);
+  DALLOC(m->gy, NT * D * 4); DALLOC(m->gxa, NT * D * 4); DALLOC(m->gxb, NT * D * 4); DALLOC(m->dh, NT * D * 4);
+  DALLOC(m->dg, NT * m->Ip * e); DALLOC(m->dab, NT * 2 * m->Ip * e); DALLOC(m->dhn, NT * D * e);
+  DALLOC(m->dO, NT * D * e); DALLOC(m->dOT, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
+  DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
+  DALLOC(m->sumsq, 64);
+  *out = m;
+  return RSYS_OK;
+}
+
+int model_destroy(Model* m) {
+  if (!m) return RSYS_OK;
+  hipSetDevice(m->device);
+  hipStreamSynchronize(m->stream);
+  for (void* p : m->allocs) hipFree(p);
+  for (auto e : m->timer.pool) hipEventDestroy(e);
+  hipStreamDestroy(m->stream);
+  delete m;
+  return RSYS_OK;
+}
+
+int model_refresh_shadow(Model* m) {
+  if (m->bf16_mode) RC(launch_cast<bf16>(m->P, (bf16*)m->Sh, m->n_total, m->stream));
+  return RSYS_OK;
+}
+
+// init_weights (model.py:5-12): N(0, 0.006) on every Linear/Embedding weight, zero bias, last row of
+// every embedding zeroed, norm scales 1, periodic phases 0.  Generated on the device from Philox.
+int model_init_random(Model* m, uint64_t seed) {
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipMemsetAsync(m->P, 0, m->n_total * 4, m->stream));
+  unsigned int stream_id = 1;
+  std::vector<float> ones(m->D, 1.0f);
+  for (const TensorInfo& t : m->tensors) {
+    if (t.frozen_table) continue;
+    const bool is_scale = t.name.size() > 6 && t.name.compare(t.name.size() - 6, 6, ".scale") == 0;
+    if (is_scale) { HIP_CHECK(hipMemcpyAsync(m->P + t.off, ones.data(), m->D * 4, hipMemcpyHostToDevice, m->stream)); HIP_CHECK(hipStreamSynchronize(m->stream)); continue; }
+    if (t.ndim == 1) continue;  // biases and phases stay zero
+    if (t.map == MAP_W3) continue;  // filled together with w1 (same interleaved block)
+    int64_t rows = t.map == MAP_W1 ? 2 * m->Ip : t.rows;
+    for (int64_t r0 = 0; r0 < rows; r0 += 4096) {  // rows*ld contiguous block incl. padding (re-zeroed below)
+      int64_t nr = std::min<int64_t>(4096, rows - r0);
+      RC(launch_fill_normal(m->P + t.off + r0 * t.ld, nr * t.ld, 0.006f, seed, stream_id++, m->stream));
+    }
+    // zero the padding the block fill touched
+    if (t.ld != t.cols) {
+      std::vector<float> host((size_t)rows * t.ld);
+      HIP_CHECK(hipStreamSynchronize(m->stream));
+      HIP_CHECK(hipMemcpy(host.data(), m->P + t.off, host.size() * 4, hipMemcpyDeviceToHost));
+      for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = t.cols; c < t.ld; ++c) host[r * t.ld + c] = 0.f;
+      HIP_CHECK(hipMemcpy(m->P + t.off, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (t.map == MAP_W1 && m->Ip != m->I) {  // padded w1/w3 rows
+      for (int64_t r = m->I; r < m->Ip; ++r) {
+        HIP_CHECK(hipMemsetAsync(m->P + t.off + ((r / 16) * 32 + (r % 16)) * t.ld, 0, t.ld * 4, m->stream));
+        HIP_CHECK(hipMemsetAsync(m->P + t.off + ((r / 16) * 32 + 16 + (r % 16)) * t.ld, 0, t.ld * 4, m->stream));
+      }
+    }
+    if (t.name.find("embedding.weight") != std::string::npos)
+      HIP_CHECK(hipMemsetAsync(m->P + t.off + (t.rows - 1) * t.ld, 0, t.cols * 4, m->stream));
+  }
+  RC(model_refresh_shadow(m));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  return RSYS_OK;
+}
+
+int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
+  ARG_CHECK(V == m->V && Mdim == m->M, "metadata table shape must be (V, metadata_dim)");  // model.py:387
+  HIP_CHECK(hipSetDevice(m->device));
+  const int64_t chunk = 4096;
+  std::vector<float> hostf((size_t)chunk * m->Mp);
+  std::vector<unsigned short> hosth;
+  if (m->bf16_mode) hosth.resize((size_t)chunk * m->Mp);
+  HIP_CHECK(hipMemset(m->Meta, 0, (size_t)(m->V + 1) * m->Mp * m->esz));  // mask row V and padding stay zero
+  for (int64_t r0 = 0; r0 < V; r0 += chunk) {
+    int64_t nr = std::min(chunk, V - r0);
+    for (int64_t r = 0; r < nr; ++r) {
+      const float* src = table + (r0 + r) * Mdim;
+      if (m->bf16_mode) {
+        unsigned short* d = hosth.data() + r * m->Mp;
+        for (int64_t c = 0; c < Mdim; ++c) {
+          uint32_t u; memcpy(&u, &src[c], 4);
+          uint32_t rb = ((u >> 16) & 1u) + 0x7FFFu;   // round to nearest even (inputs are finite table values)
+          d[c] = (unsigned short)((u + rb) >> 16);
+        }
+        for (int64_t c = Mdim; c < m->Mp; ++c) d[c] = 0;
+      } else {
+        float* d = hostf.data() + r * m->Mp;
+        memcpy(d, src, Mdim * 4);
+        for (int64_t c = Mdim; c < m->Mp; ++c) d[c] = 0.f;
+      }
+    }
+    void* dst = (unsigned char*)m->Meta + (size_t)r0 * m->Mp * m->esz;
+    HIP_CHECK(hipMemcpy(dst, m->bf16_mode ? (void*)hosth.data() : (void*)hostf.data(), (size_t)nr * m->Mp * m->esz, hipMemcpyHostToDevice));
+  }
+  return RSYS_OK;
+}
+
+int model_random_metadata(Model* m, uint64_t seed) {
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipMemsetAsync(m->Meta, 0, (size_t)(m->V + 1) * m->Mp * m->esz, m->stream));
+  const float std_ = 1.0f / sqrtf((float)m->M);
+  if (m->bf16_mode) RC(launch_fill_normal_t<bf16>((bf16*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
+  else RC(launch_fill_normal_t<float>((float*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  return RSYS_OK;
+}
+
+int model_set_rope(Model* m, const float* c, const float* s, int64_t n_pos) {
+  ARG_CHECK(n_pos == m->T, "rope tables must have 2*max_sequence_length positions");
+  HIP_CHECK(hipSetDevice(m->device));
+  size_t bytes = (size_t)n_pos * (m->hd / 2) * 4;
+  HIP_CHECK(hipMemcpy(m->rope_cos, c, bytes, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(m->rope_sin, s, bytes, hipMemcpyHostToDevice));
+  return RSYS_OK;
+}
+
+// state_dict <-> flat compute layout (which == 0: parameters, 1: gradients)
+int model_param_io(Model* m, const char* name, float* out, const float* in, int64_t n, int which) {
+  auto it = m->by_name.find(name);
+  if (it == m->by_name.end()) { set_error(std::string("unknown parameter: ") + name); return RSYS_ERR_ARG; }
+  const TensorInfo& t = m->tensors[it->second];
+  ARG_CHECK(n == t.rows * t.cols, "element count does not match the parameter's shape");
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (t.frozen_table) {
+    ARG_CHECK(which == 0, "the metadata table is frozen (model.py:113-114)");
+    if (in) {
+      // rows 0..V-1 come from the caller; the mask row is kept zero (model.py:386)
+      return model_load_metadata(m, in, m->V, m->M);
+    }
+    std::vector<unsigned char> host((size_t)t.rows * m->Mp * m->esz);
+    HIP_CHECK(hipMemcpy(host.data(), m->Meta, host.size(), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < t.rows; ++r)
+      for (int64_t c = 0; c < t.cols; ++c) {
+        if (m->bf16_mode) { uint32_t u = (uint32_t)((unsigned short*)host.data())[r * m->Mp + c] << 16; memcpy(&out[r * t.cols + c], &u, 4); }
+        else out[r * t.cols + c] = ((float*)host.data())[r * m->Mp + c];
+      }
+    return RSYS_OK;
+  }
+  if (which == 1) RC(model_finalize_grads(m));
+  float* base = (which == 0 ? m->P : m->G) + t.off;
+  const int64_t int_rows = (t.map == MAP_DIRECT) ? t.rows : 2 * m->Ip;
+  std::vector<float> host((size_t)int_rows * t.ld);
+  HIP_CHECK(hipMemcpy(host.data(), base, host.size() * 4, hipMemcpyDeviceToHost));
+  if (out) {
+    for (int64_t r = 0; r < t.rows; ++r) memcpy(out + r * t.cols, host.data() + internal_row(t, r) * t.ld, t.cols * 4);
+    return RSYS_OK;
+  }
+  for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + internal_row(t, r) * t.ld, in + r * t.cols, t.cols * 4);
+  HIP_CHECK(hipMemcpy(base, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+  if (which == 0 && m->bf16_mode)
+    RC(launch_cast<bf16>(base, (bf16*)m->Sh + t.off, (int64_t)host.size(), m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  return RSYS_OK;
+}
+
+int model_batch_upload(Model* m, const rsys_batch* b) {
+  ARG_CHECK(b != nullptr, "null batch");
+  ARG_CHECK(b->rows >= 1 && b->rows <= m->rows_max, "batch rows must be in [1, max_rows]");
+  HIP_CHECK(hipSetDevice(m->device));
+  const size_t N = (size_t)b->rows * m->S;
+  BatchDev& d = m->bd;
+  hipStream_t s = m->stream;
+#define H2D(dst, src, bytes) HIP_CHECK(hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
+  ARG_CHECK(b->userid && b->token_mask_ids && b->gender && b->source && b->matchedid && b->status && b->time && b->rating && b->progress,
+            "batch arrays must not be null");
+  H2D(d.userid, b->userid, N * 4); H2D(d.tmid, b->token_mask_ids, N * 4); H2D(d.gender, b->gender, N * 4);
+  H2D(d.source, b->source, N * 4); H2D(d.matchedid, b->matchedid, N * 4); H2D(d.status, b->status, N * 4);
+  H2D(d.time, b->time, N * 8); H2D(d.rating, b->rating, N * 4); H2D(d.progress, b->progress, N * 4);
+  for (int k = 0; k < 6; ++k) {
+    if (k % 3 == 2 && b->label[k] == nullptr) continue;  // status targets are never used by the losses (model.py:448-449)
+    ARG_CHECK(b->label[k] && b->weight[k] && b->position[k], "target arrays must not be null");
+    H2D(d.label[k], b->label[k], N * 4); H2D(d.weight[k], b->weight[k], N * 4); H2D(d.position[k], b->position[k], N * 4);
+  }
+  m->has_masks = b->watch_mask != nullptr;
+  if (m->has_masks) {
+    ARG_CHECK(b->rating_mask != nullptr, "watch_mask and rating_mask come together");
+    H2D(m->d_wm, b->watch_mask, N); H2D(m->d_rm, b->rating_mask, N);
+  }
+  m->has_rope_pos = b->rope_input_pos != nullptr;
+  if (m->has_rope_pos) {
+    // model.py:470-476: token positions 2p, 2p+1
+    std::vector<int> pos(2 * N);
+    for (size_t i = 0; i < N; ++i) { pos[2 * i] = 2 * b->rope_input_pos[i]; pos[2 * i + 1] = 2 * b->rope_input_pos[i] + 1; }
+    for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
+    HIP_CHECK(hipMemcpy(m->d_rope_pos, pos.data(), 2 * N * 4, hipMemcpyHostToDevice));
+  }
+#undef H2D
+  HIP_CHECK(hipStreamSynchronize(s));
+  // index paths are checked on the host before any kernel may dereference them
+  for (size_t i = 0; i < N; ++i) {
+    int id = b->matchedid[i];
+    ARG_CHECK(id >= -1 && id < m->V, "matchedid out of range");
+    ARG_CHECK(b->status[i] >= -1 && b->status[i] <= m->cfg.vocab_status, "status out of range");
+    ARG_CHECK(b->gender[i] >= -1 && b->gender[i] <= m->cfg.vocab_gender, "gender out of range");
+    ARG_CHECK(b->source[i] >= -1 && b->source[i] <= m->cfg.vocab_source, "source out of range");
+    ARG_CHECK(b->position[0][i] >= 0 && b->position[0][i] < m->V0 && b->position[1][i] >= 0 && b->position[1][i] < m->V0,
+              "manga target position out of range");
+    ARG_CHECK(b->position[3][i] >= 0 && b->position[3][i] < m->V1 && b->position[4][i] >= 0 && b->position[4][i] < m->V1,
+              "anime target position out of range");
+  }
+  m->cur_rows = b->rows;
+  return RSYS_OK;
+}
+
+// ------------------------------------------------------------------ GEMM helper
+static int pick_splitk(int M, int N, int K, int bk) {
+  int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int kt = (K + bk - 1) / bk;
+  int s = std::max(1, 1024 / std::max(1, tiles));
+  s = std::min(s, std::max(1, kt / 4));
+  return s;
+}
+
+template <typename T>
+static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
+  if (p.alpha == 0.f) p.alpha = 1.f;
+  if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
+  if (p.splitk == 0) p.splitk = 1;
+  tic(m, tag, 2.0 * p.M * p.N * (double)p.K);
+  int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);
+  toc(m);
+  return rc;
+}
+
+template <typename T> static inline T* W(Model* m, int64_t off) { return (T*)m->Sh + off; }
+template <typename T> static inline T* AT(void* p) { return (T*)p; }
+
+static SmallParams small_params(Model* m) {
+  SmallParams sp;
+  sp.per_cos = m->P + m->o_pcos; sp.per_sin = m->P + m->o_psin;
+  sp.status_emb = m->P + m->o_status; sp.gender_emb = m->P + m->o_gender; sp.source_emb = m->P + m->o_source;
+  sp.n_status = m->cfg.vocab_status; sp.n_gender = m->cfg.vocab_gender; sp.n_source = m->cfg.vocab_source;
+  sp.min_ts = m->cfg.min_ts; sp.max_ts = m->cfg.max_ts;
+  sp.rating_mean = m->cfg.rating_mean; sp.rating_std = m->cfg.rating_std;
+  return sp;
+}
+
+// ------------------------------------------------------------------ forward trunk (model.py:464-491, 335-343)
+template <typename T>
+static int forward_trunk(Model* m) {
+  const int D = m->D, Ip = m->Ip, hd = m->hd, rows = m->cur_rows;
+  const int N = rows * m->S, NT = 2 * N;
+  hipStream_t s = m->stream;
+  BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
+  b.rope_pos = m->has_rope_pos ? m->d_rope_pos : nullptr;
+  const int* rpos = b.rope_pos;
+  // fused item table F = E + Meta Wp^T + bp
+  tic(m, "phase_embed");
+  {
+    GemmParams p{};
+    p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = D; p.c_f32 = 1;
+    p.M = m->V + 1; p.N = D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
+    p.C2 = m->FT; p.ldc2 = D;
+    RC(gemm<T>(m, "gemm_table_fwd", p, false, false, false));
+  }
+  SmallParams sp = small_params(m);
+  RC(launch_action_features<T>(b, sp, AT<T>(m->feat), s));
+  {
+    GemmParams p{};
+    p.A = m->feat; p.lda = 32; p.B = W<T>(m, m->o_lin_w); p.ldb = 32; p.C = m->x0 + D; p.ldc = 2 * D; p.c_f32 = 1;
+    p.M = N; p.N = D; p.K = 32; p.epi = EPI_BIAS; p.bias = m->P + m->o_lin_b;
+    RC(gemm<T>(m, "gemm_action_fwd", p, false, false, false));
+  }
+  RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
+  AttnParams ap{};
+  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap;
+  RC(launch_attn_tilemap(ap, s));
+  toc(m);
+  tic(m, "phase_trunk_fwd");
+  for (int l = 0; l < m->L; ++l) {
+    Model::LayerAct& a = m->la[l];
+    float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
+    RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s));
+    {
+      GemmParams p{};
+      p.A = a.xn; p.lda = D; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = a.qkv; p.ldc = m->Nqkv;
+      p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
+      p.n_q = m->H * hd; p.n_k = m->KV * hd; p.qT = a.qT; p.kT = a.kT; p.vT = a.vT;
+      RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
+    }
+    ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
+    ap.qT = a.qT; ap.kT = a.kT; ap.vT = a.vT; ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+    tic(m, "attn_fwd");
+    RC(launch_attn_fwd<T>(ap, s));
+    toc(m);
+    {
+      GemmParams p{};
+      p.A = a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
+      p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
+      RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
+    }
+    RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
+    {
+      GemmParams p{};
+      p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
+      p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
+      RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
+    }
+    {
+      GemmParams p{};
+      p.A = a.g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = xnext; p.ldc = D; p.c_f32 = 1;
+      p.M = NT; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = a.h; p.ldr = D;
+      RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
+    }
+  }
+  RC(launch_rmsnorm_fwd<T>(m->xL, m->P + m->o_norm, AT<T>(m->out), m->rstdf, NT, D, s));
+  toc(m);
+  return RSYS_OK;
+}
+
+// ------------------------------------------------------------------ heads, fwd + bwd fused per task (model.py:501-528)
+template <typename T>
+static int heads(Model* m, int evaluate, const float tw[4]) {
+  const int D = m->D, rows = m->cur_rows, N = rows * m->S, NT = 2 * N, KB = m->K * rows;
+  hipStream_t s = m->stream;
+  const bool train = !evaluate;
+  tic(m, "phase_heads");
+  HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
+  if (train) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
+  for (int ti = 0; ti < 4; ++ti) {
+    const int medium = ti >> 1, metric = ti & 1;
+    float* st = m->stats + 2 * ti;
+    RC(launch_select_positions(m->bd.m_weight[ti], N, KB, m->idx[ti], st, s));
+    RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
+    const bool bwd = train && tw[ti] != 0.f;
+    if (metric == 0) {
+      const int vs = medium == 0 ? 0 : m->V0, Vm = medium == 0 ? m->V0 : m->V1;
+      T* Fm = AT<T>(m->FT) + (int64_t)vs * D;
+      {
+        GemmParams p{};
+        p.A = m->Ew; p.lda = D; p.B = Fm; p.ldb = D; p.C = m->logits; p.ldc = m->ldl;
+        p.M = KB; p.N = Vm; p.K = D; p.epi = EPI_STORE;
+        RC(gemm<T>(m, "gemm_logits", p, false, false, false));
+      }
+      tic(m, "ce");
+      RC(launch_ce_fwd_bwd<T>(AT<T>(m->logits), m->ldl, KB, Vm, m->idx[ti], m->bd.m_label[ti], m->bd.m_weight[ti],
+                              m->bd.m_position[ti], st, train ? tw[ti] : 0.f, m->loss_acc + 3 * ti, s));
+      toc(m);
+      if (bwd) {
+        {
+          GemmParams p{};  // dEw = dlogits . F
+          p.A = m->logits; p.lda = m->ldl; p.B = Fm; p.ldb = D; p.C = m->dE; p.ldc = D; p.c_f32 = 1;
+          p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_STORE;
+          RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
+        }
+        RC(launch_scatter_rows_add(m->dE, m->idx[ti], 0, m->gy, D, KB, D, s));
+        {
+          GemmParams p{};  // dF[s:e] += dlogits^T . Ew
+          p.A = m->logits; p.lda = m->ldl; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_E + (int64_t)vs * D; p.ldc = D; p.c_f32 = 1;
+          p.M = Vm; p.N = D; p.K = KB; p.epi = EPI_ACCUM;
+          RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
+        }
+        m->table_grads_pending = true;
+      }
+    } else {
+      {
+        GemmParams p{};
+        p.A = m->Ew; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->z; p.ldc = D;
+        p.M = KB; p.N = D; p.K = D; p.epi = EPI_GELU; p.bias = m->P + m->o_r0b; p.C2 = m->hact; p.ldc2 = D;
+        RC(gemm<T>(m, "gemm_rating_fwd", p, false, false, false));
+      }
+      RC(launch_rating_tail<T>(AT<T>(m->z), AT<T>(m->hact), KB, D, m->P + m->o_r2w, m->P + m->o_r2b, m->idx[ti],
+                               m->bd.m_label[ti], m->bd.m_weight[ti], st, m->cfg.rating_mean, bwd ? tw[ti] : 0.f,
+                               bwd ? 0 : 1, m->loss_acc + 3 * ti, m->G + m->o_r2w, m->G + m->o_r2b, m->G + m->o_r0b, s));
+      if (bwd) {
+        {
+          GemmParams p{};  // dW0 += dz^T . Er
+          p.A = m->z; p.lda = D; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_r0w; p.ldc = D; p.c_f32 = 1;
+          p.M = D; p.N = D; p.K = KB; p.epi = EPI_ATOMIC;
+          RC(gemm<T>(m, "gemm_rating_dw", p, false, true, true));
+        }
+        {
+          GemmParams p{};  // dEr = dz . W0
+          p.A = m->z; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->dE; p.ldc = D; p.c_f32 = 1;
+          p.M = KB; p.N = D; p.K = D; p.epi = EPI_STORE;
+          RC(gemm<T>(m, "gemm_rating_dx", p, false, false, true));
+        }
+        RC(launch_scatter_rows_add(m->dE, m->idx[ti], 1, m->gy, D, KB, D, s));
+      }
+    }
+  }
+  toc(m);
+  return RSYS_OK;
+}
+
+// ------------------------------------------------------------------ backward trunk + embeddings
+template <typename T>
+static int backward_trunk(Model* m) {
+  const int D = m->D, Ip = m->Ip, hd = m->hd, rows = m->cur_rows;
+  const int N = rows * m->S, NT = 2 * N;
+  hipStream_t s = m->stream;
+  const int* rpos = m->has_rope_pos ? m->d_rope_pos : nullptr;
+  float* gx = m->gxa;   // gradient w.r.t. the current layer's output
+  float* gx_other = m->gxb;
+  tic(m, "phase_trunk_bwd");
+  RC(launch_rmsnorm_bwd_f32(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, m->G + m->o_norm, NT, D, s));
+  AttnParams ap{};
+  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap;
+  ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
+  for (int l = m->L - 1; l >= 0; --l) {
+    Model::LayerAct& a = m->la[l];
+    {
+      GemmParams p{};  // dW2 += gx^T . g
+      p.A = gx; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
+      p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
+      RC(gemm<T>(m, "gemm_w2_dw", p, true, true, true));
+    }
+    {
+      GemmParams p{};  // dg = gx . W2
+      p.A = gx; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dg; p.ldc = Ip;
+      p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_STORE;
+      RC(gemm<T>(m, "gemm_w2_dx", p, true, false, true));
+    }
+    RC(launch_swiglu_bwd<T>(AT<T>(m->dg), AT<T>(a.ab), AT<T>(m->dab), NT, Ip, s));
+    {
+      GemmParams p{};  // dW13 += dab^T . hn
+      p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
+      p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
+      RC(gemm<T>(m, "gemm_w13_dw", p, false, true, true));
+    }
+    {
+      GemmParams p{};  // dhn = dab . W13
+      p.A = m->dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
+      RC(gemm<T>(m, "gemm_w13_dx", p, false, false, true));
+    }
+    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, m->G + m->lo[l].mlp, NT, D, s));
+    {
+      GemmParams p{};  // dWo += dh^T . O
+      p.A = m->dh; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
+      p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
+      RC(gemm<T>(m, "gemm_o_dw", p, true, true, true));
+    }
+    {
+      GemmParams p{};  // dO = dh . Wo  (+ per-head transposed copy)
+      p.A = m->dh; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
+      p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE_HEADS_T; p.C2 = m->dOT; p.T = m->T; p.hd = hd;
+      RC(gemm<T>(m, "gemm_o_dx", p, true, false, true));
+    }
+    ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
+    ap.qT = a.qT; ap.kT = a.kT; ap.vT = a.vT; ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+    ap.dO = m->dO; ap.dOT = m->dOT; ap.delta = m->delta;
+    ap.dq = m->dqkv; ap.dk = AT<T>(m->dqkv) + m->H * hd; ap.dv = AT<T>(m->dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
+    tic(m, "attn_bwd");
+    RC(launch_attn_delta<T>(ap, s));
+    RC(launch_attn_bwd<T>(ap, s));
+    toc(m);
+    {
+      GemmParams p{};  // dWqkv += dqkv^T . xn
+      p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
+      p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
+      RC(gemm<T>(m, "gemm_qkv_dw", p, false, true, true));
+    }
+    {
+      GemmParams p{};  // dxn = dqkv . Wqkv
+      p.A = m->dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
+      RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, true));
+    }
+    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, m->G + m->lo[l].sa, NT, D, s));
+    std::swap(gx, gx_other);
+  }
+  toc(m);
+  // gx = gradient w.r.t. the interleaved input embeddings (even rows: items, odd rows: actions)
+  tic(m, "phase_embed_bwd");
+  BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
+  RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
+  m->table_grads_pending = true;
+  {
+    GemmParams p{};  // dWlin += g_act^T . feat
+    p.A = gx + D; p.lda = 2 * D; p.B = m->feat; p.ldb = 32; p.C = m->G + m->o_lin_w; p.ldc = 32; p.c_f32 = 1;
+    p.M = D; p.N = 32; p.K = N; p.epi = EPI_ATOMIC;
+    RC(gemm<T>(m, "gemm_action_dw", p, true, true, true));
+  }
+  RC(launch_colsum_add(gx + D, 2 * D, N, D, m->G + m->o_lin_b, s));
+  {
+    GemmParams p{};  // gf = g_act . Wlin
+    p.A = gx + D; p.lda = 2 * D; p.B = W<T>(m, m->o_lin_w); p.ldb = 32; p.C = m->gf; p.ldc = 32; p.c_f32 = 1;
+    p.M = N; p.N = 32; p.K = D; p.epi = EPI_STORE;
+    RC(gemm<T>(m, "gemm_action_dx", p, true, false, true));
+  }
+  SmallParams sp = small_params(m);
+  RC(launch_action_small_bwd(m->gf, b, sp, m->G + m->o_pcos, m->G + m->o_psin, m->G + m->o_status, m->G + m->o_gender,
+                             m->G + m->o_source, s));
+  toc(m);
+  return RSYS_OK;
+}
+
+// dWp = dF^T Meta and dbp = colsum(dF), once per optimizer step from the accumulated dF (= grad of E)
+template <typename T>
+static int finalize_grads_t(Model* m) {
+  tic(m, "phase_table_bwd");
+  {
+    GemmParams p{};
+    p.A = m->G + m->o_E; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
+    p.M = m->D; p.N = m->Mp; p.K = m->V + 1; p.epi = EPI_ATOMIC;
+    RC(gemm<T>(m, "gemm_table_dw", p, true, true, true));
+  }
+  RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+  toc(m);
+  return RSYS_OK;
+}
+
+int model_finalize_grads(Model* m) {
+  if (!m->table_grads_pending) return RSYS_OK;
+  m->table_grads_pending = false;
+  return m->bf16_mode ? finalize_grads_t<bf16>(m) : finalize_grads_t<float>(m);
+}
+
+template <typename T>
+static int forward_backward_t(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step) {
+  const int rows = m->cur_rows, N = rows * m->S;
+  BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
+  if (m->has_masks) { b.watch_mask = m->d_wm; b.rating_mask = m->d_rm; }
+  RC(launch_mask_tokens(b, m->cfg.finetune, m->cfg.finetune_metric, m->cfg.mask_rate, seed, step, m->stream));
+  RC(forward_trunk<T>(m));
+  float tw[4];
+  for (int i = 0; i < 4; ++i) tw[i] = task_w ? task_w[i] * grad_scale : 0.f;
+  RC(heads<T>(m, evaluate, tw));
+  if (!evaluate) RC(backward_trunk<T>(m));
+  return RSYS_OK;
+}
+
+int model_forward_backward(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step) {
+  ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
+  ARG_CHECK(evaluate || task_w != nullptr, "task weights are required for training");
+  HIP_CHECK(hipSetDevice(m->device));
+  m->last_evaluate = evaluate != 0;
+  return m->bf16_mode ? forward_backward_t<bf16>(m, evaluate, task_w, grad_scale, seed, step)
+                      : forward_backward_t<float>(m, evaluate, task_w, grad_scale, seed, step);
+}
+
+// inference forward (model.py:531-538): the batch is used as given (no masking), rope positions optional
+template <typename T>
+static int infer_t(Model* m, int task, float* out, int64_t n) {
+  const int rows = m->cur_rows, N = rows * m->S, NT = 2 * N, D = m->D;
+  hipStream_t s = m->stream;
+  BatchDev b = m->bd;
+  HIP_CHECK(hipMemcpyAsync(b.m_tmid, b.tmid, N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(b.m_matchedid, b.matchedid, N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(b.m_status, b.status, N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(b.m_rating, b.rating, N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(b.m_progress, b.progress, N * 4, hipMemcpyDeviceToDevice, s));
+  RC(forward_trunk<T>(m));
+  std::vector<unsigned char> host((size_t)NT * D * m->esz);
+  if (task == 0) {
+    ARG_CHECK(n == (int64_t)NT * D, "retrieval output has rows*2S*D floats");
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpy(host.data(), m->out, host.size(), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < (int64_t)NT * D; ++i) {
+      if (m->bf16_mode) { uint32_t u = (uint32_t)((unsigned short*)host.data())[i] << 16; memcpy(&out[i], &u, 4); }
+      else out[i] = ((float*)host.data())[i];
+    }
+    return RSYS_OK;
+  }
+  ARG_CHECK(n == NT, "ranking output has rows*2S floats");
+  // rating_head on every token, in chunks of the head workspace
+  const int KB = m->K * m->rows_max;
+  std::vector<float> w2(D), zbuf;
+  float b2;
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipMemcpy(w2.data(), m->P + m->o_r2w, D * 4, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(&b2, m->P + m->o_r2b, 4, hipMemcpyDeviceToHost));
+  std::vector<unsigned char> hh((size_t)KB * D * m->esz);
+  for (int r0 = 0; r0 < NT; r0 += KB) {
+    int nr = std::min(KB, NT - r0);
+    GemmParams p{};
+    p.A = (unsigned char*)m->out + (size_t)r0 * D * m->esz; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->z; p.ldc = D;
+    p.M = nr; p.N = D; p.K = D; p.epi = EPI_GELU; p.bias = m->P + m->o_r0b; p.C2 = m->hact; p.ldc2 = D;
+    RC(gemm<T>(m, "gemm_rating_fwd", p, false, false, false));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipMemcpy(hh.data(), m->hact, (size_t)nr * D * m->esz, hipMemcpyDeviceToHost));
+    for (int r = 0; r < nr; ++r) {
+      double acc = b2;
+      for (int c = 0; c < D; ++c) {
+        float hv;
+        if (m->bf16_mode) { uint32_t u = (uint32_t)((unsigned short*)hh.data())[(size_t)r * D + c] << 16; memcpy(&hv, &u, 4); }
+        else hv = ((float*)hh.data())[(size_t)r * D + c];
+        acc += (double)hv * w2[c];
+      }
+      out[r0 + r] = (float)acc;
+    }
+  }
+  return RSYS_OK;
+}
+
+int model_infer(Model* m, int task, float* out, int64_t n) {
+  ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
+  ARG_CHECK(task == 0 || task == 1, "task: 0 retrieval, 1 ranking");
+  HIP_CHECK(hipSetDevice(m->device));
+  return m->bf16_mode ? infer_t<bf16>(m, task, out, n) : infer_t<float>(m, task, out, n);
+}
+
+int model_clip(Model* m, float max_norm, float* norm_out) {
+  HIP_CHECK(hipSetDevice(m->device));
+  RC(model_finalize_grads(m));
+  HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
+  RC(launch_sumsq(m->G, m->n_total, m->sumsq, m->stream));
+  RC(launch_scale(m->G, m->n_total, m->sumsq, 1.0f, max_norm, m->stream));
+  if (norm_out) {
+    float ss;
+    HIP_CHECK(hipMemcpyAsync(&ss, m->sumsq, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    *norm_out = sqrtf(ss);
+  }
+  return RSYS_OK;
+}
+
+int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
+  Model* m = o->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  RC(model_finalize_grads(m));
+  if (grad_div <= 0.f) grad_div = 1.f;
+  const float* ss = nullptr;
+  if (clip > 0.f) {
+    HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
+    tic(m, "sumsq");
+    RC(launch_sumsq(m->G, m->n_total, m->sumsq, m->stream));
+    toc(m);
+    ss = m->sumsq;
+  }
+  o->step += 1;
+  tic(m, "adamw");
+  int rc;
+  if (m->bf16_mode)
+    rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_decay, m->n_total, o->lr * lr_factor, o->b1, o->b2,
+                            o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
+  else
+    rc = launch_adamw<float>(m->P, m->G, o->mom, o->var, nullptr, m->n_decay, m->n_total, o->lr * lr_factor, o->b1, o->b2,
+                             o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
+  toc(m);
+  return rc;
+}
+
+}  // namespace rsys

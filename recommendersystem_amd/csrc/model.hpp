@@ -1,0 +1,106 @@
+// Model state + step orchestration (host side of the HIP path).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rsys.h"
+#include "gemm.hpp"
+#include "kernels.hpp"
+
+namespace rsys {
+
+enum RowMap { MAP_DIRECT = 0, MAP_W1 = 1, MAP_W3 = 2 };
+
+struct TensorInfo {
+  std::string name;      // reference state_dict key
+  int64_t rows, cols;    // external (reference) shape; 1-D tensors have rows = 1
+  int ndim;
+  int64_t off;           // offset (floats) of the internal block inside the flat buffers
+  int64_t ld;            // internal row stride
+  int map;               // RowMap
+  bool trainable;
+  bool frozen_table;     // metadata embedding (stored separately, T-typed)
+};
+
+struct LayerOff {  // offsets into the flat buffers
+  int64_t wqkv, wo, w13, w2, sa, mlp;
+};
+
+struct PhaseTimer {
+  bool enabled = false;
+  std::vector<std::pair<std::string, hipEvent_t>> marks;
+  std::map<std::string, double> acc_ms;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+};
+
+struct Model {
+  rsys_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool bf16_mode = false;
+  size_t esz = 4;
+  // dims
+  int L, H, KV, D, I, Ip, S, T, V0, V1, V, M, Mp, K, hd, Nqkv, rows_max;
+  int64_t n_decay = 0, n_total = 0;
+  std::vector<TensorInfo> tensors;
+  std::map<std::string, int> by_name;
+  // flat offsets
+  int64_t o_status, o_gender, o_source, o_lin_w, o_E, o_Wp, o_r0w, o_r2w;
+  int64_t o_pcos, o_psin, o_lin_b, o_bp, o_norm, o_r0b, o_r2b;
+  std::vector<LayerOff> lo;
+  // device memory
+  float *P = nullptr, *G = nullptr;
+  void* Sh = nullptr;        // bf16 shadow of P (bf16 mode); == P in fp32 mode
+  void* Meta = nullptr;      // [V+1][Mp] T
+  float* F32 = nullptr;      // [V+1][D]
+  void* FT = nullptr;        // [V+1][D] T
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  int rope_npos = 0;
+  std::vector<void*> allocs;
+  // batch
+  BatchDev bd;
+  void* batch_blob = nullptr;
+  bool has_masks = false, has_rope_pos = false;
+  int cur_rows = 0;
+  unsigned char *d_wm = nullptr, *d_rm = nullptr;
+  int* d_rope_pos = nullptr;
+  // activations (void* = T-typed)
+  void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap;
+  struct LayerAct { float* x; void* xn; void* qkv; void *qT, *kT, *vT; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
+  std::vector<LayerAct> la;
+  float* xL; float* rstdf; void* out;
+  // heads
+  int* idx[4]; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
+  // backward workspaces
+  float *gy, *gxa, *gxb, *dh; void *dg, *dab, *dhn, *dO, *dOT, *dqkv; float* delta; float* gf;
+  float* sumsq;
+  bool table_grads_pending = false;
+  bool last_evaluate = false;
+  PhaseTimer timer;
+};
+
+struct Optimizer {
+  Model* m;
+  float lr, b1, b2, eps, wd;
+  int step = 0;
+  float *mom = nullptr, *var = nullptr;
+};
+
+int model_create(const rsys_config* cfg, int device, Model** out);
+int model_destroy(Model* m);
+int model_init_random(Model* m, uint64_t seed);
+int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim);
+int model_random_metadata(Model* m, uint64_t seed);
+int model_set_rope(Model* m, const float* c, const float* s, int64_t n_pos);
+int model_param_io(Model* m, const char* name, float* out, const float* in, int64_t n, int which /*0 P,1 G*/);
+int model_refresh_shadow(Model* m);
+int model_batch_upload(Model* m, const rsys_batch* b);
+int model_forward_backward(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step);
+int model_infer(Model* m, int task, float* out, int64_t n);
+int model_finalize_grads(Model* m);
+int model_clip(Model* m, float max_norm, float* norm_out);
+int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div);
+
+}  // namespace rsys

@@ -1,0 +1,166 @@
+// Multi-tensor optimizer kernels over the flat fp32 parameter / gradient buffers
+// (HBM-bound; 16-byte accesses, grid-stride).  transformer.py:273 (clip_grad_norm_)
+// and :285-298 (AdamW, decoupled decay 0.1 on tensors with dim>=2, betas 0.9/0.95).
+#include "kernels.hpp"
+
+namespace rsys {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ((const float4*)g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+int launch_sumsq(const float* g, long long n, float* out, hipStream_t s) {
+  int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, out);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6)); grads are first
+// divided by grad_div (data-parallel mean, folded in here instead of a separate pass)
+__device__ __forceinline__ float grad_coef(const float* sumsq, float grad_div, float max_norm) {
+  float inv = 1.f / grad_div;
+  if (sumsq == nullptr || max_norm <= 0.f) return inv;
+  float norm = sqrtf(*sumsq) * inv;
+  float c = max_norm / (norm + 1e-6f);
+  return inv * (c < 1.f ? c : 1.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m, float* v, T* shadow, long long n_decay,
+                                                    long long n_total, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, const float* sumsq, float grad_div,
+                                                    float max_norm, int zero_grad) {
+  const float coef = grad_coef(sumsq, grad_div, max_norm);
+  const long long n4 = n_total >> 2;  // n_decay and n_total are multiples of 4 (the flat layout pads every tensor)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pv = ((float4*)p)[i], gv = ((float4*)g)[i], mv = ((float4*)m)[i], vv = ((float4*)v)[i];
+    const float decay = (i * 4 < n_decay) ? (1.f - lr * wd) : 1.f;
+    float* pp = (float*)&pv; float* gg = (float*)&gv; float* mm = (float*)&mv; float* vvp = (float*)&vv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = gg[k] * coef;
+      float pk = pp[k] * decay;
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vvp[k] = b2 * vvp[k] + (1.f - b2) * gk * gk;
+      float denom = sqrtf(vvp[k]) / bc2_sqrt + eps;
+      pp[k] = pk - (lr / bc1) * (mm[k] / denom);
+    }
+    ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)v)[i] = vv;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0, 0, 0, 0);
+    if constexpr (is_bf16<T>::value) {
+      if (shadow) {
+        bf16x4 sv; sv[0] = (bf16)pp[0]; sv[1] = (bf16)pp[1]; sv[2] = (bf16)pp[2]; sv[3] = (bf16)pp[3];
+        ((bf16x4*)shadow)[i] = sv;
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_decay, long long n_total, float lr,
+                 float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div, float max_norm,
+                 int zero_grad, hipStream_t s) {
+  ARG_CHECK(n_decay % 4 == 0 && n_total % 4 == 0, "adamw: flat sizes must be multiples of 4");
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+  int grid = (int)std::min<long long>(((n_total >> 2) + 255) / 256, 4096);
+  hipLaunchKernelGGL((adamw_kernel<T>), dim3(grid), dim3(256), 0, s, p, g, m, v, shadow, n_decay, n_total, lr, b1, b2, eps,
+                     wd, bc1, bc2s, sumsq, grad_div, max_norm, zero_grad);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_adamw<bf16>(float*, float*, float*, float*, bf16*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t);
+template int launch_adamw<float>(float*, float*, float*, float*, float*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t);
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+int launch_cast(const float* src, T* dst, long long n, hipStream_t s) {
+  int grid = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL((cast_kernel<T>), dim3(grid), dim3(256), 0, s, src, dst, n);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_cast<bf16>(const float*, bf16*, long long, hipStream_t);
+template int launch_cast<float>(const float*, float*, long long, hipStream_t);
+
+__global__ void scale_kernel(float* g, long long n, const float* sumsq, float grad_div, float max_norm) {
+  const float coef = grad_coef(sumsq, grad_div, max_norm);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) g[i] *= coef;
+}
+int launch_scale(float* g, long long n, const float* sumsq, float grad_div, float max_norm, hipStream_t s) {
+  int grid = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(256), 0, s, g, n, sumsq, grad_div, max_norm);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// ---- device-side N(0, std) fill (Box-Muller on Philox), used by random init and the synthetic metadata table
+__device__ __forceinline__ void normal4(const Philox& ph, unsigned long long ctr, unsigned int stream, float out[4]) {
+  uint32_t r[4];
+  ph.gen(ctr, stream, r);
+  float u0 = fmaxf(u01(r[0]), 5.9604645e-8f), u1 = u01(r[1]);
+  float u2 = fmaxf(u01(r[2]), 5.9604645e-8f), u3 = u01(r[3]);
+  float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+  out[0] = ra * cosf(6.2831853f * u1); out[1] = ra * sinf(6.2831853f * u1);
+  out[2] = rb * cosf(6.2831853f * u3); out[3] = rb * sinf(6.2831853f * u3);
+}
+
+__global__ void fill_normal_kernel(float* dst, long long n, float std, unsigned long long seed, unsigned int stream) {
+  Philox ph(seed);
+  const long long n4 = (n + 3) >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float z[4];
+    normal4(ph, (unsigned long long)i, stream, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i * 4 + k < n) dst[i * 4 + k] = z[k] * std;
+  }
+}
+int launch_fill_normal(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, hipStream_t s) {
+  int grid = (int)std::min<long long>((((n + 3) >> 2) + 255) / 256, 8192);
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(256), 0, s, dst, n, std, seed, stream);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+template <typename T>
+__global__ void fill_normal_t_kernel(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed) {
+  Philox ph(seed);
+  const int c4 = (cols + 3) >> 2;
+  const long long total = rows * c4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i / c4; int c = (int)(i % c4) * 4;
+    float z[4];
+    normal4(ph, (unsigned long long)i, 7u, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c + k < cols) dst[r * ld + c + k] = from_f32<T>(z[k] * std);
+  }
+}
+template <typename T>
+int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s) {
+  long long total = rows * ((cols + 3) >> 2);
+  int grid = (int)std::min<long long>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL((fill_normal_t_kernel<T>), dim3(grid), dim3(256), 0, s, dst, rows, cols, ld, std, seed);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_fill_normal_t<bf16>(bf16*, long long, int, long long, float, unsigned long long, hipStream_t);
+template int launch_fill_normal_t<float>(float*, long long, int, long long, float, unsigned long long, hipStream_t);
+
+}  // namespace rsys

@@ -1,0 +1,67 @@
+"""create_optimizer(model, config) -- notebooks/Training/transformer.py:285-298.
+
+AdamW over the flat parameter buffer: decoupled weight decay 0.1 on tensors with
+dim >= 2 (incl. the embedding tables), 0 on biases / norm scales / phases, betas
+(0.9, 0.95), eps 1e-8.  `step()` also performs optimizer.zero_grad()
+(train.py:274-275) and can fuse clip_grad_norm_ (train.py:273) and the
+data-parallel gradient mean into the single pass over the parameters.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+class AdamW:
+    def __init__(self, model, lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1):
+        self.model = model
+        self.lr = lr
+        self._h = C.c_void_p()
+        check(lib().rsys_adamw_create(model._h, lr, betas[0], betas[1], eps, weight_decay, C.byref(self._h)))
+
+    def step(self, lr_factor=1.0, clip_max_norm=0.0, grad_div=1.0):
+        check(lib().rsys_adamw_step(self._h, lr_factor, clip_max_norm, grad_div))
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad()
+
+    def state_dict(self):
+        st = C.c_int32()
+        check(lib().rsys_adamw_state_get(self._h, None, None, None, 0, C.byref(st)))
+        state = {}
+        for n, shape, tr in self.model.named_parameters():
+            if not tr:
+                continue
+            m = np.empty(shape, np.float32); v = np.empty(shape, np.float32)
+            check(lib().rsys_adamw_state_get(self._h, n.encode(), m.ctypes.data, v.ctypes.data, m.size, None))
+            state[n] = {"exp_avg": m, "exp_avg_sq": v}
+        return {"step": st.value, "lr": self.lr, "state": state}
+
+    def load_state_dict(self, sd):
+        check(lib().rsys_adamw_state_set(self._h, None, None, None, 0, int(sd["step"])))
+        for n, s in sd["state"].items():
+            m = np.ascontiguousarray(s["exp_avg"], np.float32); v = np.ascontiguousarray(s["exp_avg_sq"], np.float32)
+            check(lib().rsys_adamw_state_set(self._h, n.encode(), m.ctypes.data, v.ctypes.data, m.size, -1))
+
+    def close(self):
+        if self._h:
+            lib().rsys_adamw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_optimizer(model, config):
+    return AdamW(model, lr=config["learning_rate"], betas=(0.9, 0.95), weight_decay=0.1)
+
+
+def clip_grad_norm_(model, max_norm):
+    """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm), train.py:273 -> total norm."""
+    out = C.c_float()
+    check(lib().rsys_clip_grad_norm(model._h, max_norm, C.byref(out)))
+    return out.value

@@ -1,0 +1,203 @@
+"""Host-side training-loop logic, mirroring notebooks/Training/transformer.py ("train.py").
+
+Same names, argument meaning and behaviour as the reference functions; each cites
+the lines it restates.  Arithmetic on the device goes through RecommenderModel /
+AdamW (C ABI); nothing here touches a CPU compute fallback.
+"""
+import numpy as np
+
+from .model import ALL_MEDIUMS, ALL_METRICS
+from .optim import clip_grad_norm_
+
+
+class ConstantScheduler:  # train.py:301-307
+    def __init__(self):
+        self.steps = 0
+
+    def __call__(self, epoch):
+        self.steps += 1
+        return 1
+
+
+class WSDScheduler:  # train.py:310-328
+    def __init__(self, warmup_steps, total_steps, decay_ratio, final_ratio):
+        self.warmup_steps = warmup_steps
+        self.total_steps = total_steps
+        self.final_ratio = final_ratio
+        self.decay_steps = int(total_steps * decay_ratio)
+        self.stable_steps = total_steps - warmup_steps - self.decay_steps
+        assert self.stable_steps >= 0
+
+    def __call__(self, step):
+        s = max(0, min(int(step), self.total_steps))
+        if s <= self.warmup_steps:
+            return s / max(1, self.warmup_steps)
+        if s <= (self.warmup_steps + self.stable_steps):
+            return 1.0
+        decay_progress = (s - self.warmup_steps - self.stable_steps) / max(1, self.decay_steps)
+        return 1.0 - (1.0 - self.final_ratio) * decay_progress
+
+
+class LambdaLR:
+    """torch.optim.lr_scheduler.LambdaLR as train.py:333,347 uses it: factor(step), stepped once per optimizer step."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.last_epoch = 0
+        self._factor = fn(0)
+
+    def step(self):
+        self.last_epoch += 1
+        self._factor = self.fn(self.last_epoch)
+
+    def factor(self):
+        return self._factor
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self._factor = self.fn(self.last_epoch)
+
+
+def create_learning_rate_schedule(tokens_per_epoch, tokens_per_batch, epochs, finetune=False):
+    """train.py:331-347."""
+    if finetune:
+        return LambdaLR(ConstantScheduler())
+    total_steps = int(round(tokens_per_epoch * epochs / tokens_per_batch))
+    return LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=total_steps, decay_ratio=0.1, final_ratio=0.1))
+
+
+class EarlyStopper:  # train.py:350-372
+    def __init__(self, patience, rtol):
+        self.patience = patience
+        self.rtol = rtol
+        self.counter = 0
+        self.stop_score = float("inf")
+        self.early_stop = False
+        self.saved_score = float("inf")
+        self.save_model = False
+
+    def __call__(self, score):
+        if score < self.stop_score * (1 - self.rtol):
+            self.counter = 0
+            self.stop_score = score
+        else:
+            self.counter += 1
+            if self.counter >= self.patience:
+                self.early_stop = True
+        if score < self.saved_score:
+            self.saved_score = score
+            self.save_model = True
+        else:
+            self.save_model = False
+
+
+def make_early_stopper(config):  # train.py:409-413
+    if config["finetune"]:
+        return EarlyStopper(patience=2, rtol=0.001)
+    return EarlyStopper(patience=float("inf"), rtol=0)
+
+
+def wsum(values, weights):  # train.py:375-376
+    return sum(x * y for (x, y) in zip(values, weights))
+
+
+def make_task_weights(finetune_medium=None, finetune_metric=None):
+    """train.py:379-406 (args.finetune_medium / args.finetune_metric become parameters)."""
+    scale = {0: {"watch": 4.618602403897067, "rating": 1.1958987168236102},
+             1: {"watch": 2.5443243303769867, "rating": 1.0527565486045412}}
+    scale = [scale[x][y] for x in ALL_MEDIUMS for y in ALL_METRICS]
+    if finetune_metric is None:
+        metric_weight = {"watch": 1, "rating": 0.25}
+    else:
+        metric_weight = {"watch": 0, "rating": 0}
+        metric_weight[finetune_metric] = 1
+    if finetune_medium is None:
+        medium_weight = {0: 0.25, 1: 1}
+    else:
+        medium_weight = {finetune_medium: 1, 1 - finetune_medium: 0}
+    weights = [medium_weight[x] * metric_weight[y] for x in ALL_MEDIUMS for y in ALL_METRICS]
+    weights = [x / sum(weights) for x in weights]
+    return [(w / s) for (w, s) in zip(weights, scale)]
+
+
+def minimize_quadratic(x, y):  # train.py:187-196
+    assert len(x) == 3 and len(y) == 3
+    if max(y) == min(y):
+        return float(max(y))
+    A = np.array([[x[0] ** 2, x[0], 1], [x[1] ** 2, x[1], 1], [x[2] ** 2, x[2], 1]])
+    B = np.array(y)
+    a, b, c = np.linalg.solve(A, B)
+    x_extremum = -b / (2 * a)
+    return float(a * x_extremum ** 2 + b * x_extremum + c)
+
+
+def reduce_mean(comm, x, w):
+    """train.py:199-204: two SUM all-reduces, then the weighted mean per task."""
+    x = [float(v) for v in x]; w = [float(v) for v in w]
+    if comm is not None:
+        tot = comm.all_reduce_sum(x + w)
+        x, w = tot[: len(x)], tot[len(x):]
+    return [a / b if b != 0 else 0 for (a, b) in zip(x, w)]
+
+
+def evaluate_metrics(model, dataloader, comm=None):
+    """train.py:207-235: eval forward (fresh random masks, model(d, True)), weight-averaged per task,
+    rating -> quadratic-minimum MSE over prediction scales {1, 0, -1}."""
+    init = lambda metric: [0, 0, 0] if metric in ["rating"] else 0
+    losses = [init(metric) for m in ALL_MEDIUMS for metric in ALL_METRICS]
+    weights = [0 for _ in range(len(ALL_MEDIUMS) * len(ALL_METRICS))]
+    model.eval()
+    for data in dataloader:
+        loss = model(data, True)
+        for i in range(len(losses)):
+            w = model.last_weight_sums[i]
+            if w == 0:
+                continue
+            if isinstance(losses[i], list):
+                for j in range(len(losses[i])):
+                    losses[i][j] += float(loss[i][j]) * w
+            else:
+                losses[i] += float(loss[i]) * w
+            weights[i] += w
+    model.train()
+    for i in range(len(losses)):
+        if isinstance(losses[i], list):
+            losses[i] = minimize_quadratic([1, 0, -1], losses[i])
+    return reduce_mean(comm, losses, weights)
+
+
+def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accum_steps, comm=None, max_norm=1.0):
+    """train.py:238-283.  Micro-steps accumulate locally (DDP no_sync, :268-271); the last one is followed by the
+    gradient all-reduce (DDP hook, :272), clip_grad_norm_(1.0) (:273), optimizer.step + zero_grad (:274-275) and
+    scheduler.step (:276).  Clip + mean + AdamW run as one fused device pass."""
+    n_tasks = len(task_weights)
+    training_losses = [0.0] * n_tasks
+    training_weights = [0.0] * n_tasks
+    model.set_loss_weights(task_weights, grad_accum_steps)
+    optimizer.zero_grad(set_to_none=True)
+    world = 1 if comm is None else comm.world
+    for step, data in enumerate(dataloader):
+        tloss = model(data, False)
+        for i in range(n_tasks):
+            w = model.last_weight_sums[i]
+            training_losses[i] += tloss[i] * w
+            training_weights[i] += w
+        if (step + 1) % grad_accum_steps != 0:
+            continue
+        if comm is not None:
+            comm.all_reduce_grads(model)
+        optimizer.step(lr_factor=scheduler.factor(), clip_max_norm=max_norm, grad_div=float(world))
+        scheduler.step()
+    return reduce_mean(comm, training_losses, training_weights)
+
+
+def train_step_unfused(model, optimizer, data, task_weights, masks=None, max_norm=1.0, lr_factor=1.0):
+    """One optimizer step spelled exactly like train.py:259-276 (separate clip pass), for parity tests."""
+    model.set_loss_weights(task_weights, 1)
+    tloss = model(data, False, masks=masks)
+    norm = clip_grad_norm_(model, max_norm)
+    optimizer.step(lr_factor=lr_factor)
+    return tloss, norm

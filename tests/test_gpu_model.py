@@ -1,0 +1,221 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI via the host mirror of the reference's
+model API, against the numpy oracle (itself pinned to the reference, tests/test_oracle_golden.py) and the
+committed golden fixtures.  fp32 mode: 1e-4-class tolerances (north_star: logits within 1e-4 relative fp32);
+bf16 mode (the benchmarked arithmetic): bf16 tolerances stated per check."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TASK_W = [0.05, 0.2, 0.3, 0.25]
+
+
+def _setup(name, over, rows, seed, style="test"):
+    from oracle import model_np, synth
+    cfg = synth.make_config(name, **over)
+    P = synth.make_params(cfg, seed, style)
+    d = synth.make_batch(cfg, rows, seed + 1)
+    return cfg, P, d
+
+
+def _oracle(cfg, P, d, wm, rm, task_w=TASK_W):
+    from oracle import model_np
+    ref = model_np.OracleModel(cfg, P, np.float64)
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    y, _ = ref.embed(dm)
+    losses, G = ref.forward(dm, False, True, task_w)
+    ev = ref.forward(dm, True)
+    return y, losses, G, ev
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+CASES = [
+    ("tiny", dict(mask_rate=0.25, mask_topk=6), 3, 11),
+    ("hd64", dict(mask_rate=0.2, mask_topk=16), 2, 23),
+]
+
+
+@pytest.mark.parametrize("name,over,rows,seed", CASES)
+@pytest.mark.parametrize("dtype,tol_loss,tol_act,tol_grad", [("fp32", 1e-4, 1e-4, 5e-4), ("bf16", 4e-2, 6e-2, 1.5e-1)])
+def test_forward_backward_vs_oracle(name, over, rows, seed, dtype, tol_loss, tol_act, tol_grad):
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg, P, d = _setup(name, over, rows, seed)
+    z = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    u = z["meta/u"]; r = np.float32(cfg["mask_rate"])
+    wm = u < r; rm = (u >= r) & (u < 2 * r)
+    y_ref, l_ref, G_ref, ev_ref = _oracle(cfg, P, d, wm, rm)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    y = model.trunk_output(rows)
+    assert relerr(y, y_ref) < tol_act, ("trunk", relerr(y, y_ref))
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, l_ref)
+    # the reference's own numbers (golden fixture), not only the oracle's
+    for a, b in zip(losses, z["loss/train"]):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, z["loss/train"])
+    gn2 = 0.0
+    worst = ("", 0.0)
+    for n in synth.trainable_names(cfg):
+        g = model.grad(n)
+        gn2 += float((g.astype(np.float64) ** 2).sum())
+        scale = max(np.abs(G_ref[n]).max(), 1e-3 * np.sqrt((G_ref[n] ** 2).mean()) + 1e-12)
+        e = float(np.abs(g - G_ref[n]).max() / max(scale, 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < tol_grad, worst
+    assert abs(np.sqrt(gn2) - z["grad_norm"][0]) < tol_grad * z["grad_norm"][0]
+    # evaluate=True: rating entries are the three moments
+    ev = model(d, True, masks=(wm, rm))
+    flat = []; flat_ref = []
+    for a, b in zip(ev, ev_ref):
+        flat += a if isinstance(a, list) else [a]
+        flat_ref += b if isinstance(b, list) else [b]
+    for a, b in zip(flat, flat_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (flat, flat_ref)
+    model.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 3e-4), ("bf16", 8e-2)])
+def test_clip_adamw_three_steps_vs_golden(dtype, tol):
+    """train.py:259-276 three times on one batch; compared with the reference's own run (fixture)."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd.optim import AdamW
+    from recommendersystem_amd.train import train_step_unfused
+    name, over, rows, seed = CASES[0]
+    cfg, P, d = _setup(name, over, rows, seed)
+    z = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    u = z["meta/u"]; r = np.float32(cfg["mask_rate"])
+    wm = u < r; rm = (u >= r) & (u < 2 * r)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    opt = AdamW(model, lr=float(z["opt/lr"][0]))
+    for step in range(3):
+        losses, norm = train_step_unfused(model, opt, d, list(z["meta/task_w"]), masks=(wm, rm))
+        assert relerr(losses, z["opt/losses"][step]) < tol, (step, losses, z["opt/losses"][step])
+        assert abs(norm - z["opt/norms"][step]) < tol * z["opt/norms"][step]
+    if dtype == "fp32":
+        for n in synth.trainable_names(cfg):
+            assert relerr(model.get_parameter(n), z["opt/param/" + n]) < tol, n
+    model.close()
+
+
+def test_fused_step_equals_unfused():
+    """Fused clip+mean+AdamW (one pass) == clip_grad_norm_ then optimizer.step (train.py:273-275)."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd.optim import AdamW
+    from recommendersystem_amd.train import train_step_unfused
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, 5)
+    res = []
+    for fused in (False, True):
+        model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+        model.load_state_dict(P)
+        opt = AdamW(model, lr=1e-2)
+        if fused:
+            model.set_loss_weights(TASK_W, 1)
+            model(d, False, masks=(wm, rm))
+            opt.step(clip_max_norm=1.0, grad_div=1.0)
+        else:
+            train_step_unfused(model, opt, d, TASK_W, masks=(wm, rm))
+        res.append({n: model.get_parameter(n) for n in synth.trainable_names(cfg)})
+        g_after = model.grad("transformers.norm.scale")
+        if fused:
+            assert np.all(g_after == 0)           # optimizer.zero_grad fused
+        model.close()
+    for n in res[0]:
+        assert relerr(res[1][n], res[0][n]) < 2e-6, n
+
+
+def test_grad_accumulation_two_microsteps():
+    """no_sync micro-steps (train.py:268-271): two half-batches with grad_accum=2 == sum of scaled grads."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    S = cfg["max_sequence_length"]
+    wm, rm = synth.make_masks(cfg, rows, 7)
+    halves = [({k: v[i * S:(i + 1) * S] for k, v in d.items()}, (wm[i:i + 1], rm[i:i + 1])) for i in range(2)]
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 2)
+    for dd, mk in halves:
+        model(dd, False, masks=mk)
+    names = synth.trainable_names(cfg)
+    acc = {n: model.grad(n) for n in names}
+    ref = {n: 0.0 for n in names}
+    for dd, mk in halves:
+        o = model_np.OracleModel(cfg, P)
+        dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, dd), mk[0], mk[1])
+        _, G = o.forward(dm, False, True, [w / 2 for w in TASK_W])
+        for n in names:
+            ref[n] = ref[n] + G[n]
+    worst = max((relerr(acc[n], ref[n]), n) for n in names if np.abs(ref[n]).max() > 1e-8)
+    assert worst[0] < 1e-3, worst
+    model.close()
+
+
+def test_inference_golden():
+    """model(d, "retrieval"/"ranking") with rope_input_pos and per-candidate token_mask_ids (fixture from the reference)."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    z = np.load(os.path.join(GOLDEN, "infer_tiny.npz"))
+    cfg = synth.make_config("tiny", mask_rate=0.25, mask_topk=6)
+    cfg["forward"] = "inference"
+    P = synth.make_params(cfg, 31, "test")
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in/")}
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=2)
+    model.load_state_dict(P)
+    e = model(d, "retrieval")
+    assert relerr(e, z["out/retrieval"]) < 1e-4
+    r = model(d, "ranking")
+    assert relerr(r, z["out/ranking"]) < 1e-4
+    model.close()
+
+
+def test_random_masks_and_properties_at_scale():
+    """Size-independent properties at a larger shape (cfg-2-like, bf16): device Philox masks hit the requested
+    rate, every padded/zero-weight selected row contributes nothing, loss at reference init ~= ln(V_m),
+    two identical steps give identical losses (no atomics on the loss path)."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("cfg2", num_layers=2)
+    cfg["vocab_sizes"]["0_matchedid"] = 6000; cfg["vocab_sizes"]["1_matchedid"] = 4000
+    cfg["metadata_emb_size"] = 100
+    rows = 8
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.init_weights(7)
+    model.random_pretrained_embeddings(3)
+    d = synth.make_batch(cfg, rows, 99)
+    model.set_loss_weights(ra.make_task_weights(), 1)
+    l1 = model(d, False)
+    ws = model.last_weight_sums
+    model.zero_grad()
+    model.upload(d)
+    model.forward_resident(False, step=0)
+    model._step = 1
+    l2 = model.losses(False)
+    # same seed/step -> same masks -> identical losses
+    model.zero_grad(); model.forward_resident(False, step=0); l3 = model.losses(False)
+    assert l2 == l3
+    assert abs(l1[0] - np.log(6000)) < 0.05 * np.log(6000) or ws[0] == 0
+    assert abs(l1[2] - np.log(4000)) < 0.05 * np.log(4000) or ws[2] == 0
+    n = rows * cfg["max_sequence_length"]
+    tot_w = sum(float((d[f"{m}.watch.weight"] > 0).sum()) for m in (0, 1))
+    assert 0.03 * tot_w < ws[0] + ws[2] < 0.25 * tot_w     # ~mask_rate of the watch targets survive
+    for name in ("item_embedding.matchedid_embedding.embedding.weight", "transformers.layers.0.mlp.w1.weight"):
+        g = model.grad(name)
+        assert np.isfinite(g).all() and np.abs(g).max() > 0
+    model.close()
