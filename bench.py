@@ -1,0 +1,203 @@
+"""Benchmark of the training hot path (BASELINE.json metric): interactions/sec of
+forward + backward + gradient all-reduce + clip + AdamW on synthetic histories.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Workload = cfg-3 of SURVEY.md section 8 (retrieval d=512 seq=512, 200K items, L=8, 64 rows per GPU per
+step): data-parallel, weak scaling (per-GPU rows fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+
+GEMM_VARIANT = {  # call-site tag -> kernel instantiation (gemm.hip)
+    "gemm_table_fwd": "NT", "gemm_action_fwd": "NT", "gemm_qkv_fwd": "NT", "gemm_o_fwd": "NT", "gemm_w13_fwd": "NT",
+    "gemm_w2_fwd": "NT", "gemm_logits": "NT", "gemm_rating_fwd": "NT",
+    "gemm_head_dx": "NN", "gemm_w13_dx": "NN", "gemm_qkv_dx": "NN", "gemm_rating_dx": "NN",
+    "gemm_w2_dx": "NN_f32A", "gemm_o_dx": "NN_f32A", "gemm_action_dx": "NN_f32A",
+    "gemm_head_dw": "TN", "gemm_w13_dw": "TN", "gemm_qkv_dw": "TN", "gemm_rating_dw": "TN",
+    "gemm_w2_dw": "TN_f32A", "gemm_o_dw": "TN_f32A", "gemm_action_dw": "TN_f32A", "gemm_table_dw": "TN_f32A",
+}
+
+
+def flops_per_interaction(cfg, B):
+    """fwd+bwd, dense-attention upper bound, metadata projection once per step."""
+    L, D, I, S = cfg["num_layers"], cfg["embed_dim"], cfg["intermediate_dim"], cfg["max_sequence_length"]
+    V = cfg["vocab_sizes"]["0_matchedid"] + cfg["vocab_sizes"]["1_matchedid"]
+    M, K = cfg["metadata_emb_size"], cfg["mask_topk"]
+    return 36 * L * (D * D + D * I) + 56 * S * D * L + 6 * K * V * D / S + 4 * V * M * D / (B * S) + 6 * (D * D + D) * 2 * K / S
+
+
+def cpu_baseline(cfg, seed, budget_rows=2):
+    """The numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample:
+    one fp32 training step at `budget_rows` rows, split into the per-step fixed part (fused item table
+    fwd+bwd, AdamW/clip over all parameters) and the per-row part, then scaled to the 64-row step."""
+    from oracle import model_np, synth, train_np
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    S = cfg["max_sequence_length"]
+    small = dict(cfg)
+    P = synth.make_params(small, seed, "init")
+    P = {k: v.astype(np.float32) for k, v in P.items()}
+    d = synth.make_batch(small, budget_rows, seed + 1)
+    wm, rm = synth.make_masks(small, budget_rows, seed + 2)
+    names = synth.trainable_names(small)
+    tw = train_np.make_task_weights()
+    model = model_np.OracleModel(small, P, np.float32)
+    t0 = time.time()
+    model.fused_table()
+    t_table_fwd = time.time() - t0
+    t0 = time.time()
+    dm = model_np.mask_tokens(small, model_np.reshape_batch(small, d), wm, rm)
+    losses, G = model.forward(dm, False, True, tw)
+    t_rows = time.time() - t0          # includes the table forward and its backward GEMM (dF^T Meta)
+    t0 = time.time()
+    G = {k: G[k] for k in names}
+    G, norm = train_np.clip_grad_norm(G, 1.0)
+    opt = train_np.AdamW(model.P, names, 1e-4)
+    P2 = dict(model.P); opt.step(P2, G)
+    t_opt = time.time() - t0
+    B = 64
+    fixed = 2 * t_table_fwd + t_opt           # per step: table fwd + its backward GEMM, clip + AdamW pass
+    per_row = max(t_rows - 2 * t_table_fwd, 1e-9) / budget_rows
+    est_step = fixed + B * per_row
+    return {"value": B * S / est_step, "unit": "interactions/sec", "cores": int(threads), "kind": "port",
+            "sample": f"numpy-oracle fp32, one train step at {budget_rows} rows x S={S} (measured {t_rows + t_opt:.1f}s: "
+                      f"table {t_table_fwd:.1f}s fwd, rows {t_rows:.1f}s, clip+AdamW {t_opt:.1f}s), scaled to the 64-row step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--rows", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import recommendersystem_amd as ra
+    from oracle import synth          # synthetic corpus generator (inputs only)
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.train import WSDScheduler, LambdaLR
+
+    rank, world, local_rank = rdist.env_rank()
+    if args.gpus > 1:
+        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    hg = rdist.HostGroup(rank, world)
+    device = local_rank if world > 1 else 0
+    over = {} if args.layers is None else {"num_layers": args.layers}
+    cfg = synth.make_config(args.config, **over)
+    S = cfg["max_sequence_length"]
+    rows = args.rows
+    model = ra.RecommenderModel(cfg, device=device, dtype=args.dtype, max_rows=rows)
+    model.init_weights(0x1217)                 # same seed on every rank (replaces DDP's rank-0 broadcast, C1)
+    model.random_pretrained_embeddings(0x3E7A)
+    opt = ra.create_optimizer(model, cfg)
+    comm = rdist.Comm(hg, device) if world > 1 else None
+    if comm is not None:
+        comm.self_test()
+    sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
+    for _ in range(2000):
+        sched.step()                           # bench at the stable learning rate
+    model.set_loss_weights(ra.make_task_weights(), 1)
+    model.mask_seed = 0x3A5C ^ rank
+    d = synth.make_batch(cfg, rows, 0xD47A ^ rank, mu=4.6, sigma=1.0)
+    model.upload(d)                            # inputs resident in HBM before the timed region
+
+    def step():
+        model.forward_resident(False)
+        if comm is not None:
+            comm.all_reduce_grads(model)
+        opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=float(world))
+        sched.step()
+
+    for _ in range(args.warmup):
+        step()
+    ra.synchronize()
+    first_losses = model.losses(False)
+    hg.barrier()
+    if not args.no_kernel_timing:
+        model.timing(True)
+    ra.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ra.synchronize()
+    hg.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = hg.all_reduce([elapsed], "max")[0]
+    rep = model.timing_report() if not args.no_kernel_timing else {}
+    model.timing(False)
+    losses = model.losses(False)
+    assert all(np.isfinite(losses)), losses
+
+    if rank == 0:
+        inter = world * rows * S * args.steps
+        value = inter / elapsed
+        ms = elapsed / args.steps * 1e3
+        fpi = flops_per_interaction(cfg, rows)
+        # dominant kernel: the MFMA GEMM family, per instantiation
+        var = {}
+        for tag, r in rep.items():
+            v = GEMM_VARIANT.get(tag)
+            if v:
+                a = var.setdefault(v, {"ms": 0.0, "flops": 0.0, "launches": 0})
+                a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["launches"] += r["count"]
+        roofline = None
+        if var:
+            dom = max(var, key=lambda k: var[k]["ms"])
+            a = var[dom]
+            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": f"gemm_kernel<bf16,{dom}>", "achieved": round(ach, 1),
+                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                        "launches": a["launches"],
+                        "share_of_step": round(a["ms"] / (ms * args.steps), 3)}
+        out = {
+            "metric": "interactions/sec", "value": round(value, 1), "unit": "interactions/sec",
+            "user_seqs_per_sec": round(value / S, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.config}: train step fwd+bwd+allreduce+clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
+                                   f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
+                                   f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
+                       "parallelism": f"dp{world}"},
+            "model_flops_per_interaction": fpi,
+            "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            "roofline": roofline,
+            "losses": [round(float(x), 4) for x in losses],
+        }
+        if rep:
+            phases = {k: round(v["ms"] / args.steps, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
+            out["ms_per_step_by_phase"] = phases
+            out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, 1)
+        print(json.dumps(out))
+    if comm is not None:
+        comm.close()
+    model.close()
+    hg.close()
+
+
+if __name__ == "__main__":
+    main()

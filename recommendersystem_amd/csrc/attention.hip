@@ -57,24 +57,31 @@ template <typename T, int HD> struct ACfg {
 
 // stage a [64 tokens][HD] tile (row-major source, row stride ld) into LDS [64][LDD]
 template <typename T, int HD>
-__device__ __forceinline__ void stage_rows(T* dst, const T* src, long long ld, int t) {
+__device__ __forceinline__ void stage_rows(T* dst, const T* src, long long ld, int t, int nvalid) {
   using C = ACfg<T, HD>;
   constexpr int CPR = HD / C::E;
   for (int c = t; c < 64 * CPR; c += 256) {
     int row = c / CPR, ch = c % CPR;
-    *(uint4*)(dst + row * C::LDD + ch * C::E) = *(const uint4*)(src + row * ld + ch * C::E);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nvalid) v = *(const uint4*)(src + row * ld + ch * C::E);
+    *(uint4*)(dst + row * C::LDD + ch * C::E) = v;
   }
 }
 // stage a [HD][64 tokens] tile from a transposed copy (row stride T tokens) into LDS [HD][LDT]
 template <typename T, int HD>
-__device__ __forceinline__ void stage_trans(T* dst, const T* src, long long ldT, int t) {
+__device__ __forceinline__ void stage_trans(T* dst, const T* src, long long ldT, int t, int nvalid) {
   using C = ACfg<T, HD>;
   constexpr int CPR = 64 / C::E;
   for (int c = t; c < HD * CPR; c += 256) {
     int row = c / CPR, ch = c % CPR;
-    *(uint4*)(dst + row * C::LDT + ch * C::E) = *(const uint4*)(src + row * ldT + ch * C::E);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ch * C::E < nvalid) v = *(const uint4*)(src + row * ldT + ch * C::E);   // T % 8 == 0: chunks never straddle T
+    *(uint4*)(dst + row * C::LDT + ch * C::E) = v;
   }
 }
+// tokens past the end of a row (T % 64 != 0) get ids that match nothing
+#define SENT_Q (-2147483647)
+#define SENT_K (-2147483646)
 template <typename T, int HD>
 __device__ __forceinline__ void zero_pad_cols(T* dst, int t) {
   using C = ACfg<T, HD>;
@@ -102,9 +109,12 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   __shared__ int uq[64], tq[64];
   __shared__ unsigned int bits;
   const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-  const int nt = p.T / 64;
+  const int nt = (p.T + 63) / 64;
   const long long base = (long long)b * p.T;
-  if (t < 64) { uq[t] = p.uid[base + qt * 64 + t]; tq[t] = p.tm[base + qt * 64 + t]; }
+  if (t < 64) {
+    const bool v = qt * 64 + t < p.T;
+    uq[t] = v ? p.uid[base + qt * 64 + t] : SENT_Q; tq[t] = v ? p.tm[base + qt * 64 + t] : 0;
+  }
   if (t == 0) bits = 0u;
   __syncthreads();
   for (int kv = t; kv < p.T; kv += 256) {
@@ -119,9 +129,9 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
 }
 
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
-  ARG_CHECK(p.T % 64 == 0 && p.T / 64 <= 32, "attention: T must be a multiple of 64 and <= 2048");
-  HIP_CHECK(hipMemsetAsync(p.kmap, 0, sizeof(unsigned int) * p.B * (p.T / 64), s));
-  hipLaunchKernelGGL(attn_tilemap_kernel, dim3(p.T / 64, p.B), dim3(256), 0, s, p);
+  ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
+  HIP_CHECK(hipMemsetAsync(p.kmap, 0, sizeof(unsigned int) * p.B * ((p.T + 63) / 64), s));
+  hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -140,14 +150,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
   const int kvh = h / (p.H / p.KV);
-  const int nt = p.T / 64;
+  const int nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
   const float scale = rsqrtf((float)HD);
   const int qr0 = qt * 64 + w * 16;
   constexpr int NQS = C::HDP / C::KS;
   typename M::Frag qf[NQS];
   {
-    const T* qrow = (const T*)p.q + (tok0 + qr0 + fr) * p.ld + h * HD;
+    const T* qrow = (const T*)p.q + (tok0 + min(qr0 + fr, p.T - 1)) * p.ld + h * HD;
 #pragma unroll
     for (int s = 0; s < NQS; ++s) qf[s] = M::glb(qrow, s * C::KS, HD, l);
   }
@@ -155,8 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   float mrow[4], lrow[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    uq[r] = p.uid[tok0 + qr0 + 4 * fq + r];
-    tq[r] = p.tm[tok0 + qr0 + 4 * fq + r];
+    const int qi = qr0 + 4 * fq + r;
+    uq[r] = qi < p.T ? p.uid[tok0 + qi] : SENT_Q;
+    tq[r] = qi < p.T ? p.tm[tok0 + qi] : 0;
     mrow[r] = -1e30f; lrow[r] = 0.f;
   }
   f32x4 oacc[HD / 16];
@@ -168,9 +179,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   for (int kt = 0; kt < nt; ++kt) {
     if (!((bits >> kt) & 1u)) continue;
     __syncthreads();
-    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t);
-    stage_trans<T, HD>(Vt, (const T*)p.vT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t);
-    if (t < 64) { uk[t] = p.uid[tok0 + kt * 64 + t]; tk[t] = p.tm[tok0 + kt * 64 + t]; }
+    const int nv = min(64, p.T - kt * 64);
+    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
+    stage_trans<T, HD>(Vt, (const T*)p.vT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t, nv);
+    if (t < 64) { uk[t] = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; tk[t] = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
     __syncthreads();
     f32x4 sacc[4];
 #pragma unroll
@@ -225,6 +237,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    if (qr0 + 4 * fq + r >= p.T) continue;
     const long long row = tok0 + qr0 + 4 * fq + r;
     const float inv = 1.f / lrow[r];
 #pragma unroll
@@ -247,13 +260,13 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(p.T / 64, p.H, p.B), dim3(256), sm, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3((p.T + 63) / 64, p.H, p.B), dim3(256), sm, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
 static int check_attn(const AttnParams& p, size_t esz) {
-  ARG_CHECK(p.T % 64 == 0 && p.T / 64 <= 32, "attention: T must be a multiple of 64 and <= 2048");
+  ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
   ARG_CHECK(p.H % p.KV == 0, "attention: H % KV");
   ARG_CHECK((p.ld * esz) % 16 == 0 && (p.hd * esz) % 16 == 0, "attention: 16-byte row alignment");
   return RSYS_OK;
@@ -324,21 +337,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
   int* tqs = uqs + 64;
   const int kvt = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
-  const int rep = p.H / p.KV, nt = p.T / 64;
+  const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
   const float scale = rsqrtf((float)HD);
   const int kr0 = kvt * 64 + w * 16;
   constexpr int NDS = C::HDP / C::KS;
   typename M::Frag kf[NDS], vf[NDS];
   {
-    const T* krow = (const T*)p.k + (tok0 + kr0 + fr) * p.ld + kvh * HD;
-    const T* vrow = (const T*)p.v + (tok0 + kr0 + fr) * p.ld + kvh * HD;
+    const T* krow = (const T*)p.k + (tok0 + min(kr0 + fr, p.T - 1)) * p.ld + kvh * HD;
+    const T* vrow = (const T*)p.v + (tok0 + min(kr0 + fr, p.T - 1)) * p.ld + kvh * HD;
 #pragma unroll
     for (int s = 0; s < NDS; ++s) { kf[s] = M::glb(krow, s * C::KS, HD, l); vf[s] = M::glb(vrow, s * C::KS, HD, l); }
   }
   int ukv[4], tkv[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { ukv[r] = p.uid[tok0 + kr0 + 4 * fq + r]; tkv[r] = p.tm[tok0 + kr0 + 4 * fq + r]; }
+  for (int r = 0; r < 4; ++r) {
+    const int ki = kr0 + 4 * fq + r;
+    ukv[r] = ki < p.T ? p.uid[tok0 + ki] : SENT_K; tkv[r] = ki < p.T ? p.tm[tok0 + ki] : 0;
+  }
   f32x4 dK[HD / 16], dV[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
@@ -352,15 +368,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
     for (int qt = 0; qt < nt; ++qt) {
       if (!((bits >> qt) & 1u)) continue;
       __syncthreads();
-      stage_rows<T, HD>(Qs, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t);
-      stage_rows<T, HD>(dOs, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t);
-      stage_trans<T, HD>(QTs, (const T*)p.qT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t);
-      stage_trans<T, HD>(dOTs, (const T*)p.dOT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t);
+      const int nv = min(64, p.T - qt * 64);
+      stage_rows<T, HD>(Qs, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
+      stage_rows<T, HD>(dOs, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
+      stage_trans<T, HD>(QTs, (const T*)p.qT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t, nv);
+      stage_trans<T, HD>(dOTs, (const T*)p.dOT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t, nv);
       if (t < 64) {
-        lse_q[t] = p.lse[((long long)b * p.H + h) * p.T + qt * 64 + t];
-        del_q[t] = p.delta[((long long)b * p.H + h) * p.T + qt * 64 + t];
-        uqs[t] = p.uid[tok0 + qt * 64 + t];
-        tqs[t] = p.tm[tok0 + qt * 64 + t];
+        const bool v = t < nv;
+        lse_q[t] = v ? p.lse[((long long)b * p.H + h) * p.T + qt * 64 + t] : 0.f;
+        del_q[t] = v ? p.delta[((long long)b * p.H + h) * p.T + qt * 64 + t] : 0.f;
+        uqs[t] = v ? p.uid[tok0 + qt * 64 + t] : SENT_Q;
+        tqs[t] = v ? p.tm[tok0 + qt * 64 + t] : 0;
       }
       __syncthreads();
 #pragma unroll
@@ -399,15 +417,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int tk = kr0 + 4 * fq + r;
-    const long long row = tok0 + tk;
-    const int pos = p.rope_pos ? p.rope_pos[row] : tk;
+    const bool rv = tk < p.T;
+    const long long row = tok0 + (rv ? tk : p.T - 1);
+    const int pos = p.rope_pos ? p.rope_pos[row] : (rv ? tk : 0);
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) {
       const int d = j * 16 + fr;
       const float c = p.rope_cos[pos * (HD / 2) + (d >> 1)], sn = p.rope_sin[pos * (HD / 2) + (d >> 1)];
       float gk = rope_inv(dK[j][r], c, sn, l);
-      ((T*)p.dk)[row * p.ldg + kvh * HD + d] = from_f32<T>(gk);
-      ((T*)p.dv)[row * p.ldg + kvh * HD + d] = from_f32<T>(dV[j][r]);
+      if (rv) {
+        ((T*)p.dk)[row * p.ldg + kvh * HD + d] = from_f32<T>(gk);
+        ((T*)p.dv)[row * p.ldg + kvh * HD + d] = from_f32<T>(dV[j][r]);
+      }
     }
   }
 }
@@ -426,15 +447,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
   int* tk = uk + 64;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
-  const int kvh = h / (p.H / p.KV), nt = p.T / 64;
+  const int kvh = h / (p.H / p.KV), nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
   const float scale = rsqrtf((float)HD);
   const int qr0 = qt * 64 + w * 16;
   constexpr int NDS = C::HDP / C::KS;
   typename M::Frag qf[NDS], dof[NDS];
   {
-    const T* qrow = (const T*)p.q + (tok0 + qr0 + fr) * p.ld + h * HD;
-    const T* drow = (const T*)p.dO + (tok0 + qr0 + fr) * p.ldo + h * HD;
+    const T* qrow = (const T*)p.q + (tok0 + min(qr0 + fr, p.T - 1)) * p.ld + h * HD;
+    const T* drow = (const T*)p.dO + (tok0 + min(qr0 + fr, p.T - 1)) * p.ldo + h * HD;
 #pragma unroll
     for (int s = 0; s < NDS; ++s) { qf[s] = M::glb(qrow, s * C::KS, HD, l); dof[s] = M::glb(drow, s * C::KS, HD, l); }
   }
@@ -443,9 +464,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int tq_i = qr0 + 4 * fq + r;
-    uq[r] = p.uid[tok0 + tq_i]; tq[r] = p.tm[tok0 + tq_i];
-    lse[r] = p.lse[((long long)b * p.H + h) * p.T + tq_i];
-    dl[r] = p.delta[((long long)b * p.H + h) * p.T + tq_i];
+    const bool v = tq_i < p.T;
+    uq[r] = v ? p.uid[tok0 + tq_i] : SENT_Q; tq[r] = v ? p.tm[tok0 + tq_i] : 0;
+    lse[r] = v ? p.lse[((long long)b * p.H + h) * p.T + tq_i] : 0.f;
+    dl[r] = v ? p.delta[((long long)b * p.H + h) * p.T + tq_i] : 0.f;
   }
   f32x4 dQ[HD / 16];
 #pragma unroll
@@ -457,10 +479,11 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
   for (int kt = 0; kt < nt; ++kt) {
     if (!((bits >> kt) & 1u)) continue;
     __syncthreads();
-    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t);
-    stage_rows<T, HD>(Vs, (const T*)p.v + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t);
-    stage_trans<T, HD>(KTs, (const T*)p.kT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t);
-    if (t < 64) { uk[t] = p.uid[tok0 + kt * 64 + t]; tk[t] = p.tm[tok0 + kt * 64 + t]; }
+    const int nv = min(64, p.T - kt * 64);
+    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
+    stage_rows<T, HD>(Vs, (const T*)p.v + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
+    stage_trans<T, HD>(KTs, (const T*)p.kT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t, nv);
+    if (t < 64) { uk[t] = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; tk[t] = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -491,13 +514,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int tq_i = qr0 + 4 * fq + r;
-    const long long row = tok0 + tq_i;
-    const int pos = p.rope_pos ? p.rope_pos[row] : tq_i;
+    const bool rv = tq_i < p.T;
+    const long long row = tok0 + (rv ? tq_i : p.T - 1);
+    const int pos = p.rope_pos ? p.rope_pos[row] : (rv ? tq_i : 0);
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) {
       const int d = j * 16 + fr;
       const float c = p.rope_cos[pos * (HD / 2) + (d >> 1)], sn = p.rope_sin[pos * (HD / 2) + (d >> 1)];
-      ((T*)p.dq)[row * p.ldg + h * HD + d] = from_f32<T>(rope_inv(dQ[j][r], c, sn, l));
+      const float gq = rope_inv(dQ[j][r], c, sn, l);
+      if (rv) ((T*)p.dq)[row * p.ldg + h * HD + d] = from_f32<T>(gq);
     }
   }
 }
@@ -513,9 +538,9 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
     set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(p.T / 64, p.KV, p.B), dim3(256), sm_kv, s, p);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3((p.T + 63) / 64, p.KV, p.B), dim3(256), sm_kv, s, p);
   HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3(p.T / 64, p.H, p.B), dim3(256), sm_q, s, p);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3((p.T + 63) / 64, p.H, p.B), dim3(256), sm_q, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -3,6 +3,8 @@
 // register-staged double-buffered LDS, XOR-swizzled so that both the
 // ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads are
 // bank-conflict free, XCD-aware tile order (cdna_hip_programming.md T1/T2/T10).
+#include <utility>
+
 #include "gemm.hpp"
 
 namespace rsys {
@@ -33,19 +35,20 @@ template <> struct MmaT<float> {
 template <typename CT, bool F32SRC> struct Staged { uint4 v; };
 template <> struct Staged<bf16, true> { float4 a, b; };
 
+// Guarded 16-byte chunk load without a branch: an invalid chunk reads element 0 of the operand
+// (always mapped) and is then zeroed by a select, so the loads of a tile issue back to back.
 template <typename CT, bool F32SRC>
 __device__ __forceinline__ Staged<CT, F32SRC> load_chunk(const void* base, long long off, bool valid) {
   Staged<CT, F32SRC> r;
+  off = valid ? off : 0;
   if constexpr (is_bf16<CT>::value && F32SRC) {
-    if (valid) {
-      const float4* p = (const float4*)((const float*)base + off);
-      r.a = p[0]; r.b = p[1];
-    } else {
-      r.a = make_float4(0, 0, 0, 0); r.b = r.a;
-    }
+    const float4* p = (const float4*)((const float*)base + off);
+    float4 a = p[0], b = p[1];
+    const float4 z = make_float4(0, 0, 0, 0);
+    r.a = valid ? a : z; r.b = valid ? b : z;
   } else {
-    if (valid) r.v = *(const uint4*)((const CT*)base + off);
-    else r.v = make_uint4(0, 0, 0, 0);
+    uint4 v = *(const uint4*)((const CT*)base + off);
+    r.v = valid ? v : make_uint4(0, 0, 0, 0);
   }
   return r;
 }
@@ -106,6 +109,16 @@ __device__ __forceinline__ typename MmaT<CT>::Frag load_frag(const unsigned char
       return *(const float*)(tile + krow * 512 + (r0 + i) * 4);
     }
   }
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time loop: accumulator tiles must be indexed by constants or hipcc moves them to scratch
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 template <typename CT>
@@ -212,142 +225,178 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
 
   // ------------------------------------------------------------------ epilogue
+  // acc[i][j]: rows m0 + wr*64 + i*16 + 4*(l>>4) + r (r = 0..3), column n0 + wc*64 + j*16 + (l&15)
   const int fq = l >> 4, fr = l & 15;
   const bool cf32 = p.c_f32 != 0;
+  const long long rbase = m0 + wr * 64 + 4 * fq;
+  const int cbase = n0 + wc * 64 + fr;
+  auto tiles = [&](auto&& fn) {
+    static_for<4>([&](auto i) { static_for<4>([&](auto j) { fn(i, j, rbase + i * 16, cbase + j * 16); }); });
+  };
+  switch (p.epi) {
+    case EPI_STORE:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long row0 = m0 + wr * 64 + i * 16 + 4 * fq;
-    if (p.epi == EPI_SWIGLU) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int col_a = n0 + wc * 64 + jj * 32 + fr, col_b = col_a + 16;
-        const int gcol = ((n0 + wc * 64) >> 1) + jj * 16 + fr;
-        if (col_b < p.N) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            long long row = row0 + r;
-            if (row < p.M) {
-              float a = acc[i][2 * jj][r], b = acc[i][2 * jj + 1][r];
-              ((CT*)p.C)[row * p.ldc + col_a] = from_f32<CT>(a);
-              ((CT*)p.C)[row * p.ldc + col_b] = from_f32<CT>(b);
-              float sg = 1.f / (1.f + __expf(-a));
-              ((CT*)p.C2)[row * p.ldc2 + gcol] = from_f32<CT>(a * sg * b);
-            }
-          }
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] * p.alpha);
         }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + fr;
-      const bool cok = col < p.N;
-      f32x4 v = acc[i][j];
-      switch (p.epi) {
-        case EPI_STORE: {
+      });
+      break;
+    case EPI_ACCUM:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] * p.alpha);
-        } break;
-        case EPI_ACCUM: {
+            if (row0 + r < p.M) ((float*)p.C)[(row0 + r) * p.ldc + col] += v[r];
+        }
+      });
+      break;
+    case EPI_ATOMIC:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) ((float*)p.C)[(row0 + r) * p.ldc + col] += v[r];
-        } break;
-        case EPI_ATOMIC: {
+            if (row0 + r < p.M) atomicAdd(&((float*)p.C)[(row0 + r) * p.ldc + col], v[r]);
+        }
+      });
+      break;
+    case EPI_BIAS:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
+          const float bv = p.bias[col];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) atomicAdd(&((float*)p.C)[(row0 + r) * p.ldc + col], v[r]);
-        } break;
-        case EPI_BIAS: {
-          float bv = cok ? p.bias[col] : 0.f;
+            if (row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] + bv);
+        }
+      });
+      break;
+    case EPI_RESIDUAL:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] + bv);
-        } break;
-        case EPI_RESIDUAL: {
+            if (row0 + r < p.M) ((float*)p.C)[(row0 + r) * p.ldc + col] = p.resid[(row0 + r) * p.ldr + col] + v[r];
+        }
+      });
+      break;
+    case EPI_TABLE:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
+          const float bv = p.bias[col];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M)
-              ((float*)p.C)[(row0 + r) * p.ldc + col] = p.resid[(row0 + r) * p.ldr + col] + v[r];
-        } break;
-        case EPI_TABLE: {
-          float bv = cok ? p.bias[col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) {
-              long long row = row0 + r;
-              float f = v[r] + p.E[row * p.ldc + col] + bv;
+            if (row0 + r < p.M) {
+              const long long row = row0 + r;
+              const float f = v[r] + p.E[row * p.ldc + col] + bv;
               ((float*)p.C)[row * p.ldc + col] = f;
               ((CT*)p.C2)[row * p.ldc2 + col] = from_f32<CT>(f);
             }
-        } break;
-        case EPI_GELU: {
-          float bv = cok ? p.bias[col] : 0.f;
+        }
+      });
+      break;
+    case EPI_GELU:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        if (col < p.N) {
+          const float bv = p.bias[col];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (cok && row0 + r < p.M) {
-              long long row = row0 + r;
-              float z = v[r] + bv;
+            if (row0 + r < p.M) {
+              const long long row = row0 + r;
+              const float z = v[r] + bv;
               ((CT*)p.C)[row * p.ldc + col] = from_f32<CT>(z);
-              float ge = 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
-              ((CT*)p.C2)[row * p.ldc2 + col] = from_f32<CT>(ge);
+              ((CT*)p.C2)[row * p.ldc2 + col] = from_f32<CT>(0.5f * z * (1.f + erff(z * 0.70710678118654752f)));
             }
-        } break;
-        case EPI_QKV_ROPE:
-        case EPI_STORE_HEADS_T: {
-          // region / head bookkeeping (16 columns of an MFMA tile never straddle a head: hd % 16 == 0)
-          const int ccol = cok ? col : 0;
-          int region = 0, cc = ccol;
-          void* XT = p.C2;
-          int heads = p.N / p.hd;
-          if (p.epi == EPI_QKV_ROPE) {
-            if (ccol < p.n_q) { region = 0; cc = ccol; XT = p.qT; heads = p.n_q / p.hd; }
-            else if (ccol < p.n_q + p.n_k) { region = 1; cc = ccol - p.n_q; XT = p.kT; heads = p.n_k / p.hd; }
-            else { region = 2; cc = ccol - p.n_q - p.n_k; XT = p.vT; heads = (p.N - p.n_q - p.n_k) / p.hd; }
-          }
-          const int head = cc / p.hd, d = cc % p.hd;
-          const bool rot = (p.epi == EPI_QKV_ROPE) && region < 2;
-          float o[4];
+        }
+      });
+      break;
+    case EPI_SWIGLU:
+      // columns interleaved in 16-wide blocks [a | b]: tiles (i, 2jj) and (i, 2jj+1) of one lane pair up
+      static_for<4>([&](auto i) {
+        static_for<2>([&](auto jj) {
+          const f32x4 va = acc[i][2 * jj], vb = acc[i][2 * jj + 1];
+          const long long row0 = rbase + i * 16;
+          const int col_a = cbase + jj * 32, col_b = col_a + 16;
+          const int gcol = ((n0 + wc * 64) >> 1) + jj * 16 + fr;
+          if (col_b < p.N) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = v[r];
-            float partner = __shfl_xor(x, 1, 64);
-            if (rot) {
-              long long row = min(row0 + r, (long long)p.M - 1);
-              int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
-              float c = p.rope_cos[pos * (p.hd >> 1) + (d >> 1)];
-              float s = p.rope_sin[pos * (p.hd >> 1) + (d >> 1)];
-              x = (l & 1) ? (partner * s + x * c) : (x * c - partner * s);
-            }
-            o[r] = x;
-          }
-          if (cok) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (row0 + r < p.M) ((CT*)p.C)[(row0 + r) * p.ldc + col] = from_f32<CT>(o[r]);
-            if (XT != nullptr && row0 < p.M) {
-              const long long b = row0 / p.T;
-              const int t0 = (int)(row0 % p.T);
-              CT* dst = (CT*)XT + ((b * heads + head) * p.hd + d) * (long long)p.T + t0;
-              if (row0 + 3 < p.M) {
-                if constexpr (is_bf16<CT>::value) {
-                  bf16x4 pk; pk[0] = (bf16)o[0]; pk[1] = (bf16)o[1]; pk[2] = (bf16)o[2]; pk[3] = (bf16)o[3];
-                  *(bf16x4*)dst = pk;
-                } else {
-                  *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-                }
-              } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  if (row0 + r < p.M) dst[r] = from_f32<CT>(o[r]);
+            for (int r = 0; r < 4; ++r) {
+              const long long row = row0 + r;
+              if (row < p.M) {
+                const float a = va[r], b = vb[r];
+                ((CT*)p.C)[row * p.ldc + col_a] = from_f32<CT>(a);
+                ((CT*)p.C)[row * p.ldc + col_b] = from_f32<CT>(b);
+                const float sg = 1.f / (1.f + __expf(-a));
+                ((CT*)p.C2)[row * p.ldc2 + gcol] = from_f32<CT>(a * sg * b);
               }
             }
           }
-        } break;
-        default: break;
-      }
-    }
+        });
+      });
+      break;
+    case EPI_QKV_ROPE:
+    case EPI_STORE_HEADS_T:
+      tiles([&](auto i, auto j, long long row0, int col) {
+        const f32x4 v = acc[i][j];
+        // region / head bookkeeping (16 columns of an MFMA tile never straddle a head: hd % 16 == 0)
+        const bool cok = col < p.N;
+        const int ccol = cok ? col : 0;
+        int region = 0, cc = ccol;
+        void* XT = p.C2;
+        int heads = p.N / p.hd;
+        if (p.epi == EPI_QKV_ROPE) {
+          if (ccol < p.n_q) { region = 0; cc = ccol; XT = p.qT; heads = p.n_q / p.hd; }
+          else if (ccol < p.n_q + p.n_k) { region = 1; cc = ccol - p.n_q; XT = p.kT; heads = p.n_k / p.hd; }
+          else { region = 2; cc = ccol - p.n_q - p.n_k; XT = p.vT; heads = (p.N - p.n_q - p.n_k) / p.hd; }
+        }
+        const int head = cc / p.hd, d = cc % p.hd;
+        const bool rot = (p.epi == EPI_QKV_ROPE) && region < 2;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = v[r];
+          const float partner = __shfl_xor(x, 1, 64);
+          if (rot) {
+            const long long row = min(row0 + r, (long long)p.M - 1);
+            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
+            const float c = p.rope_cos[pos * (p.hd >> 1) + (d >> 1)];
+            const float sn = p.rope_sin[pos * (p.hd >> 1) + (d >> 1)];
+            x = (l & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
+          }
+          o[r] = x;
+        }
+        if (cok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) ((CT*)p.C)[(row0 + r) * p.ldc + col] = from_f32<CT>(o[r]);
+          if (XT != nullptr && row0 < p.M) {
+            const long long b = row0 / p.T;
+            const int t0 = (int)(row0 % p.T);
+            CT* dst = (CT*)XT + ((b * heads + head) * p.hd + d) * (long long)p.T + t0;
+            if (row0 + 3 < p.M) {
+              if constexpr (is_bf16<CT>::value) {
+                bf16x4 pk; pk[0] = (bf16)o[0]; pk[1] = (bf16)o[1]; pk[2] = (bf16)o[2]; pk[3] = (bf16)o[3];
+                *(bf16x4*)dst = pk;
+              } else {
+                *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (row0 + r < p.M) dst[r] = from_f32<CT>(o[r]);
+            }
+          }
+        }
+      });
+      break;
+    default: break;
   }
 }
 

@@ -134,8 +134,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   const int hd = cfg->embed_dim / cfg->num_heads;
   ARG_CHECK(hd == 16 || hd == 32 || hd == 64 || hd == 128, "head_dim must be 16/32/64/128");
   ARG_CHECK(cfg->embed_dim % 16 == 0 && cfg->embed_dim <= 2048, "embed_dim must be a multiple of 16 and <= 2048");
-  ARG_CHECK((2 * cfg->max_sequence_length) % 64 == 0 && 2 * cfg->max_sequence_length <= 2048,
-            "2*max_sequence_length must be a multiple of 64 and <= 2048");
+  ARG_CHECK(cfg->max_sequence_length % 4 == 0 && 2 * cfg->max_sequence_length <= 2048,
+            "max_sequence_length must be a multiple of 4 and <= 1024");
   ARG_CHECK(cfg->max_rows >= 1, "max_rows");
   ARG_CHECK(cfg->mask_topk >= 1 && cfg->mask_topk <= cfg->max_sequence_length, "mask_topk");
   ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16, "dtype");
@@ -195,7 +195,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   }
   DALLOC(m->feat, N * 32 * e); DALLOC(m->x0, NT * D * 4);
   DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
-  DALLOC(m->qmap, (int64_t)m->rows_max * (m->T / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * (m->T / 64) * 4);
+  DALLOC(m->qmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
   m->la.resize(m->L);
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
