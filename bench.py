@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     args = ap.parse_args()
 
     import recommendersystem_amd as ra
@@ -190,6 +191,10 @@ def main():
             phases = {k: round(v["ms"] / args.steps, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
             out["ms_per_step_by_phase"] = phases
             out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
+        if args.detail:
+            for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
+                print(f"  {k:22s} {v['ms'] / args.steps:8.3f} ms/step  {v['count'] // args.steps:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, 1)
         print(json.dumps(out))

@@ -1,0 +1,102 @@
+# Julia binding of librsys_hip.so (C ABI: include/rsys.h) -- thin `ccall` wrappers, 1:1 with the header.
+#
+# NOT EXECUTED in the build container (Julia is absent from the image, SURVEY.md 8(c)); it is the stub a
+# maintainer adds so that notebooks/Training/run.jl:70 (`julia rungpu.jl`, which remote-launches torchrun
+# transformer.py) can call the HIP path in-process instead.  Host arrays are kept alive with GC.@preserve
+# for the duration of each call; the library owns all device memory.
+module RsysHIP
+
+const LIB = joinpath(@__DIR__, "..", "recommendersystem_amd", "librsys_hip.so")
+
+struct RsysConfig              # mirrors rsys_config (field order and types as in rsys.h)
+    num_layers::Int32; num_heads::Int32; num_kv_heads::Int32; embed_dim::Int32; intermediate_dim::Int32
+    max_sequence_length::Int32
+    vocab_0::Int32; vocab_1::Int32
+    vocab_status::Int32; vocab_gender::Int32; vocab_source::Int32
+    metadata_dim::Int32
+    min_ts::Float64; max_ts::Float64
+    rating_mean::Float32; rating_std::Float32; mask_rate::Float32
+    mask_topk::Int32; finetune::Int32; finetune_metric::Int32
+    dtype::Int32; max_rows::Int32
+end
+
+struct RsysBatch               # mirrors rsys_batch
+    rows::Int32
+    userid::Ptr{Int32}; token_mask_ids::Ptr{Int32}; gender::Ptr{Int32}; source::Ptr{Int32}
+    matchedid::Ptr{Int32}; status::Ptr{Int32}
+    time::Ptr{Float64}; rating::Ptr{Float32}; progress::Ptr{Float32}
+    label::NTuple{6,Ptr{Float32}}; weight::NTuple{6,Ptr{Float32}}; position::NTuple{6,Ptr{Int32}}
+    watch_mask::Ptr{UInt8}; rating_mask::Ptr{UInt8}; rope_input_pos::Ptr{Int32}
+end
+
+function last_error()
+    buf = Vector{UInt8}(undef, 2048)
+    ccall((:rsys_last_error, LIB), Csize_t, (Ptr{UInt8}, Csize_t), buf, length(buf))
+    unsafe_string(pointer(buf))
+end
+check(rc) = rc == 0 ? nothing : error("rsys error $rc: $(last_error())")
+
+mutable struct Model; h::Ptr{Cvoid}; end
+mutable struct Optimizer; h::Ptr{Cvoid}; end
+mutable struct Comm; h::Ptr{Cvoid}; world::Int; end
+
+function Model(cfg::RsysConfig, device::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rsys_model_create, LIB), Int32, (Ref{RsysConfig}, Int32, Ref{Ptr{Cvoid}}), cfg, device, h))
+    m = Model(h[]); finalizer(x -> ccall((:rsys_model_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), m); m
+end
+init_weights!(m::Model, seed::Integer) = check(ccall((:rsys_model_init_random, LIB), Int32, (Ptr{Cvoid}, UInt64), m.h, seed))
+function load_pretrained_embeddings!(m::Model, W::Matrix{Float32})   # W is (M, V) column-major = (V, M) row-major (transformer.jl:58)
+    GC.@preserve W check(ccall((:rsys_model_load_metadata, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64),
+                               m.h, W, size(W, 2), size(W, 1)))
+end
+function set_parameter!(m::Model, name::String, x::Array{Float32})
+    GC.@preserve x check(ccall((:rsys_param_set, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float32}, Int64), m.h, name, x, length(x)))
+end
+function get_parameter!(m::Model, name::String, out::Array{Float32})
+    GC.@preserve out check(ccall((:rsys_param_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float32}, Int64), m.h, name, out, length(out)))
+    out
+end
+function upload!(m::Model, b::RsysBatch)    # caller wraps this in GC.@preserve of the arrays b points to
+    check(ccall((:rsys_batch_upload, LIB), Int32, (Ptr{Cvoid}, Ref{RsysBatch}), m.h, b))
+end
+function forward_backward!(m::Model, evaluate::Bool, task_w::NTuple{4,Float32}, grad_scale::Float32, seed::UInt64, step::UInt64)
+    tw = Ref(task_w)
+    check(ccall((:rsys_forward_backward, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float32}, Float32, UInt64, UInt64),
+                m.h, evaluate ? 1 : 0, tw, grad_scale, seed, step))
+end
+function losses(m::Model)
+    lo = Vector{Float32}(undef, 12); ws = Vector{Float32}(undef, 4)
+    check(ccall((:rsys_losses_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), m.h, lo, ws))
+    lo, ws
+end
+
+function create_optimizer(m::Model; lr = 1f-4, betas = (0.9f0, 0.95f0), eps = 1f-8, weight_decay = 0.1f0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rsys_adamw_create, LIB), Int32, (Ptr{Cvoid}, Float32, Float32, Float32, Float32, Float32, Ref{Ptr{Cvoid}}),
+                m.h, lr, betas[1], betas[2], eps, weight_decay, h))
+    Optimizer(h[])
+end
+step!(o::Optimizer; lr_factor = 1f0, clip = 1f0, grad_div = 1f0) =
+    check(ccall((:rsys_adamw_step, LIB), Int32, (Ptr{Cvoid}, Float32, Float32, Float32), o.h, lr_factor, clip, grad_div))
+
+function unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:rsys_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id)); id
+end
+function Comm(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rsys_comm_init, LIB), Int32, (Ptr{UInt8}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}), id, rank, world, device, h))
+    Comm(h[], world)
+end
+self_test(c::Comm) = check(ccall((:rsys_self_test, LIB), Int32, (Ptr{Cvoid},), c.h))
+allreduce_grads!(m::Model, c::Comm) = check(ccall((:rsys_allreduce_grads, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
+
+# One optimizer step of train_epoch (transformer.py:256-276) with grad_accum = 1
+function train_step!(m::Model, o::Optimizer, c::Union{Comm,Nothing}, task_w, lr_factor, seed, step)
+    forward_backward!(m, false, task_w, 1f0, seed, step)
+    c === nothing || allreduce_grads!(m, c)
+    step!(o; lr_factor = Float32(lr_factor), clip = 1f0, grad_div = Float32(c === nothing ? 1 : c.world))
+end
+
+end # module

@@ -205,7 +205,7 @@ class OracleModel:
         B, T, D = x.shape
         rep = H // KV
         scale = 1.0 / math.sqrt(hd)
-        neg = np.where(mask, 0.0, -np.inf)[:, None]                     # (B,1,T,T)
+        neg = np.where(mask, 0.0, -np.inf).astype(self.dt)[:, None]     # (B,1,T,T)
         for l in range(cfg["num_layers"]):
             p = f"transformers.layers.{l}."
             c = {}
@@ -222,10 +222,11 @@ class OracleModel:
             k = apply_rope(k.reshape(B, T, KV, hd), cos, sin)
             v = v.reshape(B, T, KV, hd)
             kk = np.repeat(k, rep, axis=2); vv = np.repeat(v, rep, axis=2)   # GQA: head h -> kv head h//rep
-            s = np.einsum("bqhd,bkhd->bhqk", q, kk) * scale + neg
+            qh = q.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)  # (B,H,T,hd)
+            s = np.matmul(qh, kh.transpose(0, 1, 3, 2)) * scale + neg
             s = s - s.max(-1, keepdims=True)
             pr = np.exp(s); pr /= pr.sum(-1, keepdims=True)
-            o = np.einsum("bhqk,bkhd->bqhd", pr, vv).reshape(B, T, H * hd)
+            o = np.matmul(pr, vh).transpose(0, 2, 1, 3).reshape(B, T, H * hd)
             h = x + o @ P[p + "attn.output_proj.weight"].T
             hn, r2 = rmsnorm(h, P[p + "mlp_norm.scale"])
             a = hn @ P[p + "mlp.w1.weight"].T
@@ -267,11 +268,14 @@ class OracleModel:
             go = (gh @ P[p + "attn.output_proj.weight"]).reshape(B, T, H, hd)
             kk = np.repeat(c["k"], rep, axis=2); vv = np.repeat(c["v"], rep, axis=2)
             pr = c["pr"]
-            gvv = np.einsum("bhqk,bqhd->bkhd", pr, go)
-            gp = np.einsum("bqhd,bkhd->bhqk", go, vv)
+            goh = go.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)
+            qh = c["q"].transpose(0, 2, 1, 3)
+            prT = pr.transpose(0, 1, 3, 2)
+            gvv = np.matmul(prT, goh).transpose(0, 2, 1, 3)
+            gp = np.matmul(goh, vh.transpose(0, 1, 3, 2))
             gs = pr * (gp - (gp * pr).sum(-1, keepdims=True)) * scale
-            gq = np.einsum("bhqk,bkhd->bqhd", gs, kk)
-            gkk = np.einsum("bhqk,bqhd->bkhd", gs, c["q"])
+            gq = np.matmul(gs, kh).transpose(0, 2, 1, 3)
+            gkk = np.matmul(gs.transpose(0, 1, 3, 2), qh).transpose(0, 2, 1, 3)
             gk = gkk.reshape(B, T, KV, rep, hd).sum(3)
             gv = gvv.reshape(B, T, KV, rep, hd).sum(3)
             gq = apply_rope_bwd(gq, cos, sin).reshape(B, T, H * hd)

@@ -290,23 +290,36 @@ template int launch_attn_fwd<float>(const AttnParams&, hipStream_t);
 
 // ------------------------------------------------------------------------ delta = rowsum(dO * O) per head
 template <typename T>
-__global__ void attn_delta_kernel(AttnParams p) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*T*H
-  const long long total = (long long)p.B * p.T * p.H;
-  if (i >= total) return;
-  const int h = (int)(i % p.H);
-  const long long row = i / p.H;
-  const T* a = (const T*)p.dO + row * p.ldo + h * p.hd;
-  const T* o = (const T*)p.o + row * p.ldo + h * p.hd;
-  float acc = 0.f;
-  for (int d = 0; d < p.hd; ++d) acc += to_f32(a[d]) * to_f32(o[d]);
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  // one wave per token row; each lane owns 16-byte chunks; lanes of one head reduce with shuffles
+  constexpr int E = 16 / sizeof(T);
+  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int l = threadIdx.x & 63;
+  if (row >= (long long)p.B * p.T) return;
+  const int D = p.H * p.hd;
+  const int lph = p.hd / E;                 // lanes per head (2..32, power of two)
   const long long b = row / p.T; const int t = (int)(row % p.T);
-  ((float*)p.delta)[(b * p.H + h) * p.T + t] = acc;
+  for (int c0 = 0; c0 < D / E; c0 += 64) {
+    const int c = c0 + l;
+    float acc = 0.f;
+    if (c < D / E) {
+      uint4 ra = *(const uint4*)((const T*)p.dO + row * p.ldo + c * E);
+      uint4 rb = *(const uint4*)((const T*)p.o + row * p.ldo + c * E);
+      const T* a = (const T*)&ra; const T* o = (const T*)&rb;
+#pragma unroll
+      for (int k = 0; k < E; ++k) acc += to_f32(a[k]) * to_f32(o[k]);
+    }
+    for (int off = 1; off < lph; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    if (c < D / E && (l & (lph - 1)) == 0) {
+      const int h = (c * E) / p.hd;
+      ((float*)p.delta)[(b * p.H + h) * p.T + t] = acc;
+    }
+  }
 }
 template <typename T>
 int launch_attn_delta(const AttnParams& p, hipStream_t s) {
-  long long total = (long long)p.B * p.T * p.H;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  long long rows = (long long)p.B * p.T;
+  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

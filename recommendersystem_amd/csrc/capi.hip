@@ -1,6 +1,7 @@
 // extern "C" surface of librsys_hip.so (declared in include/rsys.h).
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <sstream>
@@ -60,6 +61,7 @@ struct rsys_comm {
   hipStream_t stream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   double* scratch = nullptr;
+  bool force = false;   // RSYS_FORCE_RCCL=1: run the collectives even at world == 1 (exercises RCCL on one GPU)
 };
 
 #define CHECK_HANDLE(h) do { if ((h) == nullptr) { set_error("null handle"); return RSYS_ERR_ARG; } } while (0)
@@ -242,6 +244,7 @@ int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, i
   HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   HIP_CHECK(hipMalloc((void**)&c->scratch, 64 * sizeof(double)));
+  { const char* f = getenv("RSYS_FORCE_RCCL"); c->force = f && f[0] == '1'; }
   *out = c;
   return RSYS_OK;
 }
@@ -266,7 +269,7 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   HIP_CHECK(hipSetDevice(m->device));
   int rc = model_finalize_grads(m);
   if (rc) return rc;
-  if (c->world == 1) return RSYS_OK;
+  if (c->world == 1 && !c->force) return RSYS_OK;
   HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
   HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
   const int64_t bucket = 16 * 1024 * 1024;  // floats
@@ -281,7 +284,7 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n) {
   CHECK_HANDLE(c);
   ARG_CHECK(n >= 1 && n <= 64 && x, "n in [1,64]");
-  if (c->world == 1) return RSYS_OK;
+  if (c->world == 1 && !c->force) return RSYS_OK;
   HIP_CHECK(hipSetDevice(c->device));
   HIP_CHECK(hipMemcpyAsync(c->scratch, x, n * 8, hipMemcpyHostToDevice, c->stream));
   NCCL_CHECK(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));

@@ -556,9 +556,10 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
       toc(m);
       if (bwd) {
         {
-          GemmParams p{};  // dEw = dlogits . F
+          GemmParams p{};  // dEw = dlogits . F   (few output tiles, K = V_m: split-K over the vocabulary)
+          HIP_CHECK(hipMemsetAsync(m->dE, 0, (size_t)KB * D * 4, s));
           p.A = m->logits; p.lda = m->ldl; p.B = Fm; p.ldb = D; p.C = m->dE; p.ldc = D; p.c_f32 = 1;
-          p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_STORE;
+          p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_ATOMIC;
           RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
         }
         RC(launch_scatter_rows_add(m->dE, m->idx[ti], 0, m->gy, D, KB, D, s));

@@ -1,0 +1,69 @@
+"""Shard reader mirroring PretrainDataset (notebooks/Training/transformer.py:37-98).
+
+The reference reads blosc-compressed HDF5 shards written by Training/transformer.jl:202-240; neither
+libhdf5 nor h5py exists in this image, so a shard here is an `.npz` with the same 27 keys and dtypes
+(an HDF5 adapter goes where HDF5 exists).  Directory layout and rank assignment are the
+reference's: `{datadir}/{shard}/{p}.npz`, shard directory i -> rank i % world (train.py:46-51).
+"""
+import glob
+import os
+
+import numpy as np
+
+from .dist import shard_for_rank
+
+
+def get_index_permutation(arr, rng):
+    """train.py:53-68: split at userid change points, permute the user blocks, keep order inside a block."""
+    arr = np.asarray(arr)
+    change_indices = np.where(arr[:-1] != arr[1:])[0] + 1
+    starts = np.concatenate([[0], change_indices])
+    ends = np.concatenate([change_indices, [len(arr)]])
+    block_permutation = rng.permutation(len(starts))
+    return np.concatenate([np.arange(starts[b], ends[b]) for b in block_permutation]).astype(np.int64)
+
+
+def block_shuffle(d, rng):
+    """train.py:70-73."""
+    p = get_index_permutation(d["userid"], rng)
+    for k in d:
+        d[k] = d[k][p]
+
+
+class PretrainDataset:
+    """Iterates batches of `tokens_per_batch` interactions; users may straddle batch boundaries exactly as in
+    the reference (train.py:91-98)."""
+
+    def __init__(self, datadir, local_rank, local_world_size, tokens_per_batch, seed=0):
+        self.batch_size = tokens_per_batch
+        shards = sorted(glob.glob(f"{datadir}/*/"))
+        self.fns = []
+        for x in shard_for_rank(shards, local_rank, local_world_size):
+            self.fns.extend(sorted(glob.glob(f"{x}/*.npz")))
+        self.rng = np.random.default_rng(seed)
+
+    def __iter__(self):
+        fns = list(self.fns)
+        self.rng.shuffle(fns)
+        for fn in fns:
+            with np.load(fn) as f:
+                d = {k: f[k] for k in f.files}
+            block_shuffle(d, self.rng)
+            n = len(d["userid"])
+            assert n % self.batch_size == 0
+            for i in range(0, n, self.batch_size):
+                yield {k: v[i:i + self.batch_size] for k, v in d.items()}
+
+
+def write_shards(datadir, streams, num_shards):
+    """Writes one `.npz` per (shard, part) and num_tokens.txt (transformer.jl:228-239)."""
+    total = 0
+    for i, parts in enumerate(streams):
+        dest = os.path.join(datadir, str(i % num_shards + 1))
+        os.makedirs(dest, exist_ok=True)
+        for p, d in enumerate(parts):
+            np.savez(os.path.join(dest, f"{p + 1}.npz"), **d)
+            total += len(d["userid"])
+    with open(os.path.join(datadir, "num_tokens.txt"), "w") as f:
+        f.write(str(total))
+    return total

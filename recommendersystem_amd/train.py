@@ -201,3 +201,53 @@ def train_step_unfused(model, optimizer, data, task_weights, masks=None, max_nor
     norm = clip_grad_norm_(model, max_norm)
     optimizer.step(lr_factor=lr_factor)
     return tloss, norm
+
+
+def checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, training_loss, test_loss, task_weights, save,
+                     basename="transformer.masked"):
+    """train.py:431-497 (rank-local-0 only is the caller's job).  The checkpoint is an `.npz` with the reference's
+    state-dict key names + AdamW moments + scheduler state + config JSON (a torch-pickle converter is SURVEY N3);
+    the metrics CSV has the reference's exact header and row format (train.py:483-494)."""
+    import json
+    import os
+    if save:
+        blob = {"model/" + k: v for k, v in model.state_dict(include_frozen=False).items() if not k.startswith("watch_head.")}
+        if optimizer is not None:
+            osd = optimizer.state_dict()
+            blob["optimizer/step"] = np.array([osd["step"]])
+            for n, s in osd["state"].items():
+                blob["optimizer/exp_avg/" + n] = s["exp_avg"]
+                blob["optimizer/exp_avg_sq/" + n] = s["exp_avg_sq"]
+        if scheduler is not None:
+            blob["scheduler/last_epoch"] = np.array([scheduler.state_dict()["last_epoch"]])
+        blob["config"] = np.frombuffer(json.dumps(config).encode(), np.uint8)
+        blob["epoch"] = np.array([epoch])
+        blob["training_loss"] = np.array(training_loss, np.float64)
+        blob["test_loss"] = np.array(test_loss, np.float64)
+        np.savez(os.path.join(datadir, basename + ".npz"), **blob)
+    names = [f"{m}.{metric}" for m in ALL_MEDIUMS for metric in ALL_METRICS]
+    csv_fn = os.path.join(datadir, basename + ".csv")
+    if epoch < 0:
+        with open(csv_fn, "w") as f:
+            f.write(",".join(["epoch", "training_loss", "test_loss"] + names) + "\n")
+    with open(csv_fn, "a") as f:
+        vals = [epoch, wsum(training_loss, task_weights), wsum(test_loss, task_weights)] + list(test_loss)
+        f.write(",".join([str(x) for x in vals]) + "\n")
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None):
+    """Resume (train.py:657-665, 690-700): returns (epoch, config)."""
+    import json
+    z = np.load(path)
+    sd = {k[len("model/"):]: z[k] for k in z.files if k.startswith("model/")}
+    model.load_state_dict(sd, strict=False)
+    if optimizer is not None and "optimizer/step" in z.files:
+        state = {}
+        for k in z.files:
+            if k.startswith("optimizer/exp_avg/"):
+                n = k[len("optimizer/exp_avg/"):]
+                state[n] = {"exp_avg": z[k], "exp_avg_sq": z["optimizer/exp_avg_sq/" + n]}
+        optimizer.load_state_dict({"step": int(z["optimizer/step"][0]), "state": state})
+    if scheduler is not None and "scheduler/last_epoch" in z.files:
+        scheduler.load_state_dict({"last_epoch": int(z["scheduler/last_epoch"][0])})
+    return int(z["epoch"][0]), json.loads(bytes(z["config"]).decode())

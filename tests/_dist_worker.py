@@ -1,0 +1,67 @@
+"""Worker of tests/test_dist_cpu.py: one rank of a world_size-2 gloo group on CPU."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import model_np, synth  # noqa: E402
+from recommendersystem_amd import dist as rdist  # noqa: E402
+from recommendersystem_amd.train import make_task_weights, reduce_mean  # noqa: E402
+
+
+class GlooComm:
+    """Same surface as recommendersystem_amd.dist.Comm, but the reductions run over gloo on host arrays
+    (the RCCL communicator needs GPUs)."""
+
+    def __init__(self, hg):
+        self.hg, self.rank, self.world = hg, hg.rank, hg.world
+
+    def all_reduce_sum(self, values):
+        return self.hg.all_reduce(values, "sum")
+
+
+def main():
+    out_path = sys.argv[1]
+    hg = rdist.HostGroup()
+    rank, world = hg.rank, hg.world
+    res = {"rank": rank, "world": world}
+    # control plane
+    payload = bytes(range(128)) if rank == 0 else bytes(128)
+    res["bcast_ok"] = hg.broadcast_bytes(payload, 0) == bytes(range(128))
+    res["sum"] = hg.all_reduce([rank + 1.0, 10.0 * (rank + 1)], "sum")
+    res["max"] = hg.all_reduce([float(rank)], "max")
+    hg.barrier()
+    # data path semantics (DDP mean of per-rank gradients, train.py:678-682): rank r owns stream seed^r
+    cfg = synth.make_config("tiny", mask_rate=0.25, mask_topk=6)
+    P = synth.make_params(cfg, 3, "test")
+    rows = 2
+    d = synth.make_batch(cfg, rows, 100 ^ rank)
+    wm, rm = synth.make_masks(cfg, rows, 200 ^ rank)
+    tw = make_task_weights()
+    model = model_np.OracleModel(cfg, P)
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    losses, G = model.forward(dm, False, True, tw)
+    names = synth.trainable_names(cfg)
+    flat = np.concatenate([G[n].reshape(-1) for n in names])
+    red = np.array(hg.all_reduce(flat.tolist(), "sum")) / world
+    res["grad_mean_norm"] = float(np.sqrt((red ** 2).sum()))
+    res["grad_local_norm"] = float(np.sqrt((flat ** 2).sum()))
+    # epoch metrics (reduce_mean, train.py:199-204)
+    wsums = [float(dm[f"{m}.{k}.weight"].sum()) for m in (0, 1) for k in ("watch", "rating")]
+    res["reduce_mean"] = reduce_mean(GlooComm(hg), [l * w for l, w in zip(losses, wsums)], wsums)
+    res["losses"] = losses
+    res["wsums"] = wsums
+    shards = [f"s{i}" for i in range(8)]
+    res["shards"] = rdist.shard_for_rank(shards, rank, world)
+    np.save(out_path + f".grad{rank}.npy", flat)
+    with open(out_path + f".{rank}.json", "w") as f:
+        json.dump(res, f)
+    hg.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,3 +219,28 @@ def test_random_masks_and_properties_at_scale():
         g = model.grad(name)
         assert np.isfinite(g).all() and np.abs(g).max() > 0
     model.close()
+
+
+def test_rccl_communicator_world1(monkeypatch):
+    """RCCL path on one GPU: ncclCommInitRank(world=1), the bucketed gradient all-reduce and the f64
+    all-reduce really call RCCL (RSYS_FORCE_RCCL=1) and leave sums unchanged; hardware_check self test."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    monkeypatch.setenv("RSYS_FORCE_RCCL", "1")
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, 5)
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    model(d, False, masks=(wm, rm))
+    before = {n: model.grad(n) for n in ("transformers.layers.0.mlp.w2.weight", "item_embedding.projection_layer.weight")}
+    comm = rdist.Comm(rdist.HostGroup(0, 1), 0)
+    comm.self_test()
+    assert comm.all_reduce_sum([1.5, 2.5]) == [1.5, 2.5]
+    comm.all_reduce_grads(model)
+    for n, g in before.items():
+        np.testing.assert_array_equal(model.grad(n), g)
+    comm.close()
+    model.close()
