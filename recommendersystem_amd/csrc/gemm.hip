@@ -31,37 +31,42 @@ template <> struct MmaT<float> {
   }
 };
 
-// ---- staging registers: one 16-byte LDS chunk worth of source data
-template <typename CT, bool F32SRC> struct Staged { uint4 v; };
-template <> struct Staged<bf16, true> { float4 a, b; };
+// ---- staging registers: one 16-byte LDS chunk worth of source data (+ its validity mask)
+template <typename CT, bool F32SRC> struct Staged { uint4 v; unsigned int msk; };
+template <> struct Staged<bf16, true> { uint4 a, b; unsigned int msk; };
 
-// Guarded 16-byte chunk load without a branch: an invalid chunk reads element 0 of the operand
-// (always mapped) and is then zeroed by a select, so the loads of a tile issue back to back.
+// 16-byte chunk load from (uniform base + 32-bit byte offset).  A guarded (invalid) chunk is redirected to
+// element 0 of the operand (always mapped) by the caller and zeroed with an AND mask when it is written to
+// LDS (chunk_bits), i.e. after the MFMA phase the load overlaps with; the loaded bits are always consumed, so
+// hipcc cannot sink the load into a conditional block (which would turn its counted vmcnt waits into vmcnt(0)).
 template <typename CT, bool F32SRC>
-__device__ __forceinline__ Staged<CT, F32SRC> load_chunk(const void* base, long long off, bool valid) {
+__device__ __forceinline__ Staged<CT, F32SRC> load_chunk_at(const char* base, unsigned int voff, bool valid) {
   Staged<CT, F32SRC> r;
-  off = valid ? off : 0;
+  r.msk = valid ? 0xFFFFFFFFu : 0u;
   if constexpr (is_bf16<CT>::value && F32SRC) {
-    const float4* p = (const float4*)((const float*)base + off);
-    float4 a = p[0], b = p[1];
-    const float4 z = make_float4(0, 0, 0, 0);
-    r.a = valid ? a : z; r.b = valid ? b : z;
+    const uint4* p = (const uint4*)(base + voff);
+    r.a = p[0]; r.b = p[1];
   } else {
-    uint4 v = *(const uint4*)((const CT*)base + off);
-    r.v = valid ? v : make_uint4(0, 0, 0, 0);
+    r.v = *(const uint4*)(base + voff);
   }
   return r;
 }
 
-template <typename CT, bool F32SRC>
+template <typename CT, bool F32SRC, bool FULL>
 __device__ __forceinline__ uint4 chunk_bits(const Staged<CT, F32SRC>& r) {
+  const unsigned int m = r.msk;
   if constexpr (is_bf16<CT>::value && F32SRC) {
+    uint4 a = r.a, b = r.b;
+    if constexpr (!FULL) { a.x &= m; a.y &= m; a.z &= m; a.w &= m; b.x &= m; b.y &= m; b.z &= m; b.w &= m; }
+    const float4 fa = *(float4*)&a, fb = *(float4*)&b;
     bf16x8 o;
-    o[0] = (bf16)r.a.x; o[1] = (bf16)r.a.y; o[2] = (bf16)r.a.z; o[3] = (bf16)r.a.w;
-    o[4] = (bf16)r.b.x; o[5] = (bf16)r.b.y; o[6] = (bf16)r.b.z; o[7] = (bf16)r.b.w;
+    o[0] = (bf16)fa.x; o[1] = (bf16)fa.y; o[2] = (bf16)fa.z; o[3] = (bf16)fa.w;
+    o[4] = (bf16)fb.x; o[5] = (bf16)fb.y; o[6] = (bf16)fb.z; o[7] = (bf16)fb.w;
     return *(uint4*)&o;
   } else {
-    return r.v;
+    uint4 v = r.v;
+    if constexpr (!FULL) { v.x &= m; v.y &= m; v.z &= m; v.w &= m; }
+    return v;
   }
 }
 
@@ -151,48 +156,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
   // LDS: [buf 0: A 16K | B 16K][buf 1: A 16K | B 16K]
 
-  Staged<CT, AF32> ra[4];
-  Staged<CT, BF32> rb[4];
-
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
+  // ---- per-thread staging geometry, computed once: 4 A chunks + 4 B chunks of 16 bytes per tile.
+  // Global address of a chunk = uniform 64-bit tile base (SGPRs) + 32-bit per-thread byte offset (VGPR), so the
+  // steady-state loads are `global_load_dwordx4 v, voff, s[base]` with no vector address arithmetic.
+  constexpr int ESA = (is_bf16<CT>::value && AF32) ? 4 : (int)sizeof(CT);   // bytes per source element
+  constexpr int ESB = (is_bf16<CT>::value && BF32) ? 4 : (int)sizeof(CT);
+  unsigned int aoff[4], boff[4];       // byte offset of the chunk inside the operand, relative to the block base
+  int arow[4], brow[4];                // K-major: k row inside the tile; row-major: chunk's first k inside the tile
+  bool aval[4], bval[4];               // K-major: the chunk's m/n range is inside the matrix
+  int ldsa[4], ldsb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = t + 256 * j;
-      if constexpr (!AKM) {
-        int row = c >> 3, ch = c & 7;
-        long long gr = min(m0 + row, p.M - 1);
-        int kk = k0 + ch * EPC;
-        ra[j] = load_chunk<CT, AF32>(p.A, gr * p.lda + kk, kk < p.K);
-      } else {
-        constexpr int CPR = 128 / EPC;
-        int krow = c / CPR, ch = c % CPR;
-        long long kk = k0 + krow;
-        int mm = m0 + ch * EPC;
-        ra[j] = load_chunk<CT, AF32>(p.A, kk * p.lda + mm, kk < p.K && mm < p.M);
-      }
-      if constexpr (!BKM) {
-        int row = c >> 3, ch = c & 7;
-        long long gr = min(n0 + row, p.N - 1);
-        int kk = k0 + ch * EPC;
-        rb[j] = load_chunk<CT, BF32>(p.B, gr * p.ldb + kk, kk < p.K);
-      } else {
-        constexpr int CPR = 128 / EPC;
-        int krow = c / CPR, ch = c % CPR;
-        long long kk = k0 + krow;
-        int nn = n0 + ch * EPC;
-        rb[j] = load_chunk<CT, BF32>(p.B, kk * p.ldb + nn, kk < p.K && nn < p.N);
-      }
+  for (int j = 0; j < 4; ++j) {
+    const int c = t + 256 * j;
+    ldsa[j] = lds_chunk_offset<CT, AKM>(c);
+    ldsb[j] = 16384 + lds_chunk_offset<CT, BKM>(c);
+    if constexpr (!AKM) {
+      const int row = c >> 3, ch = c & 7;
+      const int gr = min(m0 + row, p.M - 1) - m0;
+      aoff[j] = (unsigned int)(((long long)gr * p.lda + ch * EPC) * ESA);
+      arow[j] = ch * EPC; aval[j] = true;
+    } else {
+      constexpr int CPR = 128 / EPC;
+      const int krow = c / CPR, ch = c % CPR;
+      aoff[j] = (unsigned int)(((long long)krow * p.lda + ch * EPC) * ESA);
+      arow[j] = krow; aval[j] = (m0 + ch * EPC) < p.M;
     }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = t + 256 * j;
-      *(uint4*)(smem + buf * 32768 + lds_chunk_offset<CT, AKM>(c)) = chunk_bits<CT, AF32>(ra[j]);
-      *(uint4*)(smem + buf * 32768 + 16384 + lds_chunk_offset<CT, BKM>(c)) = chunk_bits<CT, BF32>(rb[j]);
+    if constexpr (!BKM) {
+      const int row = c >> 3, ch = c & 7;
+      const int gr = min(n0 + row, p.N - 1) - n0;
+      boff[j] = (unsigned int)(((long long)gr * p.ldb + ch * EPC) * ESB);
+      brow[j] = ch * EPC; bval[j] = true;
+    } else {
+      constexpr int CPR = 128 / EPC;
+      const int krow = c / CPR, ch = c % CPR;
+      boff[j] = (unsigned int)(((long long)krow * p.ldb + ch * EPC) * ESB);
+      brow[j] = krow; bval[j] = (n0 + ch * EPC) < p.N;
     }
-  };
+  }
+  const char* Ablk = (const char*)p.A + (AKM ? (long long)m0 : (long long)m0 * p.lda) * ESA;
+  const char* Bblk = (const char*)p.B + (BKM ? (long long)n0 : (long long)n0 * p.ldb) * ESB;
+  // a block is "full" when no chunk of any of its tiles needs a guard
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -200,13 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  gload(kt0);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) gload(kt + 1);
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int s = 0; s < MT::KSTEPS; ++s) {
       typename MT::Frag a[4], b[4];
@@ -219,184 +217,264 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = MT::mma(a[i], b[j], acc[i][j]);
     }
-    if (more) lstore(cur ^ 1);
+  };
+
+  // Software pipeline, two register sets: the loads of tile k+2 are issued before the MFMAs of tile k while
+  // tile k+1 is in flight.  Every global load / LDS store is unconditional (tile indices past the end are
+  // clamped to the last tile, their data is never consumed): with no branch around a memory operation hipcc
+  // keeps exact vmcnt counts, so the LDS store of tile k+1 waits for ITS loads only.
+  auto run = [&](auto FULLC) {
+    constexpr bool FULL = decltype(FULLC)::value;
+    Staged<CT, AF32> ra0[4], ra1[4];
+    Staged<CT, BF32> rb0[4], rb1[4];
+    auto gload = [&](Staged<CT, AF32>(&ra)[4], Staged<CT, BF32>(&rb)[4], int kt) {
+      const int k0 = kt * BK;
+      const char* At = Ablk + (AKM ? (long long)k0 * p.lda : (long long)k0) * ESA;   // uniform
+      const char* Bt = Bblk + (BKM ? (long long)k0 * p.ldb : (long long)k0) * ESB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (FULL) {
+          ra[j] = load_chunk_at<CT, AF32>(At, aoff[j], true);
+          rb[j] = load_chunk_at<CT, BF32>(Bt, boff[j], true);
+        } else {
+          const bool va = aval[j] && (k0 + arow[j] < p.K);
+          const bool vb = bval[j] && (k0 + brow[j] < p.K);
+          ra[j] = load_chunk_at<CT, AF32>(va ? At : (const char*)p.A, va ? aoff[j] : 0u, va);
+          rb[j] = load_chunk_at<CT, BF32>(vb ? Bt : (const char*)p.B, vb ? boff[j] : 0u, vb);
+        }
+      }
+    };
+    auto lstore = [&](const Staged<CT, AF32>(&ra)[4], const Staged<CT, BF32>(&rb)[4], int buf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *(uint4*)(smem + buf * 32768 + ldsa[j]) = chunk_bits<CT, AF32, FULL>(ra[j]);
+        *(uint4*)(smem + buf * 32768 + ldsb[j]) = chunk_bits<CT, BF32, FULL>(rb[j]);
+      }
+    };
+    const int klast = kt1 - 1;
+    gload(ra0, rb0, kt0);
+    gload(ra1, rb1, min(kt0 + 1, klast));
+    lstore(ra0, rb0, 0);
     __syncthreads();
-    cur ^= 1;
-  }
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      // even phase: LDS buffer 0 holds tile kt, set 1 holds tile kt+1 (in flight)
+      gload(ra0, rb0, min(kt + 2, klast));
+      compute(0);
+      lstore(ra1, rb1, 1);
+      __syncthreads();
+      // odd phase: LDS buffer 1 holds tile kt+1, set 0 holds tile kt+2 (in flight)
+      gload(ra1, rb1, min(kt + 3, klast));
+      if (kt + 1 < kt1) compute(1);
+      lstore(ra0, rb0, 0);
+      __syncthreads();
+    }
+  };
+  if (full) run(std::true_type{});
+  else run(std::false_type{});
 
   // ------------------------------------------------------------------ epilogue
-  // acc[i][j]: rows m0 + wr*64 + i*16 + 4*(l>>4) + r (r = 0..3), column n0 + wc*64 + j*16 + (l&15)
+  // The accumulators are staged through LDS (the operand tiles are dead by now) so that every global
+  // access of the epilogue is a full 128..512-byte row segment with 8..16 bytes per lane, instead of the
+  // MFMA layout's 2..4-byte column-strided stores.  acc[i][j][r]: row wr*64 + i*16 + 4*(l>>4) + r,
+  // column wc*64 + j*16 + (l&15) of the 128x128 tile; the tile leaves in two 64-row halves.
   const int fq = l >> 4, fr = l & 15;
+  constexpr int CS_LD = 132;   // f32 row-major staging tile [64][132]
+  constexpr int CT_LD = 68;    // f32 transposed staging tile [128 cols][68]
+  float* Cs = (float*)smem;
   const bool cf32 = p.c_f32 != 0;
-  const long long rbase = m0 + wr * 64 + 4 * fq;
-  const int cbase = n0 + wc * 64 + fr;
-  auto tiles = [&](auto&& fn) {
-    static_for<4>([&](auto i) { static_for<4>([&](auto j) { fn(i, j, rbase + i * 16, cbase + j * 16); }); });
-  };
-  switch (p.epi) {
-    case EPI_STORE:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
+  __syncthreads();
+
+  if (p.epi == EPI_ATOMIC) {
+    // split-K weight gradients: 64 lanes add 256 contiguous bytes per wave-instruction (full-rate shape)
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half) {
+        static_for<4>([&](auto i) { static_for<4>([&](auto j) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] * p.alpha);
-        }
-      });
-      break;
-    case EPI_ACCUM:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
+          for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * fq + r) * CS_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+        }); });
+      }
+      __syncthreads();
+      const int col = n0 + (t & 127);
+      for (int it = 0; it < 32; ++it) {
+        const int row_l = it * 2 + (t >> 7);
+        const long long row = m0 + half * 64 + row_l;
+        if (row < p.M && col < p.N) atomicAdd(&((float*)p.C)[row * p.ldc + col], Cs[row_l * CS_LD + (t & 127)]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  if (p.epi == EPI_QKV_ROPE) {
+    // rotate interleaved pairs (transformer.model.py:182-190) in registers: the pair partner is the neighbouring lane
+    const int half_hd = p.hd >> 1;
+    static_for<4>([&](auto i) {
+      int pos[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) ((float*)p.C)[(row0 + r) * p.ldc + col] += v[r];
-        }
-      });
-      break;
-    case EPI_ATOMIC:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) atomicAdd(&((float*)p.C)[(row0 + r) * p.ldc + col], v[r]);
-        }
-      });
-      break;
-    case EPI_BIAS:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
-          const float bv = p.bias[col];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) store_c<CT>(p, p.C, p.ldc, cf32, row0 + r, col, v[r] + bv);
-        }
-      });
-      break;
-    case EPI_RESIDUAL:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) ((float*)p.C)[(row0 + r) * p.ldc + col] = p.resid[(row0 + r) * p.ldr + col] + v[r];
-        }
-      });
-      break;
-    case EPI_TABLE:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
-          const float bv = p.bias[col];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) {
-              const long long row = row0 + r;
-              const float f = v[r] + p.E[row * p.ldc + col] + bv;
-              ((float*)p.C)[row * p.ldc + col] = f;
-              ((CT*)p.C2)[row * p.ldc2 + col] = from_f32<CT>(f);
-            }
-        }
-      });
-      break;
-    case EPI_GELU:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        if (col < p.N) {
-          const float bv = p.bias[col];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) {
-              const long long row = row0 + r;
-              const float z = v[r] + bv;
-              ((CT*)p.C)[row * p.ldc + col] = from_f32<CT>(z);
-              ((CT*)p.C2)[row * p.ldc2 + col] = from_f32<CT>(0.5f * z * (1.f + erff(z * 0.70710678118654752f)));
-            }
-        }
-      });
-      break;
-    case EPI_SWIGLU:
-      // columns interleaved in 16-wide blocks [a | b]: tiles (i, 2jj) and (i, 2jj+1) of one lane pair up
-      static_for<4>([&](auto i) {
-        static_for<2>([&](auto jj) {
-          const f32x4 va = acc[i][2 * jj], vb = acc[i][2 * jj + 1];
-          const long long row0 = rbase + i * 16;
-          const int col_a = cbase + jj * 32, col_b = col_a + 16;
-          const int gcol = ((n0 + wc * 64) >> 1) + jj * 16 + fr;
-          if (col_b < p.N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const long long row = row0 + r;
-              if (row < p.M) {
-                const float a = va[r], b = vb[r];
-                ((CT*)p.C)[row * p.ldc + col_a] = from_f32<CT>(a);
-                ((CT*)p.C)[row * p.ldc + col_b] = from_f32<CT>(b);
-                const float sg = 1.f / (1.f + __expf(-a));
-                ((CT*)p.C2)[row * p.ldc2 + gcol] = from_f32<CT>(a * sg * b);
-              }
-            }
-          }
-        });
-      });
-      break;
-    case EPI_QKV_ROPE:
-    case EPI_STORE_HEADS_T:
-      tiles([&](auto i, auto j, long long row0, int col) {
-        const f32x4 v = acc[i][j];
-        // region / head bookkeeping (16 columns of an MFMA tile never straddle a head: hd % 16 == 0)
-        const bool cok = col < p.N;
-        const int ccol = cok ? col : 0;
-        int region = 0, cc = ccol;
-        void* XT = p.C2;
-        int heads = p.N / p.hd;
-        if (p.epi == EPI_QKV_ROPE) {
-          if (ccol < p.n_q) { region = 0; cc = ccol; XT = p.qT; heads = p.n_q / p.hd; }
-          else if (ccol < p.n_q + p.n_k) { region = 1; cc = ccol - p.n_q; XT = p.kT; heads = p.n_k / p.hd; }
-          else { region = 2; cc = ccol - p.n_q - p.n_k; XT = p.vT; heads = (p.N - p.n_q - p.n_k) / p.hd; }
-        }
-        const int head = cc / p.hd, d = cc % p.hd;
-        const bool rot = (p.epi == EPI_QKV_ROPE) && region < 2;
-        float o[4];
+      for (int r = 0; r < 4; ++r) {
+        const int row = min((int)(m0 + wr * 64 + i * 16 + 4 * fq + r), p.M - 1);
+        pos[r] = p.rope_pos ? p.rope_pos[row] : row % p.T;
+      }
+      static_for<4>([&](auto j) {
+        const int col = n0 + wc * 64 + j * 16 + fr;
+        const bool rot = col < p.n_q + p.n_k;       // q and k regions rotate, v does not
+        const int cc = col < p.n_q ? col : col - p.n_q;
+        const int d2 = (cc & (p.hd - 1)) >> 1;      // hd is a power of two
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x = v[r];
+          const float x = acc[i][j][r];
           const float partner = __shfl_xor(x, 1, 64);
           if (rot) {
-            const long long row = min(row0 + r, (long long)p.M - 1);
-            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
-            const float c = p.rope_cos[pos * (p.hd >> 1) + (d >> 1)];
-            const float sn = p.rope_sin[pos * (p.hd >> 1) + (d >> 1)];
-            x = (l & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
-          }
-          o[r] = x;
-        }
-        if (cok) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) ((CT*)p.C)[(row0 + r) * p.ldc + col] = from_f32<CT>(o[r]);
-          if (XT != nullptr && row0 < p.M) {
-            const long long b = row0 / p.T;
-            const int t0 = (int)(row0 % p.T);
-            CT* dst = (CT*)XT + ((b * heads + head) * p.hd + d) * (long long)p.T + t0;
-            if (row0 + 3 < p.M) {
-              if constexpr (is_bf16<CT>::value) {
-                bf16x4 pk; pk[0] = (bf16)o[0]; pk[1] = (bf16)o[1]; pk[2] = (bf16)o[2]; pk[3] = (bf16)o[3];
-                *(bf16x4*)dst = pk;
-              } else {
-                *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (row0 + r < p.M) dst[r] = from_f32<CT>(o[r]);
-            }
+            const float c = p.rope_cos[pos[r] * half_hd + d2], sn = p.rope_sin[pos[r] * half_hd + d2];
+            acc[i][j][r] = (l & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
           }
         }
       });
-      break;
-    default: break;
+    });
+  }
+
+  const bool has_t = (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T);
+  for (int half = 0; half < 2; ++half) {
+    // ---- primary tile, row-major
+    if (wr == half) {
+      static_for<4>([&](auto i) { static_for<4>([&](auto j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * fq + r) * CS_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+      }); });
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+      const int idx = t + 256 * it;
+      const int row_l = idx >> 5, c4 = (idx & 31) * 4;
+      const long long row = m0 + half * 64 + row_l;
+      const int col = n0 + c4;
+      if (row >= p.M || col >= p.N) continue;
+      float4 v4 = *(const float4*)&Cs[row_l * CS_LD + c4];
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      const int nv = min(4, p.N - col);
+      float w2[4] = {0.f, 0.f, 0.f, 0.f};   // second output (C2) where the epilogue has one
+      bool two = false;
+      switch (p.epi) {
+        case EPI_STORE:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= p.alpha;
+          break;
+        case EPI_ACCUM:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += ((const float*)p.C)[row * p.ldc + col + k];
+          break;
+        case EPI_BIAS:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += p.bias[col + k];
+          break;
+        case EPI_RESIDUAL:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += p.resid[row * p.ldr + col + k];
+          break;
+        case EPI_TABLE:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nv) { v[k] += p.E[row * p.ldc + col + k] + p.bias[col + k]; w2[k] = v[k]; }
+          two = true;
+          break;
+        case EPI_GELU:
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nv) {
+            v[k] += p.bias[col + k];
+            w2[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+          }
+          two = true;
+          break;
+        default: break;   // QKV_ROPE / STORE_HEADS_T / SWIGLU: plain store of the primary tile
+      }
+      const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
+      if (outf32) {
+        float* dst = (float*)p.C + row * p.ldc + col;
+        if (nv == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int k = 0; k < nv; ++k) dst[k] = v[k];
+      } else {
+        CT* dst = (CT*)p.C + row * p.ldc + col;
+        if (nv == 4) {
+          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v[0]; pk[1] = (bf16)v[1]; pk[2] = (bf16)v[2]; pk[3] = (bf16)v[3]; *(bf16x4*)dst = pk; }
+          else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        } else for (int k = 0; k < nv; ++k) dst[k] = from_f32<CT>(v[k]);
+      }
+      if (two) {
+        CT* dst2 = (CT*)p.C2 + row * p.ldc2 + col;
+        if (nv == 4) {
+          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)w2[0]; pk[1] = (bf16)w2[1]; pk[2] = (bf16)w2[2]; pk[3] = (bf16)w2[3]; *(bf16x4*)dst2 = pk; }
+          else *(float4*)dst2 = make_float4(w2[0], w2[1], w2[2], w2[3]);
+        } else for (int k = 0; k < nv; ++k) dst2[k] = from_f32<CT>(w2[k]);
+      }
+    }
+    __syncthreads();
+
+    // ---- per-head transposed copy [b][head][d][t] (Q^T,K^T,V^T / dO^T): tokens contiguous
+    if (has_t) {
+      float* Ct = (float*)smem;
+      if (wr == half) {
+        static_for<4>([&](auto i) { static_for<4>([&](auto j) {
+          const f32x4 v = acc[i][j];
+          *(float4*)&Ct[(wc * 64 + j * 16 + fr) * CT_LD + i * 16 + 4 * fq] = make_float4(v[0], v[1], v[2], v[3]);
+        }); });
+      }
+      __syncthreads();
+      for (int it = 0; it < 8; ++it) {
+        const int idx = t + 256 * it;
+        const int col_l = idx >> 4, r4 = (idx & 15) * 4;
+        const int col = n0 + col_l;
+        const int row0 = m0 + half * 64 + r4;
+        if (col >= p.N || row0 >= p.M) continue;
+        int cc = col, heads = p.N / p.hd;
+        void* XT = p.C2;
+        if (p.epi == EPI_QKV_ROPE) {
+          if (col < p.n_q) { XT = p.qT; heads = p.n_q / p.hd; }
+          else if (col < p.n_q + p.n_k) { cc = col - p.n_q; XT = p.kT; heads = p.n_k / p.hd; }
+          else { cc = col - p.n_q - p.n_k; XT = p.vT; heads = (p.N - p.n_q - p.n_k) / p.hd; }
+        }
+        if (XT == nullptr) continue;
+        const int head = cc / p.hd, d = cc % p.hd;
+        const int b = row0 / p.T, t0 = row0 % p.T;
+        const float4 v4 = *(const float4*)&Ct[col_l * CT_LD + r4];
+        CT* dst = (CT*)XT + ((long long)(b * heads + head) * p.hd + d) * p.T + t0;
+        const int nr = min(4, p.M - row0);
+        if (nr == 4) {
+          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v4.x; pk[1] = (bf16)v4.y; pk[2] = (bf16)v4.z; pk[3] = (bf16)v4.w; *(bf16x4*)dst = pk; }
+          else *(float4*)dst = v4;
+        } else {
+          const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+          for (int k = 0; k < nr; ++k) dst[k] = from_f32<CT>(vv[k]);
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- SwiGLU product g = silu(a)*b: columns are interleaved in 16-wide blocks [a | b], lane-local pairs
+    if (p.epi == EPI_SWIGLU) {
+      if (wr == half) {
+        static_for<4>([&](auto i) { static_for<2>([&](auto jj) {
+          const f32x4 va = acc[i][2 * jj], vb = acc[i][2 * jj + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = va[r], b = vb[r];
+            Cs[(i * 16 + 4 * fq + r) * CT_LD + wc * 32 + jj * 16 + fr] = a / (1.f + __expf(-a)) * b;
+          }
+        }); });
+      }
+      __syncthreads();
+      for (int it = 0; it < 4; ++it) {
+        const int idx = t + 256 * it;
+        const int row_l = idx >> 4, c4 = (idx & 15) * 4;
+        const long long row = m0 + half * 64 + row_l;
+        const int gcol = (n0 >> 1) + c4;
+        if (row >= p.M || gcol * 2 >= p.N) continue;
+        const float4 v4 = *(const float4*)&Cs[row_l * CT_LD + c4];
+        CT* dst = (CT*)p.C2 + row * p.ldc2 + gcol;
+        if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v4.x; pk[1] = (bf16)v4.y; pk[2] = (bf16)v4.z; pk[3] = (bf16)v4.w; *(bf16x4*)dst = pk; }
+        else *(float4*)dst = v4;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -426,7 +504,9 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   else ARG_CHECK(p.ldb >= ((p.N + EPC - 1) / EPC) * EPC, "gemm: K-major B rows must be padded to a whole chunk");
   if (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T)
     ARG_CHECK(p.hd % 16 == 0 && p.T % 4 == 0, "gemm: head epilogues need hd % 16 == 0 and T % 4 == 0");
-  if (p.epi == EPI_SWIGLU) ARG_CHECK(p.N % 32 == 0, "gemm: swiglu epilogue needs N % 32 == 0");
+  if (p.epi == EPI_SWIGLU) ARG_CHECK(p.N % 32 == 0 && p.ldc2 % 4 == 0, "gemm: swiglu epilogue needs N % 32 == 0");
+  ARG_CHECK(p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0, "gemm: C rows must keep 16-byte alignment (ldc % 4 == 0)");
+  if (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);
