@@ -145,13 +145,12 @@ int32_t rsys_dev_memset(void* dst, int value, size_t bytes);
 int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                      int64_t lda, int64_t ldb, int64_t ldc, int32_t a_km, int32_t b_km, int32_t a_f32, int32_t c_f32,
                      int32_t splitk);
-/* attention fwd+bwd on caller-provided device buffers (T-typed): qkv [B*T][(H+2KV)*hd] post-RoPE, per-head
- * transposed copies qT,kT,vT,dOT [B][heads][hd][T], dO [B*T][H*hd], uid/tm [B*T] int32, rope tables
- * [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32, dqkv [B*T][(H+2KV)*hd] (un-rotated grads) */
+/* attention fwd+bwd on caller-provided device buffers (T-typed): qkv [B*T][(H+2KV)*hd] post-RoPE, dO [B*T][H*hd],
+ * uid/tm [B*T] int32, rope tables [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32,
+ * dqkv [B*T][(H+2KV)*hd] (gradients w.r.t. the un-rotated q, k and v) */
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
-                          const void* qT, const void* kT, const void* vT, const int32_t* uid, const int32_t* tm,
-                          void* O, float* lse, const void* dO, const void* dOT, void* dqkv, const float* rope_cos,
-                          const float* rope_sin);
+                          const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
+                          const float* rope_cos, const float* rope_sin);
 int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-phase HIP-event timings */
 int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
 

@@ -3,33 +3,32 @@
 // (tmid[kv]==0 OR tmid[q]==tmid[kv]); GQA (q head h -> kv head h/(H/KV)); scores
 // scaled by 1/sqrt(hd) (flex_attention default, model.py:278-285).
 //
-// gfx950 design: 64x64 (q x kv) tiles, 4 waves per workgroup, each wave owns 16
-// rows; every contraction is an MFMA 16x16 product whose operands are read as
-// contiguous rows from LDS -- the QKV / dO GEMM epilogues also emit per-head
-// transposed copies (Q^T,K^T,V^T,dO^T: [b][head][hd][T]) so no in-kernel
-// transpose is needed.  Tiles with no allowed pair are skipped through per-row
-// tile bitmaps built once per step (the reference rebuilds a dense block mask every
-// step, model.py:488-490).  Backward is two kernels (dK/dV per kv tile, dQ per q
-// tile): no float atomics, bitwise reproducible.
+// gfx950 design.  64x64 (q x kv) tiles, 4 waves per workgroup, 16 q (or kv) per wave ON THE LANES:
+// every first-stage product is computed transposed (S^T = K Q^T: rows = kv in the accumulator registers,
+// column = q on the lane), so
+//   * softmax statistics of a query are lane-local (16 values + two cross-group shuffles), and
+//   * the probabilities never leave the registers: a 16x16 accumulator tile IS the B operand of the next
+//     MFMA (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"); the
+//     matching A operand (V^T, K^T, Q^T, dO^T fragments with the same k-slot order) is read from the
+//     row-major LDS tile with ds_read_b64_tr_b16 -- no transposed copies in HBM, no P round trip through LDS.
+// Tile pairs with no allowed element are skipped, pairs where every element is allowed skip the mask
+// arithmetic (two bitmaps per row built once per step; the reference rebuilds a dense block mask every step,
+// model.py:488-490).  K/V (resp. Q/dO) tiles are double-buffered in LDS, one barrier per tile.
+// Backward is two kernels (dK/dV per kv tile, dQ per q tile): no float atomics, bitwise reproducible.
 #include "kernels.hpp"
 
 namespace rsys {
 
+#define SENT_Q (-2147483647)
+#define SENT_K (-2147483646)
+constexpr float LOG2E = 1.4426950408889634f;
+
 template <typename T> struct AMma;
 template <> struct AMma<bf16> {
-  static constexpr int KS = 32;
+  static constexpr int KS = 32;   // contraction per MFMA
   static constexpr int PAD = 8;
   using Frag = bf16x8;
   static __device__ __forceinline__ Frag zero() { Frag f; for (int i = 0; i < 8; ++i) f[i] = (bf16)0.f; return f; }
-  // fragment of a row-major tile: row = row0 + (l&15), k = k0 + 8*(l>>4) .. +7
-  static __device__ __forceinline__ Frag lds(const bf16* tile, int ld, int row0, int k0, int l) {
-    return *(const bf16x8*)(tile + (row0 + (l & 15)) * ld + k0 + 8 * (l >> 4));
-  }
-  static __device__ __forceinline__ Frag glb(const bf16* rowptr, int k0, int kmax, int l) {
-    int k = k0 + 8 * (l >> 4);
-    if (k < kmax) return *(const bf16x8*)(rowptr + k);
-    return zero();
-  }
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct AMma<float> {
@@ -37,13 +36,6 @@ template <> struct AMma<float> {
   static constexpr int PAD = 4;
   using Frag = float;
   static __device__ __forceinline__ Frag zero() { return 0.f; }
-  static __device__ __forceinline__ Frag lds(const float* tile, int ld, int row0, int k0, int l) {
-    return tile[(row0 + (l & 15)) * ld + k0 + (l >> 4)];
-  }
-  static __device__ __forceinline__ Frag glb(const float* rowptr, int k0, int kmax, int l) {
-    int k = k0 + (l >> 4);
-    return k < kmax ? rowptr[k] : 0.f;
-  }
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 
@@ -51,63 +43,126 @@ template <typename T, int HD> struct ACfg {
   static constexpr int KS = AMma<T>::KS;
   static constexpr int HDP = HD > KS ? HD : KS;      // contraction over d padded to one k-step
   static constexpr int LDD = HDP + AMma<T>::PAD;      // [64 tokens][HDP] tiles
-  static constexpr int LDT = 64 + AMma<T>::PAD;       // [HD][64 tokens] tiles and P tiles
   static constexpr int E = 16 / sizeof(T);
+  static constexpr int NDS = HDP / KS;                // k-steps of a contraction over d
+  static constexpr int TILE = 64 * LDD;               // elements per staged tile
 };
 
-// stage a [64 tokens][HD] tile (row-major source, row stride ld) into LDS [64][LDD]
-template <typename T, int HD>
-__device__ __forceinline__ void stage_rows(T* dst, const T* src, long long ld, int t, int nvalid) {
-  using C = ACfg<T, HD>;
-  constexpr int CPR = HD / C::E;
-  for (int c = t; c < 64 * CPR; c += 256) {
-    int row = c / CPR, ch = c % CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < nvalid) v = *(const uint4*)(src + row * ld + ch * C::E);
-    *(uint4*)(dst + row * C::LDD + ch * C::E) = v;
+// ---- fragments --------------------------------------------------------------------------------------------
+// natural-order fragment of a row-major tile: row = row0 + (l&15), k = k0 + [8*(l>>4) .. +7] (bf16) / k0 + (l>>4) (f32)
+template <typename T>
+__device__ __forceinline__ typename AMma<T>::Frag frag_rows(const T* tile, int ld, int row0, int k0, int l) {
+  if constexpr (is_bf16<T>::value) return *(const bf16x8*)(tile + (row0 + (l & 15)) * ld + k0 + 8 * (l >> 4));
+  else return tile[(row0 + (l & 15)) * ld + k0 + (l >> 4)];
+}
+template <typename T>
+__device__ __forceinline__ typename AMma<T>::Frag frag_global(const T* rowptr, int k0, int kmax, int l) {
+  if constexpr (is_bf16<T>::value) {
+    const int k = k0 + 8 * (l >> 4);
+    if (k < kmax) return *(const bf16x8*)(rowptr + k);
+    return AMma<bf16>::zero();
+  } else {
+    const int k = k0 + (l >> 4);
+    return k < kmax ? rowptr[k] : 0.f;
   }
 }
-// stage a [HD][64 tokens] tile from a transposed copy (row stride T tokens) into LDS [HD][LDT]
+// bf16: transposed fragment of a row-major [token][d] tile for the contraction over 32 tokens tok0..tok0+31 in the
+// ACCUMULATOR slot order (slot j<4 -> token tok0 + 4g + j, j>=4 -> tok0 + 16 + 4g + j-4); MFMA row = d0 + (l&15).
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int ld, int tok0, int d0, int l) {
+  const int g = l >> 4, i = l & 15;
+  const bf16* a = tile + (tok0 + 4 * g + (i >> 2)) * ld + d0 + 4 * (i & 3);
+  bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)a);
+  bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(a + 16 * ld));
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+  bf16x8 o;
+  o[0] = (bf16)lo[0]; o[1] = (bf16)lo[1]; o[2] = (bf16)lo[2]; o[3] = (bf16)lo[3];
+  o[4] = (bf16)hi[0]; o[5] = (bf16)hi[1]; o[6] = (bf16)hi[2]; o[7] = (bf16)hi[3];
+  return o;
+}
+
+// acc[jd] (rows d, col = lane) += X^T[d][tok] * P[tok][lane] for the 64 tokens of a tile, where P[i] are the four
+// 16-token accumulator tiles (rows = tokens) and X is the row-major LDS tile [token][d].
 template <typename T, int HD>
-__device__ __forceinline__ void stage_trans(T* dst, const T* src, long long ldT, int t, int nvalid) {
+__device__ __forceinline__ void acc_second_stage(f32x4 (&acc)[HD / 16], const f32x4 (&P)[4], const T* X, int l) {
   using C = ACfg<T, HD>;
-  constexpr int CPR = 64 / C::E;
-  for (int c = t; c < HD * CPR; c += 256) {
-    int row = c / CPR, ch = c % CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ch * C::E < nvalid) v = *(const uint4*)(src + row * ldT + ch * C::E);   // T % 8 == 0: chunks never straddle T
-    *(uint4*)(dst + row * C::LDT + ch * C::E) = v;
+  if constexpr (is_bf16<T>::value) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const bf16x8 pf = pack8(P[2 * t2], P[2 * t2 + 1]);
+#pragma unroll
+      for (int jd = 0; jd < HD / 16; ++jd) acc[jd] = AMma<bf16>::mma(frag_tr(X, C::LDD, 32 * t2, 16 * jd, l), pf, acc[jd]);
+    }
+  } else {
+    const int g = l >> 4, fr = l & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* xr = X + (16 * i + 4 * g + r) * C::LDD + fr;
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd) acc[jd] = AMma<float>::mma(xr[16 * jd], P[i][r], acc[jd]);
+      }
   }
 }
-// tokens past the end of a row (T % 64 != 0) get ids that match nothing
-#define SENT_Q (-2147483647)
-#define SENT_K (-2147483646)
+
+// first stage: S[i] (rows = 16 tokens of tile i, col = lane) = X[tok][:] . f[:]  with f = register fragments of the lane's vector
+template <typename T, int HD>
+__device__ __forceinline__ void first_stage(f32x4 (&S)[4], const T* X, const typename AMma<T>::Frag (&f)[ACfg<T, HD>::NDS], int l) {
+  using C = ACfg<T, HD>;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    S[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < C::NDS; ++s) S[i] = AMma<T>::mma(frag_rows<T>(X, C::LDD, 16 * i, s * C::KS, l), f[s], S[i]);
+  }
+}
+
+// ---- staging ----------------------------------------------------------------------------------------------
+template <typename T, int HD> struct TileRegs { uint4 v[(64 * HD * sizeof(T) / 16 + 255) / 256]; };
+
+template <typename T, int HD>
+__device__ __forceinline__ void tile_load(TileRegs<T, HD>& r, const T* src, long long ld, int t, int nvalid) {
+  using C = ACfg<T, HD>;
+  constexpr int CPR = HD / C::E, N = 64 * CPR;
+#pragma unroll
+  for (int k = 0; k < (N + 255) / 256; ++k) {
+    const int c = t + 256 * k;
+    const int row = c / CPR, ch = c % CPR;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < N && row < nvalid) v = *(const uint4*)(src + row * ld + ch * C::E);
+    r.v[k] = v;
+  }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void tile_store(const TileRegs<T, HD>& r, T* dst, int t) {
+  using C = ACfg<T, HD>;
+  constexpr int CPR = HD / C::E, N = 64 * CPR;
+#pragma unroll
+  for (int k = 0; k < (N + 255) / 256; ++k) {
+    const int c = t + 256 * k;
+    if (c < N) *(uint4*)(dst + (c / CPR) * C::LDD + (c % CPR) * C::E) = r.v[k];
+  }
+}
 template <typename T, int HD>
 __device__ __forceinline__ void zero_pad_cols(T* dst, int t) {
   using C = ACfg<T, HD>;
   if constexpr (C::HDP > HD) {
-    for (int c = t; c < 64 * (C::HDP - HD); c += 256) {
-      int row = c / (C::HDP - HD), col = HD + c % (C::HDP - HD);
-      dst[row * C::LDD + col] = from_f32<T>(0.f);
-    }
+    for (int c = t; c < 64 * (C::HDP - HD); c += 256) dst[(c / (C::HDP - HD)) * C::LDD + HD + c % (C::HDP - HD)] = from_f32<T>(0.f);
   }
 }
-
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
+__device__ __forceinline__ int next_bit(unsigned int bits, int from) {  // lowest set bit index >= from, or 32
+  const unsigned int m = from >= 32 ? 0u : (bits >> from) << from;
+  return m ? __ffs(m) - 1 : 32;
 }
 
 // ------------------------------------------------------------------------ tile maps
+// qmap / qmap_full [b][q tile]: bit j = kv tile j has some / only allowed pairs; kmap* is the transposed relation.
 __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   __shared__ int uq[64], tq[64];
-  __shared__ unsigned int bits;
+  __shared__ unsigned int any_bits;
+  __shared__ int cnt[32];
   const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const int nt = (p.T + 63) / 64;
   const long long base = (long long)b * p.T;
@@ -115,25 +170,50 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
     const bool v = qt * 64 + t < p.T;
     uq[t] = v ? p.uid[base + qt * 64 + t] : SENT_Q; tq[t] = v ? p.tm[base + qt * 64 + t] : 0;
   }
-  if (t == 0) bits = 0u;
+  if (t == 0) any_bits = 0u;
+  if (t < 32) cnt[t] = 0;
   __syncthreads();
   for (int kv = t; kv < p.T; kv += 256) {
     const int uk = p.uid[base + kv], tk = p.tm[base + kv];
-    bool any = false;
-    for (int i = 0; i < 64; ++i) any |= (uq[i] == uk) && (tk == 0 || tq[i] == tk);
-    if (any) atomicOr(&bits, 1u << (kv >> 6));
+    int n = 0;
+    for (int i = 0; i < 64; ++i) n += ((uq[i] == uk) && (tk == 0 || tq[i] == tk)) ? 1 : 0;
+    if (n) { atomicOr(&any_bits, 1u << (kv >> 6)); atomicAdd(&cnt[kv >> 6], n); }
   }
   __syncthreads();
-  if (t == 0) p.qmap[b * nt + qt] = bits;
-  if (t < nt && ((bits >> t) & 1u)) atomicOr(&p.kmap[b * nt + t], 1u << qt);
+  if (t < nt) {
+    const bool any = (any_bits >> t) & 1u, full = cnt[t] == 4096;
+    if (any) atomicOr(&p.kmap[b * nt + t], 1u << qt);
+    if (full) atomicOr(&p.kmap_full[b * nt + t], 1u << qt);
+    if (full) atomicOr(&p.qmap_full[b * nt + qt], 1u << t);
+  }
+  if (t == 0) p.qmap[b * nt + qt] = any_bits;
 }
 
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
-  HIP_CHECK(hipMemsetAsync(p.kmap, 0, sizeof(unsigned int) * p.B * ((p.T + 63) / 64), s));
+  const size_t bytes = sizeof(unsigned int) * p.B * ((p.T + 63) / 64);
+  HIP_CHECK(hipMemsetAsync(p.kmap, 0, bytes, s));
+  HIP_CHECK(hipMemsetAsync(p.kmap_full, 0, bytes, s));
+  HIP_CHECK(hipMemsetAsync(p.qmap_full, 0, bytes, s));
   hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
+}
+
+// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS, the lane's own ids (u,tmv);
+// LANE_IS_Q: the lane is the query and the rows are keys, else the lane is the key and the rows are queries.
+template <bool LANE_IS_Q>
+__device__ __forceinline__ void mask_tile(f32x4& S, const int* us, const int* ts, int tok0, int u, int tmv, int g, float fill) {
+  const int4 u4 = *(const int4*)(us + tok0 + 4 * g);
+  const int4 t4 = *(const int4*)(ts + tok0 + 4 * g);
+  const int uu[4] = {u4.x, u4.y, u4.z, u4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bool ok;
+    if (LANE_IS_Q) ok = (u == uu[r]) && (tt[r] == 0 || tmv == tt[r]);       // row = key
+    else ok = (u == uu[r]) && (tmv == 0 || tt[r] == tmv);                     // row = query, lane = key
+    S[r] = ok ? S[r] : fill;
+  }
 }
 
 // ------------------------------------------------------------------------ forward
@@ -142,119 +222,117 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ks = (T*)smem_raw;                       // [64][LDD]
-  T* Vt = Ks + 64 * C::LDD;                   // [HD][LDT]
-  T* Ps = Vt + HD * C::LDT;                   // [4][16][LDT]
-  int* uk = (int*)(Ps + 4 * 16 * C::LDT);     // [64]
-  int* tk = uk + 64;
+  T* Ks = (T*)smem_raw;                       // [2][64][LDD]
+  T* Vs = Ks + 2 * C::TILE;                   // [2][64][LDD]
+  int* uk = (int*)(Vs + 2 * C::TILE);         // [2][64]
+  int* tk = uk + 128;                         // [2][64]
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int kvh = h / (p.H / p.KV);
   const int nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
-  const float scale = rsqrtf((float)HD);
-  const int qr0 = qt * 64 + w * 16;
-  constexpr int NQS = C::HDP / C::KS;
-  typename M::Frag qf[NQS];
+  const float c2 = rsqrtf((float)HD) * LOG2E;        // scores are handled in log2 units
+  const int q = qt * 64 + w * 16 + fr;               // this lane's query
+  const bool qv = q < p.T;
+  typename M::Frag qf[C::NDS];
   {
-    const T* qrow = (const T*)p.q + (tok0 + min(qr0 + fr, p.T - 1)) * p.ld + h * HD;
+    const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + h * HD;
 #pragma unroll
-    for (int s = 0; s < NQS; ++s) qf[s] = M::glb(qrow, s * C::KS, HD, l);
+    for (int s = 0; s < C::NDS; ++s) qf[s] = frag_global<T>(qrow, s * C::KS, HD, l);
   }
-  int uq[4], tq[4];
-  float mrow[4], lrow[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = qr0 + 4 * fq + r;
-    uq[r] = qi < p.T ? p.uid[tok0 + qi] : SENT_Q;
-    tq[r] = qi < p.T ? p.tm[tok0 + qi] : 0;
-    mrow[r] = -1e30f; lrow[r] = 0.f;
-  }
+  const int uq = qv ? p.uid[tok0 + q] : SENT_Q, tq = qv ? p.tm[tok0 + q] : 0;
+  float m_run = -1e30f, l_run = 0.f;
   f32x4 oacc[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) oacc[j] = f32x4{0, 0, 0, 0};
-  zero_pad_cols<T, HD>(Ks, t);
-  T* Pw = Ps + w * 16 * C::LDT;
-  const unsigned int bits = p.qmap[b * nt + qt];
-  for (int kt = 0; kt < nt; ++kt) {
-    if (!((bits >> kt) & 1u)) continue;
-    __syncthreads();
-    const int nv = min(64, p.T - kt * 64);
-    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
-    stage_trans<T, HD>(Vt, (const T*)p.vT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t, nv);
-    if (t < 64) { uk[t] = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; tk[t] = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
-    __syncthreads();
-    f32x4 sacc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sacc[j] = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < NQS; ++s) sacc[j] = M::mma(qf[s], M::lds(Ks, C::LDD, j * 16, s * C::KS, l), sacc[j]);
-    }
-    bool ok[4][4];
-    float rmax[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ukv = uk[j * 16 + fr], tkv = tk[j * 16 + fr];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ok[j][r] = (uq[r] == ukv) && (tkv == 0 || tq[r] == tkv);
-        float sv = ok[j][r] ? sacc[j][r] * scale : -1e30f;
-        sacc[j][r] = sv;
-        rmax[r] = fmaxf(rmax[r], sv);
-      }
-    }
-    float alpha[4], rsum[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float mx = group16_max(rmax[r]);
-      float mn = fmaxf(mrow[r], mx);
-      alpha[r] = __expf(mrow[r] - mn);
-      mrow[r] = mn;
-      rsum[r] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pv = ok[j][r] ? __expf(sacc[j][r] - mrow[r]) : 0.f;
-        rsum[r] += pv;
-        Pw[(4 * fq + r) * C::LDT + j * 16 + fr] = from_f32<T>(pv);
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      lrow[r] = lrow[r] * alpha[r] + group16_sum(rsum[r]);
-#pragma unroll
-      for (int j = 0; j < HD / 16; ++j) oacc[j][r] *= alpha[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 64 / C::KS; ++s) {
-      typename M::Frag pf = M::lds(Pw, C::LDT, 0, s * C::KS, l);
-#pragma unroll
-      for (int j = 0; j < HD / 16; ++j) oacc[j] = M::mma(pf, M::lds(Vt, C::LDT, j * 16, s * C::KS, l), oacc[j]);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (qr0 + 4 * fq + r >= p.T) continue;
-    const long long row = tok0 + qr0 + 4 * fq + r;
-    const float inv = 1.f / lrow[r];
-#pragma unroll
-    for (int j = 0; j < HD / 16; ++j) ((T*)p.o)[row * p.ldo + h * HD + j * 16 + fr] = from_f32<T>(oacc[j][r] * inv);
-    if (fr == 0) p.lse[((long long)b * p.H + h) * p.T + qr0 + 4 * fq + r] = mrow[r] + logf(lrow[r]);
-  }
-}
+  zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t);
+  const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
+  const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
 
-template <typename T, int HD>
-static size_t fwd_smem() {
-  using C = ACfg<T, HD>;
-  return sizeof(T) * (64 * C::LDD + HD * C::LDT + 4 * 16 * C::LDT) + 128 * sizeof(int);
+  TileRegs<T, HD> rk, rv;
+  int ru = 0, rt = 0;
+  auto gload = [&](int kt) {
+    const int nv = min(64, p.T - kt * 64);
+    tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
+    tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
+    if (t < 64) { ru = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; rt = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
+  };
+  auto lstore = [&](int buf) {
+    tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
+    tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
+    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; }
+  };
+
+  int kt = next_bit(bits, 0);
+  int cur = 0;
+  if (kt < nt) { gload(kt); lstore(0); }
+  __syncthreads();
+  while (kt < nt) {
+    const int nxt = next_bit(bits, kt + 1);
+    if (nxt < nt) gload(nxt);
+    const T* Kc = Ks + cur * C::TILE;
+    const T* Vc = Vs + cur * C::TILE;
+    f32x4 S[4];
+    first_stage<T, HD>(S, Kc, qf, l);
+    if (!((fullbits >> kt) & 1u)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, 16 * i, uq, tq, g, -1e30f);
+    }
+    float tmax = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, S[i][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax * c2);
+    const float mu_old = fmaxf(m_run, -1e20f), mu_new = fmaxf(m_new, -1e20f);
+    const float alpha = exp2f(mu_old - mu_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = exp2f(fmaf(S[i][r], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
+        S[i][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int j = 0; j < HD / 16; ++j) oacc[j] *= alpha;
+    acc_second_stage<T, HD>(oacc, S, Vc, l);
+    if (nxt < nt) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    kt = nxt;
+  }
+  // O^T (rows d, col q) -> row-major through LDS, then 16-byte row stores
+  T* Os = Ks;   // [64][LDD]
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+  for (int j = 0; j < HD / 16; ++j) {
+    T* dst = Os + (w * 16 + fr) * C::LDD + 16 * j + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = from_f32<T>(oacc[j][r] * inv);
+  }
+  if (g == 0 && qv) p.lse[((long long)b * p.H + h) * p.T + q] = (m_run + log2f(l_run)) * (1.f / LOG2E);
+  __syncthreads();
+  constexpr int CPR = HD / C::E;
+  for (int c = t; c < 64 * CPR; c += 256) {
+    const int row = c / CPR, ch = c % CPR;
+    if (qt * 64 + row < p.T)
+      *(uint4*)((T*)p.o + (tok0 + qt * 64 + row) * p.ldo + h * HD + ch * C::E) = *(const uint4*)(Os + row * C::LDD + ch * C::E);
+  }
 }
 
 template <typename T, int HD>
 static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
-  size_t sm = fwd_smem<T, HD>();
+  using C = ACfg<T, HD>;
+  const size_t sm = sizeof(T) * 4 * C::TILE + 256 * sizeof(int);
   static bool set = false;
   if (!set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
@@ -326,10 +404,37 @@ int launch_attn_delta(const AttnParams& p, hipStream_t s) {
 template int launch_attn_delta<bf16>(const AttnParams&, hipStream_t);
 template int launch_attn_delta<float>(const AttnParams&, hipStream_t);
 
-// inverse rotation of an accumulator tile (rows = tokens, cols = d on the lane), transformer.model.py:182-190 transposed
-__device__ __forceinline__ float rope_inv(float x, float c, float s, int l) {
-  float partner = __shfl_xor(x, 1, 64);
-  return (l & 1) ? (x * c - partner * s) : (x * c + partner * s);
+// gradient tile (rows d = 16j+4g+r, col = token on the lane) -> un-rotate (inverse of transformer.model.py:182-190; the
+// pair (d, d+1) is two consecutive registers of the lane), transpose through LDS, store rows with 16-byte accesses
+template <typename T, int HD>
+__device__ __forceinline__ void store_grad_tile(f32x4 (&acc)[HD / 16], bool rotate, const float* rope_cos, const float* rope_sin,
+                                                int pos, T* Os, int w, int l) {
+  using C = ACfg<T, HD>;
+  const int g = l >> 4, fr = l & 15;
+#pragma unroll
+  for (int j = 0; j < HD / 16; ++j) {
+    float o[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+    if (rotate) {
+      const int d2 = (16 * j + 4 * g) >> 1;
+      const float2 cc = *(const float2*)(rope_cos + pos * (HD / 2) + d2);
+      const float2 ss = *(const float2*)(rope_sin + pos * (HD / 2) + d2);
+      const float a0 = o[0] * cc.x + o[1] * ss.x, a1 = -o[0] * ss.x + o[1] * cc.x;
+      const float b0 = o[2] * cc.y + o[3] * ss.y, b1 = -o[2] * ss.y + o[3] * cc.y;
+      o[0] = a0; o[1] = a1; o[2] = b0; o[3] = b1;
+    }
+    T* dst = Os + (w * 16 + fr) * C::LDD + 16 * j + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = from_f32<T>(o[r]);
+  }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld, int tile_tok0, int T_len, int t) {
+  using C = ACfg<T, HD>;
+  constexpr int CPR = HD / C::E;
+  for (int c = t; c < 64 * CPR; c += 256) {
+    const int row = c / CPR, ch = c % CPR;
+    if (tile_tok0 + row < T_len) *(uint4*)(dst + (long long)row * ld + ch * C::E) = *(const uint4*)(Os + row * C::LDD + ch * C::E);
+  }
 }
 
 // ------------------------------------------------------------------------ backward: dK, dV (one workgroup per kv tile and kv head)
@@ -338,112 +443,103 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Qs = (T*)smem_raw;                 // [64 q][LDD]
-  T* dOs = Qs + 64 * C::LDD;            // [64 q][LDD]
-  T* QTs = dOs + 64 * C::LDD;           // [HD][LDT]
-  T* dOTs = QTs + HD * C::LDT;          // [HD][LDT]
-  T* PTs = dOTs + HD * C::LDT;          // [4][16 kv][LDT]
-  T* dSTs = PTs + 4 * 16 * C::LDT;      // [4][16 kv][LDT]
-  float* lse_q = (float*)(dSTs + 4 * 16 * C::LDT);
-  float* del_q = lse_q + 64;
-  int* uqs = (int*)(del_q + 64);
-  int* tqs = uqs + 64;
+  T* Qs = (T*)smem_raw;                  // [2][64 q][LDD]
+  T* dOs = Qs + 2 * C::TILE;             // [2][64 q][LDD]
+  float* lse2 = (float*)(dOs + 2 * C::TILE);   // [2][64]
+  float* dls = lse2 + 128;                      // [2][64]
+  int* uqs = (int*)(dls + 128);                 // [2][64]
+  int* tqs = uqs + 128;                         // [2][64]
   const int kvt = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
-  const float scale = rsqrtf((float)HD);
-  const int kr0 = kvt * 64 + w * 16;
-  constexpr int NDS = C::HDP / C::KS;
-  typename M::Frag kf[NDS], vf[NDS];
+  const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
+  const int kv = kvt * 64 + w * 16 + fr;       // this lane's key/value token
+  const bool kvv = kv < p.T;
+  typename M::Frag kf[C::NDS], vf[C::NDS];
   {
-    const T* krow = (const T*)p.k + (tok0 + min(kr0 + fr, p.T - 1)) * p.ld + kvh * HD;
-    const T* vrow = (const T*)p.v + (tok0 + min(kr0 + fr, p.T - 1)) * p.ld + kvh * HD;
+    const T* krow = (const T*)p.k + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
+    const T* vrow = (const T*)p.v + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
 #pragma unroll
-    for (int s = 0; s < NDS; ++s) { kf[s] = M::glb(krow, s * C::KS, HD, l); vf[s] = M::glb(vrow, s * C::KS, HD, l); }
+    for (int s = 0; s < C::NDS; ++s) { kf[s] = frag_global<T>(krow, s * C::KS, HD, l); vf[s] = frag_global<T>(vrow, s * C::KS, HD, l); }
   }
-  int ukv[4], tkv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ki = kr0 + 4 * fq + r;
-    ukv[r] = ki < p.T ? p.uid[tok0 + ki] : SENT_K; tkv[r] = ki < p.T ? p.tm[tok0 + ki] : 0;
-  }
+  const int ukv = kvv ? p.uid[tok0 + kv] : SENT_K, tkv = kvv ? p.tm[tok0 + kv] : 0;
   f32x4 dK[HD / 16], dV[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
-  zero_pad_cols<T, HD>(Qs, t);
-  zero_pad_cols<T, HD>(dOs, t);
-  T* PTw = PTs + w * 16 * C::LDT;
-  T* dSTw = dSTs + w * 16 * C::LDT;
-  const unsigned int bits = p.kmap[b * nt + kvt];
-  for (int hh = 0; hh < rep; ++hh) {
-    const int h = kvh * rep + hh;
-    for (int qt = 0; qt < nt; ++qt) {
-      if (!((bits >> qt) & 1u)) continue;
-      __syncthreads();
-      const int nv = min(64, p.T - qt * 64);
-      stage_rows<T, HD>(Qs, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
-      stage_rows<T, HD>(dOs, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
-      stage_trans<T, HD>(QTs, (const T*)p.qT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t, nv);
-      stage_trans<T, HD>(dOTs, (const T*)p.dOT + ((long long)(b * p.H + h) * HD) * p.T + qt * 64, p.T, t, nv);
-      if (t < 64) {
-        const bool v = t < nv;
-        lse_q[t] = v ? p.lse[((long long)b * p.H + h) * p.T + qt * 64 + t] : 0.f;
-        del_q[t] = v ? p.delta[((long long)b * p.H + h) * p.T + qt * 64 + t] : 0.f;
-        uqs[t] = v ? p.uid[tok0 + qt * 64 + t] : SENT_Q;
-        tqs[t] = v ? p.tm[tok0 + qt * 64 + t] : 0;
-      }
-      __syncthreads();
+  for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Qs + i * C::TILE, t); zero_pad_cols<T, HD>(dOs + i * C::TILE, t); }
+  const unsigned int bits = p.kmap[b * nt + kvt], fullbits = p.kmap_full[b * nt + kvt];
+
+  TileRegs<T, HD> rq, rdo;
+  float rl = 0.f, rd = 0.f; int ru = 0, rt = 0;
+  auto gload = [&](int it) {   // it = head-in-group * 32 + q tile
+    const int h = kvh * rep + (it >> 5), qt = it & 31;
+    const int nv = min(64, p.T - qt * 64);
+    tile_load<T, HD>(rq, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
+    tile_load<T, HD>(rdo, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
+    if (t < 64) {
+      const bool v = t < nv;
+      const long long o = ((long long)b * p.H + h) * p.T + qt * 64 + (v ? t : 0);
+      rl = v ? p.lse[o] * LOG2E : 0.f; rd = v ? p.delta[o] : 0.f;
+      ru = v ? p.uid[tok0 + qt * 64 + t] : SENT_Q; rt = v ? p.tm[tok0 + qt * 64 + t] : 0;
+    }
+  };
+  auto lstore = [&](int buf) {
+    tile_store<T, HD>(rq, Qs + buf * C::TILE, t);
+    tile_store<T, HD>(rdo, dOs + buf * C::TILE, t);
+    if (t < 64) { lse2[buf * 64 + t] = rl; dls[buf * 64 + t] = rd; uqs[buf * 64 + t] = ru; tqs[buf * 64 + t] = rt; }
+  };
+  auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
+    int hh = from >> 5, qt = from & 31;
+    while (hh < rep) {
+      const int n = next_bit(bits, qt);
+      if (n < nt) return hh * 32 + n;
+      ++hh; qt = 0;
+    }
+    return rep * 32;
+  };
+  const int end = rep * 32;
+  int it = next_item(0), cur = 0;
+  if (it < end) { gload(it); lstore(0); }
+  __syncthreads();
+  while (it < end) {
+    const int nxt = next_item(it + 1);
+    if (nxt < end) gload(nxt);
+    const T* Qc = Qs + cur * C::TILE;
+    const T* dOc = dOs + cur * C::TILE;
+    f32x4 S[4], dP[4];
+    first_stage<T, HD>(S, Qc, kf, l);      // S[q][kv]: rows q (registers), col kv (lane)
+    first_stage<T, HD>(dP, dOc, vf, l);    // dP[q][kv]
+    const bool fullt = (fullbits >> (it & 31)) & 1u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 sacc = f32x4{0, 0, 0, 0}, dpacc = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
+      const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
+      const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+      if (!fullt) mask_tile<false>(S[i], uqs + cur * 64, tqs + cur * 64, 16 * i, ukv, tkv, g, -1e30f);
 #pragma unroll
-        for (int s = 0; s < NDS; ++s) {
-          sacc = M::mma(kf[s], M::lds(Qs, C::LDD, j * 16, s * C::KS, l), sacc);
-          dpacc = M::mma(vf[s], M::lds(dOs, C::LDD, j * 16, s * C::KS, l), dpacc);
-        }
-        const int qc = j * 16 + fr;
-        const float lse = lse_q[qc], dl = del_q[qc];
-        const int uqv = uqs[qc], tqv = tqs[qc];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          bool ok = (uqv == ukv[r]) && (tkv[r] == 0 || tqv == tkv[r]);
-          float pv = ok ? __expf(sacc[r] * scale - lse) : 0.f;
-          float ds = pv * (dpacc[r] - dl) * scale;
-          PTw[(4 * fq + r) * C::LDT + qc] = from_f32<T>(pv);
-          dSTw[(4 * fq + r) * C::LDT + qc] = from_f32<T>(ds);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int s = 0; s < 64 / C::KS; ++s) {
-        typename M::Frag pf = M::lds(PTw, C::LDT, 0, s * C::KS, l);
-        typename M::Frag df = M::lds(dSTw, C::LDT, 0, s * C::KS, l);
-#pragma unroll
-        for (int j = 0; j < HD / 16; ++j) {
-          dV[j] = M::mma(pf, M::lds(dOTs, C::LDT, j * 16, s * C::KS, l), dV[j]);
-          dK[j] = M::mma(df, M::lds(QTs, C::LDT, j * 16, s * C::KS, l), dK[j]);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float pv = exp2f(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
+        S[i][r] = pv;
+        dP[i][r] = pv * (dP[i][r] - dd[r]) * scale;
       }
     }
+    acc_second_stage<T, HD>(dV, S, dOc, l);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
+    acc_second_stage<T, HD>(dK, dP, Qc, l);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+    if (nxt < end) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    it = nxt;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int tk = kr0 + 4 * fq + r;
-    const bool rv = tk < p.T;
-    const long long row = tok0 + (rv ? tk : p.T - 1);
-    const int pos = p.rope_pos ? p.rope_pos[row] : (rv ? tk : 0);
-#pragma unroll
-    for (int j = 0; j < HD / 16; ++j) {
-      const int d = j * 16 + fr;
-      const float c = p.rope_cos[pos * (HD / 2) + (d >> 1)], sn = p.rope_sin[pos * (HD / 2) + (d >> 1)];
-      float gk = rope_inv(dK[j][r], c, sn, l);
-      if (rv) {
-        ((T*)p.dk)[row * p.ldg + kvh * HD + d] = from_f32<T>(gk);
-        ((T*)p.dv)[row * p.ldg + kvh * HD + d] = from_f32<T>(dV[j][r]);
-      }
-    }
-  }
+  const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
+  T* Os = Qs;
+  store_grad_tile<T, HD>(dK, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  __syncthreads();
+  copy_out_tile<T, HD>(Os, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t);
+  __syncthreads();
+  store_grad_tile<T, HD>(dV, false, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  __syncthreads();
+  copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t);
 }
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and head)
@@ -452,99 +548,86 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ks = (T*)smem_raw;                 // [64 kv][LDD]
-  T* Vs = Ks + 64 * C::LDD;             // [64 kv][LDD]
-  T* KTs = Vs + 64 * C::LDD;            // [HD][LDT]
-  T* dSs = KTs + HD * C::LDT;           // [4][16 q][LDT]
-  int* uk = (int*)(dSs + 4 * 16 * C::LDT);
-  int* tk = uk + 64;
+  T* Ks = (T*)smem_raw;                  // [2][64 kv][LDD]
+  T* Vs = Ks + 2 * C::TILE;              // [2][64 kv][LDD]
+  int* uk = (int*)(Vs + 2 * C::TILE);    // [2][64]
+  int* tk = uk + 128;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, fq = l >> 4, fr = l & 15;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int kvh = h / (p.H / p.KV), nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
-  const float scale = rsqrtf((float)HD);
-  const int qr0 = qt * 64 + w * 16;
-  constexpr int NDS = C::HDP / C::KS;
-  typename M::Frag qf[NDS], dof[NDS];
+  const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
+  const int q = qt * 64 + w * 16 + fr;
+  const bool qv = q < p.T;
+  typename M::Frag qf[C::NDS], dof[C::NDS];
   {
-    const T* qrow = (const T*)p.q + (tok0 + min(qr0 + fr, p.T - 1)) * p.ld + h * HD;
-    const T* drow = (const T*)p.dO + (tok0 + min(qr0 + fr, p.T - 1)) * p.ldo + h * HD;
+    const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + h * HD;
+    const T* drow = (const T*)p.dO + (tok0 + min(q, p.T - 1)) * p.ldo + h * HD;
 #pragma unroll
-    for (int s = 0; s < NDS; ++s) { qf[s] = M::glb(qrow, s * C::KS, HD, l); dof[s] = M::glb(drow, s * C::KS, HD, l); }
+    for (int s = 0; s < C::NDS; ++s) { qf[s] = frag_global<T>(qrow, s * C::KS, HD, l); dof[s] = frag_global<T>(drow, s * C::KS, HD, l); }
   }
-  int uq[4], tq[4];
-  float lse[4], dl[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int tq_i = qr0 + 4 * fq + r;
-    const bool v = tq_i < p.T;
-    uq[r] = v ? p.uid[tok0 + tq_i] : SENT_Q; tq[r] = v ? p.tm[tok0 + tq_i] : 0;
-    lse[r] = v ? p.lse[((long long)b * p.H + h) * p.T + tq_i] : 0.f;
-    dl[r] = v ? p.delta[((long long)b * p.H + h) * p.T + tq_i] : 0.f;
-  }
+  const int uq = qv ? p.uid[tok0 + q] : SENT_Q, tq = qv ? p.tm[tok0 + q] : 0;
+  const long long so = ((long long)b * p.H + h) * p.T + min(q, p.T - 1);
+  const float lse2 = qv ? p.lse[so] * LOG2E : 0.f, dl = qv ? p.delta[so] : 0.f;
   f32x4 dQ[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) dQ[j] = f32x4{0, 0, 0, 0};
-  zero_pad_cols<T, HD>(Ks, t);
-  zero_pad_cols<T, HD>(Vs, t);
-  T* dSw = dSs + w * 16 * C::LDT;
-  const unsigned int bits = p.qmap[b * nt + qt];
-  for (int kt = 0; kt < nt; ++kt) {
-    if (!((bits >> kt) & 1u)) continue;
-    __syncthreads();
+  for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
+  const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
+  const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
+  TileRegs<T, HD> rk, rv;
+  int ru = 0, rt = 0;
+  auto gload = [&](int kt) {
     const int nv = min(64, p.T - kt * 64);
-    stage_rows<T, HD>(Ks, (const T*)p.k + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
-    stage_rows<T, HD>(Vs, (const T*)p.v + (tok0 + kt * 64) * p.ld + kvh * HD, p.ld, t, nv);
-    stage_trans<T, HD>(KTs, (const T*)p.kT + ((long long)(b * p.KV + kvh) * HD) * p.T + kt * 64, p.T, t, nv);
-    if (t < 64) { uk[t] = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; tk[t] = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
-    __syncthreads();
+    tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
+    tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
+    if (t < 64) { ru = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; rt = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
+  };
+  auto lstore = [&](int buf) {
+    tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
+    tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
+    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; }
+  };
+  int kt = next_bit(bits, 0), cur = 0;
+  if (kt < nt) { gload(kt); lstore(0); }
+  __syncthreads();
+  while (kt < nt) {
+    const int nxt = next_bit(bits, kt + 1);
+    if (nxt < nt) gload(nxt);
+    const T* Kc = Ks + cur * C::TILE;
+    const T* Vc = Vs + cur * C::TILE;
+    f32x4 S[4], dP[4];
+    first_stage<T, HD>(S, Kc, qf, l);      // S^T[kv][q]
+    first_stage<T, HD>(dP, Vc, dof, l);    // dP^T[kv][q]
+    const bool fullt = (fullbits >> kt) & 1u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 sacc = f32x4{0, 0, 0, 0}, dpacc = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < NDS; ++s) {
-        sacc = M::mma(qf[s], M::lds(Ks, C::LDD, j * 16, s * C::KS, l), sacc);
-        dpacc = M::mma(dof[s], M::lds(Vs, C::LDD, j * 16, s * C::KS, l), dpacc);
-      }
-      const int kc = j * 16 + fr;
-      const int ukv = uk[kc], tkv = tk[kc];
+    for (int i = 0; i < 4; ++i) {
+      if (!fullt) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, 16 * i, uq, tq, g, -1e30f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bool ok = (uq[r] == ukv) && (tkv == 0 || tq[r] == tkv);
-        float pv = ok ? __expf(sacc[r] * scale - lse[r]) : 0.f;
-        float ds = pv * (dpacc[r] - dl[r]) * scale;
-        dSw[(4 * fq + r) * C::LDT + kc] = from_f32<T>(ds);
+        const float pv = exp2f(fmaf(S[i][r], c2, -lse2));
+        dP[i][r] = pv * (dP[i][r] - dl) * scale;
       }
     }
+    acc_second_stage<T, HD>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
+    if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 64 / C::KS; ++s) {
-      typename M::Frag df = M::lds(dSw, C::LDT, 0, s * C::KS, l);
-#pragma unroll
-      for (int j = 0; j < HD / 16; ++j) dQ[j] = M::mma(df, M::lds(KTs, C::LDT, j * 16, s * C::KS, l), dQ[j]);
-    }
+    cur ^= 1;
+    kt = nxt;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int tq_i = qr0 + 4 * fq + r;
-    const bool rv = tq_i < p.T;
-    const long long row = tok0 + (rv ? tq_i : p.T - 1);
-    const int pos = p.rope_pos ? p.rope_pos[row] : (rv ? tq_i : 0);
-#pragma unroll
-    for (int j = 0; j < HD / 16; ++j) {
-      const int d = j * 16 + fr;
-      const float c = p.rope_cos[pos * (HD / 2) + (d >> 1)], sn = p.rope_sin[pos * (HD / 2) + (d >> 1)];
-      const float gq = rope_inv(dQ[j][r], c, sn, l);
-      if (rv) ((T*)p.dq)[row * p.ldg + h * HD + d] = from_f32<T>(gq);
-    }
-  }
+  const int pos = p.rope_pos ? p.rope_pos[tok0 + min(q, p.T - 1)] : min(q, p.T - 1);
+  T* Os = Ks;
+  store_grad_tile<T, HD>(dQ, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  __syncthreads();
+  copy_out_tile<T, HD>(Os, (T*)p.dq + (tok0 + qt * 64) * p.ldg + h * HD, p.ldg, qt * 64, p.T, t);
 }
 
 template <typename T, int HD>
 static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   using C = ACfg<T, HD>;
-  size_t sm_kv = sizeof(T) * (2 * 64 * C::LDD + 2 * HD * C::LDT + 8 * 16 * C::LDT) + 256 * 4;
-  size_t sm_q = sizeof(T) * (2 * 64 * C::LDD + HD * C::LDT + 4 * 16 * C::LDT) + 128 * 4;
+  const size_t sm_kv = sizeof(T) * 4 * C::TILE + 512 * 4;
+  const size_t sm_q = sizeof(T) * 4 * C::TILE + 256 * 4;
   static bool set = false;
   if (!set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_kv));
@@ -562,6 +645,7 @@ template <typename T>
 int launch_attn_bwd(const AttnParams& p, hipStream_t s) {
   int rc = check_attn(p, sizeof(T));
   if (rc) return rc;
+  ARG_CHECK(p.H / p.KV <= 8, "attention: at most 8 query heads per kv head");
   switch (p.hd) {
     case 16: return attn_bwd_hd<T, 16>(p, s);
     case 32: return attn_bwd_hd<T, 32>(p, s);

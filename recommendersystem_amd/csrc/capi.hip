@@ -332,22 +332,20 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
 }
 
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
-                          const void* qT, const void* kT, const void* vT, const int32_t* uid, const int32_t* tm,
-                          void* O, float* lse, const void* dO, const void* dOT, void* dqkv, const float* rope_cos,
-                          const float* rope_sin) {
+                          const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
+                          const float* rope_cos, const float* rope_sin) {
   const size_t e = dtype == RSYS_DTYPE_BF16 ? 2 : 4;
   const int nt = (T + 63) / 64;
   AttnParams p{};
   p.B = B; p.T = T; p.H = H; p.KV = KV; p.hd = hd;
   p.q = qkv; p.k = (const unsigned char*)qkv + (size_t)H * hd * e; p.v = (const unsigned char*)qkv + (size_t)(H + KV) * hd * e;
   p.ld = (long long)(H + 2 * KV) * hd;
-  p.qT = qT; p.kT = kT; p.vT = vT; p.o = O; p.ldo = (long long)H * hd; p.lse = lse; p.uid = uid; p.tm = tm;
-  unsigned int *qmap = nullptr, *kmap = nullptr; float* delta = nullptr;
-  HIP_CHECK(hipMalloc((void**)&qmap, sizeof(unsigned int) * B * nt));
-  HIP_CHECK(hipMalloc((void**)&kmap, sizeof(unsigned int) * B * nt));
+  p.o = O; p.ldo = (long long)H * hd; p.lse = lse; p.uid = uid; p.tm = tm;
+  unsigned int* maps = nullptr; float* delta = nullptr;
+  HIP_CHECK(hipMalloc((void**)&maps, sizeof(unsigned int) * 4 * B * nt));
   HIP_CHECK(hipMalloc((void**)&delta, sizeof(float) * B * H * T));
-  p.qmap = qmap; p.kmap = kmap; p.delta = delta;
-  p.dO = dO; p.dOT = dOT; p.dq = dqkv; p.dk = (unsigned char*)dqkv + (size_t)H * hd * e;
+  p.qmap = maps; p.kmap = maps + B * nt; p.qmap_full = maps + 2 * B * nt; p.kmap_full = maps + 3 * B * nt; p.delta = delta;
+  p.dO = dO; p.dq = dqkv; p.dk = (unsigned char*)dqkv + (size_t)H * hd * e;
   p.dv = (unsigned char*)dqkv + (size_t)(H + KV) * hd * e; p.ldg = p.ld;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = nullptr;
   int rc = launch_attn_tilemap(p, nullptr);
@@ -357,7 +355,7 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
     if (!rc) rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_bwd<bf16>(p, nullptr) : launch_attn_bwd<float>(p, nullptr);
   }
   hipError_t e2 = hipDeviceSynchronize();
-  hipFree(qmap); hipFree(kmap); hipFree(delta);
+  hipFree(maps); hipFree(delta);
   if (rc) return rc;
   HIP_CHECK(e2);
   return RSYS_OK;

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   // column wc*64 + j*16 + (l&15) of the 128x128 tile; the tile leaves in two 64-row halves.
   const int fq = l >> 4, fr = l & 15;
   constexpr int CS_LD = 132;   // f32 row-major staging tile [64][132]
-  constexpr int CT_LD = 68;    // f32 transposed staging tile [128 cols][68]
+  constexpr int CT_LD = 68;    // f32 staging tile of the SwiGLU product [64][68]
   float* Cs = (float*)smem;
   const bool cf32 = p.c_f32 != 0;
   __syncthreads();
@@ -305,35 +305,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     return;
   }
 
-  if (p.epi == EPI_QKV_ROPE) {
-    // rotate interleaved pairs (transformer.model.py:182-190) in registers: the pair partner is the neighbouring lane
-    const int half_hd = p.hd >> 1;
-    static_for<4>([&](auto i) {
-      int pos[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min((int)(m0 + wr * 64 + i * 16 + 4 * fq + r), p.M - 1);
-        pos[r] = p.rope_pos ? p.rope_pos[row] : row % p.T;
-      }
-      static_for<4>([&](auto j) {
-        const int col = n0 + wc * 64 + j * 16 + fr;
-        const bool rot = col < p.n_q + p.n_k;       // q and k regions rotate, v does not
-        const int cc = col < p.n_q ? col : col - p.n_q;
-        const int d2 = (cc & (p.hd - 1)) >> 1;      // hd is a power of two
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = acc[i][j][r];
-          const float partner = __shfl_xor(x, 1, 64);
-          if (rot) {
-            const float c = p.rope_cos[pos[r] * half_hd + d2], sn = p.rope_sin[pos[r] * half_hd + d2];
-            acc[i][j][r] = (l & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
-          }
-        }
-      });
-    });
-  }
-
-  const bool has_t = (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T);
   for (int half = 0; half < 2; ++half) {
     // ---- primary tile, row-major
     if (wr == half) {
@@ -385,7 +356,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           }
           two = true;
           break;
-        default: break;   // QKV_ROPE / STORE_HEADS_T / SWIGLU: plain store of the primary tile
+        case EPI_QKV_ROPE:
+          // rotate interleaved pairs (transformer.model.py:182-190): 4 consecutive columns = 2 pairs of one head
+          if (col < p.n_q + p.n_k) {
+            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
+            const int cc = col < p.n_q ? col : col - p.n_q;
+            const int d2 = (cc & (p.hd - 1)) >> 1;
+            const float2 cs = *(const float2*)(p.rope_cos + pos * (p.hd >> 1) + d2);
+            const float2 sn = *(const float2*)(p.rope_sin + pos * (p.hd >> 1) + d2);
+            const float a0 = v[0] * cs.x - v[1] * sn.x, a1 = v[0] * sn.x + v[1] * cs.x;
+            const float b0 = v[2] * cs.y - v[3] * sn.y, b1 = v[2] * sn.y + v[3] * cs.y;
+            v[0] = a0; v[1] = a1; v[2] = b0; v[3] = b1;
+          }
+          break;
+        default: break;   // SWIGLU: plain store of the primary tile
       }
       const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
       if (outf32) {
@@ -408,46 +392,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       }
     }
     __syncthreads();
-
-    // ---- per-head transposed copy [b][head][d][t] (Q^T,K^T,V^T / dO^T): tokens contiguous
-    if (has_t) {
-      float* Ct = (float*)smem;
-      if (wr == half) {
-        static_for<4>([&](auto i) { static_for<4>([&](auto j) {
-          const f32x4 v = acc[i][j];
-          *(float4*)&Ct[(wc * 64 + j * 16 + fr) * CT_LD + i * 16 + 4 * fq] = make_float4(v[0], v[1], v[2], v[3]);
-        }); });
-      }
-      __syncthreads();
-      for (int it = 0; it < 8; ++it) {
-        const int idx = t + 256 * it;
-        const int col_l = idx >> 4, r4 = (idx & 15) * 4;
-        const int col = n0 + col_l;
-        const int row0 = m0 + half * 64 + r4;
-        if (col >= p.N || row0 >= p.M) continue;
-        int cc = col, heads = p.N / p.hd;
-        void* XT = p.C2;
-        if (p.epi == EPI_QKV_ROPE) {
-          if (col < p.n_q) { XT = p.qT; heads = p.n_q / p.hd; }
-          else if (col < p.n_q + p.n_k) { cc = col - p.n_q; XT = p.kT; heads = p.n_k / p.hd; }
-          else { cc = col - p.n_q - p.n_k; XT = p.vT; heads = (p.N - p.n_q - p.n_k) / p.hd; }
-        }
-        if (XT == nullptr) continue;
-        const int head = cc / p.hd, d = cc % p.hd;
-        const int b = row0 / p.T, t0 = row0 % p.T;
-        const float4 v4 = *(const float4*)&Ct[col_l * CT_LD + r4];
-        CT* dst = (CT*)XT + ((long long)(b * heads + head) * p.hd + d) * p.T + t0;
-        const int nr = min(4, p.M - row0);
-        if (nr == 4) {
-          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v4.x; pk[1] = (bf16)v4.y; pk[2] = (bf16)v4.z; pk[3] = (bf16)v4.w; *(bf16x4*)dst = pk; }
-          else *(float4*)dst = v4;
-        } else {
-          const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-          for (int k = 0; k < nr; ++k) dst[k] = from_f32<CT>(vv[k]);
-        }
-      }
-      __syncthreads();
-    }
 
     // ---- SwiGLU product g = silu(a)*b: columns are interleaved in 16-wide blocks [a | b], lane-local pairs
     if (p.epi == EPI_SWIGLU) {
@@ -502,11 +446,11 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   else ARG_CHECK(p.lda >= ((p.M + EPC - 1) / EPC) * EPC, "gemm: K-major A rows must be padded to a whole chunk");
   if (!b_km) ARG_CHECK(p.ldb >= ((p.K + EPC - 1) / EPC) * EPC, "gemm: row-major B rows must be padded to a whole chunk");
   else ARG_CHECK(p.ldb >= ((p.N + EPC - 1) / EPC) * EPC, "gemm: K-major B rows must be padded to a whole chunk");
-  if (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T)
-    ARG_CHECK(p.hd % 16 == 0 && p.T % 4 == 0, "gemm: head epilogues need hd % 16 == 0 and T % 4 == 0");
+  if (p.epi == EPI_QKV_ROPE)
+    ARG_CHECK(p.hd % 16 == 0 && p.N % 4 == 0 && p.n_q % 4 == 0 && p.n_k % 4 == 0, "gemm: rope epilogue needs hd % 16 == 0");
   if (p.epi == EPI_SWIGLU) ARG_CHECK(p.N % 32 == 0 && p.ldc2 % 4 == 0, "gemm: swiglu epilogue needs N % 32 == 0");
   ARG_CHECK(p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0, "gemm: C rows must keep 16-byte alignment (ldc % 4 == 0)");
-  if (p.epi == EPI_QKV_ROPE || p.epi == EPI_STORE_HEADS_T) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
+  if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);

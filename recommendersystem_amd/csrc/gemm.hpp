@@ -15,11 +15,10 @@ enum GemmEpi : int {
   EPI_ATOMIC = 2,       // atomicAdd(Cf32, acc)               (split-K weight grads)
   EPI_BIAS = 3,         // C = acc + bias[col]                (C: T or f32)
   EPI_RESIDUAL = 4,     // Cf32 = resid + acc
-  EPI_QKV_ROPE = 5,     // rotate q,k pairs; write C (T) and per-head transposed copies
+  EPI_QKV_ROPE = 5,     // C = T(acc) with the q and k column regions rotated (RoPE, interleaved pairs)
   EPI_SWIGLU = 6,       // cols interleaved [16 a | 16 b]: C = ab (T), C2 = silu(a)*b (T)
   EPI_TABLE = 7,        // f = acc + E + bias: Cf32 = f, C2 = T(f)
-  EPI_GELU = 8,         // z = acc + bias: C = T(z), C2 = T(gelu(z))
-  EPI_STORE_HEADS_T = 9 // C = T(acc) and C2[b][head][d][t] = T(acc)   (dO and dO^T)
+  EPI_GELU = 8          // z = acc + bias: C = T(z), C2 = T(gelu(z))
 };
 
 struct GemmParams {
@@ -33,11 +32,10 @@ struct GemmParams {
   const float* bias;
   const float* resid; long long ldr;
   void* C2; long long ldc2;
-  // EPI_QKV_ROPE / EPI_STORE_HEADS_T
+  // EPI_QKV_ROPE
   const float* rope_cos; const float* rope_sin;   // [pos][hd/2]
   const int* rope_pos;                             // optional per-row position, else row % T
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
-  void* qT; void* kT; void* vT;                    // [b][head][hd][T]
   // EPI_TABLE
   const float* E;
 };

@@ -85,16 +85,17 @@ int launch_action_small_bwd(const float* gf /*[N][32]*/, const BatchDev& b, cons
 // ---- attention (attention.hip)
 struct AttnParams {
   int B, T, H, KV, hd;
-  const void *q, *k, *v;      // row-major views into qkv [B*T][ld]
+  const void *q, *k, *v;      // row-major views into qkv [B*T][ld] (q, k already rotated)
   long long ld;                // row stride of q/k/v (elements)
-  const void *qT, *kT, *vT;   // [B][heads][hd][T]
   void* o; long long ldo;     // [B*T][H*hd]
-  float* lse;                  // [B][H][T]
+  float* lse;                  // [B][H][T] natural-log sum-exp of the scaled scores
   const int *uid, *tm;         // [B*T]
-  unsigned int *qmap, *kmap;   // [B][T/64]: bit j set = kv tile j (resp. q tile j) has an allowed pair
+  // [B][ceil(T/64)] bitmaps: qmap bit j = kv tile j has an allowed pair with this q tile, qmap_full = every pair allowed;
+  // kmap / kmap_full: the transposed relation (bit j = q tile j)
+  unsigned int *qmap, *kmap, *qmap_full, *kmap_full;
   // backward
-  const void *dO, *dOT; const float* delta;
-  void *dq, *dk, *dv; long long ldg;
+  const void* dO; const float* delta;
+  void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv
   const float *rope_cos, *rope_sin; const int* rope_pos;
 };
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s);

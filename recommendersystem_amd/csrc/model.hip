@@ -196,12 +196,12 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->feat, N * 32 * e); DALLOC(m->x0, NT * D * 4);
   DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
   DALLOC(m->qmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
+  DALLOC(m->qmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
   m->la.resize(m->L);
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
     if (l == 0) a.x = m->x0; else DALLOC(a.x, NT * D * 4);
     DALLOC(a.xn, NT * D * e); DALLOC(a.qkv, NT * m->Nqkv * e);
-    DALLOC(a.qT, NT * m->H * hd * e); DALLOC(a.kT, NT * m->KV * hd * e); DALLOC(a.vT, NT * m->KV * hd * e);
     DALLOC(a.O, NT * D * e); DALLOC(a.lse, (int64_t)m->rows_max * m->H * m->T * 4);
     DALLOC(a.rstd1, NT * 4); DALLOC(a.h, NT * D * 4); DALLOC(a.hn, NT * D * e); DALLOC(a.rstd2, NT * 4);
     DALLOC(a.ab, NT * 2 * m->Ip * e); DALLOC(a.g, NT * m->Ip * e);
@@ -214,7 +214,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->z, KB * D * e); DALLOC(m->hact, KB * D * e); DALLOC(m->loss_acc, 16 * 4);
   DALLOC(m->gy, NT * D * 4); DALLOC(m->gxa, NT * D * 4); DALLOC(m->gxb, NT * D * 4); DALLOC(m->dh, NT * D * 4);
   DALLOC(m->dg, NT * m->Ip * e); DALLOC(m->dab, NT * 2 * m->Ip * e); DALLOC(m->dhn, NT * D * e);
-  DALLOC(m->dO, NT * D * e); DALLOC(m->dOT, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
+  DALLOC(m->dO, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
   DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
   DALLOC(m->sumsq, 64);
   *out = m;
@@ -480,7 +480,7 @@ static int forward_trunk(Model* m) {
   RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
-  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
   tic(m, "phase_trunk_fwd");
@@ -493,11 +493,11 @@ static int forward_trunk(Model* m) {
       p.A = a.xn; p.lda = D; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = a.qkv; p.ldc = m->Nqkv;
       p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
       p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
-      p.n_q = m->H * hd; p.n_k = m->KV * hd; p.qT = a.qT; p.kT = a.kT; p.vT = a.vT;
+      p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
-    ap.qT = a.qT; ap.kT = a.kT; ap.vT = a.vT; ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+    ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
     tic(m, "attn_fwd");
     RC(launch_attn_fwd<T>(ap, s));
     toc(m);
@@ -615,7 +615,7 @@ static int backward_trunk(Model* m) {
   RC(launch_rmsnorm_bwd_f32(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, m->G + m->o_norm, NT, D, s));
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
-  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
@@ -652,14 +652,14 @@ static int backward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_o_dw", p, true, true, true));
     }
     {
-      GemmParams p{};  // dO = dh . Wo  (+ per-head transposed copy)
+      GemmParams p{};  // dO = dh . Wo
       p.A = m->dh; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
-      p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE_HEADS_T; p.C2 = m->dOT; p.T = m->T; p.hd = hd;
+      p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_o_dx", p, true, false, true));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
-    ap.qT = a.qT; ap.kT = a.kT; ap.vT = a.vT; ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
-    ap.dO = m->dO; ap.dOT = m->dOT; ap.delta = m->delta;
+    ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+    ap.dO = m->dO; ap.delta = m->delta;
     ap.dq = m->dqkv; ap.dk = AT<T>(m->dqkv) + m->H * hd; ap.dv = AT<T>(m->dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
     tic(m, "attn_bwd");
     RC(launch_attn_delta<T>(ap, s));

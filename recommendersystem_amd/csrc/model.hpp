@@ -67,14 +67,14 @@ struct Model {
   unsigned char *d_wm = nullptr, *d_rm = nullptr;
   int* d_rope_pos = nullptr;
   // activations (void* = T-typed)
-  void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap;
-  struct LayerAct { float* x; void* xn; void* qkv; void *qT, *kT, *vT; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
+  void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap, *qmap_full, *kmap_full;
+  struct LayerAct { float* x; void* xn; void* qkv; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
   std::vector<LayerAct> la;
   float* xL; float* rstdf; void* out;
   // heads
   int* idx[4]; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
   // backward workspaces
-  float *gy, *gxa, *gxb, *dh; void *dg, *dab, *dhn, *dO, *dOT, *dqkv; float* delta; float* gf;
+  float *gy, *gxa, *gxb, *dh; void *dg, *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
   float* sumsq;
   bool table_grads_pending = false;
   bool last_evaluate = false;

@@ -153,17 +153,16 @@ def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd):
         uid[b, -5:] = 0
     tm = (rng.random((B, T)) < 0.15).astype(np.int32)
     q = qkv[:, :H * hd]; k = qkv[:, H * hd:(H + KV) * hd]; v = qkv[:, (H + KV) * hd:]
-    tr = lambda x, heads: np.ascontiguousarray(x.reshape(B, T, heads, hd).transpose(0, 2, 3, 1))
     cos = np.ones((T, hd // 2), np.float32); sin = np.zeros((T, hd // 2), np.float32)
     dev = lambda a: _to_dev(lib, a)
-    d_qkv = dev(_pack(qkv, bf)); d_qT = dev(_pack(tr(q, H), bf)); d_kT = dev(_pack(tr(k, KV), bf)); d_vT = dev(_pack(tr(v, KV), bf))
-    d_dO = dev(_pack(dO, bf)); d_dOT = dev(_pack(tr(dO, H), bf))
+    d_qkv = dev(_pack(qkv, bf))
+    d_dO = dev(_pack(dO, bf))
     d_uid = dev(uid); d_tm = dev(tm); d_cos = dev(cos); d_sin = dev(sin)
     esz = 2 if bf else 4
     d_O = C.c_void_p(); lib.rsys_dev_alloc(C.byref(d_O), B * T * H * hd * esz)
     d_lse = C.c_void_p(); lib.rsys_dev_alloc(C.byref(d_lse), B * H * T * 4)
     d_dqkv = C.c_void_p(); lib.rsys_dev_alloc(C.byref(d_dqkv), B * T * Nq * esz)
-    rc = lib.rsys_op_attention(dtype, B, T, H, KV, hd, d_qkv, d_qT, d_kT, d_vT, d_uid, d_tm, d_O, d_lse, d_dO, d_dOT, d_dqkv, d_cos, d_sin)
+    rc = lib.rsys_op_attention(dtype, B, T, H, KV, hd, d_qkv, d_uid, d_tm, d_O, d_lse, d_dO, d_dqkv, d_cos, d_sin)
     assert rc == 0, _lib.last_error()
     rawO = np.empty((B * T, H * hd), np.uint16 if bf else np.float32); lib.rsys_dev_d2h(rawO.ctypes.data, d_O, rawO.nbytes)
     rawG = np.empty((B * T, Nq), np.uint16 if bf else np.float32); lib.rsys_dev_d2h(rawG.ctypes.data, d_dqkv, rawG.nbytes)
@@ -176,5 +175,5 @@ def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd):
     assert err(G[:, :H * hd], gq) < tol, ("dq", err(G[:, :H * hd], gq))
     assert err(G[:, H * hd:(H + KV) * hd], gk) < tol, ("dk", err(G[:, H * hd:(H + KV) * hd], gk))
     assert err(G[:, (H + KV) * hd:], gv) < tol, ("dv", err(G[:, (H + KV) * hd:], gv))
-    for p in (d_qkv, d_qT, d_kT, d_vT, d_dO, d_dOT, d_uid, d_tm, d_cos, d_sin, d_O, d_lse, d_dqkv):
+    for p in (d_qkv, d_dO, d_uid, d_tm, d_cos, d_sin, d_O, d_lse, d_dqkv):
         lib.rsys_dev_free(p)
