@@ -167,10 +167,10 @@ template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
 constexpr int NORM_MAXJ = 8;  // D <= 64 lanes * 4 * 8 = 2048
 
-template <typename TG>
+template <typename TG, typename TO>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
-                                                          const float* resid, float* dx_out, float* dscale,
+                                                          const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
                                                           long long rows, int D) {
   extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
           o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
         }
         *(float4*)(dx_out + row * D + c) = o;
+        if (dx_out_t) {   // operand copy for the next GEMMs (bf16 mode): saves them the f32 read + conversion
+          TO* ot = dx_out_t + row * D + c;
+          ot[0] = from_f32<TO>(o.x); ot[1] = from_f32<TO>(o.y); ot[2] = from_f32<TO>(o.z); ot[3] = from_f32<TO>(o.w);
+        }
       }
     }
   }
@@ -229,27 +233,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   for (int c = threadIdx.x; c < D; c += 256) atomicAdd(&dscale[c], sds[c]);
 }
 
-template <typename TG>
+template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
-                           float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
+                           float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   int grid = (int)std::min<long long>((rows + 3) / 4, 1024);
-  hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG>), dim3(grid), dim3(256), D * sizeof(float), s, g, x, scale, rstd, resid,
-                     dx_out, dscale, rows, D);
+  hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO>), dim3(grid), dim3(256), D * sizeof(float), s, g, x, scale, rstd, resid,
+                     dx_out, dx_out_t, dscale, rows, D);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                       float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
-  return rmsnorm_bwd_any<T>(g, x, scale, rstd, resid_grad, dx_out, dscale, rows, D, s);
+                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
+  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s);
 }
-template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, float*, long long, int, hipStream_t);
-template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t);
+template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, float* dscale, long long rows, int D, hipStream_t s) {
-  return rmsnorm_bwd_any<float>(g, x, scale, rstd, resid_grad, dx_out, dscale, rows, D, s);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
+  return rmsnorm_bwd_any<float, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s);
 }
+template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t);
 
 // --------------------------------------------------------------------- SwiGLU backward (K10), model.py:205-213
 // ab is stored interleaved in 16-column blocks [a0..a15 | b0..b15 | a16.. ] (the W1/W3 rows are interleaved the same way)

@@ -371,6 +371,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           break;
         default: break;   // SWIGLU: plain store of the primary tile
       }
+      if (p.epi == EPI_SWIGLU_BWD) {
+        // column col = i index of dg; a,b live at (i>>4)*32 + (i&15) (+16) of the interleaved [a|b] rows;
+        // N % 16 == 0, so the 4 columns of an item are one 8/16-byte group of a and one of b
+        const long long base = row * p.ldc + (long long)(col >> 4) * 32 + (col & 15);
+        float av[4], bv[4];
+        if constexpr (is_bf16<CT>::value) {
+          const bf16x4 a4 = *(const bf16x4*)((const CT*)p.C2 + base), b4 = *(const bf16x4*)((const CT*)p.C2 + base + 16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { av[k] = (float)a4[k]; bv[k] = (float)b4[k]; }
+        } else {
+          const float4 a4 = *(const float4*)((const CT*)p.C2 + base), b4 = *(const float4*)((const CT*)p.C2 + base + 16);
+          av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w; bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+        }
+        float da[4], db[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float sg = 1.f / (1.f + __expf(-av[k]));
+          da[k] = v[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
+          db[k] = v[k] * av[k] * sg;
+        }
+        if constexpr (is_bf16<CT>::value) {
+          bf16x4 o1, o2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o1[k] = (bf16)da[k]; o2[k] = (bf16)db[k]; }
+          *(bf16x4*)((CT*)p.C + base) = o1; *(bf16x4*)((CT*)p.C + base + 16) = o2;
+        } else {
+          *(float4*)((CT*)p.C + base) = make_float4(da[0], da[1], da[2], da[3]);
+          *(float4*)((CT*)p.C + base + 16) = make_float4(db[0], db[1], db[2], db[3]);
+        }
+        continue;
+      }
       const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
       if (outf32) {
         float* dst = (float*)p.C + row * p.ldc + col;
@@ -449,6 +480,7 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   if (p.epi == EPI_QKV_ROPE)
     ARG_CHECK(p.hd % 16 == 0 && p.N % 4 == 0 && p.n_q % 4 == 0 && p.n_k % 4 == 0, "gemm: rope epilogue needs hd % 16 == 0");
   if (p.epi == EPI_SWIGLU) ARG_CHECK(p.N % 32 == 0 && p.ldc2 % 4 == 0, "gemm: swiglu epilogue needs N % 32 == 0");
+  if (p.epi == EPI_SWIGLU_BWD) ARG_CHECK(p.N % 16 == 0 && p.ldc2 == p.ldc && ((uintptr_t)p.C2 % 16) == 0, "gemm: swiglu-bwd epilogue needs N % 16 == 0");
   ARG_CHECK(p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0, "gemm: C rows must keep 16-byte alignment (ldc % 4 == 0)");
   if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }

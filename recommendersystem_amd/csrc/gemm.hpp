@@ -18,7 +18,8 @@ enum GemmEpi : int {
   EPI_QKV_ROPE = 5,     // C = T(acc) with the q and k column regions rotated (RoPE, interleaved pairs)
   EPI_SWIGLU = 6,       // cols interleaved [16 a | 16 b]: C = ab (T), C2 = silu(a)*b (T)
   EPI_TABLE = 7,        // f = acc + E + bias: Cf32 = f, C2 = T(f)
-  EPI_GELU = 8          // z = acc + bias: C = T(z), C2 = T(gelu(z))
+  EPI_GELU = 8,         // z = acc + bias: C = T(z), C2 = T(gelu(z))
+  EPI_SWIGLU_BWD = 9    // acc = dg: C2 = saved [a|b] (interleaved), C = [da|db] same layout (model.py:205-213 backward)
 };
 
 struct GemmParams {

@@ -43,12 +43,14 @@ template <typename T>
 int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s);
 
 // dx_out = resid_grad + d/dx rmsnorm ; dscale += column sums (atomic)
+// dx_out_t (optional): T-typed copy of dx_out, the A operand of the GEMMs that consume it
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                       float* dx_out, float* dscale, long long rows, int D, hipStream_t s);
+                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s);
 // same with an f32 incoming gradient (final norm: gy is f32)
+template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, float* dscale, long long rows, int D, hipStream_t s);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s);
 
 template <typename T>
 int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s);

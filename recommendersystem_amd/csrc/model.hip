@@ -213,7 +213,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->logits, KB * m->ldl * e); DALLOC(m->dE, KB * D * 4);
   DALLOC(m->z, KB * D * e); DALLOC(m->hact, KB * D * e); DALLOC(m->loss_acc, 16 * 4);
   DALLOC(m->gy, NT * D * 4); DALLOC(m->gxa, NT * D * 4); DALLOC(m->gxb, NT * D * 4); DALLOC(m->dh, NT * D * 4);
-  DALLOC(m->dg, NT * m->Ip * e); DALLOC(m->dab, NT * 2 * m->Ip * e); DALLOC(m->dhn, NT * D * e);
+  if (m->bf16_mode) { DALLOC(m->gxa_t, NT * D * 2); DALLOC(m->gxb_t, NT * D * 2); DALLOC(m->dh_t, NT * D * 2); }
+  else { m->gxa_t = m->gxa; m->gxb_t = m->gxb; m->dh_t = m->dh; }
+  DALLOC(m->dab, NT * 2 * m->Ip * e); DALLOC(m->dhn, NT * D * e);
   DALLOC(m->dO, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
   DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
   DALLOC(m->sumsq, 64);
@@ -609,10 +611,14 @@ static int backward_trunk(Model* m) {
   const int N = rows * m->S, NT = 2 * N;
   hipStream_t s = m->stream;
   const int* rpos = m->has_rope_pos ? m->d_rope_pos : nullptr;
-  float* gx = m->gxa;   // gradient w.r.t. the current layer's output
+  float* gx = m->gxa;   // gradient w.r.t. the current layer's output (fp32 residual stream)
   float* gx_other = m->gxb;
+  T* gxt = AT<T>(m->gxa_t);      // the same gradient as a GEMM operand (T)
+  T* gxt_other = AT<T>(m->gxb_t);
+  T* dht = AT<T>(m->dh_t);
+  const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
   tic(m, "phase_trunk_bwd");
-  RC(launch_rmsnorm_bwd_f32(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, m->G + m->o_norm, NT, D, s));
+  RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
@@ -621,17 +627,16 @@ static int backward_trunk(Model* m) {
     Model::LayerAct& a = m->la[l];
     {
       GemmParams p{};  // dW2 += gx^T . g
-      p.A = gx; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
+      p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_w2_dw", p, true, true, true));
+      RC(gemm<T>(m, "gemm_w2_dw", p, false, true, true));
     }
     {
-      GemmParams p{};  // dg = gx . W2
-      p.A = gx; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dg; p.ldc = Ip;
-      p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_w2_dx", p, true, false, true));
+      GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward: writes [da|db] directly
+      p.A = gxt; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dab; p.ldc = 2 * Ip;
+      p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
+      RC(gemm<T>(m, "gemm_w2_dx", p, false, false, true));
     }
-    RC(launch_swiglu_bwd<T>(AT<T>(m->dg), AT<T>(a.ab), AT<T>(m->dab), NT, Ip, s));
     {
       GemmParams p{};  // dW13 += dab^T . hn
       p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
@@ -644,18 +649,18 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, true));
     }
-    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, m->G + m->lo[l].mlp, NT, D, s));
+    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     {
       GemmParams p{};  // dWo += dh^T . O
-      p.A = m->dh; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
+      p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_o_dw", p, true, true, true));
+      RC(gemm<T>(m, "gemm_o_dw", p, false, true, true));
     }
     {
       GemmParams p{};  // dO = dh . Wo
-      p.A = m->dh; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
+      p.A = dht; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_o_dx", p, true, false, true));
+      RC(gemm<T>(m, "gemm_o_dx", p, false, false, true));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
@@ -677,8 +682,9 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, true));
     }
-    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, m->G + m->lo[l].sa, NT, D, s));
+    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
     std::swap(gx, gx_other);
+    std::swap(gxt, gxt_other);
   }
   toc(m);
   // gx = gradient w.r.t. the interleaved input embeddings (even rows: items, odd rows: actions)
@@ -688,16 +694,16 @@ static int backward_trunk(Model* m) {
   m->table_grads_pending = true;
   {
     GemmParams p{};  // dWlin += g_act^T . feat
-    p.A = gx + D; p.lda = 2 * D; p.B = m->feat; p.ldb = 32; p.C = m->G + m->o_lin_w; p.ldc = 32; p.c_f32 = 1;
+    p.A = gxt + D; p.lda = 2 * D; p.B = m->feat; p.ldb = 32; p.C = m->G + m->o_lin_w; p.ldc = 32; p.c_f32 = 1;
     p.M = D; p.N = 32; p.K = N; p.epi = EPI_ATOMIC;
-    RC(gemm<T>(m, "gemm_action_dw", p, true, true, true));
+    RC(gemm<T>(m, "gemm_action_dw", p, false, true, true));
   }
   RC(launch_colsum_add(gx + D, 2 * D, N, D, m->G + m->o_lin_b, s));
   {
     GemmParams p{};  // gf = g_act . Wlin
-    p.A = gx + D; p.lda = 2 * D; p.B = W<T>(m, m->o_lin_w); p.ldb = 32; p.C = m->gf; p.ldc = 32; p.c_f32 = 1;
+    p.A = gxt + D; p.lda = 2 * D; p.B = W<T>(m, m->o_lin_w); p.ldb = 32; p.C = m->gf; p.ldc = 32; p.c_f32 = 1;
     p.M = N; p.N = 32; p.K = D; p.epi = EPI_STORE;
-    RC(gemm<T>(m, "gemm_action_dx", p, true, false, true));
+    RC(gemm<T>(m, "gemm_action_dx", p, false, false, true));
   }
   SmallParams sp = small_params(m);
   RC(launch_action_small_bwd(m->gf, b, sp, m->G + m->o_pcos, m->G + m->o_psin, m->G + m->o_status, m->G + m->o_gender,
@@ -710,11 +716,16 @@ static int backward_trunk(Model* m) {
 template <typename T>
 static int finalize_grads_t(Model* m) {
   tic(m, "phase_table_bwd");
+  const void* gEt = m->G + m->o_E;
+  if (m->bf16_mode) {  // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it)
+    RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
+    gEt = m->FT;
+  }
   {
     GemmParams p{};
-    p.A = m->G + m->o_E; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
+    p.A = gEt; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
     p.M = m->D; p.N = m->Mp; p.K = m->V + 1; p.epi = EPI_ATOMIC;
-    RC(gemm<T>(m, "gemm_table_dw", p, true, true, true));
+    RC(gemm<T>(m, "gemm_table_dw", p, false, true, true));
   }
   RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
   toc(m);

@@ -74,7 +74,8 @@ struct Model {
   // heads
   int* idx[4]; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
   // backward workspaces
-  float *gy, *gxa, *gxb, *dh; void *dg, *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
+  float *gy, *gxa, *gxb, *dh; void *gxa_t, *gxb_t, *dh_t;   // *_t: T-typed operand copies (bf16 mode)
+  void *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
   float* sumsq;
   bool table_grads_pending = false;
   bool last_evaluate = false;
