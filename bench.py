@@ -147,6 +147,16 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = hg.all_reduce([elapsed], "max")[0]
     rep = model.timing_report() if not args.no_kernel_timing else {}
+    if rep:
+        # the head GEMMs stop at the positive-weight rows (device-side limit): count the flops they really did
+        npos = model.head_rows()
+        D = cfg["embed_dim"]; V0 = cfg["vocab_sizes"]["0_matchedid"]; V1 = cfg["vocab_sizes"]["1_matchedid"]
+        up = lambda n, q: (n + q - 1) // q * q
+        fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
+        fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
+        for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
+            if tag in rep:
+                rep[tag]["flops"] = fl
     model.timing(False)
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses

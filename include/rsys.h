@@ -100,6 +100,8 @@ int32_t rsys_forward_backward(rsys_model* m, int32_t evaluate, const float task_
 /* losses_out[12]: per task 3 slots (train: [loss,0,0]; evaluate rating tasks: 3 moments of model.py:395-401);
  * weight_sums_out[4]: d[name.weight].sum() after masking (train.py:261).  Synchronises. */
 int32_t rsys_losses_get(rsys_model* m, float losses_out[12], float weight_sums_out[4]);
+/* number of positive-weight positions selected per task in the last forward (they bound the head GEMMs) */
+int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
 /* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
 int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
 /* debug/parity: trunk output of the last forward (rows*2S*D floats) */

@@ -142,6 +142,14 @@ int32_t rsys_losses_get(rsys_model* h, float losses_out[12], float wsum_out[4]) 
   return RSYS_OK;
 }
 
+int32_t rsys_head_rows_get(rsys_model* h, int32_t out[4]) {
+  CHECK_HANDLE(h);
+  HIP_CHECK(hipSetDevice(h->m->device));
+  HIP_CHECK(hipStreamSynchronize(h->m->stream));
+  HIP_CHECK(hipMemcpy(out, h->m->npos, 16, hipMemcpyDeviceToHost));
+  return RSYS_OK;
+}
+
 int32_t rsys_infer(rsys_model* h, int32_t task, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_infer(h->m, task, out, n); }
 
 int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {

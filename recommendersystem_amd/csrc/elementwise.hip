@@ -287,7 +287,7 @@ template int launch_swiglu_bwd<float>(const float*, const float*, float*, long l
 // Deterministic replacement of torch.topk on 0/1 weights: positive-weight positions in
 // ascending flat index, then zero-weight positions ascending.  One
 // 1024-thread workgroup per task; two-level exclusive scan.
-__global__ __launch_bounds__(1024) void select_positions_kernel(const float* __restrict__ w, int N, int topk, int* idx, float* stats) {
+__global__ __launch_bounds__(1024) void select_positions_kernel(const float* __restrict__ w, int N, int topk, int* idx, float* stats, int* npos_out) {
   __shared__ int wave_tot[16];
   __shared__ float red[16];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -313,11 +313,11 @@ __global__ __launch_bounds__(1024) void select_positions_kernel(const float* __r
   }
   wsel = block_sum(wsel, red);
   wall = block_sum(wall, red);
-  if (t == 0) { stats[0] = wsel; stats[1] = wall; }
+  if (t == 0) { stats[0] = wsel; stats[1] = wall; if (npos_out) *npos_out = min(npos, topk); }
 }
-int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats, hipStream_t s) {
+int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats, int* npos_out, hipStream_t s) {
   ARG_CHECK(topk <= N, "select_positions: topk > N");
-  hipLaunchKernelGGL(select_positions_kernel, dim3(1), dim3(1024), 0, s, w, N, topk, idx, stats);
+  hipLaunchKernelGGL(select_positions_kernel, dim3(1), dim3(1024), 0, s, w, N, topk, idx, stats, npos_out);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -365,10 +365,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(T* logits, long long ldl, int V, const int* __restrict__ idx,
                                                  const float* __restrict__ label, const float* __restrict__ weight,
                                                  const int* __restrict__ position, const float* __restrict__ stats,
-                                                 float task_w, float* loss_out) {
+                                                 const int* __restrict__ npos, float task_w, float* loss_out) {
   __shared__ float red[16];
   constexpr int E = 16 / sizeof(T);
   const int row = blockIdx.x, t = threadIdx.x;
+  // zero-weight padding rows beyond the last 128-row GEMM tile that holds a positive row are never read by the
+  // (row-limited) head GEMMs; padding rows inside that tile are cleared below (lw == 0)
+  if (npos != nullptr && row >= ((*npos + 127) & ~127)) return;
   T* lr = logits + (long long)row * ldl;
   const int i = idx[row];
   const float w = weight[i], lab = label[i];
@@ -415,14 +418,14 @@ __global__ __launch_bounds__(256) void ce_kernel(T* logits, long long ldl, int V
 }
 template <typename T>
 int launch_ce_fwd_bwd(T* logits, long long ldl, int n, int V, const int* idx, const float* label, const float* weight,
-                      const int* position, const float* stats, float task_w, float* loss_out, hipStream_t s) {
+                      const int* position, const float* stats, const int* npos, float task_w, float* loss_out, hipStream_t s) {
   ARG_CHECK((ldl * sizeof(T)) % 16 == 0 && ldl >= V, "ce: ldl");
-  hipLaunchKernelGGL((ce_kernel<T>), dim3(n), dim3(256), 0, s, logits, ldl, V, idx, label, weight, position, stats, task_w, loss_out);
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(n), dim3(256), 0, s, logits, ldl, V, idx, label, weight, position, stats, npos, task_w, loss_out);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_ce_fwd_bwd<bf16>(bf16*, long long, int, int, const int*, const float*, const float*, const int*, const float*, float, float*, hipStream_t);
-template int launch_ce_fwd_bwd<float>(float*, long long, int, int, const int*, const float*, const float*, const int*, const float*, float, float*, hipStream_t);
+template int launch_ce_fwd_bwd<bf16>(bf16*, long long, int, int, const int*, const float*, const float*, const int*, const float*, const int*, float, float*, hipStream_t);
+template int launch_ce_fwd_bwd<float>(float*, long long, int, int, const int*, const float*, const float*, const int*, const float*, const int*, float, float*, hipStream_t);
 
 // --------------------------------------------------------------------- rating head tail (K14), model.py:355-359,391-401,520-526
 template <typename T>

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int ktiles = (p.K + BK - 1) / BK;
+  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;
+  const int ktiles = ((p.k_dev != nullptr ? min(p.K, *p.k_dev) : p.K) + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
   const int kt0 = blockIdx.y * per;
   const int kt1 = min(ktiles, kt0 + per);

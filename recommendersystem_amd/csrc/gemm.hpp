@@ -29,6 +29,9 @@ struct GemmParams {
   int epi;
   int c_f32;        // 1: C is float, 0: C is T
   int splitk;       // >=1; >1 requires EPI_ATOMIC
+  // optional device-side problem limits (no host sync): tiles whose first row is >= *m_dev exit at once, and the
+  // reduction stops at *k_dev rounded up to a tile (rows / k beyond the limit must hold data that contributes zero)
+  const int* m_dev; const int* k_dev;
   float alpha;
   const float* bias;
   const float* resid; long long ldr;

@@ -55,7 +55,8 @@ int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, c
 template <typename T>
 int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s);
 
-int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats /*[2]: wsum_sel, wsum_all*/, hipStream_t s);
+int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats /*[2]: wsum_sel, wsum_all*/,
+                            int* npos_out /*number of positive-weight rows selected (they come first)*/, hipStream_t s);
 
 template <typename T>
 int launch_gather_rows(const T* src, long long ld, const int* idx, int parity, T* dst, int n, int D, hipStream_t s);
@@ -66,7 +67,7 @@ int launch_scatter_rows_add(const float* src, const int* idx, int parity, float*
 // overwrites logits with dlogits = coef*(softmax - onehot), coef = tw*label*w/max(wsum,1e-8); pad cols zeroed
 template <typename T>
 int launch_ce_fwd_bwd(T* logits, long long ldl, int n, int V, const int* idx, const float* label, const float* weight,
-                      const int* position, const float* stats, float task_w, float* loss_out, hipStream_t s);
+                      const int* position, const float* stats, const int* npos, float task_w, float* loss_out, hipStream_t s);
 
 // rating head tail: pred = hact.w2 + b2 ; losses ; dz = dpred*w2*gelu'(z) (in place over z) ; dw2,db2,db0 accumulated
 template <typename T>

@@ -208,7 +208,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   }
   DALLOC(m->xL, NT * D * 4); DALLOC(m->rstdf, NT * 4); DALLOC(m->out, NT * D * e);
   for (int k = 0; k < 4; ++k) DALLOC(m->idx[k], KB * 4);
-  DALLOC(m->stats, 8 * 4); DALLOC(m->Ew, KB * D * e);
+  DALLOC(m->stats, 8 * 4); DALLOC(m->npos, 4 * 4); DALLOC(m->Ew, KB * D * e);
   m->ldl = pad8(std::max(m->V0, m->V1));
   DALLOC(m->logits, KB * m->ldl * e); DALLOC(m->dE, KB * D * 4);
   DALLOC(m->z, KB * D * e); DALLOC(m->hact, KB * D * e); DALLOC(m->loss_acc, 16 * 4);
@@ -540,7 +540,8 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   for (int ti = 0; ti < 4; ++ti) {
     const int medium = ti >> 1, metric = ti & 1;
     float* st = m->stats + 2 * ti;
-    RC(launch_select_positions(m->bd.m_weight[ti], N, KB, m->idx[ti], st, s));
+    int* np = m->npos + ti;   // positive-weight rows come first: the head GEMMs and the CE kernel stop there
+    RC(launch_select_positions(m->bd.m_weight[ti], N, KB, m->idx[ti], st, np, s));
     RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
     const bool bwd = train && tw[ti] != 0.f;
     if (metric == 0) {
@@ -549,26 +550,26 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
       {
         GemmParams p{};
         p.A = m->Ew; p.lda = D; p.B = Fm; p.ldb = D; p.C = m->logits; p.ldc = m->ldl;
-        p.M = KB; p.N = Vm; p.K = D; p.epi = EPI_STORE;
+        p.M = KB; p.N = Vm; p.K = D; p.epi = EPI_STORE; p.m_dev = np;
         RC(gemm<T>(m, "gemm_logits", p, false, false, false));
       }
       tic(m, "ce");
       RC(launch_ce_fwd_bwd<T>(AT<T>(m->logits), m->ldl, KB, Vm, m->idx[ti], m->bd.m_label[ti], m->bd.m_weight[ti],
-                              m->bd.m_position[ti], st, train ? tw[ti] : 0.f, m->loss_acc + 3 * ti, s));
+                              m->bd.m_position[ti], st, np, train ? tw[ti] : 0.f, m->loss_acc + 3 * ti, s));
       toc(m);
       if (bwd) {
         {
           GemmParams p{};  // dEw = dlogits . F   (few output tiles, K = V_m: split-K over the vocabulary)
           HIP_CHECK(hipMemsetAsync(m->dE, 0, (size_t)KB * D * 4, s));
           p.A = m->logits; p.lda = m->ldl; p.B = Fm; p.ldb = D; p.C = m->dE; p.ldc = D; p.c_f32 = 1;
-          p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_ATOMIC;
+          p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_ATOMIC; p.m_dev = np;
           RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
         }
         RC(launch_scatter_rows_add(m->dE, m->idx[ti], 0, m->gy, D, KB, D, s));
         {
           GemmParams p{};  // dF[s:e] += dlogits^T . Ew
           p.A = m->logits; p.lda = m->ldl; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_E + (int64_t)vs * D; p.ldc = D; p.c_f32 = 1;
-          p.M = Vm; p.N = D; p.K = KB; p.epi = EPI_ACCUM;
+          p.M = Vm; p.N = D; p.K = KB; p.epi = EPI_ACCUM; p.k_dev = np;
           RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
         }
         m->table_grads_pending = true;

@@ -72,7 +72,7 @@ struct Model {
   std::vector<LayerAct> la;
   float* xL; float* rstdf; void* out;
   // heads
-  int* idx[4]; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
+  int* idx[4]; int* npos; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
   // backward workspaces
   float *gy, *gxa, *gxb, *dh; void *gxa_t, *gxb_t, *dh_t;   // *_t: T-typed operand copies (bf16 mode)
   void *dab, *dhn, *dO, *dqkv; float* delta; float* gf;

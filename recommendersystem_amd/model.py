@@ -271,6 +271,12 @@ class RecommenderModel:
         check(lib().rsys_trunk_output_get(self._h, out.ctypes.data, out.size))
         return out
 
+    def head_rows(self):
+        """positive-weight positions per task in the last forward (the head GEMMs stop there)."""
+        out = (C.c_int32 * 4)()
+        check(lib().rsys_head_rows_get(self._h, C.byref(out)))
+        return [int(x) for x in out]
+
     # ---- instrumentation
     def timing(self, enable):
         check(lib().rsys_op_timing(self._h, 1 if enable else 0))
