@@ -26,10 +26,21 @@ GEMM_VARIANT = {  # call-site tag -> kernel instantiation (gemm.hip)
     "gemm_table_fwd": "NT", "gemm_action_fwd": "NT", "gemm_qkv_fwd": "NT", "gemm_o_fwd": "NT", "gemm_w13_fwd": "NT",
     "gemm_w2_fwd": "NT", "gemm_logits": "NT", "gemm_rating_fwd": "NT",
     "gemm_head_dx": "NN", "gemm_w13_dx": "NN", "gemm_qkv_dx": "NN", "gemm_rating_dx": "NN",
-    "gemm_w2_dx": "NN_f32A", "gemm_o_dx": "NN_f32A", "gemm_action_dx": "NN_f32A",
+    "gemm_w2_dx": "NN", "gemm_o_dx": "NN", "gemm_action_dx": "NN",
     "gemm_head_dw": "TN", "gemm_w13_dw": "TN", "gemm_qkv_dw": "TN", "gemm_rating_dw": "TN",
-    "gemm_w2_dw": "TN_f32A", "gemm_o_dw": "TN_f32A", "gemm_action_dw": "TN_f32A", "gemm_table_dw": "TN_f32A",
+    "gemm_w2_dw": "TN", "gemm_o_dw": "TN", "gemm_action_dw": "TN", "gemm_table_dw": "TN",
 }
+
+
+KERNEL_SYMBOL = {"NT": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb0EEEvNS_10GemmParamsE",
+                 "NN": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb1EEEvNS_10GemmParamsE",
+                 "TN": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb1ELb1EEEvNS_10GemmParamsE"}
+
+
+def traffic_of(db, variant):
+    """HBM bytes per launch of the kernel from the committed PMC summary (profiles/r1c_pmc_traffic.json)."""
+    k = db.get(KERNEL_SYMBOL.get(variant, ""))
+    return None if k is None else round(k["hbm_bytes_per_launch"])
 
 
 def flops_per_interaction(cfg, B):
@@ -113,9 +124,7 @@ def main():
     model.init_weights(0x1217)                 # same seed on every rank (replaces DDP's rank-0 broadcast, C1)
     model.random_pretrained_embeddings(0x3E7A)
     opt = ra.create_optimizer(model, cfg)
-    comm = rdist.Comm(hg, device) if world > 1 else None
-    if comm is not None:
-        comm.self_test()
+    comm = rdist.make_comm(hg, device)      # RCCL over xGMI (hardware_check-style self test inside)
     sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
     for _ in range(2000):
         sched.step()                           # bench at the stable learning rate
@@ -174,13 +183,18 @@ def main():
                 a = var.setdefault(v, {"ms": 0.0, "flops": 0.0, "launches": 0})
                 a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["launches"] += r["count"]
         roofline = None
+        traffic_db = {}
+        try:   # PMC passes are separate runs (rocprofv3 --pmc); their per-launch summary is committed under profiles/
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")))["kernels"]
+        except Exception:
+            pass
         if var:
             dom = max(var, key=lambda k: var[k]["ms"])
             a = var[dom]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": f"gemm_kernel<bf16,{dom}>", "achieved": round(ach, 1),
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                        "traffic": traffic_of(traffic_db, dom), "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],
                         "share_of_step": round(a["ms"] / (ms * args.steps), 3)}
         out = {
@@ -188,6 +202,7 @@ def main():
             "user_seqs_per_sec": round(value / S, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "comm": (None if comm is None else type(comm).__name__),
             "config": {"workload": f"{args.config}: train step fwd+bwd+allreduce+clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,

@@ -93,6 +93,58 @@ class Comm:
             self._h = C.c_void_p()
 
 
+class HostComm:
+    """Last-resort gradient all-reduce through host memory over gloo (same surface as Comm).  Only used when the
+    RCCL communicator cannot be created; it is orders of magnitude slower and says so on stderr."""
+
+    def __init__(self, host_group, reason=""):
+        import sys
+        self.hg = host_group
+        self.rank, self.world = host_group.rank, host_group.world
+        if self.rank == 0:
+            print(f"[recommendersystem_amd.dist] RCCL communicator unavailable ({reason}); "
+                  "falling back to a HOST all-reduce over gloo", file=sys.stderr)
+
+    def self_test(self):
+        assert self.hg.all_reduce([1.0], "sum")[0] == float(self.world)
+
+    def all_reduce_grads(self, model):
+        import torch
+        ptr = C.c_void_p(); n = C.c_int64()
+        check(lib().rsys_grad_buffer(model._h, C.byref(ptr), C.byref(n)))
+        host = np.empty(n.value, np.float32)
+        check(lib().rsys_dev_d2h(host.ctypes.data, ptr, host.nbytes))
+        t = torch.from_numpy(host)
+        self.hg.pg.all_reduce(t)
+        check(lib().rsys_dev_h2d(ptr, host.ctypes.data, host.nbytes))
+
+    def all_reduce_sum(self, values):
+        return self.hg.all_reduce(values, "sum")
+
+    def close(self):
+        pass
+
+
+def make_comm(host_group, device):
+    """RCCL communicator if possible, else the host fallback; every rank takes the same branch (the outcome of the
+    RCCL attempt is agreed on with a MIN reduction over gloo)."""
+    if host_group.world == 1:
+        return None
+    comm, err = None, ""
+    try:
+        comm = Comm(host_group, device)
+        comm.self_test()
+    except Exception as e:   # noqa: BLE001 - any failure of the native path selects the fallback
+        err = str(e)
+        comm = None
+    ok_everywhere = -host_group.all_reduce([-(1.0 if comm is not None else 0.0)], "max")[0]
+    if ok_everywhere >= 1.0:
+        return comm
+    if comm is not None:
+        comm.close()
+    return HostComm(host_group, err or "another rank failed")
+
+
 def shard_for_rank(shards, local_rank, local_world_size):
     """train.py:46-51: shard directory i goes to rank i % world; the count must divide evenly."""
     assert len(shards) % local_world_size == 0
