@@ -33,7 +33,7 @@ static RcclApi g_rccl;
 static int load_rccl() {
   if (g_rccl.lib) return RSYS_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+  for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
   if (!g_rccl.lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return RSYS_ERR_COMM; }
   g_rccl.GetUniqueId = (int (*)(ncclUniqueId_t*))dlsym(g_rccl.lib, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(ncclComm_t_*, int, ncclUniqueId_t, int))dlsym(g_rccl.lib, "ncclCommInitRank");

@@ -140,17 +140,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {  // bijective XCD remap: blocks that share an XCD (bid % 8) take consecutive tiles
+  // Work item -> (output tile, K split), XCD-aware (blocks are dealt round-robin over the 8 XCDs, each with a
+  // private L2): without split-K, blocks of one XCD take consecutive tiles (they share the A rows); with split-K
+  // (weight gradients: K = tokens) all tiles of one K split run on ONE XCD, so the K-major operand rows of that
+  // split are fetched from the fabric once instead of once per XCD (measured 2.5x less FETCH_SIZE).
+  int bid, split;
+  if (p.splitk == 1) {
+    bid = blockIdx.x; split = 0;
     int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+  } else {
+    // launcher guarantees splitk % 8 == 0: XCD x owns splits x, x+8, ...; inside an XCD tiles vary fastest
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    bid = local % ntiles;
+    split = xcd + 8 * (local / ntiles);
   }
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   if (p.m_dev != nullptr && m0 >= *p.m_dev) return;
   const int ktiles = ((p.k_dev != nullptr ? min(p.K, *p.k_dev) : p.K) + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt0 = blockIdx.y * per;
+  const int kt0 = split * per;
   const int kt1 = min(ktiles, kt0 + per);
   if (kt0 >= kt1) return;
 
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, p.splitk, 1);
+  dim3 grid(tiles * p.splitk, 1, 1);
   hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM>), grid, dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
@@ -468,6 +478,7 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   GemmParams p = p0;
   constexpr int EPC = MmaT<CT>::EPC;
   if (p.splitk < 1) p.splitk = 1;
+  if (p.splitk > 1) p.splitk = (p.splitk + 7) / 8 * 8;   // one K split never straddles XCDs (see the kernel's work mapping)
   ARG_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
   ARG_CHECK(p.splitk == 1 || p.epi == EPI_ATOMIC, "gemm: split-K needs the atomic epilogue");
   const int ea = (is_bf16<CT>::value && a_f32) ? 4 : EPC;
