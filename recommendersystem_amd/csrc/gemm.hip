@@ -132,88 +132,89 @@ __device__ __forceinline__ void store_c(const GemmParams& p, void* C, long long 
   else ((CT*)C)[row * ld + col] = from_f32<CT>(v);
 }
 
-template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
+template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   using MT = MmaT<CT>;
   constexpr int EPC = MT::EPC, BK = MT::BK;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];   // [buf 0: A 16K | B 16K][buf 1: A 16K | B 16K]
 
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
-  // Work item -> (output tile, K split), XCD-aware (blocks are dealt round-robin over the 8 XCDs, each with a
-  // private L2): without split-K, blocks of one XCD take consecutive tiles (they share the A rows); with split-K
-  // (weight gradients: K = tokens) all tiles of one K split run on ONE XCD, so the K-major operand rows of that
-  // split are fetched from the fabric once instead of once per XCD (measured 2.5x less FETCH_SIZE).
-  int bid, split;
-  if (p.splitk == 1) {
-    bid = blockIdx.x; split = 0;
-    int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
-  } else {
-    // launcher guarantees splitk % 8 == 0: XCD x owns splits x, x+8, ...; inside an XCD tiles vary fastest
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    bid = local % ntiles;
-    split = xcd + 8 * (local / ntiles);
-  }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;
-  const int ktiles = ((p.k_dev != nullptr ? min(p.K, *p.k_dev) : p.K) + BK - 1) / BK;
-  const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt0 = split * per;
-  const int kt1 = min(ktiles, kt0 + per);
-  if (kt0 >= kt1) return;
-
   const int t = threadIdx.x, l = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-  // LDS: [buf 0: A 16K | B 16K][buf 1: A 16K | B 16K]
-
-  // ---- per-thread staging geometry, computed once: 4 A chunks + 4 B chunks of 16 bytes per tile.
-  // Global address of a chunk = uniform 64-bit tile base (SGPRs) + 32-bit per-thread byte offset (VGPR), so the
-  // steady-state loads are `global_load_dwordx4 v, voff, s[base]` with no vector address arithmetic.
   constexpr int ESA = (is_bf16<CT>::value && AF32) ? 4 : (int)sizeof(CT);   // bytes per source element
   constexpr int ESB = (is_bf16<CT>::value && BF32) ? 4 : (int)sizeof(CT);
-  unsigned int aoff[4], boff[4];       // byte offset of the chunk inside the operand, relative to the block base
+
+  // ---- state of the current work item (an output tile and a K range)
+  int cm0 = 0, cn0 = 0, kt0 = 0, kt1 = 0;
+  // per-thread staging geometry: 4 A chunks + 4 B chunks of 16 bytes per tile.  Global address of a chunk =
+  // uniform 64-bit tile base (SGPRs) + 32-bit per-thread byte offset (VGPR): the steady-state loads need no
+  // vector address arithmetic.
+  unsigned int aoff[4], boff[4];       // byte offset of the chunk relative to the block base
   int arow[4], brow[4];                // K-major: k row inside the tile; row-major: chunk's first k inside the tile
   bool aval[4], bval[4];               // K-major: the chunk's m/n range is inside the matrix
   int ldsa[4], ldsb[4];
+  const char* Ablk = nullptr; const char* Bblk = nullptr;
+  bool full = true;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = t + 256 * j;
-    ldsa[j] = lds_chunk_offset<CT, AKM>(c);
-    ldsb[j] = 16384 + lds_chunk_offset<CT, BKM>(c);
-    if constexpr (!AKM) {
-      const int row = c >> 3, ch = c & 7;
-      const int gr = min(m0 + row, p.M - 1) - m0;
-      aoff[j] = (unsigned int)(((long long)gr * p.lda + ch * EPC) * ESA);
-      arow[j] = ch * EPC; aval[j] = true;
-    } else {
-      constexpr int CPR = 128 / EPC;
-      const int krow = c / CPR, ch = c % CPR;
-      aoff[j] = (unsigned int)(((long long)krow * p.lda + ch * EPC) * ESA);
-      arow[j] = krow; aval[j] = (m0 + ch * EPC) < p.M;
-    }
-    if constexpr (!BKM) {
-      const int row = c >> 3, ch = c & 7;
-      const int gr = min(n0 + row, p.N - 1) - n0;
-      boff[j] = (unsigned int)(((long long)gr * p.ldb + ch * EPC) * ESB);
-      brow[j] = ch * EPC; bval[j] = true;
-    } else {
-      constexpr int CPR = 128 / EPC;
-      const int krow = c / CPR, ch = c % CPR;
-      boff[j] = (unsigned int)(((long long)krow * p.ldb + ch * EPC) * ESB);
-      brow[j] = krow; bval[j] = (n0 + ch * EPC) < p.N;
-    }
+    ldsa[j] = lds_chunk_offset<CT, AKM>(t + 256 * j);
+    ldsb[j] = 16384 + lds_chunk_offset<CT, BKM>(t + 256 * j);
   }
-  const char* Ablk = (const char*)p.A + (AKM ? (long long)m0 : (long long)m0 * p.lda) * ESA;
-  const char* Bblk = (const char*)p.B + (BKM ? (long long)n0 : (long long)n0 * p.ldb) * ESB;
-  // a block is "full" when no chunk of any of its tiles needs a guard
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+
+  // Work item -> (output tile, K split), XCD-aware (blocks are dealt round-robin over the 8 XCDs, each with a
+  // private L2): without split-K, blocks of one XCD take consecutive tiles (they share the A rows); with split-K
+  // (weight gradients: K = tokens) all tiles of one K split run on ONE XCD, so the K-major operand rows of that
+  // split are fetched from the fabric once instead of once per XCD.  Returns false for an item with no work.
+  auto setup = [&](int tile, int split) -> bool {
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    cm0 = m0; cn0 = n0;
+    if (p.m_dev != nullptr && m0 >= *p.m_dev) return false;
+    const int ktiles = ((p.k_dev != nullptr ? min(p.K, *p.k_dev) : p.K) + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    kt0 = split * per;
+    kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = t + 256 * j;
+      if constexpr (!AKM) {
+        const int row = c >> 3, ch = c & 7;
+        const int gr = min(m0 + row, p.M - 1) - m0;
+        aoff[j] = (unsigned int)(((long long)gr * p.lda + ch * EPC) * ESA);
+        arow[j] = ch * EPC; aval[j] = true;
+      } else {
+        constexpr int CPR = 128 / EPC;
+        const int krow = c / CPR, ch = c % CPR;
+        aoff[j] = (unsigned int)(((long long)krow * p.lda + ch * EPC) * ESA);
+        arow[j] = krow; aval[j] = (m0 + ch * EPC) < p.M;
+      }
+      if constexpr (!BKM) {
+        const int row = c >> 3, ch = c & 7;
+        const int gr = min(n0 + row, p.N - 1) - n0;
+        boff[j] = (unsigned int)(((long long)gr * p.ldb + ch * EPC) * ESB);
+        brow[j] = ch * EPC; bval[j] = true;
+      } else {
+        constexpr int CPR = 128 / EPC;
+        const int krow = c / CPR, ch = c % CPR;
+        boff[j] = (unsigned int)(((long long)krow * p.ldb + ch * EPC) * ESB);
+        brow[j] = krow; bval[j] = (n0 + ch * EPC) < p.N;
+      }
+    }
+    Ablk = (const char*)p.A + (AKM ? (long long)m0 : (long long)m0 * p.lda) * ESA;
+    Bblk = (const char*)p.B + (BKM ? (long long)n0 : (long long)n0 * p.ldb) * ESB;
+    full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);   // no chunk of any tile needs a guard
+    return true;
+  };
 
   f32x4 acc[4][4];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
 
   auto compute = [&](int cur) {
 #pragma unroll
@@ -231,58 +232,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   };
 
   // Software pipeline, two register sets: the loads of tile k+2 are issued before the MFMAs of tile k while
-  // tile k+1 is in flight.  Every global load / LDS store is unconditional (tile indices past the end are
-  // clamped to the last tile, their data is never consumed): with no branch around a memory operation hipcc
-  // keeps exact vmcnt counts, so the LDS store of tile k+1 waits for ITS loads only.
-  auto run = [&](auto FULLC) {
+  // tile k+1 is in flight.  The steady-state loop has no branch around a memory operation, so hipcc keeps exact
+  // vmcnt counts (the LDS store of tile k+1 waits for ITS loads only); the last one..three phases are peeled so
+  // that no block waits for loads it does not consume.
+  Staged<CT, AF32> ra0[4], ra1[4];
+  Staged<CT, BF32> rb0[4], rb1[4];
+  auto gload = [&](Staged<CT, AF32>(&ra)[4], Staged<CT, BF32>(&rb)[4], int kt, auto FULLC) {
     constexpr bool FULL = decltype(FULLC)::value;
-    Staged<CT, AF32> ra0[4], ra1[4];
-    Staged<CT, BF32> rb0[4], rb1[4];
-    auto gload = [&](Staged<CT, AF32>(&ra)[4], Staged<CT, BF32>(&rb)[4], int kt) {
-      const int k0 = kt * BK;
-      const char* At = Ablk + (AKM ? (long long)k0 * p.lda : (long long)k0) * ESA;   // uniform
-      const char* Bt = Bblk + (BKM ? (long long)k0 * p.ldb : (long long)k0) * ESB;
+    const int k0 = kt * BK;
+    const char* At = Ablk + (AKM ? (long long)k0 * p.lda : (long long)k0) * ESA;   // uniform
+    const char* Bt = Bblk + (BKM ? (long long)k0 * p.ldb : (long long)k0) * ESB;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (FULL) {
-          ra[j] = load_chunk_at<CT, AF32>(At, aoff[j], true);
-          rb[j] = load_chunk_at<CT, BF32>(Bt, boff[j], true);
-        } else {
-          const bool va = aval[j] && (k0 + arow[j] < p.K);
-          const bool vb = bval[j] && (k0 + brow[j] < p.K);
-          ra[j] = load_chunk_at<CT, AF32>(va ? At : (const char*)p.A, va ? aoff[j] : 0u, va);
-          rb[j] = load_chunk_at<CT, BF32>(vb ? Bt : (const char*)p.B, vb ? boff[j] : 0u, vb);
-        }
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (FULL) {
+        ra[j] = load_chunk_at<CT, AF32>(At, aoff[j], true);
+        rb[j] = load_chunk_at<CT, BF32>(Bt, boff[j], true);
+      } else {
+        const bool va = aval[j] && (k0 + arow[j] < p.K);
+        const bool vb = bval[j] && (k0 + brow[j] < p.K);
+        ra[j] = load_chunk_at<CT, AF32>(va ? At : (const char*)p.A, va ? aoff[j] : 0u, va);
+        rb[j] = load_chunk_at<CT, BF32>(vb ? Bt : (const char*)p.B, vb ? boff[j] : 0u, vb);
       }
-    };
-    auto lstore = [&](const Staged<CT, AF32>(&ra)[4], const Staged<CT, BF32>(&rb)[4], int buf) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *(uint4*)(smem + buf * 32768 + ldsa[j]) = chunk_bits<CT, AF32, FULL>(ra[j]);
-        *(uint4*)(smem + buf * 32768 + ldsb[j]) = chunk_bits<CT, BF32, FULL>(rb[j]);
-      }
-    };
-    const int klast = kt1 - 1;
-    gload(ra0, rb0, kt0);
-    gload(ra1, rb1, min(kt0 + 1, klast));
-    lstore(ra0, rb0, 0);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; kt += 2) {
-      // even phase: LDS buffer 0 holds tile kt, set 1 holds tile kt+1 (in flight)
-      gload(ra0, rb0, min(kt + 2, klast));
-      compute(0);
-      lstore(ra1, rb1, 1);
-      __syncthreads();
-      // odd phase: LDS buffer 1 holds tile kt+1, set 0 holds tile kt+2 (in flight)
-      gload(ra1, rb1, min(kt + 3, klast));
-      if (kt + 1 < kt1) compute(1);
-      lstore(ra0, rb0, 0);
-      __syncthreads();
     }
   };
-  if (full) run(std::true_type{});
-  else run(std::false_type{});
+  auto lstore = [&](const Staged<CT, AF32>(&ra)[4], const Staged<CT, BF32>(&rb)[4], int buf, auto FULLC) {
+    constexpr bool FULL = decltype(FULLC)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(uint4*)(smem + buf * 32768 + ldsa[j]) = chunk_bits<CT, AF32, FULL>(ra[j]);
+      *(uint4*)(smem + buf * 32768 + ldsb[j]) = chunk_bits<CT, BF32, FULL>(rb[j]);
+    }
+  };
+  // first two tiles of the current item into the register sets (issued as early as possible: in the persistent
+  // kernel BEFORE the epilogue of the previous tile, which hides their HBM latency)
+  auto prologue_loads = [&](auto FC) {
+    gload(ra0, rb0, kt0, FC);
+    if (kt1 - kt0 > 1) gload(ra1, rb1, kt0 + 1, FC);
+  };
+  // Phase p computes tile p from LDS buffer p&1, after issuing the loads of tile p+2 and before storing tile p+1.
+  auto mainloop = [&](auto FC) {
+    const int n = kt1 - kt0;
+    lstore(ra0, rb0, 0, FC);
+    __syncthreads();
+    int pz = 0;
+    for (; pz + 3 < n; pz += 2) {
+      gload(ra0, rb0, kt0 + pz + 2, FC);     // even phase: buffer 0 = tile pz, set 1 = tile pz+1 (in flight)
+      compute(0);
+      lstore(ra1, rb1, 1, FC);
+      __syncthreads();
+      gload(ra1, rb1, kt0 + pz + 3, FC);     // odd phase: buffer 1 = tile pz+1, set 0 = tile pz+2 (in flight)
+      compute(1);
+      lstore(ra0, rb0, 0, FC);
+      __syncthreads();
+    }
+    const int rem = n - pz;              // 1, 2 or 3 phases left
+    if (rem == 3) {
+      gload(ra0, rb0, kt0 + pz + 2, FC);
+      compute(0);
+      lstore(ra1, rb1, 1, FC);
+      __syncthreads();
+      compute(1);
+      lstore(ra0, rb0, 0, FC);
+      __syncthreads();
+      compute(0);
+    } else if (rem == 2) {
+      compute(0);
+      lstore(ra1, rb1, 1, FC);
+      __syncthreads();
+      compute(1);
+    } else {
+      compute(0);
+    }
+    __syncthreads();
+  };
 
+  // `hook` runs once, right after the last read of the accumulators (they are dead from then on): the persistent
+  // kernel issues the next tile's first loads there, so they do not have to live across the whole epilogue.
+  auto epilogue = [&](const int m0, const int n0, auto&& hook) {
   // ------------------------------------------------------------------ epilogue
   // The accumulators are staged through LDS (the operand tiles are dead by now) so that every global
   // access of the epilogue is a full 128..512-byte row segment with 8..16 bytes per lane, instead of the
@@ -292,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int CS_LD = 132;   // f32 row-major staging tile [64][132]
   constexpr int CT_LD = 68;    // f32 staging tile of the SwiGLU product [64][68]
   float* Cs = (float*)smem;
-  const bool cf32 = p.c_f32 != 0;
-  __syncthreads();
+  const bool cf32 = p.c_f32 != 0;   // (the main loop ends with a barrier: the operand tiles are dead)
+  if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[3][3][3]; return; }   // timing experiment: no epilogue
 
   if (p.epi == EPI_ATOMIC) {
     // split-K weight gradients: 64 lanes add 256 contiguous bytes per wave-instruction (full-rate shape)
@@ -316,6 +342,133 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     return;
   }
 
+  // copy-out of a staged [64][*] f32 tile: every lane handles W consecutive columns of one row, so that the
+  // global accesses are 16 bytes per lane (bf16: W = 8, f32: W = 4; 8-byte stores run at ~half the rate)
+  const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL;
+  auto store_t = [&](CT* dst, const float* v, int nv, auto WC) {
+    constexpr int W = decltype(WC)::value;
+    if (nv == W) {
+      if constexpr (is_bf16<CT>::value) {
+        if constexpr (W == 8) { bf16x8 pk; for (int k = 0; k < 8; ++k) pk[k] = (bf16)v[k]; *(bf16x8*)dst = pk; }
+        else { bf16x4 pk; for (int k = 0; k < 4; ++k) pk[k] = (bf16)v[k]; *(bf16x4*)dst = pk; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < W; k += 4) *(float4*)(dst + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+      }
+    } else {
+      for (int k = 0; k < nv; ++k) dst[k] = from_f32<CT>(v[k]);
+    }
+  };
+  auto copy_primary = [&](int half, auto WC) {
+    constexpr int W = decltype(WC)::value;
+    constexpr int CPR = 128 / W, ITEMS = 64 * CPR / 256;
+#pragma unroll 2
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = t + 256 * it;
+      const int row_l = idx / CPR, cw = (idx % CPR) * W;
+      const long long row = m0 + half * 64 + row_l;
+      const int col = n0 + cw;
+      if (row >= p.M || col >= p.N) continue;
+      const int nv = min(W, p.N - col);
+      float v[W];
+#pragma unroll
+      for (int k = 0; k < W; k += 4) {
+        const float4 q = *(const float4*)&Cs[row_l * CS_LD + cw + k];
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+      }
+      switch (p.epi) {
+        case EPI_STORE:
+#pragma unroll
+          for (int k = 0; k < W; ++k) v[k] *= p.alpha;
+          break;
+        case EPI_ACCUM:
+#pragma unroll
+          for (int k = 0; k < W; ++k) if (k < nv) v[k] += ((const float*)p.C)[row * p.ldc + col + k];
+          break;
+        case EPI_BIAS:
+#pragma unroll
+          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.bias[col + k];
+          break;
+        case EPI_RESIDUAL:
+#pragma unroll
+          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.resid[row * p.ldr + col + k];
+          break;
+        case EPI_TABLE: {
+#pragma unroll
+          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.E[row * p.ldc + col + k] + p.bias[col + k];
+          float* d32 = (float*)p.C + row * p.ldc + col;
+          if (nv == W) {
+#pragma unroll
+            for (int k = 0; k < W; k += 4) *(float4*)(d32 + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+          } else for (int k = 0; k < nv; ++k) d32[k] = v[k];
+          store_t((CT*)p.C2 + row * p.ldc2 + col, v, nv, WC);
+          continue;
+        }
+        case EPI_GELU: {
+          float ge[W];
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            if (k < nv) v[k] += p.bias[col + k];
+            ge[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+          }
+          store_t((CT*)p.C + row * p.ldc + col, v, nv, WC);
+          store_t((CT*)p.C2 + row * p.ldc2 + col, ge, nv, WC);
+          continue;
+        }
+        case EPI_QKV_ROPE:
+          // rotate interleaved pairs (transformer.model.py:182-190): W consecutive columns = W/2 pairs of one head
+          if (col < p.n_q + p.n_k) {
+            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
+            const int cc = col < p.n_q ? col : col - p.n_q;
+            const int d2 = (cc & (p.hd - 1)) >> 1;
+            const float* cs = p.rope_cos + pos * (p.hd >> 1) + d2;
+            const float* sn = p.rope_sin + pos * (p.hd >> 1) + d2;
+#pragma unroll
+            for (int k = 0; k < W; k += 2) {
+              const float c = cs[k >> 1], s2 = sn[k >> 1];
+              const float a0 = v[k] * c - v[k + 1] * s2, a1 = v[k] * s2 + v[k + 1] * c;
+              v[k] = a0; v[k + 1] = a1;
+            }
+          }
+          break;
+        case EPI_SWIGLU_BWD: {
+          // column col = i index of dg; a,b live at (i>>4)*32 + (i&15) (+16) of the interleaved [a|b] rows;
+          // N % 16 == 0 and W | 16, so the W columns of an item are one aligned group of a and one of b
+          const long long base = row * p.ldc + (long long)(col >> 4) * 32 + (col & 15);
+          float av[W], bv[W], da[W], db[W];
+          if constexpr (is_bf16<CT>::value && W == 8) {
+            const bf16x8 a8 = *(const bf16x8*)((const CT*)p.C2 + base), b8 = *(const bf16x8*)((const CT*)p.C2 + base + 16);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { av[k] = (float)a8[k]; bv[k] = (float)b8[k]; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) { av[k] = to_f32(((const CT*)p.C2)[base + k]); bv[k] = to_f32(((const CT*)p.C2)[base + 16 + k]); }
+          }
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const float sg = 1.f / (1.f + __expf(-av[k]));
+            da[k] = v[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
+            db[k] = v[k] * av[k] * sg;
+          }
+          store_t((CT*)p.C + base, da, W, WC);
+          store_t((CT*)p.C + base + 16, db, W, WC);
+          continue;
+        }
+        default: break;   // SWIGLU: plain store of the primary tile
+      }
+      if (outf32) {
+        float* dst = (float*)p.C + row * p.ldc + col;
+        if (nv == W) {
+#pragma unroll
+          for (int k = 0; k < W; k += 4) *(float4*)(dst + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        } else for (int k = 0; k < nv; ++k) dst[k] = v[k];
+      } else {
+        store_t((CT*)p.C + row * p.ldc + col, v, nv, WC);
+      }
+    }
+  };
+  const bool wide = is_bf16<CT>::value && (!outf32 || p.epi == EPI_TABLE);   // bf16 outputs (incl. the bf16 copy of EPI_TABLE): 8 columns per lane
+
   for (int half = 0; half < 2; ++half) {
     // ---- primary tile, row-major
     if (wr == half) {
@@ -324,115 +477,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * fq + r) * CS_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
       }); });
     }
+    if (half == 1 && p.epi != EPI_SWIGLU) hook();
     __syncthreads();
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-      const int idx = t + 256 * it;
-      const int row_l = idx >> 5, c4 = (idx & 31) * 4;
-      const long long row = m0 + half * 64 + row_l;
-      const int col = n0 + c4;
-      if (row >= p.M || col >= p.N) continue;
-      float4 v4 = *(const float4*)&Cs[row_l * CS_LD + c4];
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
-      const int nv = min(4, p.N - col);
-      float w2[4] = {0.f, 0.f, 0.f, 0.f};   // second output (C2) where the epilogue has one
-      bool two = false;
-      switch (p.epi) {
-        case EPI_STORE:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= p.alpha;
-          break;
-        case EPI_ACCUM:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += ((const float*)p.C)[row * p.ldc + col + k];
-          break;
-        case EPI_BIAS:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += p.bias[col + k];
-          break;
-        case EPI_RESIDUAL:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nv) v[k] += p.resid[row * p.ldr + col + k];
-          break;
-        case EPI_TABLE:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nv) { v[k] += p.E[row * p.ldc + col + k] + p.bias[col + k]; w2[k] = v[k]; }
-          two = true;
-          break;
-        case EPI_GELU:
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nv) {
-            v[k] += p.bias[col + k];
-            w2[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
-          }
-          two = true;
-          break;
-        case EPI_QKV_ROPE:
-          // rotate interleaved pairs (transformer.model.py:182-190): 4 consecutive columns = 2 pairs of one head
-          if (col < p.n_q + p.n_k) {
-            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
-            const int cc = col < p.n_q ? col : col - p.n_q;
-            const int d2 = (cc & (p.hd - 1)) >> 1;
-            const float2 cs = *(const float2*)(p.rope_cos + pos * (p.hd >> 1) + d2);
-            const float2 sn = *(const float2*)(p.rope_sin + pos * (p.hd >> 1) + d2);
-            const float a0 = v[0] * cs.x - v[1] * sn.x, a1 = v[0] * sn.x + v[1] * cs.x;
-            const float b0 = v[2] * cs.y - v[3] * sn.y, b1 = v[2] * sn.y + v[3] * cs.y;
-            v[0] = a0; v[1] = a1; v[2] = b0; v[3] = b1;
-          }
-          break;
-        default: break;   // SWIGLU: plain store of the primary tile
-      }
-      if (p.epi == EPI_SWIGLU_BWD) {
-        // column col = i index of dg; a,b live at (i>>4)*32 + (i&15) (+16) of the interleaved [a|b] rows;
-        // N % 16 == 0, so the 4 columns of an item are one 8/16-byte group of a and one of b
-        const long long base = row * p.ldc + (long long)(col >> 4) * 32 + (col & 15);
-        float av[4], bv[4];
-        if constexpr (is_bf16<CT>::value) {
-          const bf16x4 a4 = *(const bf16x4*)((const CT*)p.C2 + base), b4 = *(const bf16x4*)((const CT*)p.C2 + base + 16);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { av[k] = (float)a4[k]; bv[k] = (float)b4[k]; }
-        } else {
-          const float4 a4 = *(const float4*)((const CT*)p.C2 + base), b4 = *(const float4*)((const CT*)p.C2 + base + 16);
-          av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w; bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-        }
-        float da[4], db[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float sg = 1.f / (1.f + __expf(-av[k]));
-          da[k] = v[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
-          db[k] = v[k] * av[k] * sg;
-        }
-        if constexpr (is_bf16<CT>::value) {
-          bf16x4 o1, o2;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { o1[k] = (bf16)da[k]; o2[k] = (bf16)db[k]; }
-          *(bf16x4*)((CT*)p.C + base) = o1; *(bf16x4*)((CT*)p.C + base + 16) = o2;
-        } else {
-          *(float4*)((CT*)p.C + base) = make_float4(da[0], da[1], da[2], da[3]);
-          *(float4*)((CT*)p.C + base + 16) = make_float4(db[0], db[1], db[2], db[3]);
-        }
-        continue;
-      }
-      const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
-      if (outf32) {
-        float* dst = (float*)p.C + row * p.ldc + col;
-        if (nv == 4) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int k = 0; k < nv; ++k) dst[k] = v[k];
-      } else {
-        CT* dst = (CT*)p.C + row * p.ldc + col;
-        if (nv == 4) {
-          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v[0]; pk[1] = (bf16)v[1]; pk[2] = (bf16)v[2]; pk[3] = (bf16)v[3]; *(bf16x4*)dst = pk; }
-          else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-        } else for (int k = 0; k < nv; ++k) dst[k] = from_f32<CT>(v[k]);
-      }
-      if (two) {
-        CT* dst2 = (CT*)p.C2 + row * p.ldc2 + col;
-        if (nv == 4) {
-          if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)w2[0]; pk[1] = (bf16)w2[1]; pk[2] = (bf16)w2[2]; pk[3] = (bf16)w2[3]; *(bf16x4*)dst2 = pk; }
-          else *(float4*)dst2 = make_float4(w2[0], w2[1], w2[2], w2[3]);
-        } else for (int k = 0; k < nv; ++k) dst2[k] = from_f32<CT>(w2[k]);
-      }
-    }
+    if (wide) copy_primary(half, std::integral_constant<int, 8>{});
+    else copy_primary(half, std::integral_constant<int, 4>{});
     __syncthreads();
 
     // ---- SwiGLU product g = silu(a)*b: columns are interleaved in 16-wide blocks [a | b], lane-local pairs
@@ -447,28 +495,74 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           }
         }); });
       }
+      if (half == 1) hook();
       __syncthreads();
-      for (int it = 0; it < 4; ++it) {
+      constexpr int GW = is_bf16<CT>::value ? 8 : 4, GCPR = 64 / GW;
+      for (int it = 0; it < 64 * GCPR / 256; ++it) {
         const int idx = t + 256 * it;
-        const int row_l = idx >> 4, c4 = (idx & 15) * 4;
+        const int row_l = idx / GCPR, cw = (idx % GCPR) * GW;
         const long long row = m0 + half * 64 + row_l;
-        const int gcol = (n0 >> 1) + c4;
+        const int gcol = (n0 >> 1) + cw;
         if (row >= p.M || gcol * 2 >= p.N) continue;
-        const float4 v4 = *(const float4*)&Cs[row_l * CT_LD + c4];
-        CT* dst = (CT*)p.C2 + row * p.ldc2 + gcol;
-        if constexpr (is_bf16<CT>::value) { bf16x4 pk; pk[0] = (bf16)v4.x; pk[1] = (bf16)v4.y; pk[2] = (bf16)v4.z; pk[3] = (bf16)v4.w; *(bf16x4*)dst = pk; }
-        else *(float4*)dst = v4;
+        float v[GW];
+#pragma unroll
+        for (int k = 0; k < GW; k += 4) {
+          const float4 q = *(const float4*)&Cs[row_l * CT_LD + cw + k];
+          v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        }
+        store_t((CT*)p.C2 + row * p.ldc2 + gcol, v, GW, std::integral_constant<int, GW>{});
       }
       __syncthreads();
     }
+  }
+  };   // epilogue
+
+  if constexpr (PERSIST) {
+    // Persistent workgroups (2 per CU) walk the tiles of their XCD; every tile is full (launcher).  The next
+    // tile's first loads are in flight during the epilogue of the current one and its stores drain under the
+    // next main loop: neither end of a tile exposes HBM latency (short-K GEMMs spend most of their time there).
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    int idx = blockIdx.x >> 3;
+    if (idx >= cnt) return;
+    setup(base + idx, 0);
+    prologue_loads(std::true_type{});
+    while (true) {
+      mainloop(std::true_type{});
+      const int em0 = cm0, en0 = cn0;
+      idx += nslot;
+      const bool more = idx < cnt;
+      epilogue(em0, en0, [&]() { if (more) { setup(base + idx, 0); prologue_loads(std::true_type{}); } });
+      if (!more) break;
+      zero_acc();
+    }
+  } else {
+    int tile, split;
+    if (p.splitk == 1) {
+      const int bid = blockIdx.x;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+      split = 0;
+    } else {
+      // launcher guarantees splitk % 8 == 0: XCD x owns splits x, x+8, ...; inside an XCD tiles vary fastest
+      const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+      tile = local % ntiles;
+      split = xcd + 8 * (local / ntiles);
+    }
+    if (!setup(tile, split)) return;
+    if (full) { prologue_loads(std::true_type{}); mainloop(std::true_type{}); }
+    else { prologue_loads(std::false_type{}); mainloop(std::false_type{}); }
+    epilogue(cm0, cn0, []() {});
   }
 }
 
 template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles * p.splitk, 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM>), grid, dim3(256), 0, s, p);
+  // (A persistent variant -- PERSIST = true: 512 workgroups walking the tiles with the next tile's loads issued under
+  // the epilogue -- exists in the kernel but is not instantiated: at 256 VGPRs it spills and measured 2x slower.)
+  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM, false>), dim3(tiles * p.splitk), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -494,6 +588,8 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   if (p.epi == EPI_SWIGLU) ARG_CHECK(p.N % 32 == 0 && p.ldc2 % 4 == 0, "gemm: swiglu epilogue needs N % 32 == 0");
   if (p.epi == EPI_SWIGLU_BWD) ARG_CHECK(p.N % 16 == 0 && p.ldc2 == p.ldc && ((uintptr_t)p.C2 % 16) == 0, "gemm: swiglu-bwd epilogue needs N % 16 == 0");
   ARG_CHECK(p.ldc % 4 == 0 && ((uintptr_t)p.C % 16) == 0, "gemm: C rows must keep 16-byte alignment (ldc % 4 == 0)");
+  if (is_bf16<CT>::value && !(p.c_f32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_ATOMIC))
+    ARG_CHECK(p.ldc % 8 == 0 && (p.C2 == nullptr || (p.ldc2 % 8 == 0 && ((uintptr_t)p.C2 % 16) == 0)), "gemm: bf16 outputs need ldc % 8 == 0");
   if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
   if (!a_km && !b_km) {

@@ -136,7 +136,7 @@ def test_fused_step_equals_unfused():
             assert np.all(g_after == 0)           # optimizer.zero_grad fused
         model.close()
     for n in res[0]:
-        assert relerr(res[1][n], res[0][n]) < 3e-5, n   # split-K float atomics: summation order varies run to run
+        assert relerr(res[1][n], res[0][n]) < 5e-4, n   # split-K float atomics: summation order varies run to run, and the first Adam step (m/sqrt(v)) amplifies last-bit gradient differences
 
 
 def test_grad_accumulation_two_microsteps():
