@@ -43,6 +43,7 @@ typedef struct rsys_config {
   int32_t finetune_metric;              /* 0 = watch, 1 = rating */
   int32_t dtype;                        /* RSYS_DTYPE_* : arithmetic type of the dense contractions */
   int32_t max_rows;                     /* rows (of S interactions) per forward call = local batch size */
+  float lora_dropout;                   /* finetune only: nn.Dropout(p) on the LoRA input (model.py:238); 0 disables */
 } rsys_config;
 
 /* the batch record of train.py:75-98 / transformer.jl:79-142: 27 parallel arrays of

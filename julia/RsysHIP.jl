@@ -18,6 +18,7 @@ struct RsysConfig              # mirrors rsys_config (field order and types as i
     rating_mean::Float32; rating_std::Float32; mask_rate::Float32
     mask_topk::Int32; finetune::Int32; finetune_metric::Int32
     dtype::Int32; max_rows::Int32
+    lora_dropout::Float32
 end
 
 struct RsysBatch               # mirrors rsys_batch

@@ -25,7 +25,7 @@ class rsys_config(C.Structure):
         ("min_ts", C.c_double), ("max_ts", C.c_double),
         ("rating_mean", C.c_float), ("rating_std", C.c_float), ("mask_rate", C.c_float),
         ("mask_topk", C.c_int32), ("finetune", C.c_int32), ("finetune_metric", C.c_int32),
-        ("dtype", C.c_int32), ("max_rows", C.c_int32),
+        ("dtype", C.c_int32), ("max_rows", C.c_int32), ("lora_dropout", C.c_float),
     ]
 
 

@@ -281,8 +281,8 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
   HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
   const int64_t bucket = 16 * 1024 * 1024;  // floats
-  for (int64_t o = 0; o < m->n_total; o += bucket) {
-    int64_t n = std::min(bucket, m->n_total - o);
+  for (int64_t o = 0; o < m->n_opt; o += bucket) {
+    int64_t n = std::min(bucket, m->n_opt - o);
     NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
   }
   HIP_CHECK(hipEventRecord(c->ev_done, c->stream));
@@ -313,7 +313,7 @@ int32_t rsys_grad_buffer(rsys_model* h, void** p, int64_t* n) {
   CHECK_HANDLE(h);
   int rc = model_finalize_grads(h->m);
   if (rc) return rc;
-  *p = h->m->G; *n = h->m->n_total;
+  *p = h->m->G; *n = h->m->n_opt;
   return RSYS_OK;
 }
 int32_t rsys_param_buffer(rsys_model* h, void** p, int64_t* n) { CHECK_HANDLE(h); *p = h->m->P; *n = h->m->n_total; return RSYS_OK; }

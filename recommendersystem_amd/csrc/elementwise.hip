@@ -283,6 +283,36 @@ int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, h
 template int launch_swiglu_bwd<bf16>(const bf16*, const bf16*, bf16*, long long, int, hipStream_t);
 template int launch_swiglu_bwd<float>(const float*, const float*, float*, long long, int, hipStream_t);
 
+// --------------------------------------------------------------------- dropout (LoRA input, finetune)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ src, T* dst, long long n, float p, unsigned long long seed,
+                               unsigned int stream, int accumulate) {
+  Philox ph(seed);
+  const float keep = 1.f / (1.f - p);
+  const long long n4 = (n + 3) >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    ph.gen((unsigned long long)i, stream, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long e = i * 4 + k;
+      if (e < n) {
+        const float v = u01(r[k]) >= p ? to_f32(src[e]) * keep : 0.f;
+        dst[e] = from_f32<T>(accumulate ? to_f32(dst[e]) + v : v);
+      }
+    }
+  }
+}
+template <typename T>
+int launch_dropout(const T* src, T* dst, long long n, float p, unsigned long long seed, unsigned int stream, int accumulate, hipStream_t s) {
+  int grid = (int)std::min<long long>((((n + 3) >> 2) + 255) / 256, 8192);
+  hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid), dim3(256), 0, s, src, dst, n, p, seed, stream, accumulate);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_dropout<bf16>(const bf16*, bf16*, long long, float, unsigned long long, unsigned int, int, hipStream_t);
+template int launch_dropout<float>(const float*, float*, long long, float, unsigned long long, unsigned int, int, hipStream_t);
+
 // --------------------------------------------------------------------- position selection (K11), model.py:501-513
 // Deterministic replacement of torch.topk on 0/1 weights: positive-weight positions in
 // ascending flat index, then zero-weight positions ascending.  One

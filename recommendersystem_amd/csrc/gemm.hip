@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int it = 0; it < 32; ++it) {
         const int row_l = it * 2 + (t >> 7);
         const long long row = m0 + half * 64 + row_l;
-        if (row < p.M && col < p.N) atomicAdd(&((float*)p.C)[row * p.ldc + col], Cs[row_l * CS_LD + (t & 127)]);
+        if (row < p.M && col < p.N) atomicAdd(&((float*)p.C)[row * p.ldc + col], p.alpha * Cs[row_l * CS_LD + (t & 127)]);
       }
       __syncthreads();
     }
@@ -417,6 +417,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
         case EPI_QKV_ROPE:
           // rotate interleaved pairs (transformer.model.py:182-190): W consecutive columns = W/2 pairs of one head
+#pragma unroll
+          for (int k = 0; k < W; ++k) v[k] *= p.alpha;
           if (col < p.n_q + p.n_k) {
             const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
             const int cc = col < p.n_q ? col : col - p.n_q;
@@ -463,7 +465,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           for (int k = 0; k < W; k += 4) *(float4*)(dst + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
         } else for (int k = 0; k < nv; ++k) dst[k] = v[k];
       } else {
-        store_t((CT*)p.C + row * p.ldc + col, v, nv, WC);
+        CT* dstc = (CT*)p.C + row * p.ldc + col;
+        if (p.accum) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) if (k < nv) v[k] += to_f32(dstc[k]);
+        }
+        store_t(dstc, v, nv, WC);
       }
     }
   };

@@ -33,6 +33,7 @@ struct GemmParams {
   // reduction stops at *k_dev rounded up to a tile (rows / k beyond the limit must hold data that contributes zero)
   const int* m_dev; const int* k_dev;
   float alpha;
+  int accum;        // EPI_STORE / EPI_QKV_ROPE with a T output: C = C + result (LoRA updates)
   const float* bias;
   const float* resid; long long ldr;
   void* C2; long long ldc2;

@@ -55,6 +55,11 @@ int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, c
 template <typename T>
 int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s);
 
+// dst = (accumulate ? dst : 0) + src * mask / (1 - p), mask ~ Bernoulli(1-p) from Philox(seed, stream)(element index):
+// nn.Dropout of the LoRA input (model.py:238,265,269); the backward pass regenerates the same mask
+template <typename T>
+int launch_dropout(const T* src, T* dst, long long n, float p, unsigned long long seed, unsigned int stream, int accumulate, hipStream_t s);
+
 int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats /*[2]: wsum_sel, wsum_all*/,
                             int* npos_out /*number of positive-weight rows selected (they come first)*/, hipStream_t s);
 

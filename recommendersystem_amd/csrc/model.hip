@@ -66,6 +66,12 @@ static void build_layout(Model* m) {
   const bool ft = m->cfg.finetune != 0;
   int64_t off = 0;
   auto take = [&](int64_t n) { int64_t o = off; off += pad8(n); return o; };
+  m->lo.resize(L);
+  // ---- finetune: the LoRA tensors come first so that optimizer / clip / all-reduce cover one prefix of the buffer
+  if (ft) {
+    for (int l = 0; l < L; ++l) { m->lo[l].la = take((int64_t)16 * D); m->lo[l].lb = take((int64_t)m->Nqkv * 16); }
+  }
+  const int64_t n_lora = off;
   // ---- decay group (tensors with dim >= 2, train.py:288)
   m->o_status = take((m->cfg.vocab_status + 1) * 16);
   m->o_gender = take((m->cfg.vocab_gender + 1) * 4);
@@ -73,7 +79,6 @@ static void build_layout(Model* m) {
   m->o_lin_w = take((int64_t)D * 32);
   m->o_E = take((int64_t)(m->V + 1) * D);
   m->o_Wp = take((int64_t)D * m->Mp);
-  m->lo.resize(L);
   for (int l = 0; l < L; ++l) {
     m->lo[l].wqkv = take((int64_t)m->Nqkv * D);
     m->lo[l].wo = take((int64_t)D * D);
@@ -89,6 +94,8 @@ static void build_layout(Model* m) {
   for (int l = 0; l < L; ++l) { m->lo[l].sa = take(D); m->lo[l].mlp = take(D); }
   m->o_norm = take(D); m->o_r0b = take(D); m->o_r2b = take(1);
   m->n_total = off;
+  m->n_opt = ft ? n_lora : m->n_total;
+  m->n_opt_decay = ft ? n_lora : m->n_decay;
 
   const bool tr = !ft;  // finetune freezes everything but LoRA (not built yet): base tensors are non-trainable
   add_tensor(m, "action_embedding.periodic_time_cos", 1, 2, 1, m->o_pcos, 2, MAP_DIRECT, tr);
@@ -108,6 +115,12 @@ static void build_layout(Model* m) {
     add_tensor(m, p + "attn.k_proj.weight", KV * hd, D, 2, m->lo[l].wqkv + (int64_t)H * hd * D, D, MAP_DIRECT, tr);
     add_tensor(m, p + "attn.v_proj.weight", KV * hd, D, 2, m->lo[l].wqkv + (int64_t)(H + KV) * hd * D, D, MAP_DIRECT, tr);
     add_tensor(m, p + "attn.output_proj.weight", D, H * hd, 2, m->lo[l].wo, D, MAP_DIRECT, tr);
+    if (ft) {  // model.py:235-254: rank 8 on q_proj and v_proj
+      add_tensor(m, p + "attn.q_proj_lora_A.weight", 8, D, 2, m->lo[l].la, D, MAP_DIRECT, true);
+      add_tensor(m, p + "attn.q_proj_lora_B.weight", H * hd, 8, 2, m->lo[l].lb, 16, MAP_DIRECT, true);
+      add_tensor(m, p + "attn.v_proj_lora_A.weight", 8, D, 2, m->lo[l].la + (int64_t)8 * D, D, MAP_DIRECT, true);
+      add_tensor(m, p + "attn.v_proj_lora_B.weight", KV * hd, 8, 2, m->lo[l].lb + (int64_t)(H + KV) * hd * 16 + 8, 16, MAP_DIRECT, true);
+    }
     add_tensor(m, p + "mlp.w1.weight", I, D, 2, m->lo[l].w13, D, MAP_W1, tr);
     add_tensor(m, p + "mlp.w2.weight", D, I, 2, m->lo[l].w2, Ip, MAP_DIRECT, tr);
     add_tensor(m, p + "mlp.w3.weight", I, D, 2, m->lo[l].w13, D, MAP_W3, tr);
@@ -139,7 +152,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   ARG_CHECK(cfg->max_rows >= 1, "max_rows");
   ARG_CHECK(cfg->mask_topk >= 1 && cfg->mask_topk <= cfg->max_sequence_length, "mask_topk");
   ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16, "dtype");
-  ARG_CHECK(cfg->finetune == 0, "finetune/LoRA training is not built in this round (SURVEY 8(f) N1)");
+  ARG_CHECK(cfg->lora_dropout >= 0.f && cfg->lora_dropout < 1.f, "lora_dropout must be in [0,1)");
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { set_error("no HIP device visible: the HIP path has no CPU fallback"); return RSYS_ERR_HIP; }
@@ -202,6 +215,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     Model::LayerAct& a = m->la[l];
     if (l == 0) a.x = m->x0; else DALLOC(a.x, NT * D * 4);
     DALLOC(a.xn, NT * D * e); DALLOC(a.qkv, NT * m->Nqkv * e);
+    a.xnd = a.xn; a.La = nullptr;
+    if (cfg->finetune) { DALLOC(a.La, NT * 16 * e); if (cfg->lora_dropout > 0.f) DALLOC(a.xnd, NT * D * e); }
     DALLOC(a.O, NT * D * e); DALLOC(a.lse, (int64_t)m->rows_max * m->H * m->T * 4);
     DALLOC(a.rstd1, NT * 4); DALLOC(a.h, NT * D * 4); DALLOC(a.hn, NT * D * e); DALLOC(a.rstd2, NT * 4);
     DALLOC(a.ab, NT * 2 * m->Ip * e); DALLOC(a.g, NT * m->Ip * e);
@@ -219,6 +234,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->dO, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
   DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
   DALLOC(m->sumsq, 64);
+  m->dLa = nullptr; m->dxl = nullptr;
+  if (cfg->finetune) { DALLOC(m->dLa, NT * 16 * e); DALLOC(m->dxl, NT * D * e); }
   *out = m;
   return RSYS_OK;
 }
@@ -252,6 +269,7 @@ int model_init_random(Model* m, uint64_t seed) {
     if (is_scale) { HIP_CHECK(hipMemcpyAsync(m->P + t.off, ones.data(), m->D * 4, hipMemcpyHostToDevice, m->stream)); HIP_CHECK(hipStreamSynchronize(m->stream)); continue; }
     if (t.ndim == 1) continue;  // biases and phases stay zero
     if (t.map == MAP_W3) continue;  // filled together with w1 (same interleaved block)
+    if (t.name.find("lora_B") != std::string::npos) continue;   // zeros (model.py:252,254)
     int64_t rows = t.map == MAP_W1 ? 2 * m->Ip : t.rows;
     for (int64_t r0 = 0; r0 < rows; r0 += 4096) {  // rows*ld contiguous block incl. padding (re-zeroed below)
       int64_t nr = std::min<int64_t>(4096, rows - r0);
@@ -490,6 +508,19 @@ static int forward_trunk(Model* m) {
     Model::LayerAct& a = m->la[l];
     float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
     RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s));
+    const bool ft = m->cfg.finetune != 0;
+    T* xnd = AT<T>(a.xn);   // LoRA input: dropout(x) in a training pass (model.py:265,269), else x itself
+    if (ft) {
+      if (m->drop_active) {
+        RC(launch_dropout<T>(AT<T>(a.xn), AT<T>(a.xnd), (long long)NT * D, m->cfg.lora_dropout, m->drop_seed,
+                             (unsigned int)(m->drop_step * 64 + l), 0, s));
+        xnd = AT<T>(a.xnd);
+      }
+      GemmParams p{};  // La = drop(xn) . [Aq; Av]^T   (NT x 16)
+      p.A = xnd; p.lda = D; p.B = W<T>(m, m->lo[l].la); p.ldb = D; p.C = a.La; p.ldc = 16;
+      p.M = NT; p.N = 16; p.K = D; p.epi = EPI_STORE;
+      RC(gemm<T>(m, "gemm_lora_a_fwd", p, false, false, false));
+    }
     {
       GemmParams p{};
       p.A = a.xn; p.lda = D; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = a.qkv; p.ldc = m->Nqkv;
@@ -497,6 +528,16 @@ static int forward_trunk(Model* m) {
       p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
+    }
+    if (ft) {
+      // q += 2 * La[:, :8] Bq^T, v += 2 * La[:, 8:] Bv^T (lora_scaling = 16/8, model.py:236-237,264-271).  RoPE is linear,
+      // so the rotated update is accumulated onto the rotated projection.
+      GemmParams p{};
+      p.A = a.La; p.lda = 16; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = a.qkv; p.ldc = m->Nqkv;
+      p.M = NT; p.N = m->Nqkv; p.K = 16; p.epi = EPI_QKV_ROPE; p.alpha = 2.f; p.accum = 1;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
+      p.n_q = m->H * hd; p.n_k = m->KV * hd;
+      RC(gemm<T>(m, "gemm_lora_b_fwd", p, false, false, false));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
@@ -566,13 +607,13 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
           RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
         }
         RC(launch_scatter_rows_add(m->dE, m->idx[ti], 0, m->gy, D, KB, D, s));
-        {
+        if (!m->cfg.finetune) {
           GemmParams p{};  // dF[s:e] += dlogits^T . Ew
           p.A = m->logits; p.lda = m->ldl; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_E + (int64_t)vs * D; p.ldc = D; p.c_f32 = 1;
           p.M = Vm; p.N = D; p.K = KB; p.epi = EPI_ACCUM; p.k_dev = np;
           RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
         }
-        m->table_grads_pending = true;
+        if (!m->cfg.finetune) m->table_grads_pending = true;
       }
     } else {
       {
@@ -585,7 +626,7 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
                                m->bd.m_label[ti], m->bd.m_weight[ti], st, m->cfg.rating_mean, bwd ? tw[ti] : 0.f,
                                bwd ? 0 : 1, m->loss_acc + 3 * ti, m->G + m->o_r2w, m->G + m->o_r2b, m->G + m->o_r0b, s));
       if (bwd) {
-        {
+        if (!m->cfg.finetune) {
           GemmParams p{};  // dW0 += dz^T . Er
           p.A = m->z; p.lda = D; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_r0w; p.ldc = D; p.c_f32 = 1;
           p.M = D; p.N = D; p.K = KB; p.epi = EPI_ATOMIC;
@@ -626,7 +667,8 @@ static int backward_trunk(Model* m) {
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
-    {
+    const bool ft = m->cfg.finetune != 0;   // finetune: base weights are frozen, only the dx chain and the LoRA grads run
+    if (!ft) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
@@ -638,7 +680,7 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
       RC(gemm<T>(m, "gemm_w2_dx", p, false, false, true));
     }
-    {
+    if (!ft) {
       GemmParams p{};  // dW13 += dab^T . hn
       p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
       p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -651,7 +693,7 @@ static int backward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, true));
     }
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
-    {
+    if (!ft) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -671,7 +713,7 @@ static int backward_trunk(Model* m) {
     RC(launch_attn_delta<T>(ap, s));
     RC(launch_attn_bwd<T>(ap, s));
     toc(m);
-    {
+    if (!ft) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
       p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
       p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -683,11 +725,55 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, true));
     }
+    if (ft) {
+      T* xnd = m->drop_active ? AT<T>(a.xnd) : AT<T>(a.xn);
+      const int nq = m->H * hd, nv0 = (m->H + m->KV) * hd, nkv = m->KV * hd;
+      {
+        GemmParams p{};  // dLa = 2 * dqkv . Bcat    (the unused blocks of Bcat are zero)
+        p.A = m->dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = m->dLa; p.ldc = 16;
+        p.M = NT; p.N = 16; p.K = m->Nqkv; p.epi = EPI_STORE; p.alpha = 2.f;
+        RC(gemm<T>(m, "gemm_lora_dla", p, false, false, true));
+      }
+      {
+        GemmParams p{};  // dBq += 2 * dq^T . La[:, :8]
+        p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.La; p.ldb = 16; p.C = m->G + m->lo[l].lb; p.ldc = 16; p.c_f32 = 1;
+        p.M = nq; p.N = 8; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 2.f;
+        RC(gemm<T>(m, "gemm_lora_db", p, false, true, true));
+      }
+      {
+        GemmParams p{};  // dBv += 2 * dv^T . La[:, 8:]
+        p.A = AT<T>(m->dqkv) + nv0; p.lda = m->Nqkv; p.B = AT<T>(a.La) + 8; p.ldb = 16;
+        p.C = m->G + m->lo[l].lb + (int64_t)nv0 * 16 + 8; p.ldc = 16; p.c_f32 = 1;
+        p.M = nkv; p.N = 8; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 2.f;
+        RC(gemm<T>(m, "gemm_lora_db", p, false, true, true));
+      }
+      {
+        GemmParams p{};  // d[Aq; Av] += dLa^T . drop(xn)
+        p.A = m->dLa; p.lda = 16; p.B = xnd; p.ldb = D; p.C = m->G + m->lo[l].la; p.ldc = D; p.c_f32 = 1;
+        p.M = 16; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
+        RC(gemm<T>(m, "gemm_lora_da", p, false, true, true));
+      }
+      {
+        GemmParams p{};  // dxn += dropout'(dLa . [Aq; Av])
+        p.A = m->dLa; p.lda = 16; p.B = W<T>(m, m->lo[l].la); p.ldb = D; p.ldc = D;
+        p.M = NT; p.N = D; p.K = 16; p.epi = EPI_STORE;
+        if (m->drop_active) {
+          p.C = m->dxl;
+          RC(gemm<T>(m, "gemm_lora_dx", p, false, false, true));
+          RC(launch_dropout<T>(AT<T>(m->dxl), AT<T>(m->dhn), (long long)NT * D, m->cfg.lora_dropout, m->drop_seed,
+                               (unsigned int)(m->drop_step * 64 + l), 1, s));
+        } else {
+          p.C = m->dhn; p.accum = 1;
+          RC(gemm<T>(m, "gemm_lora_dx", p, false, false, true));
+        }
+      }
+    }
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
   }
   toc(m);
+  if (m->cfg.finetune) return RSYS_OK;   // embeddings are frozen (model.py:361-369)
   // gx = gradient w.r.t. the interleaved input embeddings (even rows: items, odd rows: actions)
   tic(m, "phase_embed_bwd");
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
@@ -734,7 +820,7 @@ static int finalize_grads_t(Model* m) {
 }
 
 int model_finalize_grads(Model* m) {
-  if (!m->table_grads_pending) return RSYS_OK;
+  if (!m->table_grads_pending || m->cfg.finetune) return RSYS_OK;
   m->table_grads_pending = false;
   return m->bf16_mode ? finalize_grads_t<bf16>(m) : finalize_grads_t<float>(m);
 }
@@ -745,6 +831,8 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
   if (m->has_masks) { b.watch_mask = m->d_wm; b.rating_mask = m->d_rm; }
   RC(launch_mask_tokens(b, m->cfg.finetune, m->cfg.finetune_metric, m->cfg.mask_rate, seed, step, m->stream));
+  m->drop_active = m->cfg.finetune && !evaluate && m->cfg.lora_dropout > 0.f;   // nn.Dropout is active in train() mode only
+  m->drop_seed = seed ^ 0xD409ull; m->drop_step = step;
   RC(forward_trunk<T>(m));
   float tw[4];
   for (int i = 0; i < 4; ++i) tw[i] = task_w ? task_w[i] * grad_scale : 0.f;
@@ -773,6 +861,7 @@ static int infer_t(Model* m, int task, float* out, int64_t n) {
   HIP_CHECK(hipMemcpyAsync(b.m_status, b.status, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_rating, b.rating, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_progress, b.progress, N * 4, hipMemcpyDeviceToDevice, s));
+  m->drop_active = false;
   RC(forward_trunk<T>(m));
   std::vector<unsigned char> host((size_t)NT * D * m->esz);
   if (task == 0) {
@@ -827,8 +916,8 @@ int model_clip(Model* m, float max_norm, float* norm_out) {
   HIP_CHECK(hipSetDevice(m->device));
   RC(model_finalize_grads(m));
   HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
-  RC(launch_sumsq(m->G, m->n_total, m->sumsq, m->stream));
-  RC(launch_scale(m->G, m->n_total, m->sumsq, 1.0f, max_norm, m->stream));
+  RC(launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream));
+  RC(launch_scale(m->G, m->n_opt, m->sumsq, 1.0f, max_norm, m->stream));
   if (norm_out) {
     float ss;
     HIP_CHECK(hipMemcpyAsync(&ss, m->sumsq, 4, hipMemcpyDeviceToHost, m->stream));
@@ -847,7 +936,7 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   if (clip > 0.f) {
     HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
     tic(m, "sumsq");
-    RC(launch_sumsq(m->G, m->n_total, m->sumsq, m->stream));
+    RC(launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream));
     toc(m);
     ss = m->sumsq;
   }
@@ -855,10 +944,10 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   tic(m, "adamw");
   int rc;
   if (m->bf16_mode)
-    rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_decay, m->n_total, o->lr * lr_factor, o->b1, o->b2,
+    rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                             o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
   else
-    rc = launch_adamw<float>(m->P, m->G, o->mom, o->var, nullptr, m->n_decay, m->n_total, o->lr * lr_factor, o->b1, o->b2,
+    rc = launch_adamw<float>(m->P, m->G, o->mom, o->var, nullptr, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                              o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
   toc(m);
   return rc;

@@ -25,6 +25,7 @@ struct TensorInfo {
 
 struct LayerOff {  // offsets into the flat buffers
   int64_t wqkv, wo, w13, w2, sa, mlp;
+  int64_t la, lb;   // finetune: LoRA A = [Aq; Av] (16 x D), B = block matrix (Nqkv x 16): q rows x cols 0-7, v rows x cols 8-15
 };
 
 struct PhaseTimer {
@@ -44,6 +45,7 @@ struct Model {
   // dims
   int L, H, KV, D, I, Ip, S, T, V0, V1, V, M, Mp, K, hd, Nqkv, rows_max;
   int64_t n_decay = 0, n_total = 0;
+  int64_t n_opt = 0, n_opt_decay = 0;   // range the optimizer / clip / all-reduce cover (finetune: the LoRA segment only)
   std::vector<TensorInfo> tensors;
   std::map<std::string, int> by_name;
   // flat offsets
@@ -68,7 +70,7 @@ struct Model {
   int* d_rope_pos = nullptr;
   // activations (void* = T-typed)
   void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap, *qmap_full, *kmap_full;
-  struct LayerAct { float* x; void* xn; void* qkv; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
+  struct LayerAct { float* x; void* xn; void* xnd; void* La; void* qkv; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
   std::vector<LayerAct> la;
   float* xL; float* rstdf; void* out;
   // heads
@@ -76,8 +78,10 @@ struct Model {
   // backward workspaces
   float *gy, *gxa, *gxb, *dh; void *gxa_t, *gxb_t, *dh_t;   // *_t: T-typed operand copies (bf16 mode)
   void *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
+  void *dLa, *dxl;   // finetune workspaces
   float* sumsq;
   bool table_grads_pending = false;
+  bool drop_active = false; unsigned long long drop_seed = 0, drop_step = 0;   // LoRA dropout of the current pass
   bool last_evaluate = false;
   PhaseTimer timer;
 };

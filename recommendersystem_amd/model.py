@@ -45,6 +45,7 @@ def _c_config(config, dtype, max_rows):
     c.finetune_metric = 1 if config.get("finetune_metric") == "rating" else 0
     c.dtype = DTYPES[dtype]
     c.max_rows = int(max_rows)
+    c.lora_dropout = float(config.get("lora_dropout", 0.1 if config.get("finetune") else 0.0))   # nn.Dropout(0.1), model.py:238
     return c
 
 

@@ -244,3 +244,67 @@ def test_rccl_communicator_world1(monkeypatch):
         np.testing.assert_array_equal(model.grad(n), g)
     comm.close()
     model.close()
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-4, 1e-3), ("bf16", 4e-2, 0.2)])
+def test_finetune_lora_golden(dtype, tol_loss, tol_grad):
+    """LoRA finetune (model.py:235-271,361-371,418-435): frozen base, rank-8 updates on q and v,
+    masks derived from the chosen metric's weights; losses and LoRA gradients against the reference's own run."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    z = np.load(os.path.join(GOLDEN, "finetune_tiny.npz"))
+    cfg = synth.make_config("tiny", mask_rate=0.25, mask_topk=6, finetune=True, finetune_metric="rating")
+    cfg["lora_dropout"] = 0.0          # the fixture was generated with the dropout modules in eval()
+    P = synth.make_params(cfg, 41, "test")
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in/")}
+    rows = d["userid"].shape[0]
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    names = [n for n, _, tr in model.named_parameters() if tr]
+    assert names and all("lora_" in n for n in names)          # everything else is frozen
+    model.set_loss_weights([0.0, 1.0, 0.0, 0.5], 1)
+    losses = model(d, False)
+    for a, b in zip(losses, z["loss/train"]):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, z["loss/train"])
+    for k in [k for k in z.files if k.startswith("grad/")]:
+        g = model.grad(k[5:])
+        ref = z[k]
+        assert relerr(g, ref) < tol_grad or np.abs(ref).max() < 1e-7, (k, relerr(g, ref))
+    # optimizer touches the LoRA tensors only
+    from recommendersystem_amd.optim import AdamW
+    opt = AdamW(model, lr=1e-2)
+    before = model.get_parameter("transformers.layers.0.mlp.w1.weight")
+    a_before = model.get_parameter("transformers.layers.0.attn.q_proj_lora_A.weight")
+    opt.step(clip_max_norm=1.0)
+    np.testing.assert_array_equal(model.get_parameter("transformers.layers.0.mlp.w1.weight"), before)
+    assert np.abs(model.get_parameter("transformers.layers.0.attn.q_proj_lora_A.weight") - a_before).max() > 0
+    model.close()
+
+
+def test_finetune_dropout_runs():
+    """nn.Dropout(0.1) on the LoRA input: active in training passes only, fresh mask per step, same mask in backward."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    z = np.load(os.path.join(GOLDEN, "finetune_tiny.npz"))
+    cfg = synth.make_config("tiny", mask_rate=0.25, mask_topk=6, finetune=True, finetune_metric="rating")
+    P = synth.make_params(cfg, 41, "test")
+    for k in P:
+        if "lora_B" in k:
+            P[k] = (np.random.default_rng(1).standard_normal(P[k].shape) * 0.3).astype(np.float32)
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in/")}
+    rows = d["userid"].shape[0]
+    res = {}
+    for p_drop in (0.0, 0.5):
+        cfg["lora_dropout"] = p_drop
+        model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights([0.0, 1.0, 0.0, 0.5], 1)
+        l_train = [model(d, False)[1] for _ in range(2)]
+        l_eval = model(d, True)[1][0]
+        g = model.grad("transformers.layers.0.attn.q_proj_lora_A.weight")
+        assert np.isfinite(g).all()
+        res[p_drop] = (l_train, l_eval)
+        model.close()
+    assert res[0.0][0][0] == pytest.approx(res[0.0][0][1], rel=1e-6)       # no dropout: repeatable
+    assert abs(res[0.5][0][0] - res[0.5][0][1]) > 1e-6                      # fresh mask every step
+    assert res[0.5][1] == pytest.approx(res[0.0][1], rel=1e-5)             # evaluate: dropout off
