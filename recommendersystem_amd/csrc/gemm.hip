@@ -3,9 +3,11 @@
 // register-staged double-buffered LDS, XOR-swizzled so that both the
 // ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads are
 // bank-conflict free, XCD-aware tile order (cdna_hip_programming.md T1/T2/T10).
+#include <cstdlib>
 #include <utility>
 
 #include "gemm.hpp"
+#include "gemm_epi.hpp"
 
 namespace rsys {
 
@@ -114,16 +116,6 @@ __device__ __forceinline__ typename MmaT<CT>::Frag load_frag(const unsigned char
       return *(const float*)(tile + krow * 512 + (r0 + i) * 4);
     }
   }
-}
-
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-// compile-time loop: accumulator tiles must be indexed by constants or hipcc moves them to scratch
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 template <typename CT>
@@ -345,20 +337,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   // copy-out of a staged [64][*] f32 tile: every lane handles W consecutive columns of one row, so that the
   // global accesses are 16 bytes per lane (bf16: W = 8, f32: W = 4; 8-byte stores run at ~half the rate)
   const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL;
-  auto store_t = [&](CT* dst, const float* v, int nv, auto WC) {
-    constexpr int W = decltype(WC)::value;
-    if (nv == W) {
-      if constexpr (is_bf16<CT>::value) {
-        if constexpr (W == 8) { bf16x8 pk; for (int k = 0; k < 8; ++k) pk[k] = (bf16)v[k]; *(bf16x8*)dst = pk; }
-        else { bf16x4 pk; for (int k = 0; k < 4; ++k) pk[k] = (bf16)v[k]; *(bf16x4*)dst = pk; }
-      } else {
-#pragma unroll
-        for (int k = 0; k < W; k += 4) *(float4*)(dst + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
-      }
-    } else {
-      for (int k = 0; k < nv; ++k) dst[k] = from_f32<CT>(v[k]);
-    }
-  };
   auto copy_primary = [&](int half, auto WC) {
     constexpr int W = decltype(WC)::value;
     constexpr int CPR = 128 / W, ITEMS = 64 * CPR / 256;
@@ -376,102 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const float4 q = *(const float4*)&Cs[row_l * CS_LD + cw + k];
         v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
       }
-      switch (p.epi) {
-        case EPI_STORE:
-#pragma unroll
-          for (int k = 0; k < W; ++k) v[k] *= p.alpha;
-          break;
-        case EPI_ACCUM:
-#pragma unroll
-          for (int k = 0; k < W; ++k) if (k < nv) v[k] += ((const float*)p.C)[row * p.ldc + col + k];
-          break;
-        case EPI_BIAS:
-#pragma unroll
-          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.bias[col + k];
-          break;
-        case EPI_RESIDUAL:
-#pragma unroll
-          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.resid[row * p.ldr + col + k];
-          break;
-        case EPI_TABLE: {
-#pragma unroll
-          for (int k = 0; k < W; ++k) if (k < nv) v[k] += p.E[row * p.ldc + col + k] + p.bias[col + k];
-          float* d32 = (float*)p.C + row * p.ldc + col;
-          if (nv == W) {
-#pragma unroll
-            for (int k = 0; k < W; k += 4) *(float4*)(d32 + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
-          } else for (int k = 0; k < nv; ++k) d32[k] = v[k];
-          store_t((CT*)p.C2 + row * p.ldc2 + col, v, nv, WC);
-          continue;
-        }
-        case EPI_GELU: {
-          float ge[W];
-#pragma unroll
-          for (int k = 0; k < W; ++k) {
-            if (k < nv) v[k] += p.bias[col + k];
-            ge[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
-          }
-          store_t((CT*)p.C + row * p.ldc + col, v, nv, WC);
-          store_t((CT*)p.C2 + row * p.ldc2 + col, ge, nv, WC);
-          continue;
-        }
-        case EPI_QKV_ROPE:
-          // rotate interleaved pairs (transformer.model.py:182-190): W consecutive columns = W/2 pairs of one head
-#pragma unroll
-          for (int k = 0; k < W; ++k) v[k] *= p.alpha;
-          if (col < p.n_q + p.n_k) {
-            const int pos = p.rope_pos ? p.rope_pos[row] : (int)(row % p.T);
-            const int cc = col < p.n_q ? col : col - p.n_q;
-            const int d2 = (cc & (p.hd - 1)) >> 1;
-            const float* cs = p.rope_cos + pos * (p.hd >> 1) + d2;
-            const float* sn = p.rope_sin + pos * (p.hd >> 1) + d2;
-#pragma unroll
-            for (int k = 0; k < W; k += 2) {
-              const float c = cs[k >> 1], s2 = sn[k >> 1];
-              const float a0 = v[k] * c - v[k + 1] * s2, a1 = v[k] * s2 + v[k + 1] * c;
-              v[k] = a0; v[k + 1] = a1;
-            }
-          }
-          break;
-        case EPI_SWIGLU_BWD: {
-          // column col = i index of dg; a,b live at (i>>4)*32 + (i&15) (+16) of the interleaved [a|b] rows;
-          // N % 16 == 0 and W | 16, so the W columns of an item are one aligned group of a and one of b
-          const long long base = row * p.ldc + (long long)(col >> 4) * 32 + (col & 15);
-          float av[W], bv[W], da[W], db[W];
-          if constexpr (is_bf16<CT>::value && W == 8) {
-            const bf16x8 a8 = *(const bf16x8*)((const CT*)p.C2 + base), b8 = *(const bf16x8*)((const CT*)p.C2 + base + 16);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { av[k] = (float)a8[k]; bv[k] = (float)b8[k]; }
-          } else {
-#pragma unroll
-            for (int k = 0; k < W; ++k) { av[k] = to_f32(((const CT*)p.C2)[base + k]); bv[k] = to_f32(((const CT*)p.C2)[base + 16 + k]); }
-          }
-#pragma unroll
-          for (int k = 0; k < W; ++k) {
-            const float sg = 1.f / (1.f + __expf(-av[k]));
-            da[k] = v[k] * bv[k] * sg * (1.f + av[k] * (1.f - sg));
-            db[k] = v[k] * av[k] * sg;
-          }
-          store_t((CT*)p.C + base, da, W, WC);
-          store_t((CT*)p.C + base + 16, db, W, WC);
-          continue;
-        }
-        default: break;   // SWIGLU: plain store of the primary tile
-      }
-      if (outf32) {
-        float* dst = (float*)p.C + row * p.ldc + col;
-        if (nv == W) {
-#pragma unroll
-          for (int k = 0; k < W; k += 4) *(float4*)(dst + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
-        } else for (int k = 0; k < nv; ++k) dst[k] = v[k];
-      } else {
-        CT* dstc = (CT*)p.C + row * p.ldc + col;
-        if (p.accum) {
-#pragma unroll
-          for (int k = 0; k < W; ++k) if (k < nv) v[k] += to_f32(dstc[k]);
-        }
-        store_t(dstc, v, nv, WC);
-      }
+      epi_item<CT, W>(p, row, col, v, nv, outf32);
     }
   };
   const bool wide = is_bf16<CT>::value && (!outf32 || p.epi == EPI_TABLE);   // bf16 outputs (incl. the bf16 copy of EPI_TABLE): 8 columns per lane
@@ -517,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           const float4 q = *(const float4*)&Cs[row_l * CT_LD + cw + k];
           v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
         }
-        store_t((CT*)p.C2 + row * p.ldc2 + gcol, v, GW, std::integral_constant<int, GW>{});
+        store_vec<CT, GW>((CT*)p.C2 + row * p.ldc2 + gcol, v, GW);
       }
       __syncthreads();
     }
@@ -599,6 +482,16 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
     ARG_CHECK(p.ldc % 8 == 0 && (p.C2 == nullptr || (p.ldc2 % 8 == 0 && ((uintptr_t)p.C2 % 16) == 0)), "gemm: bf16 outputs need ldc % 8 == 0");
   if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
+  if constexpr (is_bf16<CT>::value) {
+    // row-major bf16 operands: the 256x256 LDS-DMA kernel (gemm8p.hip) once the problem fills the chip with its
+    // one-workgroup-per-CU tiles; RSYS_GEMM_KERNEL=1 / 2 forces the 128x128 / 256x256 kernel (tests, A/B timing)
+    if (!a_km && !b_km && !a_f32 && !b_f32 && gemm8p_eligible(p)) {
+      const char* e = getenv("RSYS_GEMM_KERNEL");
+      const int hint = e ? atoi(e) : 0;
+      const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+      if (hint == 2 || (hint == 0 && t256 >= 128)) return launch_gemm8p(p, s);
+    }
+  }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);
     if (a_f32 && !b_f32) return launch_one<CT, true, false, false, false>(p, s);

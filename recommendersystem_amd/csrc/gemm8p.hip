@@ -1,0 +1,283 @@
+// bf16 MFMA GEMM for row-major operands, gfx950: C[M,N] = sum_k A[m][k] * B[n][k].
+//
+// 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave = 8x4 MFMA 16x16x32 tiles),
+// K in tiles of 64.  Operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers), two 64 KB
+// LDS buffers, one workgroup per CU.  A K tile is consumed in four phases, one 64x32 quadrant of the wave's
+// output each; every phase issues its LDS reads and one 16 KB half-tile of DMA, then the 16 MFMAs between two raw
+// s_barriers.  The two wave rows run one barrier apart, so on every SIMD one wave is in its MFMA section while the
+// other issues loads (cdna_hip_programming.md 5, "256^2 8-phase": two K tiles = 8 phases per loop trip).
+//
+// Half-tiles: "A h" = rows {wr*128 + h*64 + [0,64)} for both wave rows (exactly what phase reads "A h" touch),
+// "B h" = columns {wc*64 + h*32 + [0,32)} for the four wave columns.  Schedule of tile t (buffer t & 1):
+//   P1: read B0, A0     DMA B1(t+1)                 MFMA A0 x B0
+//   P2: read B1         DMA A1(t+1)   vmcnt(8)      MFMA A0 x B1
+//   P3: read A1         DMA B0(t+2)                 MFMA A1 x B1
+//   P4:                 DMA A0(t+2)   vmcnt(6)      MFMA A1 x B0      (B0 stays in registers)
+// WAR: a half-tile is overwritten two or more phases after its last read (the waves of the other row may still have
+// that read in flight one phase later).  RAW: the counted vmcnt sits before the first barrier of a phase and the
+// data is read from the next phase on: P2's wait retires A1(t) (read in P3), P4's retires B0, A0, B1 of t+1.
+// LDS image of a half-tile: 128 rows of 128 B, 16-byte chunk c of local row r at r*128 + ((c ^ ((r>>1)&7)) << 4):
+// the 16 lanes of a ds_read_b128 group (16 rows, one chunk) cover all 64 banks.  LDS-DMA writes lane-linear, so
+// the permutation is applied to the per-lane SOURCE address.
+#include "gemm.hpp"
+#include "gemm_epi.hpp"
+
+namespace rsys {
+
+#define GLB_AS __attribute__((address_space(1)))
+
+namespace {
+
+constexpr int T8_BM = 256, T8_BN = 256, T8_BK = 64;
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// buffer_load_dwordx4 ... lds: LDS[m0-base + lane*16] <- 16 bytes at (descriptor base + voffset).  A wave-uniform
+// descriptor (SGPRs) plus a loop-invariant 32-bit per-lane offset: the K loop advances the descriptor base with
+// scalar adds and spends no vector registers or VALU work on addresses.
+extern "C" __device__ void rsys_raw_buffer_load_lds(i32x4 rsrc, LDS_AS unsigned int* lds, int size, int voffset, int soffset,
+                                                    int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+__device__ __forceinline__ i32x4 make_rsrc(const char* base) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)((a >> 32) & 0xFFFFu));   // stride 0
+  r[2] = -1;                                                                       // num_records: 4 GB window
+  r[3] = 0x00020000;                                                               // raw buffer, 32-bit data format
+  return r;
+}
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned char* lds) {
+  rsys_raw_buffer_load_lds(rsrc, (LDS_AS unsigned int*)lds, 16, (int)voff, 0, 0, 0);
+}
+
+#define T8_BARRIER()                         \
+  do {                                       \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");          \
+  } while (0)
+
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int fq = l >> 4, fr = l & 15;
+
+  // ---- output tile, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; each XCD takes a contiguous run
+  // of tiles (tn fastest), which share A rows / B rows through its private L2
+  const int tiles_n = (p.N + T8_BN - 1) / T8_BN, tiles_m = (p.M + T8_BM - 1) / T8_BM;
+  const int ntiles = tiles_m * tiles_n;
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * T8_BM, n0 = tn * T8_BN;
+  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
+  const int nt = p.K / T8_BK;                          // launcher: K % 64 == 0, nt >= 2
+
+  // ---- DMA source offsets (bytes from the operand base, k tile 0).  Instruction j of wave w fills the 1 KB piece
+  // (w*2+j) of a half-tile = local rows (w*2+j)*8 + [0,8); lane l -> local row + (l>>3), stored slot l&7.
+  unsigned int aoff[2][2], boff[2][2];   // [j][h]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int lr = (w * 2 + j) * 8 + (l >> 3);
+    const int c = (l & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int grow = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);   // clamped rows are never stored
+      const int gcol = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), p.N - 1);
+      aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * 8) * 2);
+      boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * 8) * 2);
+    }
+  }
+  const char* Ab = (const char*)p.A;
+  const char* Bb = (const char*)p.B;
+  unsigned char* const dma_base = smem + w * 2048;   // + buf*65536 + X*32768 + h*16384 + j*1024
+  auto stage_a = [&](int bo, auto H, int kt) {
+    constexpr int h = decltype(H)::value;
+    const i32x4 rs = make_rsrc(Ab + (long long)kt * (T8_BK * 2));
+    dma16(rs, aoff[0][h], dma_base + bo + h * 16384);
+    dma16(rs, aoff[1][h], dma_base + bo + h * 16384 + 1024);
+  };
+  auto stage_b = [&](int bo, auto H, int kt) {
+    constexpr int h = decltype(H)::value;
+    const i32x4 rs = make_rsrc(Bb + (long long)kt * (T8_BK * 2));
+    dma16(rs, boff[0][h], dma_base + bo + 32768 + h * 16384);
+    dma16(rs, boff[1][h], dma_base + bo + 32768 + h * 16384 + 1024);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- fragment read offsets: lane (fq, fr) takes chunk kk*4+fq of local row base+fr
+  const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
+  const int a_rd0 = (wr * 64 + fr) * 128 + sw0, a_rd1 = (wr * 64 + fr) * 128 + sw1;
+  const int b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0, b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+  auto read_a = [&](int bo, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd0);
+      af[i][1] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd1);
+    }
+  };
+  auto read_b = [&](bf16x8(&bf)[2][2], int bo, int h) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf[j][0] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd0);
+      bf[j][1] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd1);
+    }
+  };
+  auto mma_q = [&](auto IH, auto JH, const bf16x8(&bf)[2][2]) {
+    constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
+    __builtin_amdgcn_s_setprio(1);
+    static_for<4>([&](auto i) { static_for<2>([&](auto j) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bf[j][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+    }); });
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One K tile per trip; the buffer index is a run-time offset and the tail of the pipeline is handled by
+  // wave-uniform branches around the DMA issue (one loop body: the register allocation of the accumulators is the
+  // same for every tile).  Waits: P2 leaves the four half-tiles issued after A1(t) in flight, P4 the three issued
+  // after B1(t+1); at the end of K fewer are outstanding.
+  auto tile_body = [&](int kt) {
+    const int bo = (kt & 1) << 16, bn = bo ^ 65536;
+    // P1
+    read_b(bf0, bo, 0);
+    read_a(bo, 0);
+    if (kt + 1 < nt) stage_b(bn, I1{}, kt + 1);
+    T8_BARRIER();
+    mma_q(I0{}, I0{}, bf0);
+    T8_BARRIER();
+    // P2
+    read_b(bf1, bo, 1);
+    if (kt + 1 < nt) { stage_a(bn, I1{}, kt + 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T8_BARRIER();
+    mma_q(I0{}, I1{}, bf1);
+    T8_BARRIER();
+    // P3
+    read_a(bo, 1);
+    if (kt + 2 < nt) stage_b(bo, I0{}, kt + 2);
+    T8_BARRIER();
+    mma_q(I1{}, I1{}, bf1);
+    T8_BARRIER();
+    // P4
+    if (kt + 2 < nt) { stage_a(bo, I0{}, kt + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    T8_BARRIER();
+    mma_q(I1{}, I0{}, bf0);
+    T8_BARRIER();
+  };
+
+  // ---- prologue: tile 0 complete, B0/A0 of tile 1
+  stage_b(0, I0{}, 0); stage_a(0, I0{}, 0); stage_b(0, I1{}, 0); stage_a(0, I1{}, 0);
+  stage_b(65536, I0{}, 1); stage_a(65536, I0{}, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  T8_BARRIER();
+  if (wr == 1) T8_BARRIER();   // the second wave row runs one barrier behind the first
+
+#pragma unroll 1
+  for (int kt = 0; kt < nt; ++kt) tile_body(kt);
+  if (wr == 0) T8_BARRIER();   // rejoin: every wave has finished its LDS reads, no DMA is in flight
+
+  // ------------------------------------------------------------------ epilogue
+  // Each wave stages its 128x64 accumulator block through a private LDS patch, 32 rows at a time ([32][68] f32),
+  // and leaves it in full row segments of 16 bytes per lane (gemm_epi.hpp).  acc[i][j][r]: row i*16 + 4*fq + r,
+  // column j*16 + fr of the wave's block.
+  constexpr int CS_LD = 68;
+  float* Cs = (float*)(smem + w * (32 * CS_LD * 4));
+  const bool cf32 = p.c_f32 != 0;
+  const bool outf32 = cf32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL;
+  const bool wide = !outf32 || p.epi == EPI_TABLE;   // bf16 outputs: 8 columns per lane
+  const int wm0 = m0 + wr * 128, wn0 = n0 + wc * 64;
+
+  auto copy_piece = [&](int q, auto WC) {
+    constexpr int W = decltype(WC)::value;
+    constexpr int LPR = 64 / W, RPP = 64 / LPR;   // lanes per row, rows per pass
+#pragma unroll 2
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+      const int row_l = ps * RPP + l / LPR, cw = (l % LPR) * W;
+      const long long row = wm0 + q * 32 + row_l;
+      const int col = wn0 + cw;
+      if (row >= p.M || col >= p.N) continue;
+      const int nv = min(W, p.N - col);
+      float v[W];
+#pragma unroll
+      for (int k = 0; k < W; k += 4) {
+        const float4 x = *(const float4*)&Cs[row_l * CS_LD + cw + k];
+        v[k] = x.x; v[k + 1] = x.y; v[k + 2] = x.z; v[k + 3] = x.w;
+      }
+      epi_item<bf16, W>(p, row, col, v, nv, outf32);
+    }
+  };
+
+  auto stage_acc = [&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    static_for<2>([&](auto ii) { static_for<4>([&](auto j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(ii * 16 + 4 * fq + r) * CS_LD + j * 16 + fr] = acc[q * 2 + ii][j][r];
+    }); });
+  };
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    switch (q) {
+      case 0: stage_acc(std::integral_constant<int, 0>{}); break;
+      case 1: stage_acc(std::integral_constant<int, 1>{}); break;
+      case 2: stage_acc(std::integral_constant<int, 2>{}); break;
+      default: stage_acc(std::integral_constant<int, 3>{}); break;
+    }
+    if (wide) copy_piece(q, std::integral_constant<int, 8>{});
+    else copy_piece(q, std::integral_constant<int, 4>{});
+    if (p.epi == EPI_SWIGLU) {
+      // g = silu(a) * b: the wave's 64 columns are two [16 a | 16 b] groups -> 32 columns of g; 8 per lane
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int row_l = ps * 16 + (l >> 2), grp = (l >> 1) & 1, c8 = (l & 1) * 8;
+        const long long row = wm0 + q * 32 + row_l;
+        const int gcol = (wn0 >> 1) + grp * 16 + c8;
+        if (row >= p.M || gcol * 2 >= p.N) continue;
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float a = Cs[row_l * CS_LD + grp * 32 + c8 + k], b = Cs[row_l * CS_LD + grp * 32 + 16 + c8 + k];
+          g[k] = a / (1.f + __expf(-a)) * b;
+        }
+        store_vec<bf16, 8>((bf16*)p.C2 + row * p.ldc2 + gcol, g, 8);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool gemm8p_eligible(const GemmParams& p) {
+  if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr) return false;
+  if (p.K % T8_BK != 0 || p.K < 2 * T8_BK) return false;
+  if (p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
+  if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldb * 2 >= (1ull << 32)) return false;
+  if (p.epi == EPI_SWIGLU && (p.N % 32 != 0 || p.ldc2 % 8 != 0)) return false;
+  return true;
+}
+
+int launch_gemm8p(const GemmParams& p, hipStream_t s) {
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  hipLaunchKernelGGL(gemm8p_kernel, dim3(tiles), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+}  // namespace rsys

@@ -308,3 +308,12 @@ def test_finetune_dropout_runs():
     assert res[0.0][0][0] == pytest.approx(res[0.0][0][1], rel=1e-6)       # no dropout: repeatable
     assert abs(res[0.5][0][0] - res[0.5][0][1]) > 1e-6                      # fresh mask every step
     assert res[0.5][1] == pytest.approx(res[0.0][1], rel=1e-5)             # evaluate: dropout off
+
+
+def test_forward_backward_with_256_tile_gemm(monkeypatch):
+    """Same parity check with every eligible row-major bf16 GEMM forced onto the 256x256 LDS-DMA kernel
+    (gemm8p.hip; by default it takes over only at >= 128 tiles): fused RoPE / SwiGLU / residual / GELU epilogues,
+    ragged M and N, the minimum K depth of its pipeline."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    name, over, rows, seed = CASES[1]
+    test_forward_backward_vs_oracle(name, over, rows, seed, "bf16", 4e-2, 6e-2, 1.5e-1)

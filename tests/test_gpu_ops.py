@@ -105,6 +105,24 @@ def test_gemm_bf16_with_f32_source_and_splitk(a_km, b_km):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 512), (300, 264, 192), (1000, 200, 576), (2048, 1024, 1408)])
+@pytest.mark.parametrize("c_f32", [True, False])
+def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32):
+    """256x256 LDS-DMA kernel (gemm8p.hip), forced: exact on asymmetric integer data for even / odd K-tile counts,
+    ragged edges (clamped source rows, guarded stores), f32 and bf16 outputs; and it must agree with the 128x128 kernel."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    out, ref = run_gemm(1, M, N, K, False, False, c_f32=c_f32, integer=True, seed=M + N + K)
+    if c_f32:
+        np.testing.assert_array_equal(out, ref.astype(np.float32))
+    else:
+        np.testing.assert_array_equal(out, _bf16_round(ref.astype(np.float32)))
+    out_r, ref_r = run_gemm(1, M, N, K, False, False, c_f32=True, seed=7)
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "1")
+    out_1, _ = run_gemm(1, M, N, K, False, False, c_f32=True, seed=7)
+    assert np.abs(out_r - ref_r).max() / np.abs(ref_r).max() < 1e-5
+    assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
+
+
 def test_gemm_bf16_output():
     out, ref = run_gemm(1, 128, 256, 128, False, False, c_f32=False, seed=3)
     err = np.abs(out - ref).max() / np.abs(ref).max()
