@@ -173,7 +173,7 @@ int32_t rsys_adamw_create(rsys_model* h, float lr, float b1, float b2, float eps
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
   rsys_optimizer* o = new rsys_optimizer();
-  o->o.m = m; o->o.lr = lr; o->o.b1 = b1; o->o.b2 = b2; o->o.eps = eps; o->o.wd = wd;
+  o->o.m = m; o->o.device = m->device; o->o.lr = lr; o->o.b1 = b1; o->o.b2 = b2; o->o.eps = eps; o->o.wd = wd;
   HIP_CHECK(hipMalloc((void**)&o->o.mom, m->n_total * 4));
   HIP_CHECK(hipMalloc((void**)&o->o.var, m->n_total * 4));
   HIP_CHECK(hipMemset(o->o.mom, 0, m->n_total * 4));
@@ -183,8 +183,8 @@ int32_t rsys_adamw_create(rsys_model* h, float lr, float b1, float b2, float eps
 }
 int32_t rsys_adamw_destroy(rsys_optimizer* o) {
   if (!o) return RSYS_OK;
-  hipSetDevice(o->o.m->device);
-  hipStreamSynchronize(o->o.m->stream);
+  hipSetDevice(o->o.device);
+  hipDeviceSynchronize();   // (not the model's stream: the model may already be gone)
   hipFree(o->o.mom); hipFree(o->o.var);
   delete o;
   return RSYS_OK;
@@ -332,6 +332,7 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.c_f32 = c_f32; p.splitk = splitk < 1 ? 1 : splitk; p.alpha = 1.f;
   p.epi = p.splitk > 1 ? EPI_ATOMIC : EPI_STORE;
+  if (getenv("RSYS_DEBUG_STAGGER")) p.dbg = atoi(getenv("RSYS_DEBUG_STAGGER"));
   if (getenv("RSYS_DEBUG_EPI")) p.epi = atoi(getenv("RSYS_DEBUG_EPI"));   // timing experiments only (e.g. 99 = no epilogue)
   int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, a_f32 != 0, false, a_km != 0, b_km != 0, nullptr)
                                     : launch_gemm<float>(p, false, false, a_km != 0, b_km != 0, nullptr);

@@ -172,7 +172,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   const int64_t D = m->D, N = (int64_t)m->rows_max * m->S, NT = 2 * N, KB = (int64_t)m->K * m->rows_max;
   const size_t e = m->esz;
   DALLOC(m->P, m->n_total * 4); DALLOC(m->G, m->n_total * 4);
-  if (m->bf16_mode) { DALLOC(m->Sh, m->n_total * 2); } else { m->Sh = m->P; }
+  if (m->bf16_mode) { DALLOC(m->Sh, m->n_total * 2); DALLOC(m->ShT, m->n_total * 2); } else { m->Sh = m->P; }
   DALLOC(m->Meta, (int64_t)(m->V + 1) * m->Mp * e);
   DALLOC(m->F32, (int64_t)(m->V + 1) * D * 4); DALLOC(m->FT, (int64_t)(m->V + 1) * D * e);
   // RoPE tables (model.py:173-179), fp32 like torch; the host may overwrite them (rsys_model_set_rope)
@@ -252,6 +252,7 @@ int model_destroy(Model* m) {
 }
 
 int model_refresh_shadow(Model* m) {
+  m->wt_dirty = true;
   if (m->bf16_mode) RC(launch_cast<bf16>(m->P, (bf16*)m->Sh, m->n_total, m->stream));
   return RSYS_OK;
 }
@@ -383,6 +384,7 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   }
   for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + internal_row(t, r) * t.ld, in + r * t.cols, t.cols * 4);
   HIP_CHECK(hipMemcpy(base, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+  if (which == 0) m->wt_dirty = true;
   if (which == 0 && m->bf16_mode)
     RC(launch_cast<bf16>(base, (bf16*)m->Sh + t.off, (int64_t)host.size(), m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -460,6 +462,29 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
 
 template <typename T> static inline T* W(Model* m, int64_t off) { return (T*)m->Sh + off; }
 template <typename T> static inline T* AT(void* p) { return (T*)p; }
+template <typename T> static inline T* WT(Model* m, int64_t off) { return (T*)m->ShT + off; }
+
+// bf16 mode: the dx GEMMs of the trunk (dX = dY . W, W stored [out][in]) read W^T as a row-major [in][out] operand
+static int ensure_transposes(Model* m) {
+  if (!m->bf16_mode || !m->wt_dirty) return RSYS_OK;
+  const int D = m->D, Ip = m->Ip;
+  TransposeBatch b; b.n = 0;
+  auto add = [&](int64_t off, int rows, int cols, long long ld) -> int {
+    TransposeJob& j = b.job[b.n++];
+    j.src = (const bf16*)m->Sh + off; j.dst = (bf16*)m->ShT + off; j.rows = rows; j.cols = cols; j.ld_src = ld; j.ld_dst = rows;
+    if (b.n == 64) { int rc = launch_transpose_bf16(b, m->stream); b.n = 0; return rc; }
+    return RSYS_OK;
+  };
+  for (int l = 0; l < m->L; ++l) {
+    RC(add(m->lo[l].wqkv, m->Nqkv, D, D));
+    RC(add(m->lo[l].wo, D, D, D));
+    RC(add(m->lo[l].w13, 2 * Ip, D, D));
+    RC(add(m->lo[l].w2, D, Ip, Ip));
+  }
+  RC(launch_transpose_bf16(b, m->stream));
+  m->wt_dirty = false;
+  return RSYS_OK;
+}
 
 static SmallParams small_params(Model* m) {
   SmallParams sp;
@@ -659,6 +684,8 @@ static int backward_trunk(Model* m) {
   T* gxt_other = AT<T>(m->gxb_t);
   T* dht = AT<T>(m->dh_t);
   const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
+  RC(ensure_transposes(m));
+  const bool wt = m->bf16_mode;   // dx GEMMs: row-major W^T (bf16 mode) or the K-major read of W itself (fp32 parity mode)
   tic(m, "phase_trunk_bwd");
   RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
   AttnParams ap{};
@@ -677,8 +704,9 @@ static int backward_trunk(Model* m) {
     {
       GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward: writes [da|db] directly
       p.A = gxt; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dab; p.ldc = 2 * Ip;
+      if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
-      RC(gemm<T>(m, "gemm_w2_dx", p, false, false, true));
+      RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
     }
     if (!ft) {
       GemmParams p{};  // dW13 += dab^T . hn
@@ -689,8 +717,9 @@ static int backward_trunk(Model* m) {
     {
       GemmParams p{};  // dhn = dab . W13
       p.A = m->dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_w13_dx", p, false, false, true));
+      RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
     }
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     if (!ft) {
@@ -702,8 +731,9 @@ static int backward_trunk(Model* m) {
     {
       GemmParams p{};  // dO = dh . Wo
       p.A = dht; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
+      if (wt) p.B = WT<T>(m, m->lo[l].wo);
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_o_dx", p, false, false, true));
+      RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
@@ -722,8 +752,9 @@ static int backward_trunk(Model* m) {
     {
       GemmParams p{};  // dxn = dqkv . Wqkv
       p.A = m->dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      if (wt) { p.B = WT<T>(m, m->lo[l].wqkv); p.ldb = m->Nqkv; }
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, true));
+      RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
     }
     if (ft) {
       T* xnd = m->drop_active ? AT<T>(a.xnd) : AT<T>(a.xn);
@@ -943,6 +974,7 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   o->step += 1;
   tic(m, "adamw");
   int rc;
+  if (!m->cfg.finetune) m->wt_dirty = true;   // (finetune: only the LoRA segment moves, the base weights and their transposes stay)
   if (m->bf16_mode)
     rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                             o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);

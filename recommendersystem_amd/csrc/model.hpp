@@ -55,6 +55,9 @@ struct Model {
   // device memory
   float *P = nullptr, *G = nullptr;
   void* Sh = nullptr;        // bf16 shadow of P (bf16 mode); == P in fp32 mode
+  void* ShT = nullptr;       // bf16 mode: the trunk weight matrices of Sh, transposed ([in][out]), same offsets: the dx GEMMs then
+                             // read row-major operands (256x256 LDS-DMA kernel); rebuilt lazily when wt_dirty
+  bool wt_dirty = true;
   void* Meta = nullptr;      // [V+1][Mp] T
   float* F32 = nullptr;      // [V+1][D]
   void* FT = nullptr;        // [V+1][D] T
@@ -88,6 +91,7 @@ struct Model {
 
 struct Optimizer {
   Model* m;
+  int device = 0;   // (kept here: the optimizer may be destroyed after its model)
   float lr, b1, b2, eps, wd;
   int step = 0;
   float *mom = nullptr, *var = nullptr;

@@ -163,4 +163,53 @@ int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float s
 template int launch_fill_normal_t<bf16>(bf16*, long long, int, long long, float, unsigned long long, hipStream_t);
 template int launch_fill_normal_t<float>(float*, long long, int, long long, float, unsigned long long, hipStream_t);
 
+
+// dst[c][r] = src[r][c] for a batch of bf16 matrices: 64x64 tiles through LDS, 16-byte global accesses on both sides
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(TransposeBatch b) {
+  __shared__ unsigned short tile[64][66];
+  const TransposeJob j = b.job[blockIdx.z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= j.rows || c0 >= j.cols) return;
+  const unsigned short* src = (const unsigned short*)j.src;
+  unsigned short* dst = (unsigned short*)j.dst;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = (t >> 3) + 32 * it, c = (t & 7) * 8;
+    if (r0 + r < j.rows) {
+      if (c0 + c + 8 <= j.cols) {
+        const uint4 q = *(const uint4*)(src + (long long)(r0 + r) * j.ld_src + c0 + c);
+        const unsigned short* e = (const unsigned short*)&q;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[r][c + k] = e[k];
+      } else {
+        for (int k = 0; k < 8; ++k) tile[r][c + k] = (c0 + c + k < j.cols) ? src[(long long)(r0 + r) * j.ld_src + c0 + c + k] : (unsigned short)0;
+      }
+    } else {
+      for (int k = 0; k < 8; ++k) tile[r][c + k] = 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c = (t >> 3) + 32 * it, r = (t & 7) * 8;   // output row c0+c, output columns r0+r..+8
+    if (c0 + c < j.cols) {
+      __attribute__((aligned(16))) unsigned short e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = tile[r + k][c];
+      if (r0 + r + 8 <= j.rows) *(uint4*)(dst + (long long)(c0 + c) * j.ld_dst + r0 + r) = *(const uint4*)e;
+      else for (int k = 0; k < 8; ++k) if (r0 + r + k < j.rows) dst[(long long)(c0 + c) * j.ld_dst + r0 + r + k] = e[k];
+    }
+  }
+}
+
+int launch_transpose_bf16(const TransposeBatch& b, hipStream_t s) {
+  if (b.n <= 0) return RSYS_OK;
+  int mr = 0, mc = 0;
+  for (int i = 0; i < b.n; ++i) { mr = b.job[i].rows > mr ? b.job[i].rows : mr; mc = b.job[i].cols > mc ? b.job[i].cols : mc; }
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((mc + 63) / 64, (mr + 63) / 64, b.n), dim3(256), 0, s, b);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 }  // namespace rsys
