@@ -491,6 +491,10 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
       const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
       if (hint == 2 || (hint == 0 && t256 >= 128)) return launch_gemm8p(p, s);
     }
+    if (!a_km && !b_km && !a_f32 && !b_f32 && gemm4w_eligible(p)) {
+      const char* e = getenv("RSYS_GEMM_KERNEL");
+      if (e && atoi(e) == 3) return launch_gemm4w(p, s);
+    }
   }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);

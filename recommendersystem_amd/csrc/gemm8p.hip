@@ -21,6 +21,7 @@
 // the permutation is applied to the per-lane SOURCE address.
 #include "gemm.hpp"
 #include "gemm_epi.hpp"
+#include "gemm_epi_reg.hpp"
 
 namespace rsys {
 
@@ -202,259 +203,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   for (int kt = 0; kt < nt; ++kt) tile_body(kt);
   if (wr == 0) T8_BARRIER();   // rejoin (equal barrier counts)
 
-  // ------------------------------------------------------------------ epilogue
-  // The MFMAs computed the TRANSPOSED product (B fragment as the first operand), so lane (fq, fr) holds, for the
-  // 16x16 block (i, j) of its wave's 128x64 output, FOUR CONSECUTIVE COLUMNS of one row:
-  //   acc[i][j][r] = C[wm0 + 16 i + fr][wn0 + 16 j + 4 fq + r].
-  // Every fused epilogue is lane-local in this layout (RoPE pairs, the [16 a | 16 b] SwiGLU groups = blocks j, j+1)
-  // and the results leave straight from registers: f32 outputs as 16-byte stores; bf16 outputs after one
-  // v_permlane16_swap per dword between two blocks, which gives every lane 8 consecutive columns (16 bytes,
-  // 64-byte row segments per wave instruction).  No LDS round trip, no barrier: the stores are in flight when the
-  // workgroup retires and drain under the next workgroup's prologue.
+  // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; return; }   // timing experiment: no epilogue
-  const bool cf32 = p.c_f32 != 0;
-  const int wm0 = m0 + wr * 128, wn0 = n0 + wc * 64;
-
-  auto pk2 = [](float a, float b) -> unsigned int {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t v; v[0] = (bf16)a; v[1] = (bf16)b;
-    return __builtin_bit_cast(unsigned int, v);
-  };
-  // x: 4 values at columns cx + 4 fq + r, y: 4 values at columns cy + 4 fq + r of row `rowp` (T-typed, element
-  // pointer of the row).  After the swaps lane rows (fq) 0/2 hold columns cx + 8 (fq>>1) + [0,8), rows 1/3 the same
-  // of cy.  Every lane takes part in the swaps; only the store is guarded.
-  // Everything below is straight-line code per epilogue class (no branch around a load): hipcc then keeps exact vmcnt
-  // counts, and because operands of row block i+1 are requested BEFORE the stores of row block i are issued, no wait
-  // ever has to drain a store (memory operations retire in issue order).  Out-of-range rows / columns are handled by
-  // clamping the load addresses and masking the stores; the launcher guarantees N % 8 == 0, so a lane's group of
-  // 4 (f32) or 8 (bf16) columns is inside or outside as a whole.
-  auto store_pair = [&](bf16* rowp, bool rowok, int cx, int cy, int ncols, const float (&x)[4], const float (&y)[4]) {
-    // x: 4 values at columns cx + 4 fq + r, y: at cy + 4 fq + r.  After the swaps lane rows (fq) 0/2 hold columns
-    // cx + 8 (fq>>1) + [0,8), rows 1/3 the same of cy.  Every lane takes part in the swaps; only the store is masked.
-    unsigned int x0 = pk2(x[0], x[1]), x1 = pk2(x[2], x[3]), y0 = pk2(y[0], y[1]), y1 = pk2(y[2], y[3]);
-    auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-    const int col = ((fq & 1) ? cy : cx) + 8 * (fq >> 1);
-    if (rowok && col < ncols) *(uint4*)(rowp + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-  };
-  auto store_f32 = [&](float* rowp, bool rowok, int col, int ncols, const float (&x)[4]) {
-    if (rowok && col < ncols) *(float4*)(rowp + col) = make_float4(x[0], x[1], x[2], x[3]);
-  };
-  auto ldf4 = [&](const float* rowp, int col, int ncols) -> float4 { return *(const float4*)(rowp + (col < ncols ? col : 0)); };
-  auto ldt4 = [&](const bf16* rowp, int col, int ncols) -> bf16x4 { return *(const bf16x4*)(rowp + (col < ncols ? col : 0)); };
-
-  auto run = [&](auto EC) {
-    constexpr int ec = decltype(EC)::value;
-    const bool outf32 = cf32 || ec == EPI_ACCUM || ec == EPI_RESIDUAL;
-    const int cb = wn0 + 4 * fq;   // this lane's first column in block 0; block j adds 16 j
-    // per-column vectors, the same for all rows
-    float4 bias4[4];
-    if constexpr (ec == EPI_BIAS || ec == EPI_GELU || ec == EPI_TABLE) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bias4[j] = ldf4(p.bias, cb + 16 * j, p.N);
-    }
-    const unsigned int rope_p0 = ec == EPI_QKV_ROPE ? (unsigned int)(wm0 + fr) % (unsigned int)p.T : 0u;
-    // per-row-block operands, requested one row block ahead (16 registers per stage)
-    struct Pre { float4 f[4]; };
-    auto request = [&](auto I, Pre& pre) {
-      constexpr int i = decltype(I)::value;
-      const long long rl = min((long long)(wm0 + i * 16 + fr), (long long)p.M - 1);
-      if constexpr (ec == EPI_ACCUM) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pre.f[j] = ldf4((const float*)p.C + rl * p.ldc, cb + 16 * j, p.N);
-      } else if constexpr (ec == EPI_RESIDUAL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pre.f[j] = ldf4(p.resid + rl * p.ldr, cb + 16 * j, p.N);
-      } else if constexpr (ec == EPI_TABLE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pre.f[j] = ldf4(p.E + rl * p.ldc, cb + 16 * j, p.N);
-      } else if constexpr (ec == EPI_QKV_ROPE) {
-        // (cos, sin) of the lane's two pairs in every block: f[j] = {cos0, cos1, sin0, sin1}
-        // position = row % T, without a 64-bit division per row block: one 32-bit modulo per lane (rope_p0), then +16 i
-        int pos;
-        if (p.rope_pos) pos = p.rope_pos[rl];
-        else {
-          const unsigned int q = rope_p0 + 16u * i;
-          pos = (int)(p.T >= 128 ? (q >= (unsigned int)p.T ? q - (unsigned int)p.T : q) : q % (unsigned int)p.T);
-          if (wm0 + i * 16 + fr >= p.M) pos = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = cb + 16 * j;
-          const int cc = col < p.n_q ? col : col - p.n_q;
-          const int d2 = (cc & (p.hd - 1)) >> 1;
-          const float2 c2 = *(const float2*)(p.rope_cos + pos * (p.hd >> 1) + d2);
-          const float2 s2 = *(const float2*)(p.rope_sin + pos * (p.hd >> 1) + d2);
-          pre.f[j] = make_float4(c2.x, c2.y, s2.x, s2.y);
-        }
-      } else if constexpr (ec == EPI_SWIGLU_BWD) {
-        // saved a, b of dg column c live at (c>>4)*32 + (c&15) (+16) of the [a|b] rows: f[j] = {a (4 bf16), b (4 bf16)}
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ob = ((wn0 + 16 * j) >> 4) * 32 + 4 * fq;
-          const bf16x4 a4 = ldt4((const bf16*)p.C2 + rl * p.ldc2, ob, 2 * p.N);
-          const bf16x4 b4 = ldt4((const bf16*)p.C2 + rl * p.ldc2, ob + 16, 2 * p.N);
-          pre.f[j] = make_float4(__builtin_bit_cast(float2, a4).x, __builtin_bit_cast(float2, a4).y,
-                                 __builtin_bit_cast(float2, b4).x, __builtin_bit_cast(float2, b4).y);
-        }
-      } else if constexpr (ec == EPI_STORE) {
-        if (!outf32 && p.accum) {   // C (T) += result: LoRA updates; f[j] holds the old 4 bf16 values in .x, .y
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bf16x4 o4 = ldt4((const bf16*)p.C + rl * p.ldc, cb + 16 * j, p.N);
-            pre.f[j] = make_float4(__builtin_bit_cast(float2, o4).x, __builtin_bit_cast(float2, o4).y, 0.f, 0.f);
-          }
-        }
-      }
-    };
-    auto unpack4 = [](float lo, float hi, float (&o)[4]) {
-      const bf16x4 q = __builtin_bit_cast(bf16x4, make_float2(lo, hi));
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (float)q[r];
-    };
-    auto finish = [&](auto I, const Pre& pre) {
-      constexpr int i = decltype(I)::value;
-      const long long row = wm0 + i * 16 + fr;
-      const bool rowok = row < p.M;
-      float v[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
-      if constexpr (ec == EPI_STORE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[j][r] *= p.alpha;
-        if (!outf32 && p.accum) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float o[4]; unpack4(pre.f[j].x, pre.f[j].y, o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[j][r] += o[r];
-          }
-        }
-      } else if constexpr (ec == EPI_BIAS || ec == EPI_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j][0] += bias4[j].x; v[j][1] += bias4[j].y; v[j][2] += bias4[j].z; v[j][3] += bias4[j].w; }
-      } else if constexpr (ec == EPI_ACCUM || ec == EPI_RESIDUAL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j][0] += pre.f[j].x; v[j][1] += pre.f[j].y; v[j][2] += pre.f[j].z; v[j][3] += pre.f[j].w; }
-      } else if constexpr (ec == EPI_TABLE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j][0] += pre.f[j].x + bias4[j].x; v[j][1] += pre.f[j].y + bias4[j].y;
-          v[j][2] += pre.f[j].z + bias4[j].z; v[j][3] += pre.f[j].w + bias4[j].w;
-        }
-      } else if constexpr (ec == EPI_QKV_ROPE) {
-        // rotate interleaved pairs (transformer.model.py:182-190): 4 consecutive columns = 2 pairs of one head
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[j][r] *= p.alpha;
-          if (cb + 16 * j < p.n_q + p.n_k) {
-            const float c0 = pre.f[j].x, c1 = pre.f[j].y, s0 = pre.f[j].z, s1 = pre.f[j].w;
-            const float a0 = v[j][0] * c0 - v[j][1] * s0, a1 = v[j][0] * s0 + v[j][1] * c0;
-            const float a2 = v[j][2] * c1 - v[j][3] * s1, a3 = v[j][2] * s1 + v[j][3] * c1;
-            v[j][0] = a0; v[j][1] = a1; v[j][2] = a2; v[j][3] = a3;
-          }
-        }
-        if (!outf32 && p.accum) {   // (LoRA B update of the rotated q / v columns; small problems only)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const long long rl = min(row, (long long)p.M - 1);
-            const bf16x4 o4 = ldt4((const bf16*)p.C + rl * p.ldc, cb + 16 * j, p.N);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[j][r] += (float)o4[r];
-          }
-        }
-      }
-
-      if constexpr (ec == EPI_SWIGLU_BWD) {
-        // acc = dg; (da, db) of one block pair up: 32 consecutive columns of the [a|b] layout
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float av[4], bv[4], da[4], db[4];
-          unpack4(pre.f[j].x, pre.f[j].y, av); unpack4(pre.f[j].z, pre.f[j].w, bv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sg = 1.f / (1.f + __expf(-av[r]));
-            da[r] = v[j][r] * bv[r] * sg * (1.f + av[r] * (1.f - sg));
-            db[r] = v[j][r] * av[r] * sg;
-          }
-          const int ob = ((wn0 + 16 * j) >> 4) * 32;
-          store_pair((bf16*)p.C + row * p.ldc, rowok, ob, ob + 16, 2 * p.N, da, db);
-        }
-      } else if constexpr (ec == EPI_GELU) {
-#pragma unroll
-        for (int jp = 0; jp < 4; jp += 2) {
-          float gx[4], gy[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            gx[r] = 0.5f * v[jp][r] * (1.f + erff(v[jp][r] * 0.70710678118654752f));
-            gy[r] = 0.5f * v[jp + 1][r] * (1.f + erff(v[jp + 1][r] * 0.70710678118654752f));
-          }
-          store_pair((bf16*)p.C + row * p.ldc, rowok, wn0 + jp * 16, wn0 + jp * 16 + 16, p.N, v[jp], v[jp + 1]);
-          store_pair((bf16*)p.C2 + row * p.ldc2, rowok, wn0 + jp * 16, wn0 + jp * 16 + 16, p.N, gx, gy);
-        }
-      } else if constexpr (ec == EPI_SWIGLU) {
-        // blocks (0,1) and (2,3) are [16 a | 16 b] groups: C gets [a|b] as is, C2 the products g = silu(a) * b
-        float g0[4], g1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          g0[r] = v[0][r] / (1.f + __expf(-v[0][r])) * v[1][r];
-          g1[r] = v[2][r] / (1.f + __expf(-v[2][r])) * v[3][r];
-        }
-        store_pair((bf16*)p.C + row * p.ldc, rowok, wn0, wn0 + 16, p.N, v[0], v[1]);
-        store_pair((bf16*)p.C + row * p.ldc, rowok, wn0 + 32, wn0 + 48, p.N, v[2], v[3]);
-        store_pair((bf16*)p.C2 + row * p.ldc2, rowok, (wn0 >> 1), (wn0 >> 1) + 16, p.N >> 1, g0, g1);
-      } else if constexpr (ec == EPI_TABLE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) store_f32((float*)p.C + row * p.ldc, rowok, cb + 16 * j, p.N, v[j]);
-        store_pair((bf16*)p.C2 + row * p.ldc2, rowok, wn0, wn0 + 16, p.N, v[0], v[1]);
-        store_pair((bf16*)p.C2 + row * p.ldc2, rowok, wn0 + 32, wn0 + 48, p.N, v[2], v[3]);
-      } else {
-        if (outf32) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) store_f32((float*)p.C + row * p.ldc, rowok, cb + 16 * j, p.N, v[j]);
-        } else {
-          store_pair((bf16*)p.C + row * p.ldc, rowok, wn0, wn0 + 16, p.N, v[0], v[1]);
-          store_pair((bf16*)p.C + row * p.ldc, rowok, wn0 + 32, wn0 + 48, p.N, v[2], v[3]);
-        }
-      }
-    };
-    Pre pa, pb;
-    request(std::integral_constant<int, 0>{}, pa);
-    static_for<4>([&](auto H) {
-      constexpr int i = decltype(H)::value * 2;
-      request(std::integral_constant<int, i + 1>{}, pb);
-      finish(std::integral_constant<int, i>{}, pa);
-      if constexpr (i + 2 < 8) request(std::integral_constant<int, i + 2>{}, pa);
-      finish(std::integral_constant<int, i + 1>{}, pb);
-    });
-  };
-  switch (p.epi) {
-    case EPI_STORE: run(std::integral_constant<int, EPI_STORE>{}); break;
-    case EPI_ACCUM: run(std::integral_constant<int, EPI_ACCUM>{}); break;
-    case EPI_BIAS: run(std::integral_constant<int, EPI_BIAS>{}); break;
-    case EPI_RESIDUAL: run(std::integral_constant<int, EPI_RESIDUAL>{}); break;
-    case EPI_QKV_ROPE: run(std::integral_constant<int, EPI_QKV_ROPE>{}); break;
-    case EPI_SWIGLU: run(std::integral_constant<int, EPI_SWIGLU>{}); break;
-    case EPI_TABLE: run(std::integral_constant<int, EPI_TABLE>{}); break;
-    case EPI_GELU: run(std::integral_constant<int, EPI_GELU>{}); break;
-    case EPI_SWIGLU_BWD: run(std::integral_constant<int, EPI_SWIGLU_BWD>{}); break;
-    default: break;
-  }
+  epilogue_regs(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
 }
 
 }  // namespace
 
 bool gemm8p_eligible(const GemmParams& p) {
-  if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr) return false;
+  if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr || p.accum) return false;
   if (p.K % T8_BK != 0 || p.K < 2 * T8_BK) return false;
   if (p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
   if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldb * 2 >= (1ull << 32)) return false;
   if (p.N % 8 != 0) return false;   // whole 8-column groups per lane in the epilogue
+  const unsigned long long lim = 1ull << 32;   // 32-bit byte offsets in the epilogue
+  const bool cf = p.c_f32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
+  if ((unsigned long long)p.M * p.ldc * (cf ? 4 : 2) >= lim) return false;
+  if (p.C2 != nullptr && (unsigned long long)p.M * p.ldc2 * 2 >= lim) return false;
+  if (p.epi == EPI_RESIDUAL && (unsigned long long)p.M * p.ldr * 4 >= lim) return false;
+  if (p.epi == EPI_QKV_ROPE && p.alpha != 1.f) return false;
   if (p.epi == EPI_SWIGLU && (p.N % 32 != 0 || p.ldc2 % 8 != 0)) return false;
   return true;
 }

@@ -140,5 +140,8 @@ __device__ __forceinline__ void epi_item(const GemmParams& p, long long row, int
 // gemm8p_eligible: the problem satisfies that kernel's layout / size preconditions.
 bool gemm8p_eligible(const GemmParams& p);
 int launch_gemm8p(const GemmParams& p, hipStream_t s);
+// row-major bf16 operands, 256x128 tiles, two workgroups per CU (gemm4w.hip)
+bool gemm4w_eligible(const GemmParams& p);
+int launch_gemm4w(const GemmParams& p, hipStream_t s);
 
 }  // namespace rsys

@@ -310,10 +310,11 @@ def test_finetune_dropout_runs():
     assert res[0.5][1] == pytest.approx(res[0.0][1], rel=1e-5)             # evaluate: dropout off
 
 
-def test_forward_backward_with_256_tile_gemm(monkeypatch):
+@pytest.mark.parametrize("kern", ["2", "3"])
+def test_forward_backward_with_256_tile_gemm(monkeypatch, kern):
     """Same parity check with every eligible row-major bf16 GEMM forced onto the 256x256 LDS-DMA kernel
     (gemm8p.hip; by default it takes over only at >= 128 tiles): fused RoPE / SwiGLU / residual / GELU epilogues,
     ragged M and N, the minimum K depth of its pipeline."""
-    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)
     name, over, rows, seed = CASES[1]
     test_forward_backward_vs_oracle(name, over, rows, seed, "bf16", 4e-2, 6e-2, 1.5e-1)

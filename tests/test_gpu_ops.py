@@ -107,10 +107,11 @@ def test_gemm_bf16_with_f32_source_and_splitk(a_km, b_km):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 512), (300, 264, 192), (1000, 200, 576), (2048, 1024, 1408)])
 @pytest.mark.parametrize("c_f32", [True, False])
-def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32):
-    """256x256 LDS-DMA kernel (gemm8p.hip), forced: exact on asymmetric integer data for even / odd K-tile counts,
+@pytest.mark.parametrize("kern", ["2", "3"])
+def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
+    """LDS-DMA kernels (gemm8p.hip / gemm4w.hip), forced: exact on asymmetric integer data for even / odd K-tile counts,
     ragged edges (clamped source rows, guarded stores), f32 and bf16 outputs; and it must agree with the 128x128 kernel."""
-    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)   # 2: 256x256 (gemm8p.hip), 3: 256x128, two workgroups per CU (gemm4w.hip)
     out, ref = run_gemm(1, M, N, K, False, False, c_f32=c_f32, integer=True, seed=M + N + K)
     if c_f32:
         np.testing.assert_array_equal(out, ref.astype(np.float32))

@@ -8,7 +8,7 @@ SHAPES = [(NT, 1024, 512, False), (NT, 512, 512, True), (NT, 2816, 512, False), 
           (NT, 512, 2816, False), (NT, 512, 1024, False), (4096, 120000, 512, False), (200001, 512, 6208, True),
           (4096, 4096, 4096, False), (8192, 8192, 8192, False)]
 for (M, N, K, cf32) in SHAPES:
-    for k in ("1", "2", "1", "2"):
+    for k in ("2", "3", "2", "3"):
         os.environ["RSYS_GEMM_KERNEL"] = k
         print("kernel", k, end="  ")
         bg.run(M, N, K, False, False, c_f32=cf32, reps=10)
