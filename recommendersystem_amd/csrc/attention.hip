@@ -22,6 +22,8 @@ namespace rsys {
 #define SENT_Q (-2147483647)
 #define SENT_K (-2147483646)
 constexpr float LOG2E = 1.4426950408889634f;
+// v_exp_f32 directly (exp2f adds range scaling the softmax arguments never need: they are <= 0 or hugely negative)
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <typename T> struct AMma;
 template <> struct AMma<bf16> {
@@ -200,25 +202,28 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   return RSYS_OK;
 }
 
-// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS, the lane's own ids (u,tmv);
-// LANE_IS_Q: the lane is the query and the rows are keys, else the lane is the key and the rows are queries.
+// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS, the lane's own ids (u, tmv).
+// allowed(q, kv) = uid equal AND (tm[kv] == 0 OR tm equal)  <=>  ((uq ^ uk) | ((tq ^ tk) & mk)) == 0 with mk = tm[kv] ? ~0 : 0.
+// LANE_IS_Q: the lane is the query and the rows are keys (ms = the keys' mk, staged with the tile); else the lane is
+// the key (lane_m = its own mk) and the rows are queries.  Five vector ops per score.
 template <bool LANE_IS_Q>
-__device__ __forceinline__ void mask_tile(f32x4& S, const int* us, const int* ts, int tok0, int u, int tmv, int g, float fill) {
+__device__ __forceinline__ void mask_tile(f32x4& S, const int* us, const int* ts, const int* ms, int tok0, int u, int tmv, int lane_m, int g, float fill) {
   const int4 u4 = *(const int4*)(us + tok0 + 4 * g);
   const int4 t4 = *(const int4*)(ts + tok0 + 4 * g);
   const int uu[4] = {u4.x, u4.y, u4.z, u4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+  int mm[4];
+  if (LANE_IS_Q) { const int4 m4 = *(const int4*)(ms + tok0 + 4 * g); mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w; }
+  else { mm[0] = mm[1] = mm[2] = mm[3] = lane_m; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    bool ok;
-    if (LANE_IS_Q) ok = (u == uu[r]) && (tt[r] == 0 || tmv == tt[r]);       // row = key
-    else ok = (u == uu[r]) && (tmv == 0 || tt[r] == tmv);                     // row = query, lane = key
-    S[r] = ok ? S[r] : fill;
+    const int bad = (u ^ uu[r]) | ((tmv ^ tt[r]) & mm[r]);
+    S[r] = bad == 0 ? S[r] : fill;
   }
 }
 
 // ------------------------------------------------------------------------ forward
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   T* Vs = Ks + 2 * C::TILE;                   // [2][64][LDD]
   int* uk = (int*)(Vs + 2 * C::TILE);         // [2][64]
   int* tk = uk + 128;                         // [2][64]
+  int* mk = tk + 128;                         // [2][64]  tm[kv] ? ~0 : 0
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int kvh = h / (p.H / p.KV);
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; }
+    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; mk[buf * 64 + t] = rt ? -1 : 0; }
   };
 
   int kt = next_bit(bits, 0);
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     first_stage<T, HD>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, 16 * i, uq, tq, g, -1e30f);
+      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, mk + cur * 64, 16 * i, uq, tq, 0, g, -1e30f);
     }
     float tmax = -1e30f;
 #pragma unroll
@@ -288,13 +294,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax * c2);
     const float mu_old = fmaxf(m_run, -1e20f), mu_new = fmaxf(m_new, -1e20f);
-    const float alpha = exp2f(mu_old - mu_new);
+    const float alpha = fexp2(mu_old - mu_new);
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = exp2f(fmaf(S[i][r], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
+        const float pv = fexp2(fmaf(S[i][r], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
         S[i][r] = pv;
         psum += pv;
       }
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 template <typename T, int HD>
 static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
   using C = ACfg<T, HD>;
-  const size_t sm = sizeof(T) * 4 * C::TILE + 256 * sizeof(int);
+  const size_t sm = sizeof(T) * 4 * C::TILE + 384 * sizeof(int);
   static bool set = false;
   if (!set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
@@ -439,7 +445,7 @@ __device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld,
 
 // ------------------------------------------------------------------------ backward: dK, dV (one workgroup per kv tile and kv head)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 2 : 1) void attn_bwd_kv_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -516,10 +522,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
       const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
       const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
       const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-      if (!fullt) mask_tile<false>(S[i], uqs + cur * 64, tqs + cur * 64, 16 * i, ukv, tkv, g, -1e30f);
+      if (!fullt) mask_tile<false>(S[i], uqs + cur * 64, tqs + cur * 64, nullptr, 16 * i, ukv, tkv, tkv ? -1 : 0, g, -1e30f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = exp2f(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
+        const float pv = fexp2(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
         S[i][r] = pv;
         dP[i][r] = pv * (dP[i][r] - dd[r]) * scale;
       }
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and head)
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_bwd_q_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
   T* Vs = Ks + 2 * C::TILE;              // [2][64 kv][LDD]
   int* uk = (int*)(Vs + 2 * C::TILE);    // [2][64]
   int* tk = uk + 128;
+  int* mk = tk + 128;                    // [2][64]  tm[kv] ? ~0 : 0
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int kvh = h / (p.H / p.KV), nt = (p.T + 63) / 64;
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; }
+    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; mk[buf * 64 + t] = rt ? -1 : 0; }
   };
   int kt = next_bit(bits, 0), cur = 0;
   if (kt < nt) { gload(kt); lstore(0); }
@@ -603,10 +610,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
     const bool fullt = (fullbits >> kt) & 1u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!fullt) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, 16 * i, uq, tq, g, -1e30f);
+      if (!fullt) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, mk + cur * 64, 16 * i, uq, tq, 0, g, -1e30f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = exp2f(fmaf(S[i][r], c2, -lse2));
+        const float pv = fexp2(fmaf(S[i][r], c2, -lse2));
         dP[i][r] = pv * (dP[i][r] - dl) * scale;
       }
     }
@@ -627,7 +634,7 @@ template <typename T, int HD>
 static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   using C = ACfg<T, HD>;
   const size_t sm_kv = sizeof(T) * 4 * C::TILE + 512 * 4;
-  const size_t sm_q = sizeof(T) * 4 * C::TILE + 256 * 4;
+  const size_t sm_q = sizeof(T) * 4 * C::TILE + 384 * 4;
   static bool set = false;
   if (!set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_kv));

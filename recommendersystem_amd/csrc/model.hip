@@ -168,6 +168,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   m->Mp = (m->M + 63) / 64 * 64; m->K = cfg->mask_topk; m->hd = hd;
   m->Nqkv = (m->H + 2 * m->KV) * hd; m->rows_max = cfg->max_rows;
   HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   build_layout(m);
   const int64_t D = m->D, N = (int64_t)m->rows_max * m->S, NT = 2 * N, KB = (int64_t)m->K * m->rows_max;
   const size_t e = m->esz;
@@ -244,7 +247,9 @@ int model_destroy(Model* m) {
   if (!m) return RSYS_OK;
   hipSetDevice(m->device);
   hipStreamSynchronize(m->stream);
+  hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
+  hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
   for (auto e : m->timer.pool) hipEventDestroy(e);
   hipStreamDestroy(m->stream);
   delete m;
@@ -459,6 +464,28 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
   int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);
   toc(m);
   return rc;
+}
+
+// Weight-gradient GEMM on the side stream, beside whatever the main stream launches until join_side(): the side
+// stream first waits for everything the main stream has enqueued so far (the GEMM's operands).  With per-kernel
+// timing on (model.timing) it runs in line instead, so that the phase breakdown stays meaningful.
+template <typename T>
+static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
+  static const bool off = getenv("RSYS_NO_SIDE_STREAM") != nullptr;
+  if (m->timer.enabled || off) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
+  if (p.alpha == 0.f) p.alpha = 1.f;
+  if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
+  if (p.splitk == 0) p.splitk = 1;
+  HIP_CHECK(hipEventRecord(m->ev_fork, m->stream));
+  HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+  RC(launch_gemm<T>(p, a_f32, false, a_km, b_km, m->side));
+  HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+  m->side_pending = true;
+  return RSYS_OK;
+}
+static int join_side(Model* m) {
+  if (m->side_pending) { HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_join, 0)); m->side_pending = false; }
+  return RSYS_OK;
 }
 
 template <typename T> static inline T* W(Model* m, int64_t off) { return (T*)m->Sh + off; }
@@ -700,7 +727,7 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_w2_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_w2_dw", p, false, true, true));
     }
     {
       GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward: writes [da|db] directly
@@ -708,12 +735,13 @@ static int backward_trunk(Model* m) {
       if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
       RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
+      RC(join_side(m));
     }
     if (!ft) {
       GemmParams p{};  // dW13 += dab^T . hn
       p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
       p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_w13_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_w13_dw", p, false, true, true));
     }
     {
       GemmParams p{};  // dhn = dab . W13
@@ -721,13 +749,14 @@ static int backward_trunk(Model* m) {
       if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
+      RC(join_side(m));
     }
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     if (!ft) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_o_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_o_dw", p, false, true, true));
     }
     {
       GemmParams p{};  // dO = dh . Wo
@@ -735,6 +764,7 @@ static int backward_trunk(Model* m) {
       if (wt) p.B = WT<T>(m, m->lo[l].wo);
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
+      RC(join_side(m));
     }
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
@@ -748,7 +778,7 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
       p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
       p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm<T>(m, "gemm_qkv_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_qkv_dw", p, false, true, true));
     }
     {
       GemmParams p{};  // dxn = dqkv . Wqkv
@@ -756,6 +786,7 @@ static int backward_trunk(Model* m) {
       if (wt) { p.B = WT<T>(m, m->lo[l].wqkv); p.ldb = m->Nqkv; }
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
+      RC(join_side(m));
     }
     if (ft) {
       T* xnd = m->drop_active ? AT<T>(a.xnd) : AT<T>(a.xn);

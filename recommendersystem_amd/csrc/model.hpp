@@ -40,6 +40,11 @@ struct Model {
   rsys_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream for the weight-gradient GEMMs of the trunk backward: each runs beside the dx GEMM that shares its
+  // input (MFMA-bound beside output-bound), forked and joined with events around the pair
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_pending = false;
   bool bf16_mode = false;
   size_t esz = 4;
   // dims
