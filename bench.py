@@ -22,23 +22,21 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
 
-GEMM_VARIANT = {  # call-site tag -> kernel instantiation (gemm.hip)
-    "gemm_table_fwd": "NT", "gemm_action_fwd": "NT", "gemm_qkv_fwd": "NT", "gemm_o_fwd": "NT", "gemm_w13_fwd": "NT",
-    "gemm_w2_fwd": "NT", "gemm_logits": "NT", "gemm_rating_fwd": "NT",
-    "gemm_head_dx": "NN", "gemm_w13_dx": "NN", "gemm_qkv_dx": "NN", "gemm_rating_dx": "NN",
-    "gemm_w2_dx": "NN", "gemm_o_dx": "NN", "gemm_action_dx": "NN",
-    "gemm_head_dw": "TN", "gemm_w13_dw": "TN", "gemm_qkv_dw": "TN", "gemm_rating_dw": "TN",
-    "gemm_w2_dw": "TN", "gemm_o_dw": "TN", "gemm_action_dw": "TN", "gemm_table_dw": "TN",
+# kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
+KERNEL_SYMBOL = {
+    "8p": "rsys::(anonymous namespace)::gemm8p_kernel(rsys::GemmParams)",        # 256x256 LDS-DMA, row-major operands (gemm8p.hip)
+    "4w": "rsys::(anonymous namespace)::gemm4w_kernel(rsys::GemmParams)",        # 256x128, two workgroups per CU (gemm4w.hip)
+    "nt": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb0ELb0EEEvNS_10GemmParamsE",  # 128x128 register-staged (gemm.hip)
+    "nn": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb1ELb0EEEvNS_10GemmParamsE",
+    "tn": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb1ELb1ELb0EEEvNS_10GemmParamsE",
 }
-
-
-KERNEL_SYMBOL = {"NT": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb0EEEvNS_10GemmParamsE",
-                 "NN": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb1EEEvNS_10GemmParamsE",
-                 "TN": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb1ELb1EEEvNS_10GemmParamsE"}
+KERNEL_LABEL = {"8p": "gemm8p_kernel (256x256 LDS-DMA, row-major bf16)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+                "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
+TRAFFIC_FILE = "r1d_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
-    """HBM bytes per launch of the kernel from the committed PMC summary (profiles/r1c_pmc_traffic.json)."""
+    """HBM bytes per launch of the kernel from the committed PMC summary (profiles/<TRAFFIC_FILE>)."""
     k = db.get(KERNEL_SYMBOL.get(variant, ""))
     return None if k is None else round(k["hbm_bytes_per_launch"])
 
@@ -146,7 +144,10 @@ def main():
     first_losses = model.losses(False)
     hg.barrier()
     if not args.no_kernel_timing:
-        model.timing(True)
+        # per-kernel HIP events on the stream each kernel runs on; the weight-gradient GEMMs run in line on the main
+        # stream while they are timed (model.timing serialize), so every duration is that of the kernel alone and agrees
+        # with rocprofv3 --kernel-trace of this command.  --no-kernel-timing: production mode (wgrad side stream, ~1% faster).
+        model.timing(True, serialize=True)
     ra.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,8 +165,8 @@ def main():
         fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
         fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
-            if tag in rep:
-                rep[tag]["flops"] = fl
+            for full in [k for k in rep if k.split("@")[0] == tag]:
+                rep[full]["flops"] = fl
     model.timing(False)
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses
@@ -178,21 +179,21 @@ def main():
         # dominant kernel: the MFMA GEMM family, per instantiation
         var = {}
         for tag, r in rep.items():
-            v = GEMM_VARIANT.get(tag)
+            v = tag.split("@")[1] if tag.startswith("gemm_") and "@" in tag else None
             if v:
                 a = var.setdefault(v, {"ms": 0.0, "flops": 0.0, "launches": 0})
                 a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["launches"] += r["count"]
         roofline = None
         traffic_db = {}
         try:   # PMC passes are separate runs (rocprofv3 --pmc); their per-launch summary is committed under profiles/
-            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")))["kernels"]
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels"]
         except Exception:
             pass
         if var:
             dom = max(var, key=lambda k: var[k]["ms"])
             a = var[dom]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": f"gemm_kernel<bf16,{dom}>", "achieved": round(ach, 1),
+            roofline = {"bound": "mfma", "kernel": KERNEL_LABEL.get(dom, dom), "achieved": round(ach, 1),
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                         "traffic": traffic_of(traffic_db, dom), "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],

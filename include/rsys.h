@@ -154,7 +154,7 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin);
-int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-phase HIP-event timings */
+int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-call-site HIP-event timings; 2: also run the side-stream GEMMs in line */
 int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
 
 #ifdef __cplusplus

@@ -221,6 +221,22 @@ __device__ __forceinline__ void mask_tile(f32x4& S, const int* us, const int* ts
   }
 }
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each); all workgroups of one
+// (row, kv head) group read the same K/V (forward, dQ) or Q/dO (dK/dV) tiles, so a group is kept on ONE XCD: its tiles
+// are fetched from HBM once instead of once per XCD (rocprofv3 FETCH_SIZE: 2.9x the algorithmic bytes before).
+// 1-D grid of n_groups * n_inner workgroups; falls back to the plain order when n_groups is not a multiple of 8.
+__device__ __forceinline__ void attn_work(int n_groups, int n_inner, int& group, int& inner) {
+  const int bid = blockIdx.x;
+  if ((n_groups & 7) == 0) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    group = (slot / n_inner) * 8 + xcd;
+    inner = slot % n_inner;
+  } else {
+    group = bid / n_inner;
+    inner = bid % n_inner;
+  }
+}
+
 // ------------------------------------------------------------------------ forward
 template <typename T, int HD>
 __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
@@ -232,10 +248,11 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int* uk = (int*)(Vs + 2 * C::TILE);         // [2][64]
   int* tk = uk + 128;                         // [2][64]
   int* mk = tk + 128;                         // [2][64]  tm[kv] ? ~0 : 0
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
-  const int kvh = h / (p.H / p.KV);
   const int nt = (p.T + 63) / 64;
+  int grp, inner;
+  attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
+  const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
   const float c2 = rsqrtf((float)HD) * LOG2E;        // scores are handled in log2 units
   const int q = qt * 64 + w * 16 + fr;               // this lane's query
@@ -344,7 +361,7 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3((p.T + 63) / 64, p.H, p.B), dim3(256), sm, s, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -455,9 +472,11 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 2 : 1) void 
   float* dls = lse2 + 128;                      // [2][64]
   int* uqs = (int*)(dls + 128);                 // [2][64]
   int* tqs = uqs + 128;                         // [2][64]
-  const int kvt = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
+  int grp, kvt;
+  attn_work(p.B * p.KV, nt, grp, kvt);
+  const int b = grp / p.KV, kvh = grp % p.KV;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
   const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
   const int kv = kvt * 64 + w * 16 + fr;       // this lane's key/value token
@@ -559,9 +578,11 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int* uk = (int*)(Vs + 2 * C::TILE);    // [2][64]
   int* tk = uk + 128;
   int* mk = tk + 128;                    // [2][64]  tm[kv] ? ~0 : 0
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nt = (p.T + 63) / 64;
+  int grp, inner;
+  attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
+  const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
-  const int kvh = h / (p.H / p.KV), nt = (p.T + 63) / 64;
   const long long tok0 = (long long)b * p.T;
   const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
   const int q = qt * 64 + w * 16 + fr;
@@ -641,9 +662,9 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
     set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3((p.T + 63) / 64, p.KV, p.B), dim3(256), sm_kv, s, p);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), sm_kv, s, p);
   HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3((p.T + 63) / 64, p.H, p.B), dim3(256), sm_q, s, p);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -377,6 +377,8 @@ int32_t rsys_op_timing(rsys_model* h, int32_t enable) {
   HIP_CHECK(hipSetDevice(m->device));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   m->timer.enabled = enable != 0;
+  m->timer.serialize = enable == 2;
+  HIP_CHECK(hipStreamSynchronize(m->side));
   m->timer.marks.clear(); m->timer.acc_ms.clear(); m->timer.used = 0;
   return RSYS_OK;
 }
@@ -387,6 +389,7 @@ int32_t rsys_timing_get(rsys_model* h, char* buf, size_t cap) {
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
   HIP_CHECK(hipStreamSynchronize(m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->side));
   PhaseTimer& t = m->timer;
   std::map<std::string, std::pair<double, long>> agg;
   std::vector<size_t> stack;

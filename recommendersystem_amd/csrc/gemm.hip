@@ -457,6 +457,31 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   return RSYS_OK;
 }
 
+// which kernel a row-major bf16 problem goes to: 0 = 128x128 register-staged (this file), 2 = 256x256 LDS-DMA (gemm8p.hip),
+// 3 = 256x128 two-per-CU (gemm4w.hip).  RSYS_GEMM_KERNEL=1 / 2 / 3 forces one of them where it is eligible (tests, A/B timing).
+static int pick_rowmajor_kernel(const GemmParams& p) {
+  const char* e = getenv("RSYS_GEMM_KERNEL");
+  const int hint = e ? atoi(e) : 0;
+  if (hint == 1) return 0;
+  const bool e8 = gemm8p_eligible(p), e4 = gemm4w_eligible(p);
+  if (hint == 2) return e8 ? 2 : 0;
+  if (hint == 3) return e4 ? 3 : 0;
+  const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (e8 && t256 >= 128) return 2;   // at least half the CUs get a 256x256 tile
+  return 0;
+}
+
+const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km) {
+  GemmParams p = p0;
+  if (p.splitk < 1) p.splitk = 1;
+  if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32) {
+    const int k = pick_rowmajor_kernel(p);
+    if (k == 2) return "8p";
+    if (k == 3) return "4w";
+  }
+  return a_km ? "tn" : (b_km ? "nn" : "nt");
+}
+
 template <typename CT>
 int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s) {
   GemmParams p = p0;
@@ -483,17 +508,10 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
   if constexpr (is_bf16<CT>::value) {
-    // row-major bf16 operands: the 256x256 LDS-DMA kernel (gemm8p.hip) once the problem fills the chip with its
-    // one-workgroup-per-CU tiles; RSYS_GEMM_KERNEL=1 / 2 forces the 128x128 / 256x256 kernel (tests, A/B timing)
-    if (!a_km && !b_km && !a_f32 && !b_f32 && gemm8p_eligible(p)) {
-      const char* e = getenv("RSYS_GEMM_KERNEL");
-      const int hint = e ? atoi(e) : 0;
-      const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-      if (hint == 2 || (hint == 0 && t256 >= 128)) return launch_gemm8p(p, s);
-    }
-    if (!a_km && !b_km && !a_f32 && !b_f32 && gemm4w_eligible(p)) {
-      const char* e = getenv("RSYS_GEMM_KERNEL");
-      if (e && atoi(e) == 3) return launch_gemm4w(p, s);
+    if (!a_km && !b_km && !a_f32 && !b_f32) {
+      const int k = pick_rowmajor_kernel(p);
+      if (k == 2) return launch_gemm8p(p, s);
+      if (k == 3) return launch_gemm4w(p, s);
     }
   }
   if (!a_km && !b_km) {

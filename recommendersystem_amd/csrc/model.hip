@@ -34,22 +34,22 @@ static int dalloc(Model* m, void** p, size_t bytes) {
 #define DALLOC(ptr, bytes) RC(dalloc(m, (void**)&(ptr), (size_t)(bytes)))
 
 // ------------------------------------------------------------------ timing
-static void tic(Model* m, const char* name, double flops = 0.0) {
+static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st = nullptr) {
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
   if (t.used + 2 > t.pool.size()) {
     for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); t.pool.push_back(e); }
   }
   hipEvent_t e = t.pool[t.used++];
-  hipEventRecord(e, m->stream);
+  hipEventRecord(e, st ? st : m->stream);
   t.marks.push_back({std::string(name), e});
   t.acc_ms[std::string("#flops:") + name] += flops;
 }
-static void toc(Model* m) {
+static void toc(Model* m, hipStream_t st = nullptr) {
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
   hipEvent_t e = t.pool[t.used++];
-  hipEventRecord(e, m->stream);
+  hipEventRecord(e, st ? st : m->stream);
   t.marks.push_back({std::string(""), e});
 }
 
@@ -460,25 +460,27 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
   { static const char* e = getenv("RSYS_DEBUG_STAGGER"); if (e) p.dbg = atoi(e); }   // timing experiment
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
-  tic(m, tag, 2.0 * p.M * p.N * (double)p.K);
+  if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K);
   int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);
   toc(m);
   return rc;
 }
 
 // Weight-gradient GEMM on the side stream, beside whatever the main stream launches until join_side(): the side
-// stream first waits for everything the main stream has enqueued so far (the GEMM's operands).  With per-kernel
-// timing on (model.timing) it runs in line instead, so that the phase breakdown stays meaningful.
+// stream first waits for everything the main stream has enqueued so far (the GEMM's operands).  rsys_op_timing(2)
+// (bench.py --detail) runs it in line instead, so that every kernel's time is measured without a neighbour.
 template <typename T>
 static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
   static const bool off = getenv("RSYS_NO_SIDE_STREAM") != nullptr;
-  if (m->timer.enabled || off) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
+  if ((m->timer.enabled && m->timer.serialize) || off) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
   HIP_CHECK(hipEventRecord(m->ev_fork, m->stream));
   HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+  if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K, m->side);   // (events on the stream the kernel runs on)
   RC(launch_gemm<T>(p, a_f32, false, a_km, b_km, m->side));
+  toc(m, m->side);
   HIP_CHECK(hipEventRecord(m->ev_join, m->side));
   m->side_pending = true;
   return RSYS_OK;

@@ -30,6 +30,7 @@ struct LayerOff {  // offsets into the flat buffers
 
 struct PhaseTimer {
   bool enabled = false;
+  bool serialize = false;   // run the side-stream GEMMs in line (clean per-kernel attribution)
   std::vector<std::pair<std::string, hipEvent_t>> marks;
   std::map<std::string, double> acc_ms;
   std::vector<hipEvent_t> pool;

@@ -279,8 +279,10 @@ class RecommenderModel:
         return [int(x) for x in out]
 
     # ---- instrumentation
-    def timing(self, enable):
-        check(lib().rsys_op_timing(self._h, 1 if enable else 0))
+    def timing(self, enable, serialize=False):
+        """HIP-event timing of every kernel call site.  serialize=True additionally runs the side-stream GEMMs in
+        line, so that each kernel is measured without a concurrent neighbour (bench.py --detail)."""
+        check(lib().rsys_op_timing(self._h, (2 if serialize else 1) if enable else 0))
 
     def timing_report(self):
         buf = C.create_string_buffer(1 << 16)
