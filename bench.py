@@ -143,31 +143,36 @@ def main():
     ra.synchronize()
     first_losses = model.losses(False)
     hg.barrier()
-    if not args.no_kernel_timing:
-        # per-kernel HIP events on the stream each kernel runs on; the weight-gradient GEMMs run in line on the main
-        # stream while they are timed (model.timing serialize), so every duration is that of the kernel alone and agrees
-        # with rocprofv3 --kernel-trace of this command.  --no-kernel-timing: production mode (wgrad side stream, ~1% faster).
+    # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first fifth of the timed steps: ~300 event
+    # records per step cost about 4 % of the step, and while kernels are timed the weight-gradient GEMMs run in line on
+    # the main stream (model.timing serialize) so that every duration is that of the kernel alone.  The remaining steps
+    # run in production mode (no events, wgrad GEMMs on the side stream).  --detail instruments every step.
+    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else max(1, args.steps // 5))
+    if n_instr:
         model.timing(True, serialize=True)
     ra.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    rep = {}
+    for i in range(args.steps):
         step()
+        if n_instr and i + 1 == n_instr:
+            rep = model.timing_report()
+            model.timing(False)
     ra.synchronize()
     hg.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = hg.all_reduce([elapsed], "max")[0]
-    rep = model.timing_report() if not args.no_kernel_timing else {}
     if rep:
         # the head GEMMs stop at the positive-weight rows (device-side limit): count the flops they really did
         npos = model.head_rows()
         D = cfg["embed_dim"]; V0 = cfg["vocab_sizes"]["0_matchedid"]; V1 = cfg["vocab_sizes"]["1_matchedid"]
         up = lambda n, q: (n + q - 1) // q * q
-        fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
-        fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * args.steps
+        fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
+        fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
+        fl_rows256 = sum(2.0 * up(npos[2 * m_], 256) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
-                rep[full]["flops"] = fl
-    model.timing(False)
+                rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith("@8p")) else fl   # 256-row tiles
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses
 
@@ -197,7 +202,7 @@ def main():
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                         "traffic": traffic_of(traffic_db, dom), "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],
-                        "share_of_step": round(a["ms"] / (ms * args.steps), 3)}
+                        "share_of_step": round(a["ms"] / n_instr / ms, 3), "instrumented_steps": n_instr}
         out = {
             "metric": "interactions/sec", "value": round(value, 1), "unit": "interactions/sec",
             "user_seqs_per_sec": round(value / S, 2),
@@ -214,13 +219,13 @@ def main():
             "losses": [round(float(x), 4) for x in losses],
         }
         if rep:
-            phases = {k: round(v["ms"] / args.steps, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
+            phases = {k: round(v["ms"] / n_instr, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
             out["ms_per_step_by_phase"] = phases
-            out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
+            out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
         if args.detail:
             for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
-                print(f"  {k:22s} {v['ms'] / args.steps:8.3f} ms/step  {v['count'] // args.steps:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
+                print(f"  {k:22s} {v['ms'] / n_instr:8.3f} ms/step  {v['count'] // n_instr:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, 1)
         print(json.dumps(out))
