@@ -471,6 +471,18 @@ static int pick_rowmajor_kernel(const GemmParams& p) {
   return 0;
 }
 
+// K-major bf16 operands with the atomic epilogue (weight gradients): the LDS-DMA pipeline unless RSYS_GEMM_KERNEL_TN=1
+static bool use_8p_tn(const GemmParams& p) {
+  const char* e = getenv("RSYS_GEMM_KERNEL_TN");
+  if (e && atoi(e) == 1) return false;
+  if (!gemm8p_tn_eligible(p)) return false;
+  const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  // measured (tools/bench_gemm_tn.py and in the step): the two transposed reads per fragment make this pipeline ~35 %
+  // slower per FLOP than its row-major form, so it wins only where the 128x128 kernel needs many K splits per output
+  // tile AND the output is large: the metadata-projection gradient (50 tiles); the per-layer gradients (4..22 tiles) stay
+  return (e && atoi(e) == 2) || t256 >= 32;
+}
+
 const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km) {
   GemmParams p = p0;
   if (p.splitk < 1) p.splitk = 1;
@@ -479,6 +491,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
     if (k == 2) return "8p";
     if (k == 3) return "4w";
   }
+  if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
   return a_km ? "tn" : (b_km ? "nn" : "nt");
 }
 
@@ -513,6 +526,7 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
       if (k == 2) return launch_gemm8p(p, s);
       if (k == 3) return launch_gemm4w(p, s);
     }
+    if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return launch_gemm8p_tn(p, s);
   }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);

@@ -58,6 +58,10 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
     asm volatile("" ::: "memory");          \
   } while (0)
 
+// KM = false: row-major operands (A [M][K], B [N][K]).  KM = true: K-major operands (A [K][M], B [K][N]: the weight
+// gradients dW = dY^T X with K = tokens), split-K with fp32 atomics; the LDS image of a half-tile is then [64 k][256 B]
+// and the fragments are read with ds_read_b64_tr_b16 (two per fragment).
+template <bool KM>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l = t & 63;
@@ -69,16 +73,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // of tiles (tn fastest), which share A rows / B rows through its private L2
   const int tiles_n = (p.N + T8_BN - 1) / T8_BN, tiles_m = (p.M + T8_BM - 1) / T8_BM;
   const int ntiles = tiles_m * tiles_n;
-  int tile;
-  {
+  int tile, kt0 = 0, nt;
+  if constexpr (!KM) {
     const int bid = blockIdx.x;
     const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+    nt = p.K / T8_BK;                                  // launcher: K % 64 == 0, nt >= 2
+  } else {
+    // split-K (launcher: splitk % 8 == 0): XCD x owns the K splits x, x+8, ...; inside an XCD the tiles of one split
+    // vary fastest, so the K-major operand rows of a split are fetched from HBM by one L2 only
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    tile = local % ntiles;
+    const int split = xcd + 8 * (local / ntiles);
+    const int ktiles = (p.K + T8_BK - 1) / T8_BK, per = (ktiles + p.splitk - 1) / p.splitk;
+    kt0 = split * per;
+    nt = min(ktiles, kt0 + per) - kt0;
+    if (nt <= 0) return;
   }
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * T8_BM, n0 = tn * T8_BN;
   if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
-  const int nt = p.K / T8_BK;                          // launcher: K % 64 == 0, nt >= 2
   if (p.dbg > 0) {
     // EXPERIMENT: de-synchronise the CUs (odd CUs start half a tile late) so that one half's output bursts overlap the
     // other half's MFMA phases
@@ -93,28 +107,60 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   unsigned int aoff[2][2], boff[2][2];   // [j][h]
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int lr = (w * 2 + j) * 8 + (l >> 3);
-    const int c = (l & 7) ^ ((lr >> 1) & 7);
+    if constexpr (!KM) {
+      const int lr = (w * 2 + j) * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int grow = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);   // clamped rows are never stored
-      const int gcol = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), p.N - 1);
-      aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * 8) * 2);
-      boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * 8) * 2);
+      for (int h = 0; h < 2; ++h) {
+        const int grow = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);   // clamped rows are never stored
+        const int gcol = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), p.N - 1);
+        aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * 8) * 2);
+        boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * 8) * 2);
+      }
+    } else {
+      // K-major: piece (w*2+j) = k rows (w*2+j)*4 + [0,4) of the half-tile, 256 B = eight 16-column blocks per row;
+      // lane l -> row + (l>>4), 16-byte chunk l&15.  Block mb of row k is stored at block mb ^ f(k),
+      // f(k) = ((k>>3)&1)<<2 | (k&3): the eight rows one half-wave of a transposed read touches land on distinct banks.
+      const int krow = (w * 2 + j) * 4 + (l >> 4), ch = l & 15;
+      const int f = (((krow >> 3) & 1) << 2) | (krow & 3);
+      const int mb = (ch >> 1) ^ f, half = ch & 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ma = min(m0 + (mb >> 2) * 128 + h * 64 + (mb & 3) * 16 + half * 8, p.M - 8);   // (clamped columns are never added)
+        const int nb = min(n0 + (mb >> 1) * 64 + h * 32 + (mb & 1) * 16 + half * 8, p.N - 8);
+        aoff[j][h] = (unsigned int)(((long long)krow * p.lda + ma) * 2);
+        boff[j][h] = (unsigned int)(((long long)krow * p.ldb + nb) * 2);
+      }
     }
   }
-  const char* Ab = (const char*)p.A;
-  const char* Bb = (const char*)p.B;
+  // Running operand windows (wave-uniform, SGPRs): a_cur / b_cur = base of K tile kt, a_rem / b_rem = bytes from there
+  // to the end of the operand (K-major only: rows past K read as zeros, so the K tail of the last split needs no guard).
+  // The K loop advances them with two scalar adds per operand instead of rebuilding 64-bit products per DMA.
+  const long long stepA = KM ? (long long)T8_BK * p.lda * 2 : (long long)T8_BK * 2;
+  const long long stepB = KM ? (long long)T8_BK * p.ldb * 2 : (long long)T8_BK * 2;
+  const char* a_cur = (const char*)p.A + (long long)kt0 * stepA;
+  const char* b_cur = (const char*)p.B + (long long)kt0 * stepB;
+  long long a_rem = KM ? (long long)p.K * p.lda * 2 - (long long)kt0 * stepA : 0;
+  long long b_rem = KM ? (long long)p.K * p.ldb * 2 - (long long)kt0 * stepB : 0;
+  auto window = [&](const char* cur, long long rem, long long step, int d) __attribute__((always_inline)) -> i32x4 {
+    i32x4 r = make_rsrc(cur + d * step);
+    if constexpr (KM) {
+      const long long left = rem - d * step;
+      r[2] = __builtin_amdgcn_readfirstlane((int)(unsigned int)(left <= 0 ? 0 : (left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left)));
+    }
+    return r;
+  };
   unsigned char* const dma_base = smem + w * 2048;   // + buf*65536 + X*32768 + h*16384 + j*1024
-  auto stage_a = [&](int bo, auto H, int kt) {
+  // stage_x(bo, h, d): half-tile h of K tile (current + d) into the buffer at byte offset bo
+  auto stage_a = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
-    const i32x4 rs = make_rsrc(Ab + (long long)kt * (T8_BK * 2));
+    const i32x4 rs = window(a_cur, a_rem, stepA, d);
     dma16(rs, aoff[0][h], dma_base + bo + h * 16384);
     dma16(rs, aoff[1][h], dma_base + bo + h * 16384 + 1024);
   };
-  auto stage_b = [&](int bo, auto H, int kt) {
+  auto stage_b = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
-    const i32x4 rs = make_rsrc(Bb + (long long)kt * (T8_BK * 2));
+    const i32x4 rs = window(b_cur, b_rem, stepB, d);
     dma16(rs, boff[0][h], dma_base + bo + 32768 + h * 16384);
     dma16(rs, boff[1][h], dma_base + bo + 32768 + h * 16384 + 1024);
   };
@@ -125,6 +171,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
   const int a_rd0 = (wr * 64 + fr) * 128 + sw0, a_rd1 = (wr * 64 + fr) * 128 + sw1;
   const int b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0, b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
+  // K-major: lane (fq, fr) supplies the address of row k = 32 kk + 8 fq + (fr>>2) (+4 for the second read), columns
+  // 4 (fr&3) .. +3 of block mb; the 16-lane group receives the block's 4 x 16 piece transposed (column fr on lane fr)
+  int a_rdk[4], b_rdk[2];
+  {
+    const int q = fr >> 2, pp = fr & 3, fK = ((fq & 1) << 2) | q, rowb = (8 * fq + q) * 256 + pp * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_rdk[i] = rowb + (((wr * 4 + i) ^ fK) << 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_rdk[j] = 32768 + rowb + (((wc * 2 + j) ^ fK) << 5);
+  }
+  auto tr_frag = [&](int off) __attribute__((always_inline)) -> bf16x8 {
+    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(smem + off));
+    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(smem + off + 1024));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -136,15 +197,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   auto read_a = [&](int bo, int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      af[i][0] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd0);
-      af[i][1] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd1);
+      if constexpr (!KM) {
+        af[i][0] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd0);
+        af[i][1] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd1);
+      } else {
+        af[i][0] = tr_frag(bo + h * 16384 + a_rdk[i]);
+        af[i][1] = tr_frag(bo + h * 16384 + 8192 + a_rdk[i]);
+      }
     }
   };
   auto read_b = [&](bf16x8(&bf)[2][2], int bo, int h) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bf[j][0] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd0);
-      bf[j][1] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd1);
+      if constexpr (!KM) {
+        bf[j][0] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd0);
+        bf[j][1] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd1);
+      } else {
+        bf[j][0] = tr_frag(bo + h * 16384 + b_rdk[j]);
+        bf[j][1] = tr_frag(bo + h * 16384 + 8192 + b_rdk[j]);
+      }
     }
   };
   auto mma_q = [&](auto IH, auto JH, const bf16x8(&bf)[2][2]) {
@@ -167,29 +238,30 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     // P1
     read_b(bf0, bo, 0);
     read_a(bo, 0);
-    if (kt + 1 < nt) stage_b(bn, I1{}, kt + 1);
+    if (kt + 1 < nt) stage_b(bn, I1{}, 1);
     T8_BARRIER();
     mma_q(I0{}, I0{}, bf0);
     T8_BARRIER();
     // P2
     read_b(bf1, bo, 1);
-    if (kt + 1 < nt) { stage_a(bn, I1{}, kt + 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    if (kt + 1 < nt) { stage_a(bn, I1{}, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     T8_BARRIER();
     mma_q(I0{}, I1{}, bf1);
     T8_BARRIER();
     // P3
     read_a(bo, 1);
-    if (kt + 2 < nt) stage_b(bo, I0{}, kt + 2);
+    if (kt + 2 < nt) stage_b(bo, I0{}, 2);
     T8_BARRIER();
     mma_q(I1{}, I1{}, bf1);
     T8_BARRIER();
     // P4
-    if (kt + 2 < nt) { stage_a(bo, I0{}, kt + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    if (kt + 2 < nt) { stage_a(bo, I0{}, 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     T8_BARRIER();
     mma_q(I1{}, I0{}, bf0);
     T8_BARRIER();
+    a_cur += stepA; b_cur += stepB; a_rem -= stepA; b_rem -= stepB;
   };
 
   // ---- prologue: tile 0 complete, B0/A0 of tile 1
@@ -205,7 +277,40 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 
   // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; return; }   // timing experiment: no epilogue
-  epilogue_regs(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
+  if constexpr (!KM) {
+    epilogue_regs(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
+  } else {
+    // split-K partial sums: fp32 atomics.  An atomic wave instruction runs at full rate only when its 64 lanes add 256
+    // contiguous bytes, so each wave passes its 128x64 block through a private LDS patch, 32 rows at a time
+    // ([32][68] f32; the operand tiles are dead: every wave is past the last barrier and no DMA is in flight).
+    constexpr int CS_LD = 68;
+    float* const Cs = (float*)(smem + w * (32 * CS_LD * 4));
+    float* const C = (float*)p.C;
+    const int wm0 = m0 + wr * 128, wn0 = n0 + wc * 64;
+    const int col = wn0 + l;
+    auto stage_acc = [&](auto Q) __attribute__((always_inline)) {
+      constexpr int q = decltype(Q)::value;
+      static_for<2>([&](auto ii) { static_for<4>([&](auto j) {
+        *(f32x4*)&Cs[(ii * 16 + fr) * CS_LD + j * 16 + 4 * fq] = acc[q * 2 + ii][j];   // lane: 4 consecutive columns of one row
+      }); });
+    };
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      switch (q) {
+        case 0: stage_acc(std::integral_constant<int, 0>{}); break;
+        case 1: stage_acc(std::integral_constant<int, 1>{}); break;
+        case 2: stage_acc(std::integral_constant<int, 2>{}); break;
+        default: stage_acc(std::integral_constant<int, 3>{}); break;
+      }
+      if (col < p.N) {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+          const int row = wm0 + q * 32 + r;
+          if (row < p.M) atomicAdd(C + (long long)row * p.ldc + col, p.alpha * Cs[r * CS_LD + l]);
+        }
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -226,9 +331,39 @@ bool gemm8p_eligible(const GemmParams& p) {
   return true;
 }
 
+// K-major operands + split-K atomics (weight gradients)
+bool gemm8p_tn_eligible(const GemmParams& p) {
+  if (p.epi != EPI_ATOMIC || !p.c_f32 || p.k_dev != nullptr || p.m_dev != nullptr) return false;
+  if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8 || p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
+  if ((unsigned long long)64 * p.lda * 2 + (unsigned long long)p.M * 2 >= (1ull << 31)) return false;
+  if ((unsigned long long)64 * p.ldb * 2 + (unsigned long long)p.N * 2 >= (1ull << 31)) return false;
+  return true;
+}
+
+int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  const int ktiles = (p.K + T8_BK - 1) / T8_BK;
+  // K splits (a multiple of 8: one split never straddles XCDs): fill whole rounds of the 256 CUs while keeping the
+  // K range of a workgroup long against its fixed cost (first tiles from HBM + 256 KB of atomics ~ 8 K tiles)
+  int best = 8; double best_score = -1.0;
+  for (int sk = 8; sk <= 256; sk += 8) {
+    const int per = (ktiles + sk - 1) / sk;
+    if (per < 2 && sk > 8) break;
+    const long long wgs = (long long)tiles * sk;
+    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    const double score = eff * per / (per + 8.0);
+    if (score > best_score) { best_score = score; best = sk; }
+  }
+  p.splitk = best;
+  hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 int launch_gemm8p(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
-  hipLaunchKernelGGL(gemm8p_kernel, dim3(tiles), dim3(512), 0, s, p);
+  hipLaunchKernelGGL(gemm8p_kernel<false>, dim3(tiles), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -140,6 +140,9 @@ __device__ __forceinline__ void epi_item(const GemmParams& p, long long row, int
 // gemm8p_eligible: the problem satisfies that kernel's layout / size preconditions.
 bool gemm8p_eligible(const GemmParams& p);
 int launch_gemm8p(const GemmParams& p, hipStream_t s);
+// the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
+bool gemm8p_tn_eligible(const GemmParams& p);
+int launch_gemm8p_tn(const GemmParams& p, hipStream_t s);
 // row-major bf16 operands, 256x128 tiles, two workgroups per CU (gemm4w.hip)
 bool gemm4w_eligible(const GemmParams& p);
 int launch_gemm4w(const GemmParams& p, hipStream_t s);

@@ -316,5 +316,6 @@ def test_forward_backward_with_256_tile_gemm(monkeypatch, kern):
     (gemm8p.hip; by default it takes over only at >= 128 tiles): fused RoPE / SwiGLU / residual / GELU epilogues,
     ragged M and N, the minimum K depth of its pipeline."""
     monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)
+    monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "2")   # weight gradients on the K-major LDS-DMA kernel too
     name, over, rows, seed = CASES[1]
     test_forward_backward_vs_oracle(name, over, rows, seed, "bf16", 4e-2, 6e-2, 1.5e-1)

@@ -124,6 +124,21 @@ def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1408, 8192), (1024, 512, 4160), (520, 264, 1000), (64, 72, 640)])
+def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K):
+    """K-major operands (weight-gradient shape, K = tokens) on the LDS-DMA pipeline with ds_read_b64_tr_b16 fragments
+    and split-K fp32 atomics (gemm8p_kernel<true>), forced: exact on asymmetric integer data, ragged M / N / K (the K tail
+    is zero-filled by the buffer descriptor), and agreement with the 128x128 kernel on random data."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "2")
+    out, ref = run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, integer=True, seed=M + N + K)
+    np.testing.assert_array_equal(out, ref.astype(np.float32))
+    out_r, ref_r = run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, seed=11)
+    monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "1")
+    out_1, _ = run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, seed=11)
+    assert np.abs(out_r - ref_r).max() / np.abs(ref_r).max() < 1e-5
+    assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
+
+
 def test_gemm_bf16_output():
     out, ref = run_gemm(1, 128, 256, 128, False, False, c_f32=False, seed=3)
     err = np.abs(out - ref).max() / np.abs(ref).max()
