@@ -275,15 +275,41 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   CHECK_HANDLE(h); CHECK_HANDLE(c);
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
-  int rc = model_finalize_grads(m);
-  if (rc) return rc;
-  if (c->world == 1 && !c->force) return RSYS_OK;
-  HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
-  HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
   const int64_t bucket = 16 * 1024 * 1024;  // floats
-  for (int64_t o = 0; o < m->n_opt; o += bucket) {
-    int64_t n = std::min(bucket, m->n_opt - o);
-    NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+  auto reduce_range = [&](int64_t lo, int64_t hi) -> int {
+    for (int64_t o = lo; o < hi; o += bucket) {
+      const int64_t n = std::min(bucket, hi - o);
+      NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+    }
+    return RSYS_OK;
+  };
+  if (c->world == 1 && !c->force) return model_finalize_grads(m);
+  if (model_finalize_splittable(m)) {
+    // The last piece of the backward -- the metadata-projection gradient dWp = dF^T Meta, a ~2 ms GEMM on a bf16 copy
+    // of dF -- runs on the model's stream while the communication stream already reduces everything else (80 % of the
+    // bytes are dF itself, final since the token scatter); dWp follows when the GEMM is done.
+    int64_t wo = 0, wn = 0;
+    int rc = model_finalize_stage(m, 1, &wo, &wn);
+    if (rc) return rc;
+    HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    rc = reduce_range(0, std::min(wo, m->n_opt));
+    if (rc) return rc;
+    rc = reduce_range(std::min(wo + wn, m->n_opt), m->n_opt);
+    if (rc) return rc;
+    rc = model_finalize_stage(m, 2, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    rc = reduce_range(wo, std::min(wo + wn, m->n_opt));
+    if (rc) return rc;
+  } else {
+    int rc = model_finalize_grads(m);
+    if (rc) return rc;
+    HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    rc = reduce_range(0, m->n_opt);
+    if (rc) return rc;
   }
   HIP_CHECK(hipEventRecord(c->ev_done, c->stream));
   HIP_CHECK(hipStreamWaitEvent(m->stream, c->ev_done, 0));

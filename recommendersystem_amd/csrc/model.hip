@@ -382,6 +382,8 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   float* base = (which == 0 ? m->P : m->G) + t.off;
   const int64_t int_rows = (t.map == MAP_DIRECT) ? t.rows : 2 * m->Ip;
   std::vector<float> host((size_t)int_rows * t.ld);
+  HIP_CHECK(hipStreamSynchronize(m->stream));   // (the model's streams are non-blocking: a plain hipMemcpy does not wait for them)
+  HIP_CHECK(hipStreamSynchronize(m->side));
   HIP_CHECK(hipMemcpy(host.data(), base, host.size() * 4, hipMemcpyDeviceToHost));
   if (out) {
     for (int64_t r = 0; r < t.rows; ++r) memcpy(out + r * t.cols, host.data() + internal_row(t, r) * t.ld, t.cols * 4);
@@ -864,22 +866,24 @@ static int backward_trunk(Model* m) {
   return RSYS_OK;
 }
 
-// dWp = dF^T Meta and dbp = colsum(dF), once per optimizer step from the accumulated dF (= grad of E)
+// dWp = dF^T Meta and dbp = colsum(dF), once per optimizer step from the accumulated dF (= grad of E).
+// stage 1: operand copy of dF + bias gradient (afterwards nothing reads G[E] any more: in bf16 mode the GEMM works on the
+// copy, so the gradient all-reduce of the item table can run beside it); stage 2: the GEMM; stage 0: both.
 template <typename T>
-static int finalize_grads_t(Model* m) {
-  tic(m, "phase_table_bwd");
-  const void* gEt = m->G + m->o_E;
-  if (m->bf16_mode) {  // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it)
-    RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
-    gEt = m->FT;
+static int finalize_grads_t(Model* m, int stage) {
+  tic(m, stage == 2 ? "phase_table_bwd_gemm" : "phase_table_bwd");
+  if (stage != 2) {
+    if (m->bf16_mode)   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it)
+      RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
+    RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
   }
-  {
+  if (stage != 1) {
     GemmParams p{};
-    p.A = gEt; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
+    p.A = m->bf16_mode ? (const void*)m->FT : (const void*)(m->G + m->o_E);
+    p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
     p.M = m->D; p.N = m->Mp; p.K = m->V + 1; p.epi = EPI_ATOMIC;
     RC(gemm<T>(m, "gemm_table_dw", p, false, true, true));
   }
-  RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
   toc(m);
   return RSYS_OK;
 }
@@ -887,7 +891,16 @@ static int finalize_grads_t(Model* m) {
 int model_finalize_grads(Model* m) {
   if (!m->table_grads_pending || m->cfg.finetune) return RSYS_OK;
   m->table_grads_pending = false;
-  return m->bf16_mode ? finalize_grads_t<bf16>(m) : finalize_grads_t<float>(m);
+  return m->bf16_mode ? finalize_grads_t<bf16>(m, 0) : finalize_grads_t<float>(m, 0);
+}
+
+// the two halves separately (gradient all-reduce overlap, capi.hip); only when model_finalize_splittable
+bool model_finalize_splittable(const Model* m) { return m->table_grads_pending && !m->cfg.finetune && m->bf16_mode; }
+int model_finalize_stage(Model* m, int stage, int64_t* wp_off, int64_t* wp_n) {
+  if (wp_off) *wp_off = m->o_Wp;
+  if (wp_n) *wp_n = (int64_t)m->D * m->Mp;
+  if (stage == 2) m->table_grads_pending = false;
+  return finalize_grads_t<bf16>(m, stage);
 }
 
 template <typename T>

@@ -246,6 +246,35 @@ def test_rccl_communicator_world1(monkeypatch):
     model.close()
 
 
+def test_rccl_overlapped_table_gradient(monkeypatch):
+    """bf16 mode: rsys_allreduce_grads reduces the item-table gradient on the communication stream while the
+    metadata-projection gradient GEMM (the last piece of the backward) still runs, then reduces that gradient.  With RCCL
+    forced at world 1 every gradient must equal the one of the plain (un-overlapped) finalisation."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    monkeypatch.setenv("RSYS_FORCE_RCCL", "1")
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, 5)
+    names = ("item_embedding.projection_layer.weight", "item_embedding.projection_layer.bias",
+             "item_embedding.matchedid_embedding.embedding.weight", "transformers.layers.1.attn.q_proj.weight", "transformers.norm.scale")
+    grads = []
+    for overlapped in (False, True):
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        model(d, False, masks=(wm, rm))
+        if overlapped:
+            comm = rdist.Comm(rdist.HostGroup(0, 1), 0)
+            comm.all_reduce_grads(model)
+            comm.close()
+        grads.append({n: model.grad(n) for n in names})
+        model.close()
+    for n in names:
+        assert relerr(grads[1][n], grads[0][n]) < 1e-5, n
+
+
 @pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-4, 1e-3), ("bf16", 4e-2, 0.2)])
 def test_finetune_lora_golden(dtype, tol_loss, tol_grad):
     """LoRA finetune (model.py:235-271,361-371,418-435): frozen base, rank-8 updates on q and v,
