@@ -172,6 +172,17 @@ def run_case(ns, name, cfg, rows, seed, full):
         norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)))
         opt.step()
         step_losses.append([float(x) for x in losses])
+        if full and step == 1:
+            # checkpoint after two steps in the reference's own format (transformer.py:456-466): the third step above is
+            # then the known answer for "convert, resume, step" (tests: checkpoint interchange)
+            fns = load_reference_train_fns(["WSDScheduler"], {"np": np})
+            sched_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+            sched = torch.optim.lr_scheduler.LambdaLR(sched_opt, fns["WSDScheduler"](4, 40, 0.1, 0.1))
+            sched_opt.step(); sched.step(); sched_opt.step(); sched.step()
+            ckpt = {"model": {k: v.detach().clone() for k, v in model.state_dict().items()},
+                    "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "config": dict(cfg), "epoch": 1,
+                    "training_loss": [float(x) for x in losses], "test_loss": [float(x) for x in losses]}
+            torch.save(ckpt, os.path.join(OUT, f"checkpoint_{name}.pt"))
     out["opt/lr"] = np.array([lr])
     out["opt/losses"] = np.array(step_losses, np.float64)
     out["opt/norms"] = np.array(norms, np.float64)

@@ -348,3 +348,35 @@ def test_forward_backward_with_256_tile_gemm(monkeypatch, kern):
     monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "2")   # weight gradients on the K-major LDS-DMA kernel too
     name, over, rows, seed = CASES[1]
     test_forward_backward_vs_oracle(name, over, rows, seed, "bf16", 4e-2, 6e-2, 1.5e-1)
+
+
+def test_resume_from_reference_checkpoint(tmp_path):
+    """the reference's own checkpoint (torch pickle written after two steps by its model / AdamW,
+    tests/golden/checkpoint_tiny.pt) -> `recommendersystem_amd.checkpoint.from_reference` -> resume -> the third step must
+    land on the parameters the reference reached (model_tiny.npz opt/param)."""
+    torch = pytest.importorskip("torch")
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import checkpoint as ck
+    from recommendersystem_amd.optim import AdamW
+    from recommendersystem_amd.train import load_checkpoint, train_step_unfused
+    name, over, rows, seed = CASES[0]
+    cfg, P, d = _setup(name, over, rows, seed)
+    z = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    u = z["meta/u"]; r = np.float32(cfg["mask_rate"])
+    wm = u < r; rm = (u >= r) & (u < 2 * r)
+    ref = torch.load(os.path.join(GOLDEN, "checkpoint_tiny.pt"), weights_only=False, map_location="cpu")
+    path = str(tmp_path / "resume.npz")
+    np.savez(path, **ck.from_reference(ref))
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+    model.init_weights(1)                                   # whatever: everything trainable comes from the checkpoint
+    model.load_pretrained_embeddings(P["item_embedding.metadata_embedding.embedding.weight"][:-1])
+    opt = AdamW(model, lr=float(z["opt/lr"][0]))
+    epoch, config = load_checkpoint(path, model, opt)
+    assert epoch == 1 and config["embed_dim"] == cfg["embed_dim"]
+    losses, norm = train_step_unfused(model, opt, d, list(z["meta/task_w"]), masks=(wm, rm))
+    assert relerr(losses, z["opt/losses"][2]) < 3e-4, (losses, z["opt/losses"][2])
+    assert abs(norm - z["opt/norms"][2]) < 3e-4 * z["opt/norms"][2]
+    for n in synth.trainable_names(cfg):
+        assert relerr(model.get_parameter(n), z["opt/param/" + n]) < 3e-4, n
+    model.close()
