@@ -55,6 +55,42 @@ class PretrainDataset:
                 yield {k: v[i:i + self.batch_size] for k, v in d.items()}
 
 
+class FinetuneDataset:
+    """FinetuneDataset (train.py:101-160): every shard file holds one user per row (arrays of shape (N, S)); only rows
+    whose target weights for the finetuned medium (watch or rating) are positive are used.  Training (`shuffle`): a
+    quarter of those rows per pass (partition p of 4, advancing every pass), shuffled, padded to whole batches with
+    random repeats; evaluation: all rows in order, the last batch may be short."""
+
+    def __init__(self, datadir, local_rank, local_world_size, batch_size, shuffle, finetune_medium, seed=0):
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.medium = finetune_medium
+        shards = sorted(glob.glob(f"{datadir}/*/"))
+        self.fns = []
+        for x in shard_for_rank(shards, local_rank, local_world_size):
+            self.fns.extend(sorted(glob.glob(f"{x}/*.npz")))
+        checkpoints_per_epoch = 4
+        self.partition = [0, checkpoints_per_epoch]
+        self.rng = np.random.default_rng(seed)
+
+    def __iter__(self):
+        for fn in self.fns:
+            with np.load(fn) as f:
+                d = {k: f[k] for k in f.files}
+            N = d["userid"].shape[0]
+            idxs = [i for i in range(N)
+                    if any(d[f"{self.medium}.{metric}.weight"][i, :].sum() > 0 for metric in ["watch", "rating"])]
+            if self.shuffle:
+                idxs = [x for (i, x) in enumerate(idxs) if i % self.partition[1] == self.partition[0]]
+                self.rng.shuffle(idxs)
+                while len(idxs) % self.batch_size != 0:
+                    idxs.append(int(self.rng.choice(idxs)))
+            for i in range(0, len(idxs), self.batch_size):
+                idx = idxs[i:i + self.batch_size]
+                yield {k: v[idx, :] for k, v in d.items()}
+        self.partition[0] = (self.partition[0] + 1) % self.partition[1]
+
+
 def write_shards(datadir, streams, num_shards):
     """Writes one `.npz` per (shard, part) and num_tokens.txt (transformer.jl:228-239)."""
     total = 0

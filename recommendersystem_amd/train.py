@@ -251,3 +251,42 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None):
     if scheduler is not None and "scheduler/last_epoch" in z.files:
         scheduler.load_state_dict({"last_epoch": int(z["scheduler/last_epoch"][0])})
     return int(z["epoch"][0]), json.loads(bytes(z["config"]).decode())
+
+
+def get_run_config(finetune):
+    """train.py:591-604: epochs / global batch / local batch / gradient accumulation of the two modes."""
+    if finetune:
+        num_epochs, global_batch, local_batch = 16, 32, 16
+    else:
+        num_epochs, global_batch, local_batch = 64, 512, 64
+    assert global_batch % local_batch == 0
+    return {"num_epochs": num_epochs, "global_batch_size": global_batch, "local_batch_size": local_batch}
+
+
+def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weights, num_epochs, grad_accum_steps,
+          comm=None, rank=0, starting_epoch=0, basename="transformer.masked", log=print):
+    """The epoch loop of train() (train.py:697-757): initial evaluation (CSV row of epoch start-1), then per epoch
+    train_epoch -> evaluate_metrics -> early stopper -> checkpoint when the stopper says the model improved; stops early
+    when the stopper runs out of patience.  Returns the list of (epoch, training_loss, test_loss)."""
+    stopper = make_early_stopper(config)
+    get_loss = lambda: evaluate_metrics(model, dataloaders["test"], comm)
+    initial_loss = get_loss()
+    log(f"Initial Loss: {wsum(initial_loss, task_weights)}, {initial_loss}")
+    stopper(wsum(initial_loss, task_weights))
+    if rank == 0:
+        checkpoint_model(datadir, model, optimizer, scheduler, config, starting_epoch - 1, initial_loss, initial_loss,
+                         task_weights, bool(config.get("finetune")), basename)
+    history = []
+    for epoch in range(starting_epoch, num_epochs):
+        training_loss = train_epoch(model, dataloaders["training"], optimizer, scheduler, task_weights, grad_accum_steps, comm)
+        log(f"Epoch: {epoch}, Training Loss: {wsum(training_loss, task_weights)} {training_loss}, LR factor: {scheduler.factor()}")
+        test_loss = get_loss()
+        log(f"Epoch: {epoch}, Test Loss: {wsum(test_loss, task_weights)} {test_loss}")
+        stopper(wsum(test_loss, task_weights))
+        if rank == 0:
+            checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, training_loss, test_loss, task_weights,
+                             stopper.save_model, basename)
+        history.append((epoch, training_loss, test_loss))
+        if stopper.early_stop:
+            break
+    return history
