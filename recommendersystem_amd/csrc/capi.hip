@@ -358,7 +358,6 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.c_f32 = c_f32; p.splitk = splitk < 1 ? 1 : splitk; p.alpha = 1.f;
   p.epi = p.splitk > 1 ? EPI_ATOMIC : EPI_STORE;
-  if (getenv("RSYS_DEBUG_STAGGER")) p.dbg = atoi(getenv("RSYS_DEBUG_STAGGER"));
   if (getenv("RSYS_DEBUG_EPI")) p.epi = atoi(getenv("RSYS_DEBUG_EPI"));   // timing experiments only (e.g. 99 = no epilogue)
   int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, a_f32 != 0, false, a_km != 0, b_km != 0, nullptr)
                                     : launch_gemm<float>(p, false, false, a_km != 0, b_km != 0, nullptr);

@@ -43,7 +43,6 @@ struct GemmParams {
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
   // EPI_TABLE
   const float* E;
-  int dbg;          // timing experiments only (0 in production)
 };
 
 // CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).

@@ -93,15 +93,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * T8_BM, n0 = tn * T8_BN;
   if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
-  if (p.dbg > 0) {
-    // EXPERIMENT: de-synchronise the CUs (odd CUs start half a tile late) so that one half's output bursts overlap the
-    // other half's MFMA phases
-    const unsigned int cu = __builtin_amdgcn_s_getreg(6660);   // HW_ID.cu_id
-    if (blockIdx.x < 256 && (cu & 1)) {
-      for (int k = 0; k < p.dbg; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-  }
-
   // ---- DMA source offsets (bytes from the operand base, k tile 0).  Instruction j of wave w fills the 1 KB piece
   // (w*2+j) of a half-tile = local rows (w*2+j)*8 + [0,8); lane l -> local row + (l>>3), stored slot l&7.
   unsigned int aoff[2][2], boff[2][2];   // [j][h]

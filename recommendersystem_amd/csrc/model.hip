@@ -459,7 +459,6 @@ static int pick_splitk(int M, int N, int K, int bk) {
 template <typename T>
 static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
   if (p.alpha == 0.f) p.alpha = 1.f;
-  { static const char* e = getenv("RSYS_DEBUG_STAGGER"); if (e) p.dbg = atoi(e); }   // timing experiment
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
   if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K);

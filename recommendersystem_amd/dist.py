@@ -131,6 +131,16 @@ def make_comm(host_group, device):
     if host_group.world == 1:
         return None
     comm, err = None, ""
+    # pre-flight on every rank (RCCL loadable, id can be made) BEFORE any collective RCCL call: a rank that cannot load
+    # the library must not leave the others waiting inside ncclCommInitRank
+    try:
+        scratch = (C.c_uint8 * 128)()
+        check(lib().rsys_comm_unique_id(C.byref(scratch)))
+        loadable = 1.0
+    except Exception as e:   # noqa: BLE001
+        loadable, err = 0.0, str(e)
+    if -host_group.all_reduce([-loadable], "max")[0] < 1.0:
+        return HostComm(host_group, err or "RCCL not loadable on another rank")
     try:
         comm = Comm(host_group, device)
         comm.self_test()
