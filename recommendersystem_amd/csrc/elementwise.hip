@@ -130,34 +130,65 @@ int launch_gather_items(const BatchDev& b, const float* F32, int V, int D, float
 }
 
 // --------------------------------------------------------------------- RMSNorm (K6), transformer.model.py:193-202
-template <typename T>
-__global__ void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
-                                   long long rows, int D) {
+// One wave per row, 4 consecutive columns per lane and 256-column group; the number of groups NJ is a template
+// parameter (EXACT: D == 256 NJ, no column guards), so a row lives in NJ float4 registers, is read once, and the
+// outputs leave as 16-byte (f32) / 8-byte (bf16) vector stores.  HBM-bound: 6 B per element forward, 14 B backward.
+constexpr int NORM_MAXJ = 8;  // D <= 64 lanes * 4 * 8 = 2048
+
+template <typename T> __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d) { *(float4*)dst = make_float4(a, b, c, d); }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* dst, float a, float b, float c, float d) {
+  bf16x4 v; v[0] = (bf16)a; v[1] = (bf16)b; v[2] = (bf16)c; v[3] = (bf16)d;
+  *(bf16x4*)dst = v;
+}
+template <typename T> __device__ __forceinline__ float4 load4(const T* src);
+template <> __device__ __forceinline__ float4 load4<float>(const float* src) { return *(const float4*)src; }
+template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* src) {
+  const bf16x4 v = *(const bf16x4*)src;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+template <typename T, int NJ, bool EXACT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
+                                                          long long rows, int D) {
   const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int l = threadIdx.x & 63;
   if (row >= rows) return;
-  const float4* xr = (const float4*)(x + row * D);
+  float4 v[NJ];
   float ss = 0.f;
-  for (int c = l; c < (D >> 2); c += 64) {
-    float4 v = xr[c];
-    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + l) * 4;
+    v[j] = (EXACT || c < D) ? *(const float4*)(x + row * D + c) : make_float4(0, 0, 0, 0);
+    ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
   }
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + 1e-5f);
   if (l == 0 && rstd) rstd[row] = r;
-  for (int c = l; c < (D >> 2); c += 64) {
-    float4 v = xr[c];
-    float4 sc = ((const float4*)scale)[c];
-    T* o = y + row * D + 4 * c;
-    o[0] = from_f32<T>(v.x * r * sc.x); o[1] = from_f32<T>(v.y * r * sc.y);
-    o[2] = from_f32<T>(v.z * r * sc.z); o[3] = from_f32<T>(v.w * r * sc.w);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + l) * 4;
+    if (EXACT || c < D) {
+      const float4 sc = *(const float4*)(scale + c);
+      store4<T>(y + row * D + c, v[j].x * r * sc.x, v[j].y * r * sc.y, v[j].z * r * sc.z, v[j].w * r * sc.w);
+    }
   }
 }
 
 template <typename T>
 int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s) {
-  ARG_CHECK(D % 4 == 0, "rmsnorm: D % 4");
-  hipLaunchKernelGGL((rmsnorm_fwd_kernel<T>), dim3(div_up(rows, 4)), dim3(256), 0, s, x, scale, y, rstd, rows, D);
+  ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
+  const dim3 grid(div_up(rows, 4)), block(256);
+#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D)
+  if (D == 256) RSYS_NORM_FWD(1, true);
+  else if (D == 512) RSYS_NORM_FWD(2, true);
+  else if (D == 1024) RSYS_NORM_FWD(4, true);
+  else if (D == 2048) RSYS_NORM_FWD(8, true);
+  else if (D < 256) RSYS_NORM_FWD(1, false);
+  else if (D < 512) RSYS_NORM_FWD(2, false);
+  else if (D < 1024) RSYS_NORM_FWD(4, false);
+  else RSYS_NORM_FWD(8, false);
+#undef RSYS_NORM_FWD
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -165,9 +196,7 @@ template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*,
 template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t);
 
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
-constexpr int NORM_MAXJ = 8;  // D <= 64 lanes * 4 * 8 = 2048
-
-template <typename TG, typename TO>
+template <typename TG, typename TO, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
@@ -175,56 +204,50 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
-  float4 acc[NORM_MAXJ];
+  float4 acc[NJ], sc[NJ];
 #pragma unroll
-  for (int j = 0; j < NORM_MAXJ; ++j) acc[j] = make_float4(0, 0, 0, 0);
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + l) * 4;
+    acc[j] = make_float4(0, 0, 0, 0);
+    sc[j] = (EXACT || c < D) ? *(const float4*)(scale + c) : make_float4(0, 0, 0, 0);
+  }
   for (int c = threadIdx.x; c < D; c += 256) sds[c] = 0.f;
   __syncthreads();
-  const int nj = D >> 8;  // full groups of 256 columns; tail handled by guard
   for (long long row = wave0; row < rows; row += nwaves) {
     const float r = rstd[row];
-    float4 gv[NORM_MAXJ], xv[NORM_MAXJ];
+    float4 gv[NJ], xv[NJ], rv[NJ];
     float dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < NORM_MAXJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int c = (j * 64 + l) * 4;
-      if (c < D) {
-        const TG* gp = g + row * D + c;
-        float4 sc = *(const float4*)(scale + c);
-        gv[j] = make_float4(to_f32(gp[0]) * sc.x, to_f32(gp[1]) * sc.y, to_f32(gp[2]) * sc.z, to_f32(gp[3]) * sc.w);
-        xv[j] = *(const float4*)(x + row * D + c);
-        dot += gv[j].x * xv[j].x + gv[j].y * xv[j].y + gv[j].z * xv[j].z + gv[j].w * xv[j].w;
-        // dscale uses the un-scaled g: g*x*r = (g*s)*x*r/s is avoided by recomputing from gp
-        acc[j].x += to_f32(gp[0]) * xv[j].x * r; acc[j].y += to_f32(gp[1]) * xv[j].y * r;
-        acc[j].z += to_f32(gp[2]) * xv[j].z * r; acc[j].w += to_f32(gp[3]) * xv[j].w * r;
-      }
+      const bool ok = EXACT || c < D;
+      const float4 g4 = ok ? load4<TG>(g + row * D + c) : make_float4(0, 0, 0, 0);
+      xv[j] = ok ? *(const float4*)(x + row * D + c) : make_float4(0, 0, 0, 0);
+      rv[j] = (ok && resid) ? *(const float4*)(resid + row * D + c) : make_float4(0, 0, 0, 0);
+      gv[j] = make_float4(g4.x * sc[j].x, g4.y * sc[j].y, g4.z * sc[j].z, g4.w * sc[j].w);
+      dot += gv[j].x * xv[j].x + gv[j].y * xv[j].y + gv[j].z * xv[j].z + gv[j].w * xv[j].w;
+      // dscale uses the un-scaled g
+      acc[j].x += g4.x * xv[j].x * r; acc[j].y += g4.y * xv[j].y * r;
+      acc[j].z += g4.z * xv[j].z * r; acc[j].w += g4.w * xv[j].w * r;
     }
     dot = wave_sum(dot);
     const float k = r * r * r * dot / (float)D;
 #pragma unroll
-    for (int j = 0; j < NORM_MAXJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int c = (j * 64 + l) * 4;
-      if (c < D) {
+      if (EXACT || c < D) {
         float4 o;
-        o.x = r * gv[j].x - xv[j].x * k; o.y = r * gv[j].y - xv[j].y * k;
-        o.z = r * gv[j].z - xv[j].z * k; o.w = r * gv[j].w - xv[j].w * k;
-        if (resid) {
-          float4 rv = *(const float4*)(resid + row * D + c);
-          o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-        }
+        o.x = r * gv[j].x - xv[j].x * k + rv[j].x; o.y = r * gv[j].y - xv[j].y * k + rv[j].y;
+        o.z = r * gv[j].z - xv[j].z * k + rv[j].z; o.w = r * gv[j].w - xv[j].w * k + rv[j].w;
         *(float4*)(dx_out + row * D + c) = o;
-        if (dx_out_t) {   // operand copy for the next GEMMs (bf16 mode): saves them the f32 read + conversion
-          TO* ot = dx_out_t + row * D + c;
-          ot[0] = from_f32<TO>(o.x); ot[1] = from_f32<TO>(o.y); ot[2] = from_f32<TO>(o.z); ot[3] = from_f32<TO>(o.w);
-        }
+        if (dx_out_t) store4<TO>(dx_out_t + row * D + c, o.x, o.y, o.z, o.w);   // operand copy for the next GEMMs (bf16 mode)
       }
     }
   }
-  (void)nj;
 #pragma unroll
-  for (int j = 0; j < NORM_MAXJ; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + l) * 4;
-    if (c < D) {
+    if (EXACT || c < D) {
       atomicAdd(&sds[c], acc[j].x); atomicAdd(&sds[c + 1], acc[j].y);
       atomicAdd(&sds[c + 2], acc[j].z); atomicAdd(&sds[c + 3], acc[j].w);
     }
@@ -237,9 +260,18 @@ template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
                            float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
-  int grid = (int)std::min<long long>((rows + 3) / 4, 1024);
-  hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO>), dim3(grid), dim3(256), D * sizeof(float), s, g, x, scale, rstd, resid,
-                     dx_out, dx_out_t, dscale, rows, D);
+  const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
+#define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, D * sizeof(float), s, g, x, scale, \
+                                                 rstd, resid, dx_out, dx_out_t, dscale, rows, D)
+  if (D == 256) RSYS_NORM_BWD(1, true);
+  else if (D == 512) RSYS_NORM_BWD(2, true);
+  else if (D == 1024) RSYS_NORM_BWD(4, true);
+  else if (D == 2048) RSYS_NORM_BWD(8, true);
+  else if (D < 256) RSYS_NORM_BWD(1, false);
+  else if (D < 512) RSYS_NORM_BWD(2, false);
+  else if (D < 1024) RSYS_NORM_BWD(4, false);
+  else RSYS_NORM_BWD(8, false);
+#undef RSYS_NORM_BWD
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
