@@ -582,6 +582,33 @@ int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, fl
 template int launch_colsum_add_t<bf16>(const bf16*, long long, long long, int, float*, hipStream_t);
 template int launch_colsum_add_t<float>(const float*, long long, long long, int, float*, hipStream_t);
 
+// dst (bf16) = src (f32) and colsum[c] += sum_r src[r][c] in ONE pass over src: the operand copy of dF and the
+// projection-bias gradient of the table backward (model.hip finalize) both stream the same 410 MB.
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long rows, int D,
+                                                          float* colsum, int rows_per_block) {
+  const int cg = D >> 2;                         // 4-column groups per row (launcher: D % 4 == 0, cg <= 256, 256 % cg == 0)
+  const int c = (threadIdx.x % cg) * 4, lane_r = threadIdx.x / cg, nr = 256 / cg;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (long long r = r0 + lane_r; r < r1; r += nr) {
+    const float4 v = *(const float4*)(src + r * D + c);
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *(bf16x4*)(dst + r * D + c) = o;
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (acc.x != 0.f) atomicAdd(&colsum[c], acc.x);
+  if (acc.y != 0.f) atomicAdd(&colsum[c + 1], acc.y);
+  if (acc.z != 0.f) atomicAdd(&colsum[c + 2], acc.z);
+  if (acc.w != 0.f) atomicAdd(&colsum[c + 3], acc.w);
+}
+int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s) {
+  ARG_CHECK(D % 4 == 0 && (D >> 2) <= 256 && 256 % (D >> 2) == 0, "cast_colsum: D/4 must divide 256");
+  const int rpb = (int)std::max<long long>(64, (rows + 1023) / 1024);
+  hipLaunchKernelGGL(cast_colsum_kernel, dim3(div_up(rows, rpb)), dim3(256), 0, s, src, dst, rows, D, colsum, rpb);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 // --------------------------------------------------------------------- embedding scatter-add (K16)
 // gE[id'] += gx0[2n]; one wave per interaction, 256 contiguous bytes per atomic wave-instruction
 // (MI355X_MICROARCH.md "Global float atomics": full rate for this shape).

@@ -81,6 +81,8 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
                        int evaluate, float* loss_out /*[3]*/, float* dw2, float* db2, float* db0, hipStream_t s);
 
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
+// dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 256)
+int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s);
 template <typename T>
 int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
 

@@ -872,9 +872,13 @@ template <typename T>
 static int finalize_grads_t(Model* m, int stage) {
   tic(m, stage == 2 ? "phase_table_bwd_gemm" : "phase_table_bwd");
   if (stage != 2) {
-    if (m->bf16_mode)   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it)
-      RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
-    RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+    const bool fused = m->bf16_mode && (m->D >> 2) <= 256 && 256 % (m->D >> 2) == 0;
+    if (fused) {   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it) + bias gradient, one pass
+      RC(launch_cast_colsum(m->G + m->o_E, (bf16*)m->FT, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+    } else {
+      if (m->bf16_mode) RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
+      RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+    }
   }
   if (stage != 1) {
     GemmParams p{};
