@@ -23,22 +23,26 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-le
 HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
-KERNEL_SYMBOL = {
-    "8p": "rsys::(anonymous namespace)::gemm8p_kernel(rsys::GemmParams)",        # 256x256 LDS-DMA, row-major operands (gemm8p.hip)
-    "4w": "rsys::(anonymous namespace)::gemm4w_kernel(rsys::GemmParams)",        # 256x128, two workgroups per CU (gemm4w.hip)
-    "nt": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb0ELb0EEEvNS_10GemmParamsE",  # 128x128 register-staged (gemm.hip)
-    "nn": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb0ELb1ELb0EEEvNS_10GemmParamsE",
-    "tn": "_ZN4rsys11gemm_kernelIDF16bLb0ELb0ELb1ELb1ELb0EEEvNS_10GemmParamsE",
+KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
+    "8p": "gemm8p_kernel<false>",                         # 256x256 LDS-DMA, row-major operands (gemm8p.hip)
+    "8t": "gemm8p_kernel<true>",                          # the same pipeline, K-major operands + split-K atomics
+    "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
+    "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0ELb0EEE",      # 128x128 register-staged (gemm.hip)
+    "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1ELb0EEE",
+    "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1ELb0EEE",
 }
-KERNEL_LABEL = {"8p": "gemm8p_kernel (256x256 LDS-DMA, row-major bf16)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+KERNEL_LABEL = {"8p": "gemm8p_kernel<false> (256x256 LDS-DMA, row-major bf16)", "8t": "gemm8p_kernel<true> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r1d_pmc_traffic.json"
+TRAFFIC_FILE = "r1e_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
     """HBM bytes per launch of the kernel from the committed PMC summary (profiles/<TRAFFIC_FILE>)."""
-    k = db.get(KERNEL_SYMBOL.get(variant, ""))
-    return None if k is None else round(k["hbm_bytes_per_launch"])
+    sym = KERNEL_SYMBOL.get(variant)
+    for name, k in db.items():
+        if sym and sym in name:
+            return round(k["hbm_bytes_per_launch"])
+    return None
 
 
 def flops_per_interaction(cfg, B):
@@ -144,9 +148,7 @@ def main():
     first_losses = model.losses(False)
     hg.barrier()
     # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first fifth of the timed steps: ~300 event
-    # records per step cost about 4 % of the step, and while kernels are timed the weight-gradient GEMMs run in line on
-    # the main stream (model.timing serialize) so that every duration is that of the kernel alone.  The remaining steps
-    # run in production mode (no events, wgrad GEMMs on the side stream).  --detail instruments every step.
+    # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
     n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else max(1, args.steps // 5))
     if n_instr:
         model.timing(True, serialize=True)

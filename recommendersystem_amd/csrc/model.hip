@@ -467,13 +467,13 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
   return rc;
 }
 
-// Weight-gradient GEMM on the side stream, beside whatever the main stream launches until join_side(): the side
-// stream first waits for everything the main stream has enqueued so far (the GEMM's operands).  rsys_op_timing(2)
+// Weight-gradient GEMM, optionally (RSYS_SIDE_STREAM=1) on the side stream beside whatever the main stream launches
+// until join_side(): the side stream first waits for everything the main stream has enqueued so far (the operands).  rsys_op_timing(2)
 // (bench.py --detail) runs it in line instead, so that every kernel's time is measured without a neighbour.
 template <typename T>
 static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
-  static const bool off = getenv("RSYS_NO_SIDE_STREAM") != nullptr;
-  if ((m->timer.enabled && m->timer.serialize) || off) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
+  static const bool on = getenv("RSYS_SIDE_STREAM") != nullptr;   // opt-in: measured +1 % on the step, but it makes per-kernel durations depend on a neighbour
+  if (!on || (m->timer.enabled && m->timer.serialize)) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
