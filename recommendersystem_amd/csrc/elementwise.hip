@@ -349,7 +349,10 @@ template int launch_dropout<float>(const float*, float*, long long, float, unsig
 // Deterministic replacement of torch.topk on 0/1 weights: positive-weight positions in
 // ascending flat index, then zero-weight positions ascending.  One
 // 1024-thread workgroup per task; two-level exclusive scan.
-__global__ __launch_bounds__(1024) void select_positions_kernel(const float* __restrict__ w, int N, int topk, int* idx, float* stats, int* npos_out) {
+struct SelectBatch { const float* w[4]; int* idx[4]; float* stats[4]; int* npos[4]; };
+__global__ __launch_bounds__(1024) void select_positions_kernel(SelectBatch sb, int N, int topk) {
+  const float* __restrict__ w = sb.w[blockIdx.x];
+  int* idx = sb.idx[blockIdx.x]; float* stats = sb.stats[blockIdx.x]; int* npos_out = sb.npos[blockIdx.x];
   __shared__ int wave_tot[16];
   __shared__ float red[16];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -378,8 +381,15 @@ __global__ __launch_bounds__(1024) void select_positions_kernel(const float* __r
   if (t == 0) { stats[0] = wsel; stats[1] = wall; if (npos_out) *npos_out = min(npos, topk); }
 }
 int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats, int* npos_out, hipStream_t s) {
-  ARG_CHECK(topk <= N, "select_positions: topk > N");
-  hipLaunchKernelGGL(select_positions_kernel, dim3(1), dim3(1024), 0, s, w, N, topk, idx, stats, npos_out);
+  const float* ws[1] = {w}; int* is[1] = {idx}; float* st[1] = {stats}; int* np[1] = {npos_out};
+  return launch_select_positions_batch(1, ws, N, topk, is, st, np, s);
+}
+int launch_select_positions_batch(int ntask, const float* const* w, int N, int topk, int* const* idx, float* const* stats,
+                                  int* const* npos_out, hipStream_t s) {
+  ARG_CHECK(topk <= N && ntask >= 1 && ntask <= 4, "select_positions: topk > N or more than 4 tasks");
+  SelectBatch sb{};
+  for (int i = 0; i < ntask; ++i) { sb.w[i] = w[i]; sb.idx[i] = idx[i]; sb.stats[i] = stats[i]; sb.npos[i] = npos_out[i]; }
+  hipLaunchKernelGGL(select_positions_kernel, dim3(ntask), dim3(1024), 0, s, sb, N, topk);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -584,27 +594,51 @@ template int launch_colsum_add_t<float>(const float*, long long, long long, int,
 
 // dst (bf16) = src (f32) and colsum[c] += sum_r src[r][c] in ONE pass over src: the operand copy of dF and the
 // projection-bias gradient of the table backward (model.hip finalize) both stream the same 410 MB.
-__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long rows, int D,
-                                                          float* colsum, int rows_per_block) {
-  const int cg = D >> 2;                         // 4-column groups per row (launcher: D % 4 == 0, cg <= 256, 256 % cg == 0)
-  const int c = (threadIdx.x % cg) * 4, lane_r = threadIdx.x / cg, nr = 256 / cg;
+__global__ __launch_bounds__(1024) void cast_colsum_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long rows, int D,
+                                                           float* colsum, int rows_per_block) {
+  __shared__ float red[2048];                    // [row lane][D] partial sums (launcher: 1024 / (D/4) row lanes, D <= 1024... see launcher)
+  const int cg = D >> 2;                         // 4-column groups per row (launcher: D % 4 == 0, 1024 % cg == 0)
+  const int c = (threadIdx.x % cg) * 4, lane_r = threadIdx.x / cg, nr = 1024 / cg;
   const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float4 acc = make_float4(0, 0, 0, 0);
-  for (long long r = r0 + lane_r; r < r1; r += nr) {
+  long long r = r0 + lane_r;
+  for (; r + 3 * nr < r1; r += 4 * nr) {   // four independent rows in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(src + (r + u * nr) * D + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bf16x4 o; o[0] = (bf16)v[u].x; o[1] = (bf16)v[u].y; o[2] = (bf16)v[u].z; o[3] = (bf16)v[u].w;
+      *(bf16x4*)(dst + (r + u * nr) * D + c) = o;
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+    }
+  }
+  for (; r < r1; r += nr) {
     const float4 v = *(const float4*)(src + r * D + c);
     bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
     *(bf16x4*)(dst + r * D + c) = o;
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  if (acc.x != 0.f) atomicAdd(&colsum[c], acc.x);
-  if (acc.y != 0.f) atomicAdd(&colsum[c + 1], acc.y);
-  if (acc.z != 0.f) atomicAdd(&colsum[c + 2], acc.z);
-  if (acc.w != 0.f) atomicAdd(&colsum[c + 3], acc.w);
+  // row lanes -> one partial sum per column and workgroup (few hundred atomics per address in total)
+  if (lane_r < 2) *(float4*)&red[lane_r * D + c] = acc;
+  __syncthreads();
+  for (int base = 2; base < nr; base += 2) {
+    if (lane_r >= base && lane_r < base + 2) {
+      float4 o = *(float4*)&red[(lane_r - base) * D + c];
+      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+      *(float4*)&red[(lane_r - base) * D + c] = o;
+    }
+    __syncthreads();
+  }
+  for (int cc = threadIdx.x; cc < D; cc += 1024) {
+    const float v = red[cc] + (nr > 1 ? red[D + cc] : 0.f);
+    if (v != 0.f) atomicAdd(&colsum[cc], v);
+  }
 }
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s) {
-  ARG_CHECK(D % 4 == 0 && (D >> 2) <= 256 && 256 % (D >> 2) == 0, "cast_colsum: D/4 must divide 256");
-  const int rpb = (int)std::max<long long>(64, (rows + 1023) / 1024);
-  hipLaunchKernelGGL(cast_colsum_kernel, dim3(div_up(rows, rpb)), dim3(256), 0, s, src, dst, rows, D, colsum, rpb);
+  ARG_CHECK(D % 4 == 0 && D <= 1024 && 1024 % (D >> 2) == 0, "cast_colsum: D/4 must divide 1024, D <= 1024");
+  const int rpb = (int)std::max<long long>(32, (rows + 511) / 512);
+  hipLaunchKernelGGL(cast_colsum_kernel, dim3(div_up(rows, rpb)), dim3(1024), 0, s, src, dst, rows, D, colsum, rpb);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -62,6 +62,9 @@ int launch_dropout(const T* src, T* dst, long long n, float p, unsigned long lon
 
 int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats /*[2]: wsum_sel, wsum_all*/,
                             int* npos_out /*number of positive-weight rows selected (they come first)*/, hipStream_t s);
+// up to four independent selections (the four (medium, metric) tasks) in one launch, one workgroup each
+int launch_select_positions_batch(int ntask, const float* const* w, int N, int topk, int* const* idx, float* const* stats,
+                                  int* const* npos_out, hipStream_t s);
 
 template <typename T>
 int launch_gather_rows(const T* src, long long ld, const int* idx, int parity, T* dst, int n, int D, hipStream_t s);
@@ -81,7 +84,7 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
                        int evaluate, float* loss_out /*[3]*/, float* dw2, float* db2, float* db0, hipStream_t s);
 
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
-// dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 256)
+// dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 1024)
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s);
 template <typename T>
 int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);

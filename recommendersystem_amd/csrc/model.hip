@@ -634,11 +634,15 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   tic(m, "phase_heads");
   HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
   if (train) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
+  {   // position selection of the four (medium, metric) tasks in one launch
+    const float* ws[4]; int* is[4]; float* sts[4]; int* nps[4];
+    for (int ti = 0; ti < 4; ++ti) { ws[ti] = m->bd.m_weight[ti]; is[ti] = m->idx[ti]; sts[ti] = m->stats + 2 * ti; nps[ti] = m->npos + ti; }
+    RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
+  }
   for (int ti = 0; ti < 4; ++ti) {
     const int medium = ti >> 1, metric = ti & 1;
     float* st = m->stats + 2 * ti;
     int* np = m->npos + ti;   // positive-weight rows come first: the head GEMMs and the CE kernel stop there
-    RC(launch_select_positions(m->bd.m_weight[ti], N, KB, m->idx[ti], st, np, s));
     RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
     const bool bwd = train && tw[ti] != 0.f;
     if (metric == 0) {
@@ -872,7 +876,7 @@ template <typename T>
 static int finalize_grads_t(Model* m, int stage) {
   tic(m, stage == 2 ? "phase_table_bwd_gemm" : "phase_table_bwd");
   if (stage != 2) {
-    const bool fused = m->bf16_mode && (m->D >> 2) <= 256 && 256 % (m->D >> 2) == 0;
+    const bool fused = m->bf16_mode && m->D <= 1024 && 1024 % (m->D >> 2) == 0;
     if (fused) {   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it) + bias gradient, one pass
       RC(launch_cast_colsum(m->G + m->o_E, (bf16*)m->FT, m->V + 1, m->D, m->G + m->o_bp, m->stream));
     } else {
