@@ -119,13 +119,14 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
           pre.f[j] = make_float4(c2.x, c2.y, s2.x, s2.y);
         }
       } else if constexpr (ec == EPI_SWIGLU_BWD) {
-        // saved a, b of dg column c live at (c>>4)*32 + (c&15) (+16) of the [a|b] rows: f[j] = {a (4 bf16), b (4 bf16)}
+        // saved a, b of dg column c live at (c>>4)*32 + (c&15) (+16) of the [a|b] rows: f[j] = {a (4 bf16), b (4 bf16)}.
+        // Loaded the way store_pair writes -- 16 bytes per lane, 64-byte row segments -- and brought back to "4 columns of
+        // a, 4 of b" with the same two swaps (the transformation is an involution); half the load instructions of 8-byte loads.
         const unsigned int ro = rowoff(i, p.ldc2, 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int oc = colclamp(((wn0 >> 4) + j) * 32 + 4 * fq, 2 * p.N);
-          const float2 a2 = ldf2(p.C2, ro + (unsigned int)oc * 2u), b2 = ldf2(p.C2, ro + (unsigned int)oc * 2u + 32u);
-          pre.f[j] = make_float4(a2.x, a2.y, b2.x, b2.y);
+          const int oc = colclamp(((wn0 >> 4) + j) * 32 + ((fq & 1) << 4) + ((fq >> 1) << 3), 2 * p.N);
+          pre.f[j] = *(const float4*)((const char*)p.C2 + ro + (unsigned int)oc * 2u);   // raw; un-swapped where it is consumed
         }
       }
     };
@@ -173,7 +174,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float av[4], bv[4], da[4], db[4];
-          unpack4(pre.f[j].x, pre.f[j].y, av); unpack4(pre.f[j].z, pre.f[j].w, bv);
+          auto r0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned int, pre.f[j].x), __builtin_bit_cast(unsigned int, pre.f[j].z), false, false);
+          auto r1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned int, pre.f[j].y), __builtin_bit_cast(unsigned int, pre.f[j].w), false, false);
+          unpack4(__builtin_bit_cast(float, (unsigned int)r0[0]), __builtin_bit_cast(float, (unsigned int)r1[0]), av);
+          unpack4(__builtin_bit_cast(float, (unsigned int)r0[1]), __builtin_bit_cast(float, (unsigned int)r1[1]), bv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-av[r]));
