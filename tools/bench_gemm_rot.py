@@ -22,8 +22,9 @@ def run(M, N, K, c_f32=False, nbuf=6, reps=12):
     for p in As + Cs + [B]: lib.rsys_dev_free(p)
 
 NT = 65536
-for (M, N, K, cf) in [(NT, 1024, 512, False), (NT, 2816, 512, False), (NT, 512, 512, True)]:
+if __name__ == "__main__":
+  for (M, N, K, cf) in [(NT, 1024, 512, False), (NT, 2816, 512, False), (NT, 512, 512, True)]:
     for nbuf in (1, 6):
-        for k in ("1", "2", "3"):
-            os.environ["RSYS_GEMM_KERNEL"] = k
-            run(M, N, K, cf, nbuf)
+      for k in ("1", "2", "3"):
+        os.environ["RSYS_GEMM_KERNEL"] = k
+        run(M, N, K, cf, nbuf)
