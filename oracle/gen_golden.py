@@ -312,6 +312,63 @@ def run_host_fns():
     print("host fns ok", out["task_w/pretrain"])
 
 
+def run_serving_case():
+    """Request -> batch -> response steps of the reference's embedding server (notebooks/Finetune/embed.py:27-161): its own
+    `predict` runs on synthetic users with a recording stand-in for the model; the fixture holds the batch it built and what
+    it extracted from a known `embs` tensor."""
+    import contextlib
+    with open("/root/reference/notebooks/Finetune/embed.py") as f:
+        tree = ast.parse(f.read())
+    ns = {"np": np, "torch": torch, "time": __import__("time"), "device": "cpu", "gpu_lock": contextlib.nullcontext()}
+    ns["logger"] = types.SimpleNamespace(debug=lambda *a, **k: None)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("make_item", "tokenize", "project", "predict"):
+            exec(compile(ast.Module([node], []), "embed.py", "exec"), ns)
+    rng = np.random.default_rng(77)
+    num_items_0 = 500
+
+    def make_user(n_events, n_rank, gender):
+        items, ts, hs, hr = [], 1.0e9, {}, {}
+        mid = None
+        for _ in range(n_events):
+            if mid is None or rng.random() > 0.35:
+                mid = (int(rng.integers(0, 2)), int(rng.integers(1, 400)))
+            ts += float(rng.integers(1, 100000))
+            st = int(rng.integers(0, 9)); rt = float(rng.integers(0, 11)) if rng.random() > 0.4 else 0.0
+            if rng.random() < 0.25 and mid in hs:
+                st, rt = hs[mid], hr[mid]                       # an event that changes nothing (dropped by project)
+            items.append({"medium": mid[0], "matchedid": mid[1], "history_max_ts": ts, "status": st, "rating": rt,
+                          "progress": float(rng.random()), "history_status": hs.get(mid, -1), "history_rating": hr.get(mid, 0.0)})
+            hs[mid], hr[mid] = st, rt
+        return {"user": {"gender": gender, "source": int(rng.integers(0, 4))}, "items": items, "timestamp": ts + 5.0,
+                "ranking_items": [int(x) for x in rng.integers(1, 400, n_rank)]}
+
+    users = [make_user(40, 5, None), make_user(3, 17, 1), make_user(2600, 9, 0)]   # the last one overflows 1023 history tokens
+    out = {}
+    import json
+    out["users_json"] = np.frombuffer(json.dumps(users).encode(), np.uint8)
+    for task, medium in (("retrieval", 1), ("ranking", 0)):
+        rec = {}
+
+        class Stub:
+            module = types.SimpleNamespace(config={"vocab_sizes": {"0_matchedid": num_items_0}})
+
+            def __call__(self, d, t):
+                rec["d"] = {k: v.numpy().copy() for k, v in d.items()}
+                n, L = d["userid"].shape
+                width = 3 if t == "retrieval" else 1
+                return (torch.arange(n * 2 * L * width, dtype=torch.float32) * 0.5).reshape(n, 2 * L, width)
+
+        ns["models"] = {f"{medium}.{task}": Stub()}
+        ret = ns["predict"](users, task, medium)
+        for k, v in rec["d"].items():
+            out[f"{task}/in/{k}"] = v
+        out[f"{task}/ret_json"] = np.frombuffer(json.dumps(ret).encode(), np.uint8)
+    out["num_items_0"] = np.array([num_items_0])
+    np.savez_compressed(os.path.join(OUT, "serving.npz"), **out)
+    print("serving fixture ok", {k: v.shape for k, v in out.items() if k.endswith("userid")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -323,6 +380,7 @@ def main():
     run_inference_case(ns, "tiny", tiny, seed=31)
     run_finetune_case(ns, "tiny", tiny, seed=41)
     run_host_fns()
+    run_serving_case()
 
 
 if __name__ == "__main__":

@@ -380,3 +380,45 @@ def test_resume_from_reference_checkpoint(tmp_path):
     for n in synth.trainable_names(cfg):
         assert relerr(model.get_parameter(n), z["opt/param/" + n]) < 3e-4, n
     model.close()
+
+
+def test_serving_predict_end_to_end():
+    """Request -> response through `serve.predict` (embed.py:74-161) on the HIP inference forward: retrieval returns the
+    trunk output at the query item token, ranking the rating head at each candidate's action token; compared with the
+    oracle on the batch the same host code built.  Also: a candidate's score must not depend on the other candidates."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    from recommendersystem_amd import serve
+    cfg = synth.make_config("tiny", mask_rate=0.25, mask_topk=6)
+    cfg["forward"] = "inference"
+    S = cfg["max_sequence_length"]
+    P = synth.make_params(cfg, 31, "test")
+    rng = np.random.default_rng(9)
+
+    def user(n_events, cands):
+        items, ts = [], 1.2e9
+        for _ in range(n_events):
+            ts += float(rng.integers(10, 10 ** 6))
+            items.append({"medium": int(rng.integers(0, 2)), "matchedid": int(rng.integers(1, 25)), "history_max_ts": ts,
+                          "status": int(rng.integers(0, 9)), "rating": float(rng.integers(0, 11)), "progress": float(rng.random()),
+                          "history_status": -1, "history_rating": -1.0})
+        return {"user": {"gender": None, "source": 2}, "items": items, "timestamp": ts + 60.0, "ranking_items": cands}
+
+    users = [user(5, [3, 7, 11]), user(S, [4, 9])]            # the second history overflows and is truncated
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=2)
+    model.load_state_dict(P)
+    ref = model_np.OracleModel(cfg, P, np.float64)
+    for task, medium in (("retrieval", 1), ("ranking", 0)):
+        got = serve.predict(model, users, task, medium)
+        mul, mri = (S, 0) if task == "retrieval" else (S // 2, S - S // 2)
+        d = serve.build_batch(users, task, medium, cfg["vocab_sizes"]["0_matchedid"], mul, mri)
+        exp = serve.extract(ref.inference({k: np.asarray(v) for k, v in d.items()}, task), users, task, medium, mul)
+        for g, e in zip(got, exp):
+            k = f"{medium}.{task}"
+            assert relerr(np.array(g[k]), np.array(e[k])) < 1e-4, (task, g[k], e[k])
+    # ranking: candidates are isolated from each other by their token_mask_ids
+    a = serve.predict(model, [users[0]], "ranking", 0)[0]["0.ranking"]
+    solo = dict(users[0]); solo["ranking_items"] = [users[0]["ranking_items"][1]]
+    b = serve.predict(model, [solo], "ranking", 0)[0]["0.ranking"]
+    assert abs(a[1] - b[0]) < 1e-4 * max(1.0, abs(a[1]))
+    model.close()
