@@ -27,9 +27,9 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8p": "gemm8p_kernel<false>",                         # 256x256 LDS-DMA, row-major operands (gemm8p.hip)
     "8t": "gemm8p_kernel<true>",                          # the same pipeline, K-major operands + split-K atomics
     "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
-    "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0ELb0EEE",      # 128x128 register-staged (gemm.hip)
-    "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1ELb0EEE",
-    "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1ELb0EEE",
+    "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
+    "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
+    "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false> (256x256 LDS-DMA, row-major bf16)", "8t": "gemm8p_kernel<true> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}

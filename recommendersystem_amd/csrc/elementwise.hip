@@ -290,31 +290,6 @@ int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, c
 template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t);
 template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t);
 
-// --------------------------------------------------------------------- SwiGLU backward (K10), model.py:205-213
-// ab is stored interleaved in 16-column blocks [a0..a15 | b0..b15 | a16.. ] (the W1/W3 rows are interleaved the same way)
-template <typename T>
-__global__ void swiglu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ ab, T* dab, long long total, int I) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; e < total; e += (long long)gridDim.x * blockDim.x) {
-    long long row = e / I; int i = (int)(e % I);
-    long long base = row * (2LL * I) + (i >> 4) * 32 + (i & 15);
-    float a = to_f32(ab[base]), b = to_f32(ab[base + 16]), d = to_f32(dg[e]);
-    float sg = 1.f / (1.f + __expf(-a));
-    dab[base] = from_f32<T>(d * b * sg * (1.f + a * (1.f - sg)));
-    dab[base + 16] = from_f32<T>(d * a * sg);
-  }
-}
-template <typename T>
-int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s) {
-  long long total = rows * I;
-  int grid = (int)std::min<long long>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL((swiglu_bwd_kernel<T>), dim3(grid), dim3(256), 0, s, dg, ab, dab, total, I);
-  HIP_CHECK(hipGetLastError());
-  return RSYS_OK;
-}
-template int launch_swiglu_bwd<bf16>(const bf16*, const bf16*, bf16*, long long, int, hipStream_t);
-template int launch_swiglu_bwd<float>(const float*, const float*, float*, long long, int, hipStream_t);
-
 // --------------------------------------------------------------------- dropout (LoRA input, finetune)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ src, T* dst, long long n, float p, unsigned long long seed,
@@ -585,12 +560,6 @@ static int colsum_any(const TS* src, long long ld, long long rows, int cols, flo
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
   return colsum_any<float>(src, ld, rows, cols, dst, s);
 }
-template <typename T>
-int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
-  return colsum_any<T>(src, ld, rows, cols, dst, s);
-}
-template int launch_colsum_add_t<bf16>(const bf16*, long long, long long, int, float*, hipStream_t);
-template int launch_colsum_add_t<float>(const float*, long long, long long, int, float*, hipStream_t);
 
 // dst (bf16) = src (f32) and colsum[c] += sum_r src[r][c] in ONE pass over src: the operand copy of dF and the
 // projection-bias gradient of the table backward (model.hip finalize) both stream the same 410 MB.

@@ -124,7 +124,7 @@ __device__ __forceinline__ void store_c(const GemmParams& p, void* C, long long 
   else ((CT*)C)[row * ld + col] = from_f32<CT>(v);
 }
 
-template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM, bool PERSIST>
+template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   using MT = MmaT<CT>;
   constexpr int EPC = MT::EPC, BK = MT::BK;
@@ -298,9 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     __syncthreads();
   };
 
-  // `hook` runs once, right after the last read of the accumulators (they are dead from then on): the persistent
-  // kernel issues the next tile's first loads there, so they do not have to live across the whole epilogue.
-  auto epilogue = [&](const int m0, const int n0, auto&& hook) {
+  auto epilogue = [&](const int m0, const int n0) {
   // ------------------------------------------------------------------ epilogue
   // The accumulators are staged through LDS (the operand tiles are dead by now) so that every global
   // access of the epilogue is a full 128..512-byte row segment with 8..16 bytes per lane, instead of the
@@ -367,7 +365,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int r = 0; r < 4; ++r) Cs[(i * 16 + 4 * fq + r) * CS_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
       }); });
     }
-    if (half == 1 && p.epi != EPI_SWIGLU) hook();
     __syncthreads();
     if (wide) copy_primary(half, std::integral_constant<int, 8>{});
     else copy_primary(half, std::integral_constant<int, 4>{});
@@ -385,7 +382,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
           }
         }); });
       }
-      if (half == 1) hook();
       __syncthreads();
       constexpr int GW = is_bf16<CT>::value ? 8 : 4, GCPR = 64 / GW;
       for (int it = 0; it < 64 * GCPR / 256; ++it) {
@@ -407,27 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
   };   // epilogue
 
-  if constexpr (PERSIST) {
-    // Persistent workgroups (2 per CU) walk the tiles of their XCD; every tile is full (launcher).  The next
-    // tile's first loads are in flight during the epilogue of the current one and its stores drain under the
-    // next main loop: neither end of a tile exposes HBM latency (short-K GEMMs spend most of their time there).
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
-    const int cnt = q + (xcd < r ? 1 : 0);
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    int idx = blockIdx.x >> 3;
-    if (idx >= cnt) return;
-    setup(base + idx, 0);
-    prologue_loads(std::true_type{});
-    while (true) {
-      mainloop(std::true_type{});
-      const int em0 = cm0, en0 = cn0;
-      idx += nslot;
-      const bool more = idx < cnt;
-      epilogue(em0, en0, [&]() { if (more) { setup(base + idx, 0); prologue_loads(std::true_type{}); } });
-      if (!more) break;
-      zero_acc();
-    }
-  } else {
+  {
     int tile, split;
     if (p.splitk == 1) {
       const int bid = blockIdx.x;
@@ -443,16 +419,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     if (!setup(tile, split)) return;
     if (full) { prologue_loads(std::true_type{}); mainloop(std::true_type{}); }
     else { prologue_loads(std::false_type{}); mainloop(std::false_type{}); }
-    epilogue(cm0, cn0, []() {});
+    epilogue(cm0, cn0);
   }
 }
 
 template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  // (A persistent variant -- PERSIST = true: 512 workgroups walking the tiles with the next tile's loads issued under
-  // the epilogue -- exists in the kernel but is not instantiated: at 256 VGPRs it spills and measured 2x slower.)
-  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM, false>), dim3(tiles * p.splitk), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM>), dim3(tiles * p.splitk), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

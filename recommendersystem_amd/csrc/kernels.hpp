@@ -52,9 +52,6 @@ template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
                            float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s);
 
-template <typename T>
-int launch_swiglu_bwd(const T* dg, const T* ab, T* dab, long long rows, int I, hipStream_t s);
-
 // dst = (accumulate ? dst : 0) + src * mask / (1 - p), mask ~ Bernoulli(1-p) from Philox(seed, stream)(element index):
 // nn.Dropout of the LoRA input (model.py:238,265,269); the backward pass regenerates the same mask
 template <typename T>
@@ -86,8 +83,6 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
 // dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 1024)
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s);
-template <typename T>
-int launch_colsum_add_t(const T* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
 
 int launch_embedding_scatter_add(const float* gx0, const BatchDev& b, int V, int D, float* gE, hipStream_t s);
 
