@@ -422,3 +422,82 @@ def test_serving_predict_end_to_end():
     b = serve.predict(model, [solo], "ranking", 0)[0]["0.ranking"]
     assert abs(a[1] - b[0]) < 1e-4 * max(1.0, abs(a[1]))
     model.close()
+
+
+def test_full_size_cfg3_parity_and_properties():
+    """At BASELINE's full model size (cfg-3: D=512, L=8, S=512, 200 K items, M=6148).
+    (1) fp32 mode, one row: trunk output against the fp64 oracle at 1e-4 (the oracle gets the fused item-table rows the row
+        uses, computed on the host from the same parameters -- the full 200 K x 6148 projection is not needed for one row);
+    (2) bf16 mode, 4 rows: user isolation (changing one user's events leaves every other user's outputs bit-identical:
+        the document mask, model.py:479-487) and row-permutation equivariance of the forward."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg = synth.make_config("cfg3")
+    S, D, M = cfg["max_sequence_length"], cfg["embed_dim"], cfg["metadata_emb_size"]
+    V0, V1 = cfg["vocab_sizes"]["0_matchedid"], cfg["vocab_sizes"]["1_matchedid"]
+    V = V0 + V1
+    rng = np.random.default_rng(17)
+    base = (rng.standard_normal((997, M)) / np.sqrt(M)).astype(np.float32)
+    table = base[np.arange(V) % 997] * (1.0 + (np.arange(V) % 13)[:, None].astype(np.float32) / 13.0)   # (V, M), cheap to rebuild per row
+
+    # ---- (1) fp32, one row, vs oracle
+    d = synth.make_batch(cfg, 1, 123, mu=4.6, sigma=1.0)
+    wm, rm = synth.make_masks(cfg, 1, 7)
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=1)
+    model.init_weights(5)
+    for n, shape, tr in model.named_parameters():            # init leaves norm scales at 1 and phases at 0: perturb them
+        if tr and (n.endswith(".scale") or "periodic_time" in n):
+            model.set_parameter(n, (1.0 if n.endswith(".scale") else 0.0) + 0.1 * rng.standard_normal(shape).astype(np.float32))
+    model.load_pretrained_embeddings(table)
+    model.set_loss_weights(TASK_W, 1)
+    model(d, False, masks=(wm, rm))
+    y = model.trunk_output(1)
+    P = model.state_dict(include_frozen=False)
+    P = {k: v for k, v in P.items() if not k.startswith("watch_head.")}
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    ids = np.unique(np.where(dm["matchedid"] == -1, V, dm["matchedid"]))
+    E = P["item_embedding.matchedid_embedding.embedding.weight"].astype(np.float64)
+    Wp = P["item_embedding.projection_layer.weight"].astype(np.float64); bp = P["item_embedding.projection_layer.bias"].astype(np.float64)
+    meta = np.zeros((len(ids), M), np.float64)
+    meta[ids < V] = table[ids[ids < V]]                     # the mask row V has zero metadata (model.py:386)
+    F = np.zeros((V + 1, D), np.float64)
+    F[ids] = E[ids] + meta @ Wp.T + bp
+    P64 = {k: v.astype(np.float64) for k, v in P.items() if "matchedid_embedding" not in k}
+    P64["item_embedding.fused_embedding"] = F
+    P64["item_embedding.matchedid_embedding.embedding.weight"] = E
+    ref = model_np.OracleModel(cfg, P64, np.float64)
+    y_ref, _ = ref.embed(dm)
+    assert relerr(y, y_ref) < 1e-4, relerr(y, y_ref)
+    model.close()
+
+    # ---- (2) bf16, 4 rows: isolation and permutation
+    rows = 4
+    d = synth.make_batch(cfg, rows, 321, mu=4.6, sigma=1.0)
+    wm, rm = synth.make_masks(cfg, rows, 9)
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.init_weights(5)
+    model.load_pretrained_embeddings(table)
+    model.set_loss_weights(TASK_W, 1)
+    model(d, True, masks=(wm, rm))
+    y0 = model.trunk_output(rows).copy()
+    uid = np.asarray(d["userid"]).reshape(rows, S)
+    victim = uid[1, S // 2]
+    sel = (uid == victim)
+    assert sel.any() and not sel.all()
+    d2 = {k: np.array(v, copy=True) for k, v in d.items()}
+    flat = sel.reshape(-1)
+    d2["rating"] = np.where(flat, 10.0 - np.asarray(d["rating"]).reshape(-1), np.asarray(d["rating"]).reshape(-1)).astype(np.float32)
+    d2["status"] = np.where(flat, (np.asarray(d["status"]).reshape(-1) + 3) % 9, np.asarray(d["status"]).reshape(-1)).astype(np.int32)
+    mid = np.asarray(d["matchedid"]).reshape(-1)
+    d2["matchedid"] = np.where(flat, (mid + 17) % V, mid).astype(np.int32)
+    model(d2, True, masks=(wm, rm))
+    y1 = model.trunk_output(rows)
+    tok = np.repeat(sel, 2, axis=1)                          # tokens of the victim user (item + action per event)
+    assert np.array_equal(y0[~tok], y1[~tok])                # everybody else: bit-identical
+    assert np.abs(y0[tok] - y1[tok]).max() > 1e-3            # the victim's own outputs moved
+    perm = np.array([2, 0, 3, 1])
+    dp = {k: np.asarray(v).reshape(rows, S)[perm].reshape(-1) for k, v in d.items()}
+    model(dp, True, masks=(wm[perm], rm[perm]))
+    yp = model.trunk_output(rows)
+    assert np.array_equal(yp, y0[perm])
+    model.close()
