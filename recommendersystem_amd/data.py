@@ -73,22 +73,28 @@ class FinetuneDataset:
         self.partition = [0, checkpoints_per_epoch]
         self.rng = np.random.default_rng(seed)
 
+    def _eligible(self, d):
+        """row indices with a positive watch or rating target weight for the finetuned medium, ascending."""
+        w = d[f"{self.medium}.watch.weight"].sum(axis=1) > 0
+        r = d[f"{self.medium}.rating.weight"].sum(axis=1) > 0
+        return np.flatnonzero(w | r)
+
     def __iter__(self):
+        part, nparts = self.partition
         for fn in self.fns:
             with np.load(fn) as f:
                 d = {k: f[k] for k in f.files}
-            N = d["userid"].shape[0]
-            idxs = [i for i in range(N)
-                    if any(d[f"{self.medium}.{metric}.weight"][i, :].sum() > 0 for metric in ["watch", "rating"])]
+            rows = self._eligible(d)
             if self.shuffle:
-                idxs = [x for (i, x) in enumerate(idxs) if i % self.partition[1] == self.partition[0]]
-                self.rng.shuffle(idxs)
-                while len(idxs) % self.batch_size != 0:
-                    idxs.append(int(self.rng.choice(idxs)))
-            for i in range(0, len(idxs), self.batch_size):
-                idx = idxs[i:i + self.batch_size]
-                yield {k: v[idx, :] for k, v in d.items()}
-        self.partition[0] = (self.partition[0] + 1) % self.partition[1]
+                rows = rows[part::nparts].copy()              # this pass's quarter of the users
+                self.rng.shuffle(rows)
+                short = (-len(rows)) % self.batch_size
+                if short and len(rows):                        # whole batches: repeat random rows of the same quarter
+                    rows = np.concatenate([rows, self.rng.choice(rows, short)])
+            for i in range(0, len(rows), self.batch_size):
+                take = rows[i:i + self.batch_size]
+                yield {k: v[take, :] for k, v in d.items()}
+        self.partition[0] = (part + 1) % nparts
 
 
 def write_shards(datadir, streams, num_shards):

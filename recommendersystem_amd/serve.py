@@ -12,82 +12,90 @@ other), and returns the rating head at the candidates' action tokens.
 import numpy as np
 
 
-def make_item(ts, medium=0, itemid=-1):   # embed.py:27-36
-    return {"medium": medium, "history_max_ts": ts, "matchedid": itemid, "status": -1, "rating": 0, "progress": 0}
+_STATE_KEYS = ("status", "rating", "progress")
+_INT_COLS = ("userid", "rope_input_pos", "token_mask_ids", "gender", "source", "matchedid", "status")
 
 
-def tokenize(user_items):   # embed.py:39-60
-    def span_to_token(x):
-        token = x[0].copy()
-        for k in ["status", "rating", "progress"]:
-            token[k] = x[-1][k]
-        return token
-
-    items, last_mid, span = [], None, []
-    for x in user_items:
-        mid = (x["medium"], x["matchedid"])
-        if mid == last_mid:
-            span.append(x)
-        else:
-            if span:
-                items.append(span_to_token(span))
-            span = [x]
-            last_mid = mid
-    if span:
-        items.append(span_to_token(span))
-    return items
+def make_item(ts, medium=0, itemid=-1):
+    """A query / candidate token: item `itemid` of `medium` at time `ts` with the masked action state (embed.py:27-36)."""
+    return dict(medium=medium, history_max_ts=ts, matchedid=itemid, status=-1, rating=0, progress=0)
 
 
-def project(user_items):   # embed.py:63-71
-    return [x for x in user_items
-            if not ((x["history_status"] == x["status"]) and (x["history_rating"] == x["rating"]))]
+def tokenize(user_items):
+    """Runs of consecutive events on the same (medium, item) collapse into one token that keeps the first event's fields
+    and takes status / rating / progress from the last one (embed.py:39-60)."""
+    from itertools import groupby
+    tokens = []
+    for _, run in groupby(user_items, key=lambda e: (e["medium"], e["matchedid"])):
+        run = list(run)
+        tok = dict(run[0])
+        tok.update({k: run[-1][k] for k in _STATE_KEYS})
+        tokens.append(tok)
+    return tokens
+
+
+def project(user_items):
+    """Keeps the tokens whose status or rating differs from the item's previous state (embed.py:63-71)."""
+    changed = lambda e: e["history_status"] != e["status"] or e["history_rating"] != e["rating"]
+    return [e for e in user_items if changed(e)]
+
+
+def _history(user, max_user_len):
+    """projected tokens of a user, newest `max_user_len - 1` kept (one slot is reserved for the query, embed.py:103-106)."""
+    hist = project(tokenize(user["items"]))
+    return hist[-(max_user_len - 1):] if len(hist) > max_user_len - 1 else hist
 
 
 def build_batch(users, task, medium, num_items_0, max_user_len=1024, max_ranking_items=1024):
-    """embed.py:74-138: the ten (len(users), max_seq_len) arrays of one inference request."""
-    assert task in ("retrieval", "ranking")
-    max_seq_len = max_user_len if task == "retrieval" else max_user_len + max_ranking_items
+    """The ten (len(users), max_seq_len) arrays of one inference request (embed.py:74-138): history tokens first, then the
+    query token (retrieval) or one token per candidate (ranking).  History tokens get positions 0..n-1 and mask id 0; every
+    appended token sits at position n, and ranking candidates carry their own index as `token_mask_ids`, which hides them
+    from each other (model.py:479-487)."""
+    if task not in ("retrieval", "ranking"):
+        raise AssertionError(task)
+    width = max_user_len + (max_ranking_items if task == "ranking" else 0)
     n = len(users)
-    d = {"userid": np.zeros((n, max_seq_len), np.int32), "time": np.zeros((n, max_seq_len), np.float64),
-         "rope_input_pos": np.zeros((n, max_seq_len), np.int32), "token_mask_ids": np.zeros((n, max_seq_len), np.int32),
-         "gender": np.zeros((n, max_seq_len), np.int32), "source": np.zeros((n, max_seq_len), np.int32),
-         "matchedid": np.zeros((n, max_seq_len), np.int32), "status": np.zeros((n, max_seq_len), np.int32),
-         "rating": np.zeros((n, max_seq_len), np.float32), "progress": np.zeros((n, max_seq_len), np.float32)}
-    for u in range(n):
-        user = users[u]["user"]
-        items = project(tokenize(users[u]["items"]))
-        extra_tokens = 1
-        if len(items) > max_user_len - extra_tokens:
-            items = items[-(max_user_len - extra_tokens):]
+    d = {k: np.zeros((n, width), np.int32) for k in _INT_COLS}
+    d["time"] = np.zeros((n, width), np.float64)
+    d["rating"] = np.zeros((n, width), np.float32)
+    d["progress"] = np.zeros((n, width), np.float32)
+    for row, u in enumerate(users):
+        hist = _history(u, max_user_len)
         if task == "ranking":
-            test_items = [make_item(users[u]["timestamp"], medium, x) for x in users[u]["ranking_items"]]
+            tail = [make_item(u["timestamp"], medium, cand) for cand in u["ranking_items"]]
         else:
-            test_items = [make_item(users[u]["timestamp"])]
-        for i, x in enumerate(items + test_items):
-            d["userid"][u, i] = u + 1
-            d["time"][u, i] = x["history_max_ts"]
-            d["gender"][u, i] = 0 if user["gender"] is None else user["gender"] + 1
-            d["source"][u, i] = user["source"]
-            d["rope_input_pos"][u, i] = i if i < len(items) else len(items)
-            d["token_mask_ids"][u, i] = i if task == "ranking" and i >= len(items) else 0
-            d["matchedid"][u, i] = x["matchedid"] + (num_items_0 if x["medium"] == 1 else 0)
-            d["status"][u, i] = x["status"]
-            d["rating"][u, i] = x["rating"]
-            d["progress"][u, i] = x["progress"]
+            tail = [make_item(u["timestamp"])]
+        seq = hist + tail
+        L, nh = len(seq), len(hist)
+        who = u["user"]
+        d["userid"][row, :L] = row + 1
+        d["gender"][row, :L] = 0 if who["gender"] is None else who["gender"] + 1
+        d["source"][row, :L] = who["source"]
+        d["time"][row, :L] = [e["history_max_ts"] for e in seq]
+        d["rope_input_pos"][row, :L] = np.minimum(np.arange(L), nh)
+        if task == "ranking":
+            d["token_mask_ids"][row, nh:L] = np.arange(nh, L)
+        d["matchedid"][row, :L] = [e["matchedid"] + (num_items_0 if e["medium"] == 1 else 0) for e in seq]
+        d["status"][row, :L] = [e["status"] for e in seq]
+        d["rating"][row, :L] = [e["rating"] for e in seq]
+        d["progress"][row, :L] = [e["progress"] for e in seq]
     return d
 
 
 def extract(embs, users, task, medium, max_user_len=1024):
-    """embed.py:147-161: the query item token (retrieval) / the candidates' action tokens (ranking) of every row."""
-    ret = []
-    for i, u in enumerate(users):
-        N = min(len(project(tokenize(u["items"]))), max_user_len - 1)
+    """Per user, the rows of the model output that answer the request (embed.py:147-161): token 2n is the query's item token
+    (retrieval: its trunk output), tokens 2(n+j)+1 are the candidates' action tokens (ranking: their rating-head value)."""
+    key = f"{medium}.{task}"
+    embs = np.asarray(embs)
+    out = []
+    for row, u in enumerate(users):
+        n = len(_history(u, max_user_len))
         if task == "retrieval":
-            ret.append({f"{medium}.{task}": np.asarray(embs[i, 2 * N, :]).tolist()})
+            out.append({key: embs[row, 2 * n, :].tolist()})
         else:
-            idxs = [2 * (N + j) + 1 for j in range(len(u["ranking_items"]))]
-            ret.append({f"{medium}.{task}": np.asarray(embs[i, idxs, 0]).tolist()})
-    return ret
+            rows = 2 * (n + np.arange(len(u["ranking_items"]))) + 1
+            out.append({key: embs[row, rows, 0].tolist()})
+    return out
 
 
 def predict(model, users, task, medium, max_user_len=None, max_ranking_items=None):
