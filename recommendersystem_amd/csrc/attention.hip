@@ -462,7 +462,7 @@ __device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld,
 
 // ------------------------------------------------------------------------ backward: dK, dV (one workgroup per kv tile and kv head)
 template <typename T, int HD>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 2 : 1) void attn_bwd_kv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_bwd_kv_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
