@@ -183,6 +183,8 @@ def run_case(ns, name, cfg, rows, seed, full):
                     "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "config": dict(cfg), "epoch": 1,
                     "training_loss": [float(x) for x in losses], "test_loss": [float(x) for x in losses]}
             torch.save(ckpt, os.path.join(OUT, f"checkpoint_{name}.pt"))
+            from recommendersystem_amd import checkpoint as _ck   # the converted form, so GPU tests need no torch
+            np.savez_compressed(os.path.join(OUT, f"checkpoint_{name}_converted.npz"), **_ck.from_reference(ckpt))
     out["opt/lr"] = np.array([lr])
     out["opt/losses"] = np.array(step_losses, np.float64)
     out["opt/norms"] = np.array(norms, np.float64)

@@ -50,3 +50,15 @@ def test_blob_uses_the_state_dict_names_of_the_model():
     decay, nodecay = ck.trainable_order(names, {n: tuple(synth.param_shapes(cfg)[n]) for n in names})
     assert all(len(synth.param_shapes(cfg)[n]) >= 2 for n in decay) and all(len(synth.param_shapes(cfg)[n]) < 2 for n in nodecay)
     assert len(decay) == 22 and len(nodecay) == 11
+
+
+def test_committed_conversion_is_current():
+    """tests/golden/checkpoint_tiny_converted.npz (what the GPU resume test loads, so that it needs no torch) is exactly
+    from_reference(checkpoint_tiny.pt)."""
+    from recommendersystem_amd import checkpoint as ck
+    _, ref = _load()
+    blob = ck.from_reference(ref)
+    z = np.load(os.path.join(GOLDEN, "checkpoint_tiny_converted.npz"))
+    assert sorted(z.files) == sorted(blob.keys())
+    for k in z.files:
+        np.testing.assert_array_equal(z[k], blob[k], err_msg=k)
