@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
       for (int r = 0; r < 4; ++r) {
         const float pv = fexp2(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
         S[i][r] = pv;
-        dP[i][r] = pv * (dP[i][r] - dd[r]) * scale;
+        dP[i][r] = pv * (dP[i][r] - dd[r]);   // (the 1/sqrt(hd) factor of dS is applied once to dK at the end)
       }
     }
     acc_second_stage<T, HD>(dV, S, dOc, l);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
@@ -558,6 +558,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   }
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
   T* Os = Qs;
+#pragma unroll
+  for (int j = 0; j < HD / 16; ++j) dK[j] *= scale;
   store_grad_tile<T, HD>(dK, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
   copy_out_tile<T, HD>(Os, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t);
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pv = fexp2(fmaf(S[i][r], c2, -lse2));
-        dP[i][r] = pv * (dP[i][r] - dl) * scale;
+        dP[i][r] = pv * (dP[i][r] - dl);   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
       }
     }
     acc_second_stage<T, HD>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
@@ -646,6 +648,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   }
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(q, p.T - 1)] : min(q, p.T - 1);
   T* Os = Ks;
+#pragma unroll
+  for (int j = 0; j < HD / 16; ++j) dQ[j] *= scale;
   store_grad_tile<T, HD>(dQ, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
   copy_out_tile<T, HD>(Os, (T*)p.dq + (tok0 + qt * 64) * p.ldg + h * HD, p.ldg, qt * 64, p.T, t);
