@@ -1,9 +1,9 @@
 """Shard reader mirroring PretrainDataset (notebooks/Training/transformer.py:37-98).
 
-The reference reads blosc-compressed HDF5 shards written by Training/transformer.jl:202-240; neither
-libhdf5 nor h5py exists in this image, so a shard here is an `.npz` with the same 27 keys and dtypes
-(an HDF5 adapter goes where HDF5 exists).  Directory layout and rank assignment are the
-reference's: `{datadir}/{shard}/{p}.npz`, shard directory i -> rank i % world (train.py:46-51).
+The reference reads blosc-compressed HDF5 shards written by Training/transformer.jl:202-240 (written here by
+shards.py); `.h5` files go through the libhdf5 + blosc adapter (h5.py, include/rsys_h5.h), and an `.npz` with the
+same 27 keys and dtypes is accepted beside them (tests and hosts without libhdf5).  Directory layout and rank
+assignment are the reference's: `{datadir}/{shard}/{p}.h5`, shard directory i -> rank i % world (train.py:46-51).
 """
 import glob
 import os
@@ -11,6 +11,20 @@ import os
 import numpy as np
 
 from .dist import shard_for_rank
+
+
+def shard_files(shard_dir):
+    """train.py:51: every `.h5` of a shard directory (pad.h5 included), plus `.npz` stand-ins."""
+    return sorted(glob.glob(f"{shard_dir}/*.h5")) + sorted(glob.glob(f"{shard_dir}/*.npz"))
+
+
+def load_shard(fn):
+    """train.py:86-89: `for k in f: d[k] = f[k][:]`."""
+    if fn.endswith(".h5"):
+        from . import h5
+        return h5.read_h5(fn)
+    with np.load(fn) as f:
+        return {k: f[k] for k in f.files}
 
 
 def get_index_permutation(arr, rng):
@@ -39,15 +53,14 @@ class PretrainDataset:
         shards = sorted(glob.glob(f"{datadir}/*/"))
         self.fns = []
         for x in shard_for_rank(shards, local_rank, local_world_size):
-            self.fns.extend(sorted(glob.glob(f"{x}/*.npz")))
+            self.fns.extend(shard_files(x))
         self.rng = np.random.default_rng(seed)
 
     def __iter__(self):
         fns = list(self.fns)
         self.rng.shuffle(fns)
         for fn in fns:
-            with np.load(fn) as f:
-                d = {k: f[k] for k in f.files}
+            d = load_shard(fn)
             block_shuffle(d, self.rng)
             n = len(d["userid"])
             assert n % self.batch_size == 0
@@ -68,7 +81,7 @@ class FinetuneDataset:
         shards = sorted(glob.glob(f"{datadir}/*/"))
         self.fns = []
         for x in shard_for_rank(shards, local_rank, local_world_size):
-            self.fns.extend(sorted(glob.glob(f"{x}/*.npz")))
+            self.fns.extend(shard_files(x))
         checkpoints_per_epoch = 4
         self.partition = [0, checkpoints_per_epoch]
         self.rng = np.random.default_rng(seed)
@@ -82,8 +95,7 @@ class FinetuneDataset:
     def __iter__(self):
         part, nparts = self.partition
         for fn in self.fns:
-            with np.load(fn) as f:
-                d = {k: f[k] for k in f.files}
+            d = load_shard(fn)
             rows = self._eligible(d)
             if self.shuffle:
                 rows = rows[part::nparts].copy()              # this pass's quarter of the users
@@ -97,14 +109,18 @@ class FinetuneDataset:
         self.partition[0] = (part + 1) % nparts
 
 
-def write_shards(datadir, streams, num_shards):
-    """Writes one `.npz` per (shard, part) and num_tokens.txt (transformer.jl:228-239)."""
+def write_shards(datadir, streams, num_shards, fmt="npz"):
+    """Writes one file per (shard, part) and num_tokens.txt (transformer.jl:228-239); fmt "h5" = blosc-3 HDF5."""
     total = 0
     for i, parts in enumerate(streams):
         dest = os.path.join(datadir, str(i % num_shards + 1))
         os.makedirs(dest, exist_ok=True)
         for p, d in enumerate(parts):
-            np.savez(os.path.join(dest, f"{p + 1}.npz"), **d)
+            if fmt == "h5":
+                from . import h5
+                h5.write_h5(os.path.join(dest, f"{p + 1}.h5"), d, blosc=3)
+            else:
+                np.savez(os.path.join(dest, f"{p + 1}.npz"), **d)
             total += len(d["userid"])
     with open(os.path.join(datadir, "num_tokens.txt"), "w") as f:
         f.write(str(total))

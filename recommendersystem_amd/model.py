@@ -17,6 +17,7 @@ and calls loss.backward() (train.py:264-272); here the task weights and the
 All arrays are numpy; device memory is owned by the library.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -104,7 +105,12 @@ class RecommenderModel:
         check(lib().rsys_model_init_random(self._h, seed))
 
     def load_pretrained_embeddings(self, table):
-        """model.py:379-389; `table` is the (V, M) float32 `metadata` array of media_embeddings.h5."""
+        """model.py:379-389; `table` is the (V, M) float32 `metadata` array of media_embeddings.h5, or, as in the
+        reference, the directory that holds that file."""
+        if isinstance(table, (str, os.PathLike)):
+            from . import h5
+            with h5.File(os.path.join(table, "media_embeddings.h5")) as f:
+                table = f["metadata"]
         table = np.ascontiguousarray(table, np.float32)
         check(lib().rsys_model_load_metadata(self._h, table.ctypes.data, table.shape[0], table.shape[1]))
 

@@ -1,0 +1,197 @@
+"""Shard writer: per-user msgpack histories -> flat per-token HDF5 shards.
+
+Restates the data-preparation step the reference runs in Julia before training (notebooks/Training/transformer.jl,
+history_tools.jl); Julia is not in this image, so this module is checked against hand-derived cases and the format
+round trip only (tests/test_shards.py) -- "parity unpinned" for the label rules, pinned for tokenize / project, which
+the reference also has in Python (Finetune/embed.py:39-71, see serve.py).
+
+    get_data            transformer.jl:79-146    one user -> the 27 per-token arrays
+    concat              transformer.jl:148-168   users of one part, zero-padded to a whole number of batches
+    save_data           transformer.jl:202-240   users -> {datadir}/{split}/{shard}/{p}.h5, num_tokens.txt
+    pad_splits          transformer.jl:181-200   pad.h5 so that every shard holds the same number of tokens
+    save_media_embeddings  transformer.jl:56-77  media_embeddings.h5 ("metadata": text | image | 4 date features)
+
+The random choices (mini subsample, duplicate users to fill the last round of shards, shuffles) use a numpy generator;
+they are statistically, not bitwise, those of the Julia run.
+"""
+import datetime
+import glob
+import os
+
+import numpy as np
+
+from . import h5
+from .serve import project, tokenize
+
+MEDIUMS = (0, 1)
+METRICS = ("watch", "rating", "status")
+PLANNED_STATUS = 5                      # transformer.jl:19
+BATCH_SIZE = 128 * 1024                 # transformer.jl:21: local_batch_size * max_sequence_length
+NUM_GPUS = 8                            # transformer.jl:22
+MIN_TS = datetime.datetime(2000, 1, 1, tzinfo=datetime.timezone.utc).timestamp()   # transformer.jl:23
+USERS_PER_PART = 65_536                 # transformer.jl:217
+
+_INT_KEYS = ("userid", "token_mask_ids", "gender", "source", "matchedid", "status")
+
+
+def max_ts_of(list_tag):
+    """transformer.jl:24-26: `list_tag` is the yyyymmdd snapshot tag."""
+    return datetime.datetime.strptime(list_tag.strip(), "%Y%m%d").replace(tzinfo=datetime.timezone.utc).timestamp()
+
+
+def optdate(x, max_ts, min_ts=MIN_TS):
+    """transformer.jl:38-54: (present, normalised date); a date that does not parse loses trailing fields until it does."""
+    if x is None or x == "":
+        return 0, 0.0
+    fields = str(x).split("-")
+    try:
+        ymd = [int(f) for f in fields]
+        if not 1 <= len(ymd) <= 3:
+            raise ValueError(x)
+        ymd += [1] * (3 - len(ymd))
+        ts = datetime.datetime(*ymd, tzinfo=datetime.timezone.utc).timestamp()
+        y = (ts - min_ts) / (max_ts - min_ts)
+        return 1, float(min(max(y, -5.0), 5.0))
+    except ValueError:
+        if len(fields) > 1:
+            return optdate("-".join(fields[:-1]), max_ts, min_ts)
+    return 0, 0.0
+
+
+def media_embedding_matrix(media, num_items, max_ts, text_dim=3072, image_dim=3072):
+    """transformer.jl:56-71.  `media[m]` = records of medium m with `matchedid`, `text_embedding.embedding`,
+    `image_embedding`, `metadata.dates.{startdate,enddate}`; returns the (V, M) float32 table h5py shows the reference
+    (the Julia array is its (M, V) transpose), V = num_items[0] + num_items[1], M = text + image + 4."""
+    W = np.zeros((sum(num_items[m] for m in MEDIUMS), text_dim + image_dim + 4), np.float32)
+    for m in MEDIUMS:
+        for x in media.get(m, []):
+            has_sd, sd = optdate(x["metadata"]["dates"]["startdate"], max_ts)
+            has_ed, ed = optdate(x["metadata"]["dates"]["enddate"], max_ts)
+            row = x["matchedid"] + (num_items[0] if m == 1 else 0)
+            W[row] = np.concatenate([np.asarray(x["text_embedding"]["embedding"], np.float32),
+                                     np.asarray(x["image_embedding"], np.float32), [has_sd, sd, has_ed, ed]])
+    return W
+
+
+def save_media_embeddings(datadir, media, num_items, max_ts, **dims):
+    """transformer.jl:72-77."""
+    h5.write_h5(os.path.join(datadir, "media_embeddings.h5"), {"metadata": media_embedding_matrix(media, num_items, max_ts, **dims)}, blosc=3)
+
+
+def get_data(data, userid, num_items_0):
+    """transformer.jl:79-146.  `data` = {"user": {...}, "items": [events]}; returns the 27 arrays of this user's tokens.
+    Targets: watch = first time the item leaves the planned states (or an inferred watch), rating / status = the value
+    changed; `token_mask_ids` marks tokens that carry a rating target (they can be masked, model.py:479-487)."""
+    items = project(tokenize(data["items"]))
+    u = data["user"]
+    N = len(items)
+    d = {k: np.zeros(N, np.int32) for k in _INT_KEYS}
+    d["time"] = np.zeros(N, np.float64)
+    d["rating"] = np.zeros(N, np.float32)
+    d["progress"] = np.zeros(N, np.float32)
+    for m in MEDIUMS:
+        for metric in METRICS:
+            d[f"{m}.{metric}.label"] = np.zeros(N, np.float32)
+            d[f"{m}.{metric}.weight"] = np.zeros(N, np.float32)
+            d[f"{m}.{metric}.position"] = np.zeros(N, np.int32)
+    for i, x in enumerate(items):
+        m = x["medium"]
+        d["userid"][i] = userid
+        d["time"][i] = x["history_max_ts"]
+        d["gender"][i] = 0 if u["gender"] is None else u["gender"] + 1
+        d["source"][i] = u["source"]
+        d["matchedid"][i] = x["matchedid"] + (num_items_0 if m == 1 else 0)
+        d["status"][i] = x["status"]
+        d["rating"][i] = x["rating"]
+        d["progress"][i] = x["progress"]
+        hs, hr = x["history_status"], x["history_rating"]
+        inferred_watch = x["status"] == 0 and hs is None
+        new_watch = x["status"] > PLANNED_STATUS and (hs is None or 0 < hs <= PLANNED_STATUS)
+        if inferred_watch or new_watch:
+            d[f"{m}.watch.label"][i] = 1
+            d[f"{m}.watch.weight"][i] = 1
+            d[f"{m}.watch.position"][i] = x["matchedid"]
+        if x["rating"] > 0 and x["rating"] != hr:
+            d["token_mask_ids"][i] = 1
+            d[f"{m}.rating.label"][i] = x["rating"]
+            d[f"{m}.rating.weight"][i] = 1
+            d[f"{m}.rating.position"][i] = x["matchedid"]
+        if x["status"] > 0 and x["status"] != hs:
+            d[f"{m}.status.label"][i] = x["status"]
+            d[f"{m}.status.weight"][i] = 1
+            d[f"{m}.status.position"][i] = x["matchedid"]
+    return d
+
+
+def concat(ds, batch_size=BATCH_SIZE):
+    """transformer.jl:148-168: users back to back, zero tokens up to the next multiple of `batch_size`."""
+    n = sum(len(x["userid"]) for x in ds)
+    total = n + (-n) % batch_size
+    out = {}
+    for k, v in ds[0].items():
+        out[k] = np.zeros(total, v.dtype)
+        out[k][:n] = np.concatenate([x[k] for x in ds])
+    return out
+
+
+def get_num_tokens(splitdir, shard):
+    """transformer.jl:170-179."""
+    tokens = 0
+    for fn in glob.glob(os.path.join(splitdir, str(shard), "*.h5")):
+        with h5.File(fn) as f:
+            tokens += f.info("userid")[1][0]
+    return tokens
+
+
+def pad_splits(splitdir, num_shards):
+    """transformer.jl:181-200: shards short of the longest one get a pad.h5 whose first tokens repeat the start of their
+    1.h5 and whose remainder is zero (zero tokens carry zero target weights)."""
+    counts = [get_num_tokens(splitdir, s) for s in range(1, num_shards + 1)]
+    for s, have in zip(range(1, num_shards + 1), counts):
+        num_padding = max(counts) - have
+        if num_padding == 0:
+            continue
+        with h5.File(os.path.join(splitdir, str(s), "1.h5")) as f:
+            out = {}
+            for k in f:
+                v = f[k]
+                n = min(num_padding, len(v))
+                out[k] = np.zeros(num_padding, v.dtype)
+                out[k][:n] = v[:n]
+        h5.write_h5(os.path.join(splitdir, str(s), "pad.h5"), out, blosc=3)
+
+
+def save_data(datadir, datasplit, transdir, num_items_0, mini=False, num_shards=NUM_GPUS, batch_size=BATCH_SIZE,
+              users_per_part=USERS_PER_PART, seed=0, load=None):
+    """transformer.jl:202-240: `{datadir}/users/{datasplit}/*/*.msgpack` -> `{datadir}/{transdir}/{datasplit}/{shard}/{p}.h5`
+    (+ pad.h5, num_tokens.txt).  Users are dealt round-robin to `num_shards` shards after a shuffle; `userid` is the
+    user's 1-based index inside its part, which is all the block shuffle of the reader needs (train.py:53-73)."""
+    if load is None:
+        import msgpack
+
+        def load(fn):
+            with open(fn, "rb") as f:
+                return msgpack.unpackb(f.read(), raw=False, strict_map_key=False)
+    rng = np.random.default_rng(seed)
+    users = sorted(glob.glob(os.path.join(datadir, "users", datasplit, "*", "*.msgpack")))
+    if mini:
+        users = [x for x in users if rng.random() < 0.5]
+    assert users, f"no user files under {datadir}/users/{datasplit}"
+    while len(users) % num_shards != 0:
+        users.append(users[rng.integers(len(users))])
+    users = [users[i] for i in rng.permutation(len(users))]
+    splitdir = os.path.join(datadir, transdir, datasplit)
+    for shard in range(1, num_shards + 1):
+        dest = os.path.join(splitdir, str(shard))
+        os.makedirs(dest, exist_ok=True)
+        files = [x for i, x in enumerate(users, start=1) if i % num_shards + 1 == shard]
+        files = [files[i] for i in rng.permutation(len(files))]
+        for p, lo in enumerate(range(0, len(files), users_per_part), start=1):
+            part = files[lo:lo + users_per_part]
+            ds = [get_data(load(fn), i, num_items_0) for i, fn in enumerate(part, start=1)]
+            h5.write_h5(os.path.join(dest, f"{p}.h5"), concat(ds, batch_size), blosc=3)
+    pad_splits(splitdir, num_shards)
+    total = sum(get_num_tokens(splitdir, s) for s in range(1, num_shards + 1))
+    with open(os.path.join(splitdir, "num_tokens.txt"), "w") as f:
+        f.write(str(total))
+    return total

@@ -380,6 +380,36 @@ def test_resume_from_reference_checkpoint():
     model.close()
 
 
+def test_hdf5_shards_and_embeddings_feed_the_step(tmp_path):
+    """a blosc-3 HDF5 shard (transformer.jl:228-231) read back through PretrainDataset's loader and
+    media_embeddings.h5 loaded by directory (model.py:379-389) give the step the same bits as the arrays themselves."""
+    import recommendersystem_amd as ra
+    from recommendersystem_amd import data, h5
+    if not os.path.exists(h5.LIB_PATH):
+        pytest.skip("librsys_h5.so not built (no libhdf5 on this host)")
+    name, over, rows, seed = CASES[0]
+    cfg, P, d = _setup(name, over, rows, seed)
+    table = P["item_embedding.metadata_embedding.embedding.weight"][:-1]
+    data.write_shards(str(tmp_path / "training"), [[d]], 1, fmt="h5")
+    h5.write_h5(str(tmp_path / "media_embeddings.h5"), {"metadata": table}, blosc=3)
+    ds = data.PretrainDataset(str(tmp_path / "training"), 0, 1, len(d["userid"]))
+    assert [os.path.basename(f) for f in ds.fns] == ["1.h5"]
+    got = data.load_shard(ds.fns[0])
+    assert sorted(got) == sorted(d) and all(got[k].dtype == d[k].dtype and np.array_equal(got[k], d[k]) for k in d)
+    out = []
+    for batch, tab in ((d, table), (got, str(tmp_path))):
+        model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+        model.load_state_dict(P)
+        model.load_pretrained_embeddings(tab)
+        model.set_loss_weights(TASK_W)
+        model.zero_grad()
+        out.append((model(batch, False), model.grad("item_embedding.projection_layer.weight")))
+        model.close()
+    assert out[0][0] == out[1][0]
+    assert relerr(out[1][1], out[0][1]) < 1e-5          # split-K fp32 atomics: summation order differs run to run
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0
+
+
 def test_serving_predict_end_to_end():
     """Request -> response through `serve.predict` (embed.py:74-161) on the HIP inference forward: retrieval returns the
     trunk output at the query item token, ranking the rating head at each candidate's action token; compared with the
