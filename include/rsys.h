@@ -148,6 +148,11 @@ int32_t rsys_dev_memset(void* dst, int value, size_t bytes);
 int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                      int64_t lda, int64_t ldb, int64_t ldc, int32_t a_km, int32_t b_km, int32_t a_f32, int32_t c_f32,
                      int32_t splitk);
+/* the same product with the row count taken from device memory, as the head GEMMs over the selected positions do
+ * (model.py:501-516: only rows with a positive target weight reach the heads): rows >= *rows_dev are not computed
+ * (rows up to the end of the last started tile may be written); row-major A, c_f32 / b_km as above */
+int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
+                          int64_t lda, int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev);
 /* attention fwd+bwd on caller-provided device buffers (T-typed): qkv [B*T][(H+2KV)*hd] post-RoPE, dO [B*T][H*hd],
  * uid/tm [B*T] int32, rope tables [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32,
  * dqkv [B*T][(H+2KV)*hd] (gradients w.r.t. the un-rotated q, k and v) */

@@ -366,6 +366,19 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
   return RSYS_OK;
 }
 
+int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                          int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev) {
+  ARG_CHECK(rows_dev != nullptr, "rsys_op_gemm_rows: rows_dev is null");
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.c_f32 = c_f32; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE; p.m_dev = rows_dev;
+  int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, false, false, false, b_km != 0, nullptr)
+                                    : launch_gemm<float>(p, false, false, false, b_km != 0, nullptr);
+  if (rc) return rc;
+  HIP_CHECK(hipDeviceSynchronize());
+  return RSYS_OK;
+}
+
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin) {

@@ -32,6 +32,7 @@ struct GemmParams {
   // optional device-side problem limits (no host sync): tiles whose first row is >= *m_dev exit at once, and the
   // reduction stops at *k_dev rounded up to a tile (rows / k beyond the limit must hold data that contributes zero)
   const int* m_dev; const int* k_dev;
+  int row_groups;   // set by the 256x256 launcher for m_dev problems: row tiles covered by the grid (the kernel strides over the rest)
   float alpha;
   int accum;        // EPI_STORE / EPI_QKV_ROPE with a T output: C = C + result (LoRA updates)
   const float* bias;
@@ -50,7 +51,7 @@ struct GemmParams {
 template <typename CT>
 int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s);
 
-// short name of the kernel launch_gemm picks for this problem ("8p", "4w", "nt", "nn", "tn"): timing tags
+// short name of the kernel launch_gemm picks for this problem ("8p", "8r", "8t", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
 }  // namespace rsys

@@ -61,8 +61,13 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // KM = false: row-major operands (A [M][K], B [N][K]).  KM = true: K-major operands (A [K][M], B [K][N]: the weight
 // gradients dW = dY^T X with K = tokens), split-K with fp32 atomics; the LDS image of a half-tile is then [64 k][256 B]
 // and the fragments are read with ds_read_b64_tr_b16 (two per fragment).
-template <bool KM>
+// RL (row loop, row-major only): for problems whose row count is only known on the device (*m_dev).  The grid covers
+// every column tile but only p.row_groups row tiles; a workgroup walks the row tiles tm, tm + row_groups, ... below
+// *m_dev.  (One workgroup per tile would leave thousands of workgroups with nothing to do, and each still has to wait
+// for a CU with 128 KB of free LDS: at 717 of 4096 rows the logits GEMM spent 2/3 of its time launching them.)
+template <bool KM, bool RL>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+  static_assert(!(KM && RL), "row loop is for row-major operands");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // ---- output tile, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; each XCD takes a contiguous run
   // of tiles (tn fastest), which share A rows / B rows through its private L2
   const int tiles_n = (p.N + T8_BN - 1) / T8_BN, tiles_m = (p.M + T8_BM - 1) / T8_BM;
-  const int ntiles = tiles_m * tiles_n;
+  const int ntiles = RL ? p.row_groups * tiles_n : tiles_m * tiles_n;
   int tile, kt0 = 0, nt;
   if constexpr (!KM) {
     const int bid = blockIdx.x;
@@ -90,9 +95,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     nt = min(ktiles, kt0 + per) - kt0;
     if (nt <= 0) return;
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  int tm = tile / tiles_n;
+  const int tn = tile % tiles_n;
+  for (;;) {   // one trip unless RL
   const int m0 = tm * T8_BM, n0 = tn * T8_BN;
-  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
+  if constexpr (RL) { if (m0 >= min(*p.m_dev, p.M)) return; }
+  else if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
   // ---- DMA source offsets (bytes from the operand base, k tile 0).  Instruction j of wave w fills the 1 KB piece
   // (w*2+j) of a half-tile = local rows (w*2+j)*8 + [0,8); lane l -> local row + (l>>3), stored slot l&7.
   unsigned int aoff[2][2], boff[2][2];   // [j][h]
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; return; }   // timing experiment: no epilogue
   if constexpr (!KM) {
-    epilogue_regs(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
+    epilogue_regs<RL>(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
   } else {
     // split-K partial sums: fp32 atomics.  An atomic wave instruction runs at full rate only when its 64 lanes add 256
     // contiguous bytes, so each wave passes its 128x64 block through a private LDS patch, 32 rows at a time
@@ -301,6 +309,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
         }
       }
     }
+  }
+  if constexpr (!RL) break;
+  else {
+    // next row tile of this column: the output stores share vmcnt with the DMA loads the prologue counts, and every
+    // wave must be done with the operand tiles before they are overwritten
+    tm += p.row_groups;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   }
 }
 
@@ -347,14 +364,23 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
     if (score > best_score) { best_score = score; best = sk; }
   }
   p.splitk = best;
-  hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
+  hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
-int launch_gemm8p(const GemmParams& p, hipStream_t s) {
-  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
-  hipLaunchKernelGGL(gemm8p_kernel<false>, dim3(tiles), dim3(512), 0, s, p);
+int launch_gemm8p(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  const int tiles_m = (p.M + T8_BM - 1) / T8_BM, tiles_n = (p.N + T8_BN - 1) / T8_BN;
+  if (p.m_dev != nullptr && tiles_m > 1 && p.epi == EPI_STORE) {
+    // device-side row count: about 2048 workgroups, each walking a strided set of row tiles
+    p.row_groups = std::min(tiles_m, std::max(1, 2048 / tiles_n));
+    hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(tiles_n * p.row_groups), dim3(512), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+    return RSYS_OK;
+  }
+  const int tiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(tiles), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -14,6 +14,8 @@
 namespace rsys {
 
 // wm0 / wn0: first row / column of the wave's block; full: the whole workgroup tile lies inside the matrix
+// STORE_ONLY: the caller guarantees p.epi == EPI_STORE (the row-loop kernel: fewer live values across its outer loop)
+template <bool STORE_ONLY = false>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[8][4], int wm0, int wn0, bool full,
                                               int fq, int fr) {
   auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
@@ -243,6 +245,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     });
   };
   auto run2 = [&](auto EC) __attribute__((always_inline))  { if (full) run(EC, std::true_type{}); else run(EC, std::false_type{}); };
+  if constexpr (STORE_ONLY) { run2(std::integral_constant<int, EPI_STORE>{}); return; }
   switch (p.epi) {
     case EPI_STORE: run2(std::integral_constant<int, EPI_STORE>{}); break;
     case EPI_ACCUM: run2(std::integral_constant<int, EPI_ACCUM>{}); break;

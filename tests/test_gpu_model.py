@@ -405,8 +405,8 @@ def test_hdf5_shards_and_embeddings_feed_the_step(tmp_path):
         model.zero_grad()
         out.append((model(batch, False), model.grad("item_embedding.projection_layer.weight")))
         model.close()
-    assert out[0][0] == out[1][0]
-    assert relerr(out[1][1], out[0][1]) < 1e-5          # split-K fp32 atomics: summation order differs run to run
+    assert relerr(out[1][0], out[0][0]) < 1e-6          # fp32 atomics (loss sums, split-K): summation order differs run to run
+    assert relerr(out[1][1], out[0][1]) < 1e-5
     assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0
 
 

@@ -124,6 +124,38 @@ def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("rows", [0, 1, 256, 300, 717, 1280, 2048, 5000])
+@pytest.mark.parametrize("kern", ["1", "2"])
+def test_gemm_device_side_row_count(monkeypatch, rows, kern):
+    """Head GEMMs run over "the rows selected on the device" (GemmParams.m_dev): the 256x256 kernel walks row tiles in
+    a loop (gemm8p_kernel<false, true>), the 128x128 kernel drops whole workgroups.  Rows below the count are exact; rows
+    past the last started tile keep their previous contents."""
+    from recommendersystem_amd import _lib
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)
+    lib = _lib.lib()
+    M, N, K = 2048, 2056, 192
+    rng = np.random.default_rng(rows)
+    A = rng.integers(-3, 4, (M, K)).astype(np.float32); B = rng.integers(-3, 4, (N, K)).astype(np.float32)
+    A[:, 0] = np.arange(M) % 5 - 2; B[:, 1] = np.arange(N) % 7 - 3
+    dA = _to_dev(lib, _pack(A, True)); dB = _to_dev(lib, _pack(B, True))
+    sentinel = np.full((M, N), 0x4300, np.uint16)                    # whole rows of bf16 128.0: untouched rows stay exactly this
+    dC = _to_dev(lib, sentinel)
+    dR = _to_dev(lib, np.array([rows], np.int32))
+    rc = lib.rsys_op_gemm_rows(1, dA, dB, dC, M, N, K, K, K, N, 0, 0, dR)
+    assert rc == 0, _lib.last_error()
+    raw = np.empty((M, N), np.uint16)
+    assert lib.rsys_dev_d2h(raw.ctypes.data, dC, raw.nbytes) == 0
+    for p in (dA, dB, dC, dR):
+        lib.rsys_dev_free(p)
+    out = _unpack(raw, True)
+    ref = _bf16_round((A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32))
+    live = min(rows, M)
+    np.testing.assert_array_equal(out[:live], ref[:live])
+    tile = 256 if kern == "2" else 128
+    started = min(M, (live + tile - 1) // tile * tile)
+    assert (raw[started:] == 0x4300).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1408, 8192), (1024, 512, 4160), (520, 264, 1000), (64, 72, 640)])
 def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K):
     """K-major operands (weight-gradient shape, K = tokens) on the LDS-DMA pipeline with ds_read_b64_tr_b16 fragments
