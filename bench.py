@@ -24,16 +24,14 @@ HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
 KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
-    "8p": "gemm8p_kernel<false, false>",                  # 256x256 LDS-DMA, row-major operands (gemm8p.hip)
-    "8r": "gemm8p_kernel<false, true>",                   # the same, row count read on the device (logits)
-    "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
+    "8p": "gemm8p_kernel<false>",                         # 256x256 LDS-DMA, persistent, row-major operands (gemm8p.hip)
+    "8t": "gemm8p_kernel<true>",                          # the same pipeline, K-major operands + split-K atomics
     "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
-KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, row-major bf16)", "8r": "gemm8p_kernel<false, true> (256x256 LDS-DMA, device-side row count)",
-                "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+KERNEL_LABEL = {"8p": "gemm8p_kernel<false> (256x256 LDS-DMA, persistent, row-major bf16)", "8t": "gemm8p_kernel<true> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 TRAFFIC_FILE = "r1e_pmc_traffic.json"
 
@@ -176,7 +174,7 @@ def main():
         fl_rows256 = sum(2.0 * up(npos[2 * m_], 256) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
-                rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith(("@8p", "@8r"))) else fl   # 256-row tiles
+                rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith("@8p")) else fl   # 256-row tiles
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses
 

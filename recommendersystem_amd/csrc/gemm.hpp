@@ -29,10 +29,9 @@ struct GemmParams {
   int epi;
   int c_f32;        // 1: C is float, 0: C is T
   int splitk;       // >=1; >1 requires EPI_ATOMIC
-  // optional device-side problem limits (no host sync): tiles whose first row is >= *m_dev exit at once, and the
+  // optional device-side problem limits (no host sync): tiles whose first row is >= *m_dev are not computed, and the
   // reduction stops at *k_dev rounded up to a tile (rows / k beyond the limit must hold data that contributes zero)
   const int* m_dev; const int* k_dev;
-  int row_groups;   // set by the 256x256 launcher for m_dev problems: row tiles covered by the grid (the kernel strides over the rest)
   float alpha;
   int accum;        // EPI_STORE / EPI_QKV_ROPE with a T output: C = C + result (LoRA updates)
   const float* bias;
@@ -44,6 +43,7 @@ struct GemmParams {
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
   // EPI_TABLE
   const float* E;
+  int dbg;          // timing experiments only (0 in production)
 };
 
 // CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).
@@ -51,7 +51,7 @@ struct GemmParams {
 template <typename CT>
 int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s);
 
-// short name of the kernel launch_gemm picks for this problem ("8p", "8r", "8t", "4w", "nt", "nn", "tn"): timing tags
+// short name of the kernel launch_gemm picks for this problem ("8p", "8t", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
 }  // namespace rsys

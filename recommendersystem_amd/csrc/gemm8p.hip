@@ -61,32 +61,41 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // KM = false: row-major operands (A [M][K], B [N][K]).  KM = true: K-major operands (A [K][M], B [K][N]: the weight
 // gradients dW = dY^T X with K = tokens), split-K with fp32 atomics; the LDS image of a half-tile is then [64 k][256 B]
 // and the fragments are read with ds_read_b64_tr_b16 (two per fragment).
-// RL (row loop, row-major only): for problems whose row count is only known on the device (*m_dev).  The grid covers
-// every column tile but only p.row_groups row tiles; a workgroup walks the row tiles tm, tm + row_groups, ... below
-// *m_dev.  (One workgroup per tile would leave thousands of workgroups with nothing to do, and each still has to wait
-// for a CU with 128 KB of free LDS: at 717 of 4096 rows the logits GEMM spent 2/3 of its time launching them.)
-template <bool KM, bool RL>
+// Row-major form (KM = false) is PERSISTENT: the grid has at most one workgroup per CU and a workgroup walks a strided
+// run of output tiles.  After the last K tile of a tile it first issues the LDS-DMA of the next tile's first two K tiles
+// (both LDS buffers are free by then) and only then runs the epilogue, so the next tile's HBM latency hides behind
+// the epilogue and the epilogue's stores drain behind the next tile's first MFMAs; the counted vmcnt waits of the
+// first K tiles allow for those stores (vector memory operations retire in issue order).  A device-side row count
+// (*m_dev, the head GEMMs) just shortens the tile run: no idle workgroups.
+template <bool KM>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
-  static_assert(!(KM && RL), "row loop is for row-major operands");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
-  const int t = threadIdx.x, l = t & 63;
+  const int t = threadIdx.x, l0 = t & 63;
+  int l = l0;   // refreshed per tile through an opaque move: nothing derived from it is carried across an epilogue
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const int fq = l >> 4, fr = l & 15;
+  int fq = l >> 4, fr = l & 15;
 
-  // ---- output tile, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; each XCD takes a contiguous run
-  // of tiles (tn fastest), which share A rows / B rows through its private L2
-  const int tiles_n = (p.N + T8_BN - 1) / T8_BN, tiles_m = (p.M + T8_BM - 1) / T8_BM;
-  const int ntiles = RL ? p.row_groups * tiles_n : tiles_m * tiles_n;
-  int tile, kt0 = 0, nt;
+  // ---- output tiles, XCD-aware: workgroups are dealt round-robin over the 8 XCDs; each XCD owns a contiguous run of
+  // tiles (tn fastest) and its workgroups walk that run side by side, so neighbouring tiles share A rows / B rows
+  // through the XCD's private L2
+  const int tiles_n = (p.N + T8_BN - 1) / T8_BN;
+  int tile, tile_first = 0, tile_end = 0, tile_step = 1, kt0 = 0, nt;
   if constexpr (!KM) {
-    const int bid = blockIdx.x;
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+    const int rows = p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M;
+    const int ntiles = ((rows + T8_BM - 1) / T8_BM) * tiles_n;
+    const int xcd = blockIdx.x & 7, G = gridDim.x;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    tile_end = (xcd < r ? (xcd + 1) * (q + 1) : r * (q + 1) + (xcd + 1 - r) * q);
+    tile_step = (G + 7 - xcd) >> 3;                    // workgroups on this XCD
+    if (tile >= tile_end) return;                      // uniform: whole workgroup leaves
+    tile_first = tile;
     nt = p.K / T8_BK;                                  // launcher: K % 64 == 0, nt >= 2
   } else {
     // split-K (launcher: splitk % 8 == 0): XCD x owns the K splits x, x+8, ...; inside an XCD the tiles of one split
     // vary fastest, so the K-major operand rows of a split are fetched from HBM by one L2 only
+    const int ntiles = ((p.M + T8_BM - 1) / T8_BM) * tiles_n;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     tile = local % ntiles;
     const int split = xcd + 8 * (local / ntiles);
@@ -95,15 +104,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     nt = min(ktiles, kt0 + per) - kt0;
     if (nt <= 0) return;
   }
-  int tm = tile / tiles_n;
-  const int tn = tile % tiles_n;
-  for (;;) {   // one trip unless RL
-  const int m0 = tm * T8_BM, n0 = tn * T8_BN;
-  if constexpr (RL) { if (m0 >= min(*p.m_dev, p.M)) return; }
-  else if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
+  int m0 = (tile / tiles_n) * T8_BM, n0 = (tile % tiles_n) * T8_BN;
   // ---- DMA source offsets (bytes from the operand base, k tile 0).  Instruction j of wave w fills the 1 KB piece
   // (w*2+j) of a half-tile = local rows (w*2+j)*8 + [0,8); lane l -> local row + (l>>3), stored slot l&7.
   unsigned int aoff[2][2], boff[2][2];   // [j][h]
+  auto tile_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (!KM) {
@@ -132,6 +137,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
   }
+  };
+  tile_offsets();
   // Running operand windows (wave-uniform, SGPRs): a_cur / b_cur = base of K tile kt, a_rem / b_rem = bytes from there
   // to the end of the operand (K-major only: rows past K read as zeros, so the K tail of the last split needs no guard).
   // The K loop advances them with two scalar adds per operand instead of rebuilding 64-bit products per DMA.
@@ -167,9 +174,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   using I1 = std::integral_constant<int, 1>;
 
   // ---- fragment read offsets: lane (fq, fr) takes chunk kk*4+fq of local row base+fr
-  const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
-  const int a_rd0 = (wr * 64 + fr) * 128 + sw0, a_rd1 = (wr * 64 + fr) * 128 + sw1;
-  const int b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0, b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
+  int a_rd0, a_rd1, b_rd0, b_rd1;
+  auto lane_offsets = [&]() __attribute__((always_inline)) {
+    const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
+    a_rd0 = (wr * 64 + fr) * 128 + sw0; a_rd1 = (wr * 64 + fr) * 128 + sw1;
+    b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0; b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
+  };
+  lane_offsets();
   // K-major: lane (fq, fr) supplies the address of row k = 32 kk + 8 fq + (fr>>2) (+4 for the second read), columns
   // 4 (fr&3) .. +3 of block mb; the 16-lane group receives the block's 4 x 16 piece transposed (column fr on lane fr)
   int a_rdk[4], b_rdk[2];
@@ -187,10 +198,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
   auto read_a = [&](int bo, int h) {
@@ -228,22 +235,42 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // One K tile per trip; the buffer index is a run-time offset and the tail of the pipeline is handled by
+  // One K tile per trip; the buffer index is a run-time offset and the ends of the pipeline are handled by
   // wave-uniform branches around the DMA issue (one loop body: the register allocation of the accumulators is the
-  // same for every tile).  Waits: P2 leaves the four half-tiles issued after A1(t) in flight, P4 the three issued
-  // after B1(t+1); at the end of K fewer are outstanding.
+  // same for every tile).  K tiles 0 and 1 are complete in the prologue, so tile 0 issues nothing in P1 / P2.
+  // Waits: P2 leaves the four half-tiles issued after A1(t) in flight, P4 the three issued after B1(t+1); at the end of
+  // K fewer are outstanding.  `pend` = stores of the previous tile's epilogue that were issued after this tile's
+  // prologue: they retire after the prologue's DMA and before everything issued later, so the waits that guard
+  // prologue data (P2, P4 of K tile 0, P2 of K tile 1) allow for them.
+  auto wait_vm = [&](auto BASE, int extra) __attribute__((always_inline)) {
+    constexpr int b = decltype(BASE)::value;
+    switch (extra) {
+      case 16: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 16) : "memory"); break;
+      case 24: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 24) : "memory"); break;
+      case 32: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 32) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b) : "memory"); break;
+    }
+  };
+  using W0 = std::integral_constant<int, 0>;
+  using W2 = std::integral_constant<int, 2>;
+  using W6 = std::integral_constant<int, 6>;
+  using W8 = std::integral_constant<int, 8>;
+  using W10 = std::integral_constant<int, 10>;
+  int pend = 0;
   auto tile_body = [&](int kt) {
     const int bo = (kt & 1) << 16, bn = bo ^ 65536;
     // P1
     read_b(bf0, bo, 0);
     read_a(bo, 0);
-    if (kt + 1 < nt) stage_b(bn, I1{}, 1);
+    if (kt > 0 && kt + 1 < nt) stage_b(bn, I1{}, 1);
     T8_BARRIER();
     mma_q(I0{}, I0{}, bf0);
     T8_BARRIER();
     // P2
     read_b(bf1, bo, 1);
-    if (kt + 1 < nt) { stage_a(bn, I1{}, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    if (kt > 0 && kt + 1 < nt) stage_a(bn, I1{}, 1);
+    if (kt < 2 && pend) { if (kt + 1 < nt) wait_vm(W8{}, pend); else wait_vm(W0{}, pend); }
+    else if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     T8_BARRIER();
     mma_q(I0{}, I1{}, bf1);
@@ -255,29 +282,81 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     mma_q(I1{}, I1{}, bf1);
     T8_BARRIER();
     // P4
-    if (kt + 2 < nt) { stage_a(bo, I0{}, 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    if (kt + 2 < nt) stage_a(bo, I0{}, 2);
+    if (kt == 0 && pend) { if (kt + 2 < nt) wait_vm(W6{}, pend); else wait_vm(W2{}, pend); }
+    else if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     T8_BARRIER();
     mma_q(I1{}, I0{}, bf0);
     T8_BARRIER();
     a_cur += stepA; b_cur += stepB; a_rem -= stepA; b_rem -= stepB;
   };
+  // K tile 0 into buffer 0 and (nt > 1) K tile 1 into buffer 1: 16 DMA instructions per wave
+  auto prologue = [&]() __attribute__((always_inline)) {
+    stage_b(0, I0{}, 0); stage_a(0, I0{}, 0); stage_b(0, I1{}, 0); stage_a(0, I1{}, 0);
+    if (nt > 1) { stage_b(65536, I0{}, 1); stage_a(65536, I0{}, 1); stage_b(65536, I1{}, 1); stage_a(65536, I1{}, 1); }
+  };
+  // Full tiles and edge tiles of the workgroup's run are processed in two passes, each with its own copy of the loops:
+  // in edge tiles the consumers of some epilogue loads are masked stores, which leaves loads "pending" for the
+  // compiler's wait-count pass on some paths; inside one loop nest that would put a vmcnt(0) at the head of every
+  // K-loop trip.  The edge pass ends each tile with a real s_waitcnt vmcnt(0) instead (and so lets its stores drain).
+  auto is_full = [&](int tl) __attribute__((always_inline)) -> bool {
+    return (tl / tiles_n) * T8_BM + T8_BM <= p.M && (tl % tiles_n) * T8_BN + T8_BN <= p.N;
+  };
+  auto run_tiles = [&](auto FULLC) __attribute__((always_inline)) {
+  constexpr bool WANT = decltype(FULLC)::value;
+  if constexpr (!KM) {
+    tile = tile_first;
+    while (tile < tile_end && is_full(tile) != WANT) tile += tile_step;
+    if (tile >= tile_end) return;
+    m0 = (tile / tiles_n) * T8_BM; n0 = (tile % tiles_n) * T8_BN;
+    a_cur = (const char*)p.A; b_cur = (const char*)p.B;
+    tile_offsets();
+  }
+  pend = 0;
+  prologue();
 
-  // ---- prologue: tile 0 complete, B0/A0 of tile 1
-  stage_b(0, I0{}, 0); stage_a(0, I0{}, 0); stage_b(0, I1{}, 0); stage_a(0, I1{}, 0);
-  stage_b(65536, I0{}, 1); stage_a(65536, I0{}, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  for (;;) {   // tiles of this pass (one trip for the K-major form)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // B0, A0, B1 of K tile 0 have landed
+  if (nt > 1) wait_vm(W10{}, pend); else wait_vm(W2{}, pend);
   T8_BARRIER();
   if (wr == 1) T8_BARRIER();   // the second wave row runs one barrier behind the first
 
 #pragma unroll 1
   for (int kt = 0; kt < nt; ++kt) tile_body(kt);
-  if (wr == 0) T8_BARRIER();   // rejoin (equal barrier counts)
+  if (wr == 0) T8_BARRIER();   // rejoin (equal barrier counts): every wave is done with both LDS buffers
 
-  // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
-  if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; return; }   // timing experiment: no epilogue
+  // ---- next tile: its first two K tiles are requested before this tile's results are written
+  const int em0 = m0, en0 = n0;
+  bool more = false;
   if constexpr (!KM) {
-    epilogue_regs<RL>(p, acc, m0 + wr * 128, n0 + wc * 64, m0 + T8_BM <= p.M && n0 + T8_BN <= p.N, fq, fr);
+    tile += tile_step;
+    while (tile < tile_end && is_full(tile) != WANT) tile += tile_step;
+    more = tile < tile_end;
+    if (more) {
+      m0 = (tile / tiles_n) * T8_BM; n0 = (tile % tiles_n) * T8_BN;
+      a_cur = (const char*)p.A; b_cur = (const char*)p.B;
+      tile_offsets();
+      prologue();
+    }
+  }
+  // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
+  if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; if (!more) return; l = l0; asm volatile("" : "+v"(l)); fq = l >> 4; fr = l & 15; lane_offsets(); tile_offsets(); continue; }   // timing experiment: no epilogue
+  if constexpr (!KM) {
+    epilogue_regs<WANT ? 1 : 0>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+    // vector memory instructions of the epilogue that follow its last load (0 where loads are part of it: the next
+    // tile then simply waits a little longer than it must)
+    pend = 0;
+    if constexpr (WANT) {
+      if (more && !(p.dbg & 1)) {
+        if (p.epi == EPI_STORE) pend = p.c_f32 ? 32 : 16;
+        else if (p.epi == EPI_SWIGLU) pend = 24;
+      }
+    } else __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   } else {
     // split-K partial sums: fp32 atomics.  An atomic wave instruction runs at full rate only when its 64 lanes add 256
     // contiguous bytes, so each wave passes its 128x64 block through a private LDS patch, 32 rows at a time
@@ -285,7 +364,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     constexpr int CS_LD = 68;
     float* const Cs = (float*)(smem + w * (32 * CS_LD * 4));
     float* const C = (float*)p.C;
-    const int wm0 = m0 + wr * 128, wn0 = n0 + wc * 64;
+    const int wm0 = em0 + wr * 128, wn0 = en0 + wc * 64;
     const int col = wn0 + l;
     auto stage_acc = [&](auto Q) __attribute__((always_inline)) {
       constexpr int q = decltype(Q)::value;
@@ -310,15 +389,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
   }
-  if constexpr (!RL) break;
-  else {
-    // next row tile of this column: the output stores share vmcnt with the DMA loads the prologue counts, and every
-    // wave must be done with the operand tiles before they are overwritten
-    tm += p.row_groups;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  if (!more) break;
+  // (the DMA offsets of the next tile were consumed by its prologue above; recompute them and the LDS read offsets from
+  // a fresh copy of the lane id instead of holding 12 registers through the epilogue)
+  l = l0; asm volatile("" : "+v"(l));
+  fq = l >> 4; fr = l & 15;
+  lane_offsets();
+  tile_offsets();
   }
-  }
+  };
+  if constexpr (KM) run_tiles(std::true_type{});
+  else { run_tiles(std::true_type{}); run_tiles(std::false_type{}); }
 }
 
 }  // namespace
@@ -364,23 +445,28 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
     if (score > best_score) { best_score = score; best = sk; }
   }
   p.splitk = best;
-  hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(tiles * p.splitk), dim3(512), 0, s, p);
+  hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
+// at most one workgroup per CU (128 KB of LDS each): the kernel walks the remaining tiles itself
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
-  const int tiles_m = (p.M + T8_BM - 1) / T8_BM, tiles_n = (p.N + T8_BN - 1) / T8_BN;
-  if (p.m_dev != nullptr && tiles_m > 1 && p.epi == EPI_STORE) {
-    // device-side row count: about 2048 workgroups, each walking a strided set of row tiles
-    p.row_groups = std::min(tiles_m, std::max(1, 2048 / tiles_n));
-    hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(tiles_n * p.row_groups), dim3(512), 0, s, p);
-    HIP_CHECK(hipGetLastError());
-    return RSYS_OK;
-  }
-  const int tiles = tiles_m * tiles_n;
-  hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(tiles), dim3(512), 0, s, p);
+  static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
+  p.dbg = dbg;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((dbg & 2) ? tiles : std::min(tiles, cu_count())), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -13,9 +13,10 @@
 
 namespace rsys {
 
-// wm0 / wn0: first row / column of the wave's block; full: the whole workgroup tile lies inside the matrix
-// STORE_ONLY: the caller guarantees p.epi == EPI_STORE (the row-loop kernel: fewer live values across its outer loop)
-template <bool STORE_ONLY = false>
+// wm0 / wn0: first row / column of the wave's block; full: the whole workgroup tile lies inside the matrix.
+// MODE 1 / 0: the caller knows at compile time that the tile is full / an edge tile (the persistent kernel runs its
+// full tiles and its edge tiles in two separate loops); -1: decided by `full` at run time.
+template <int MODE = -1>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[8][4], int wm0, int wn0, bool full,
                                               int fq, int fr) {
   auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
@@ -81,6 +82,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     if constexpr (ec == EPI_BIAS || ec == EPI_GELU || ec == EPI_TABLE) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) bias4[j] = ldf4(p.bias, (unsigned int)colclamp(c4 + 16 * j, p.N) * 4u);
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bias4[j].x), "v"(bias4[j].y), "v"(bias4[j].z), "v"(bias4[j].w));
+      }
     }
     // RoPE: byte offset of the lane's (cos, sin) pair inside one position's row for every block; blocks beyond the
     // q and k columns read position 0 (cos 1, sin 0: the rotation is the identity there)
@@ -135,6 +140,14 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     auto finish = [&](auto I, const Pre& pre) __attribute__((always_inline))  {
       constexpr int i = decltype(I)::value;
       const bool rowok = FULL || lrow + 16 * i < p.M;
+      if constexpr (!FULL && (ec == EPI_ACCUM || ec == EPI_RESIDUAL || ec == EPI_TABLE || ec == EPI_QKV_ROPE || ec == EPI_SWIGLU_BWD)) {
+        // Edge tiles: the only consumers of the requested operands are masked stores, and hipcc sinks the wait for a
+        // load into the masked block with them; where the mask is empty the load then stays "pending" for the compiler's
+        // wait-count pass, and in a persistent kernel it would guard the first instructions of the next tile's K loop
+        // on every trip.  An unconditional (empty) use retires the loads here.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(pre.f[j].x), "v"(pre.f[j].y), "v"(pre.f[j].z), "v"(pre.f[j].w));
+      }
       float v[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -244,8 +257,11 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
       finish(std::integral_constant<int, i + 1>{}, pb);
     });
   };
-  auto run2 = [&](auto EC) __attribute__((always_inline))  { if (full) run(EC, std::true_type{}); else run(EC, std::false_type{}); };
-  if constexpr (STORE_ONLY) { run2(std::integral_constant<int, EPI_STORE>{}); return; }
+  auto run2 = [&](auto EC) __attribute__((always_inline))  {
+    if constexpr (MODE == 1) run(EC, std::true_type{});
+    else if constexpr (MODE == 0) run(EC, std::false_type{});
+    else { if (full) run(EC, std::true_type{}); else run(EC, std::false_type{}); }
+  };
   switch (p.epi) {
     case EPI_STORE: run2(std::integral_constant<int, EPI_STORE>{}); break;
     case EPI_ACCUM: run2(std::integral_constant<int, EPI_ACCUM>{}); break;

@@ -128,7 +128,7 @@ def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
 @pytest.mark.parametrize("kern", ["1", "2"])
 def test_gemm_device_side_row_count(monkeypatch, rows, kern):
     """Head GEMMs run over "the rows selected on the device" (GemmParams.m_dev): the 256x256 kernel walks row tiles in
-    a loop (gemm8p_kernel<false, true>), the 128x128 kernel drops whole workgroups.  Rows below the count are exact; rows
+    its persistent tile loop (gemm8p_kernel<false>), the 128x128 kernel drops whole workgroups.  Rows below the count are exact; rows
     past the last started tile keep their previous contents."""
     from recommendersystem_amd import _lib
     monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)
