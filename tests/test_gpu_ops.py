@@ -105,7 +105,9 @@ def test_gemm_bf16_with_f32_source_and_splitk(a_km, b_km):
     assert err < 1e-5, err
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 512), (300, 264, 192), (1000, 200, 576), (2048, 1024, 1408)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 512), (300, 264, 192), (1000, 200, 576), (2048, 1024, 1408),
+                                   # more tiles than CUs: the 256x256 kernel walks 2-3 tiles per workgroup (full and edge passes)
+                                   (9000, 2816, 192), (16384, 1408, 128), (33000, 776, 256)])
 @pytest.mark.parametrize("c_f32", [True, False])
 @pytest.mark.parametrize("kern", ["2", "3"])
 def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):

@@ -11,7 +11,7 @@ rng = np.random.default_rng(2024)
 bad = 0; n = 0
 cases = []
 for _ in range(36):
-    M = int(rng.choice([256, 512, 768, 1024, 2048, 4096, 8192, 1000, 3000]))
+    M = int(rng.choice([256, 512, 768, 1024, 2048, 4096, 8192, 1000, 3000, 16384, 20000]))
     N = int(rng.choice([256, 512, 1024, 1408, 2816, 264, 200, 776]))
     K = int(rng.choice([128, 192, 256, 512, 576, 1024, 1408, 2816]))
     cases.append((M, N, K))
