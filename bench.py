@@ -109,7 +109,7 @@ def main():
     args = ap.parse_args()
 
     import recommendersystem_amd as ra
-    from oracle import synth          # synthetic corpus generator (inputs only)
+    from recommendersystem_amd import workload as synth   # configurations + synthetic corpus (inputs only)
     from recommendersystem_amd import dist as rdist
     from recommendersystem_amd.train import WSDScheduler, LambdaLR
 

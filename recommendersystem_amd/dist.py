@@ -94,8 +94,9 @@ class Comm:
 
 
 class HostComm:
-    """Last-resort gradient all-reduce through host memory over gloo (same surface as Comm).  Only used when the
-    RCCL communicator cannot be created; it is orders of magnitude slower and says so on stderr."""
+    """Gradient all-reduce through host memory over gloo (same surface as Comm): a debugging aid for machines whose RCCL
+    cannot initialise.  Never chosen silently: `make_comm` raises unless RSYS_ALLOW_HOST_ALLREDUCE=1 is set, and the
+    class says what it is on stderr (it is orders of magnitude slower than RCCL over xGMI)."""
 
     def __init__(self, host_group, reason=""):
         import sys
@@ -125,9 +126,16 @@ class HostComm:
         pass
 
 
+def _no_rccl(host_group, reason):
+    if os.environ.get("RSYS_ALLOW_HOST_ALLREDUCE") == "1":
+        return HostComm(host_group, reason)
+    raise RuntimeError(f"RCCL communicator unavailable on at least one rank ({reason}); the gradient all-reduce has no "
+                       "silent host path (set RSYS_ALLOW_HOST_ALLREDUCE=1 to debug with a gloo all-reduce)")
+
+
 def make_comm(host_group, device):
-    """RCCL communicator if possible, else the host fallback; every rank takes the same branch (the outcome of the
-    RCCL attempt is agreed on with a MIN reduction over gloo)."""
+    """RCCL communicator of this rank; every rank takes the same branch (the outcome of the RCCL attempt is agreed on
+    with a MIN reduction over gloo, so a failure raises on all ranks instead of leaving some inside a collective)."""
     if host_group.world == 1:
         return None
     comm, err = None, ""
@@ -140,7 +148,7 @@ def make_comm(host_group, device):
     except Exception as e:   # noqa: BLE001
         loadable, err = 0.0, str(e)
     if -host_group.all_reduce([-loadable], "max")[0] < 1.0:
-        return HostComm(host_group, err or "RCCL not loadable on another rank")
+        return _no_rccl(host_group, err or "RCCL not loadable on another rank")
     try:
         comm = Comm(host_group, device)
         comm.self_test()
@@ -152,7 +160,7 @@ def make_comm(host_group, device):
         return comm
     if comm is not None:
         comm.close()
-    return HostComm(host_group, err or "another rank failed")
+    return _no_rccl(host_group, err or "another rank failed")
 
 
 def shard_for_rank(shards, local_rank, local_world_size):
