@@ -106,7 +106,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
     args = ap.parse_args()
+
+    # the contract is ONE JSON line on stdout: native libraries (RCCL prints a banner at communicator creation) write to
+    # file descriptor 1 behind Python's back, so everything but that line is sent to stderr at the descriptor level
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import recommendersystem_amd as ra
     from recommendersystem_amd import workload as synth   # configurations + synthetic corpus (inputs only)
@@ -127,6 +135,9 @@ def main():
     model.random_pretrained_embeddings(0x3E7A)
     opt = ra.create_optimizer(model, cfg)
     comm = rdist.make_comm(hg, device)      # RCCL over xGMI (hardware_check-style self test inside)
+    if comm is None and args.rehearse_comm:
+        os.environ["RSYS_FORCE_RCCL"] = "1"
+        comm = rdist.Comm(hg, device)
     sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
     for _ in range(2000):
         sched.step()                           # bench at the stable learning rate
@@ -136,6 +147,8 @@ def main():
     model.upload(d)                            # inputs resident in HBM before the timed region
 
     def step():
+        if comm is not None:
+            comm.begin_grad_sync(model)        # trunk gradient buckets are reduced while the backward runs
         model.forward_resident(False)
         if comm is not None:
             comm.all_reduce_grads(model)
@@ -230,7 +243,7 @@ def main():
                 print(f"  {k:22s} {v['ms'] / n_instr:8.3f} ms/step  {v['count'] // n_instr:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, 1)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if comm is not None:
         comm.close()
     model.close()

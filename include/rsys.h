@@ -128,8 +128,15 @@ int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* e
 int32_t rsys_comm_unique_id(uint8_t id_buf[128]);
 int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, int32_t device, rsys_comm** out);
 int32_t rsys_comm_destroy(rsys_comm* c);
-/* sum-all-reduce of the flat gradient buffer in buckets (the mean is folded into rsys_adamw_step's grad_div) */
+/* DDP launches a bucket's all-reduce as soon as its gradients are final (train.py:678-682): call before the backward of
+ * the LAST micro-step of an optimizer step; the trunk backward then starts the all-reduce of each finished >= 25 MB run
+ * of per-layer weight gradients on the communicator's stream while it continues, and rsys_allreduce_grads reduces the
+ * rest.  comm == NULL disarms.  (Micro-steps before the last one accumulate locally: DDP no_sync, train.py:268-271.) */
+int32_t rsys_set_grad_sync(rsys_model* m, rsys_comm* c);
+/* sum-all-reduce of (the rest of) the flat gradient buffer in buckets (the mean is folded into rsys_adamw_step's
+ * grad_div); *early_floats (optional query): how many gradient elements the last call found already reduced */
 int32_t rsys_allreduce_grads(rsys_model* m, rsys_comm* c);
+int32_t rsys_grad_sync_early(rsys_model* m, int64_t* early_floats);
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n);   /* reduce_mean, train.py:199-204 */
 int32_t rsys_self_test(rsys_comm* c);                              /* hardware_check.py:6-12 */
 

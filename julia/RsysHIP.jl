@@ -92,9 +92,12 @@ function Comm(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
 end
 self_test(c::Comm) = check(ccall((:rsys_self_test, LIB), Int32, (Ptr{Cvoid},), c.h))
 allreduce_grads!(m::Model, c::Comm) = check(ccall((:rsys_allreduce_grads, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
+# arm the early gradient buckets for the next backward (the last micro-step of an optimizer step)
+begin_grad_sync!(m::Model, c::Comm) = check(ccall((:rsys_set_grad_sync, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
 
 # One optimizer step of train_epoch (transformer.py:256-276) with grad_accum = 1
 function train_step!(m::Model, o::Optimizer, c::Union{Comm,Nothing}, task_w, lr_factor, seed, step)
+    c === nothing || begin_grad_sync!(m, c)
     forward_backward!(m, false, task_w, 1f0, seed, step)
     c === nothing || allreduce_grads!(m, c)
     step!(o; lr_factor = Float32(lr_factor), clip = 1f0, grad_div = Float32(c === nothing ? 1 : c.world))

@@ -74,7 +74,9 @@ _SIGS = [
     ("rsys_comm_unique_id", C.c_int32, [C.POINTER(C.c_uint8 * 128)]),
     ("rsys_comm_init", C.c_int32, [C.POINTER(C.c_uint8 * 128), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("rsys_comm_destroy", C.c_int32, [_P]),
+    ("rsys_set_grad_sync", C.c_int32, [_P, _P]),
     ("rsys_allreduce_grads", C.c_int32, [_P, _P]),
+    ("rsys_grad_sync_early", C.c_int32, [_P, C.POINTER(C.c_int64)]),
     ("rsys_allreduce_f64", C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32]),
     ("rsys_self_test", C.c_int32, [_P]),
     ("rsys_grad_buffer", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),

@@ -1,4 +1,5 @@
 // extern "C" surface of librsys_hip.so (declared in include/rsys.h).
+#include <algorithm>
 #include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
@@ -268,22 +269,63 @@ int32_t rsys_comm_destroy(rsys_comm* c) {
   return RSYS_OK;
 }
 
-// DDP's bucketed gradient all-reduce (train.py:678-682, 272): the flat gradient buffer is reduced in
-// 64 MiB buckets on the communicator's own stream, ordered after the backward kernels by an event; the
-// compute stream waits for the last bucket before the optimizer reads the gradients.
+// DDP's bucketed gradient all-reduce (train.py:678-682, 272) on the communicator's own stream.
+//
+// rsys_set_grad_sync(model, comm) before the backward of the last micro-step arms the early buckets: the trunk backward
+// hands over each >= 25 MB run of finished per-layer weight gradients (reverse layer order), and its all-reduce is
+// enqueued behind an event while the backward of the lower layers is still running.  rsys_allreduce_grads then reduces
+// whatever is left (heads, small tensors, the item table and the metadata projection, final only after the token
+// scatter) and makes the compute stream wait for the last bucket before the optimizer reads the gradients.
+static int reduce_range(Model* m, rsys_comm* c, int64_t lo, int64_t hi) {
+  const int64_t bucket = 16 * 1024 * 1024;  // floats
+  for (int64_t o = lo; o < hi; o += bucket) {
+    const int64_t n = std::min(bucket, hi - o);
+    NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+  }
+  return RSYS_OK;
+}
+
+int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  m->reduced.clear();
+  m->grad_bucket_hook = nullptr;
+  if (c == nullptr || (c->world == 1 && !c->force) || m->cfg.finetune) return RSYS_OK;
+  m->grad_bucket_hook = [m, c](int64_t lo, int64_t hi) -> int {
+    hi = std::min(hi, m->n_opt);
+    if (lo >= hi) return RSYS_OK;
+    HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    int rc = reduce_range(m, c, lo, hi);
+    if (rc) return rc;
+    m->reduced.emplace_back(lo, hi);
+    return RSYS_OK;
+  };
+  return RSYS_OK;
+}
+
 int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   CHECK_HANDLE(h); CHECK_HANDLE(c);
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
-  const int64_t bucket = 16 * 1024 * 1024;  // floats
-  auto reduce_range = [&](int64_t lo, int64_t hi) -> int {
-    for (int64_t o = lo; o < hi; o += bucket) {
-      const int64_t n = std::min(bucket, hi - o);
-      NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+  m->grad_bucket_hook = nullptr;   // one backward per arming
+  m->early_reduced = 0;
+  for (auto& r : m->reduced) m->early_reduced += r.second - r.first;
+  if (c->world == 1 && !c->force) { m->reduced.clear(); return model_finalize_grads(m); }
+  // what the early buckets have not covered, ascending
+  std::vector<std::pair<int64_t, int64_t>> done = m->reduced, rem;
+  m->reduced.clear();
+  std::sort(done.begin(), done.end());
+  int64_t at = 0;
+  for (auto& r : done) { if (r.first > at) rem.emplace_back(at, r.first); at = std::max(at, r.second); }
+  if (at < m->n_opt) rem.emplace_back(at, m->n_opt);
+  auto reduce_rest = [&](int64_t lo, int64_t hi) -> int {
+    for (auto& r : rem) {
+      const int64_t a = std::max(r.first, lo), b = std::min(r.second, hi);
+      if (a < b) { int rc = reduce_range(m, c, a, b); if (rc) return rc; }
     }
     return RSYS_OK;
   };
-  if (c->world == 1 && !c->force) return model_finalize_grads(m);
   if (model_finalize_splittable(m)) {
     // The last piece of the backward -- the metadata-projection gradient dWp = dF^T Meta, a ~2 ms GEMM on a bf16 copy
     // of dF -- runs on the model's stream while the communication stream already reduces everything else (80 % of the
@@ -293,28 +335,29 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
-    rc = reduce_range(0, std::min(wo, m->n_opt));
+    rc = reduce_rest(0, std::min(wo, m->n_opt));
     if (rc) return rc;
-    rc = reduce_range(std::min(wo + wn, m->n_opt), m->n_opt);
+    rc = reduce_rest(std::min(wo + wn, m->n_opt), m->n_opt);
     if (rc) return rc;
     rc = model_finalize_stage(m, 2, nullptr, nullptr);
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
-    rc = reduce_range(wo, std::min(wo + wn, m->n_opt));
+    rc = reduce_rest(wo, std::min(wo + wn, m->n_opt));
     if (rc) return rc;
   } else {
     int rc = model_finalize_grads(m);
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
-    rc = reduce_range(0, m->n_opt);
+    rc = reduce_rest(0, m->n_opt);
     if (rc) return rc;
   }
   HIP_CHECK(hipEventRecord(c->ev_done, c->stream));
   HIP_CHECK(hipStreamWaitEvent(m->stream, c->ev_done, 0));
   return RSYS_OK;
 }
+int32_t rsys_grad_sync_early(rsys_model* h, int64_t* n) { CHECK_HANDLE(h); ARG_CHECK(n, "null"); *n = h->m->early_reduced; return RSYS_OK; }
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n) {
   CHECK_HANDLE(c);
   ARG_CHECK(n >= 1 && n <= 64 && x, "n in [1,64]");

@@ -738,6 +738,7 @@ static int backward_trunk(Model* m) {
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
+  int bucket_top = m->L - 1;
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
     const bool ft = m->cfg.finetune != 0;   // finetune: base weights are frozen, only the dx chain and the LoRA grads run
@@ -852,6 +853,15 @@ static int backward_trunk(Model* m) {
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
+    if (m->grad_bucket_hook && !ft) {
+      // weight gradients of layers l .. bucket_top are final (the four tensors of a layer are contiguous, layers ascending)
+      const int64_t lo = m->lo[l].wqkv, hi = m->lo[bucket_top].w2 + pad8((int64_t)D * Ip);
+      if (l == 0 || (hi - lo) * 4 >= (25ll << 20)) {
+        RC(join_side(m));
+        RC(m->grad_bucket_hook(lo, hi));
+        bucket_top = l - 1;
+      }
+    }
   }
   toc(m);
   if (m->cfg.finetune) return RSYS_OK;   // embeddings are frozen (model.py:361-369)

@@ -1,5 +1,6 @@
 // Model state + step orchestration (host side of the HIP path).
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +47,12 @@ struct Model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  // DDP-style early gradient reduction (train.py:678-682): when set, the trunk backward hands every finished bucket of
+  // per-layer weight gradients [lo, hi) of the flat buffer to this hook (>= 25 MB each, reverse layer order); the hook
+  // enqueues its all-reduce on the communicator's stream behind an event and records the range in `reduced`
+  std::function<int(int64_t, int64_t)> grad_bucket_hook;
+  std::vector<std::pair<int64_t, int64_t>> reduced;
+  int64_t early_reduced = 0;   // elements the last rsys_allreduce_grads found already reduced (tests)
   bool bf16_mode = false;
   size_t esz = 4;
   // dims

@@ -79,8 +79,19 @@ class Comm:
         """hardware_check.py:6-12: all-reduce of ones must equal the world size."""
         check(lib().rsys_self_test(self._h))
 
+    def begin_grad_sync(self, model):
+        """Before the backward of an optimizer step's last micro-step: finished gradient buckets of the trunk are reduced
+        while the backward is still running (DDP's bucket hooks, train.py:678-682)."""
+        check(lib().rsys_set_grad_sync(model._h, self._h))
+
     def all_reduce_grads(self, model):
         check(lib().rsys_allreduce_grads(model._h, self._h))
+
+    def early_reduced(self, model):
+        """gradient elements the last all_reduce_grads found already reduced by the backward's bucket hooks"""
+        n = C.c_int64()
+        check(lib().rsys_grad_sync_early(model._h, C.byref(n)))
+        return n.value
 
     def all_reduce_sum(self, values):
         arr = (C.c_double * len(values))(*[float(v) for v in values])
@@ -108,6 +119,9 @@ class HostComm:
 
     def self_test(self):
         assert self.hg.all_reduce([1.0], "sum")[0] == float(self.world)
+
+    def begin_grad_sync(self, model):
+        pass
 
     def all_reduce_grads(self, model):
         import torch

@@ -180,6 +180,8 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     optimizer.zero_grad(set_to_none=True)
     world = 1 if comm is None else comm.world
     for step, data in enumerate(dataloader):
+        if comm is not None and (step + 1) % grad_accum_steps == 0:
+            comm.begin_grad_sync(model)        # last micro-step: finished buckets are reduced during the backward
         tloss = model(data, False)
         for i in range(n_tasks):
             w = model.last_weight_sums[i]

@@ -275,6 +275,48 @@ def test_rccl_overlapped_table_gradient(monkeypatch):
         assert relerr(grads[1][n], grads[0][n]) < 1e-5, n
 
 
+def test_rccl_early_gradient_buckets(monkeypatch):
+    """DDP-style bucket hooks (train.py:678-682): armed with rsys_set_grad_sync, the trunk backward starts the all-reduce
+    of finished per-layer weight gradients while it is still running, and rsys_allreduce_grads covers the rest exactly
+    once.  With RCCL forced at world 1 every gradient must equal the plain path's, the early part must be the trunk's
+    weight matrices, and a second (un-armed) step must reduce nothing early."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    monkeypatch.setenv("RSYS_FORCE_RCCL", "1")
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, 5)
+    names = synth.trainable_names(cfg)
+    grads, early = [], []
+    for armed in (False, True):
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        comm = rdist.Comm(rdist.HostGroup(0, 1), 0)
+        if armed:
+            comm.begin_grad_sync(model)
+        model(d, False, masks=(wm, rm))
+        comm.all_reduce_grads(model)
+        early.append(comm.early_reduced(model))
+        grads.append({n: model.grad(n) for n in names})
+        if armed:                                   # arming lasts for one backward
+            model.zero_grad()
+            model(d, False, masks=(wm, rm))
+            comm.all_reduce_grads(model)
+            assert comm.early_reduced(model) == 0
+            for n in names:
+                assert relerr(model.grad(n), grads[0][n]) < 1e-5, n
+        comm.close()
+        model.close()
+    D, I, L = cfg["embed_dim"], cfg["intermediate_dim"], cfg["num_layers"]
+    Ip = (I + 15) // 16 * 16
+    nqkv = (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * (D // cfg["num_heads"])
+    assert early[0] == 0 and early[1] >= L * (nqkv * D + D * D + 2 * I * D + D * I), early
+    for n in names:
+        assert relerr(grads[1][n], grads[0][n]) < 1e-5, n
+
+
 @pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-4, 1e-3), ("bf16", 4e-2, 0.2)])
 def test_finetune_lora_golden(dtype, tol_loss, tol_grad):
     """LoRA finetune (model.py:235-271,361-371,418-435): frozen base, rank-8 updates on q and v,
