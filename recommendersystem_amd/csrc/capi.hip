@@ -290,6 +290,7 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
   Model* m = h->m;
   m->reduced.clear();
   m->grad_bucket_hook = nullptr;
+  m->gemm_flags &= ~2;
   if (c == nullptr || (c->world == 1 && !c->force) || m->cfg.finetune) return RSYS_OK;
   m->grad_bucket_hook = [m, c](int64_t lo, int64_t hi) -> int {
     hi = std::min(hi, m->n_opt);
@@ -309,6 +310,7 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
   m->grad_bucket_hook = nullptr;   // one backward per arming
+  m->gemm_flags &= ~2;             // the optimizer waits for the reduction: nothing after this call overlaps with it
   m->early_reduced = 0;
   for (auto& r : m->reduced) m->early_reduced += r.second - r.first;
   if (c->world == 1 && !c->force) { m->reduced.clear(); return model_finalize_grads(m); }

@@ -43,7 +43,8 @@ struct GemmParams {
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
   // EPI_TABLE
   const float* E;
-  int dbg;          // timing experiments only (0 in production)
+  int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
+                    // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip)
 };
 
 // CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).

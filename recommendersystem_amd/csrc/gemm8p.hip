@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     // tile then simply waits a little longer than it must)
     pend = 0;
     if constexpr (WANT) {
-      if (more && !(p.dbg & 1)) {
+      if (more && !(p.flags & 1)) {
         if (p.epi == EPI_STORE) pend = p.c_f32 ? 32 : 16;
         else if (p.epi == EPI_SWIGLU) pend = 24;
       }
@@ -464,9 +464,9 @@ static int cu_count() {
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
-  p.dbg = dbg;
+  p.flags |= dbg;
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
-  hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((dbg & 2) ? tiles : std::min(tiles, cu_count())), dim3(512), 0, s, p);
+  hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cu_count())), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

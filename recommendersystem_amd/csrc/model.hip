@@ -472,6 +472,7 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
+  p.flags |= m->gemm_flags;
   if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K);
   int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);
   toc(m);
@@ -860,6 +861,10 @@ static int backward_trunk(Model* m) {
         RC(join_side(m));
         RC(m->grad_bucket_hook(lo, hi));
         bucket_top = l - 1;
+        // From here on all-reduce kernels share the CUs with the backward.  A persistent grid (one workgroup pinned per
+        // CU, a fixed share of the tiles each) would stall on every CU a communication kernel holds, so the 256x256
+        // GEMMs go back to one workgroup per tile until the reduction is over: the tiles flow to whatever CUs are free.
+        m->gemm_flags |= 2;
       }
     }
   }

@@ -52,6 +52,7 @@ struct Model {
   // enqueues its all-reduce on the communicator's stream behind an event and records the range in `reduced`
   std::function<int(int64_t, int64_t)> grad_bucket_hook;
   std::vector<std::pair<int64_t, int64_t>> reduced;
+  int gemm_flags = 0;          // OR-ed into GemmParams.flags: 2 while all-reduce kernels may share the CUs with the backward
   int64_t early_reduced = 0;   // elements the last rsys_allreduce_grads found already reduced (tests)
   bool bf16_mode = false;
   size_t esz = 4;
