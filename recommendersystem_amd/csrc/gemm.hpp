@@ -43,6 +43,7 @@ struct GemmParams {
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
   // EPI_TABLE
   const float* E;
+  unsigned long long* trace;   // tools/micro/gemm8p_trace.hip only (kernel built with RSYS_8P_TRACE): per-workgroup cycle sums
   int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
                     // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip)
 };

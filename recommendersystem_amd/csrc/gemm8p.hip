@@ -245,6 +245,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   auto wait_vm = [&](auto BASE, int extra) __attribute__((always_inline)) {
     constexpr int b = decltype(BASE)::value;
     switch (extra) {
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 4) : "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 8) : "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 12) : "memory"); break;
       case 16: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 16) : "memory"); break;
       case 24: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 24) : "memory"); break;
       case 32: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(b + 32) : "memory"); break;
@@ -303,6 +306,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   auto is_full = [&](int tl) __attribute__((always_inline)) -> bool {
     return (tl / tiles_n) * T8_BM + T8_BM <= p.M && (tl % tiles_n) * T8_BN + T8_BN <= p.N;
   };
+#ifdef RSYS_8P_TRACE   // instrumented build of tools/micro/gemm8p_trace.hip: where a workgroup's cycles go, per tile section
+  unsigned long long tr_sum[5] = {0, 0, 0, 0, 0}, tr_at = 0, tr_tiles = 0;
+#define TR_START() (tr_at = __builtin_amdgcn_s_memtime())
+#define TR_MARK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tr_sum[i] += n_ - tr_at; tr_at = n_; } while (0)
+#else
+#define TR_START() ((void)0)
+#define TR_MARK(i) ((void)0)
+#endif
   auto run_tiles = [&](auto FULLC) __attribute__((always_inline)) {
   constexpr bool WANT = decltype(FULLC)::value;
   if constexpr (!KM) {
@@ -314,7 +325,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     tile_offsets();
   }
   pend = 0;
+  if constexpr (!KM) {
+    if (p.flags & 4) {   // timing experiment: every other workgroup of an XCD starts p.T microsecond-ish naps late
+      if ((blockIdx.x >> 3) & 1) for (int k = 0; k < p.T; ++k) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   prologue();
+  TR_START();
 
   for (;;) {   // tiles of this pass (one trip for the K-major form)
 #pragma unroll
@@ -325,10 +342,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   if (nt > 1) wait_vm(W10{}, pend); else wait_vm(W2{}, pend);
   T8_BARRIER();
   if (wr == 1) T8_BARRIER();   // the second wave row runs one barrier behind the first
+  TR_MARK(0);
 
 #pragma unroll 1
   for (int kt = 0; kt < nt; ++kt) tile_body(kt);
   if (wr == 0) T8_BARRIER();   // rejoin (equal barrier counts): every wave is done with both LDS buffers
+  TR_MARK(1);
 
   // ---- next tile: its first two K tiles are requested before this tile's results are written
   const int em0 = m0, en0 = n0;
@@ -344,17 +363,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       prologue();
     }
   }
+  TR_MARK(2);
   // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; if (!more) return; l = l0; asm volatile("" : "+v"(l)); fq = l >> 4; fr = l & 15; lane_offsets(); tile_offsets(); continue; }   // timing experiment: no epilogue
   if constexpr (!KM) {
     epilogue_regs<WANT ? 1 : 0>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
-    // vector memory instructions of the epilogue that follow its last load (0 where loads are part of it: the next
-    // tile then simply waits a little longer than it must)
+    // A lower bound on the vector memory instructions of the epilogue that follow its last load: all stores where the
+    // epilogue has no loads, else the stores of its last two row blocks (the last operand request precedes them).  A
+    // smaller number only makes the next tile wait for more of the stores than it must.
     pend = 0;
     if constexpr (WANT) {
       if (more && !(p.flags & 1)) {
-        if (p.epi == EPI_STORE) pend = p.c_f32 ? 32 : 16;
-        else if (p.epi == EPI_SWIGLU) pend = 24;
+        switch (p.epi) {
+          case EPI_STORE: pend = p.c_f32 ? 32 : 16; break;
+          case EPI_SWIGLU: pend = 24; break;
+          case EPI_ACCUM: case EPI_RESIDUAL: case EPI_SWIGLU_BWD: pend = 8; break;
+          case EPI_TABLE: pend = 12; break;
+          case EPI_QKV_ROPE: pend = p.c_f32 ? 8 : 4; break;
+          default: break;
+        }
       }
     } else __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   } else {
@@ -389,6 +416,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
   }
+  TR_MARK(3);
+#ifdef RSYS_8P_TRACE
+  ++tr_tiles;
+#endif
   if (!more) break;
   // (the DMA offsets of the next tile were consumed by its prologue above; recompute them and the LDS read offsets from
   // a fresh copy of the lane id instead of holding 12 registers through the epilogue)
@@ -396,10 +427,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   fq = l >> 4; fr = l & 15;
   lane_offsets();
   tile_offsets();
+  TR_MARK(4);
   }
   };
   if constexpr (KM) run_tiles(std::true_type{});
   else { run_tiles(std::true_type{}); run_tiles(std::false_type{}); }
+#ifdef RSYS_8P_TRACE
+  if (p.trace != nullptr && t == 0) {
+    for (int i = 0; i < 5; ++i) p.trace[blockIdx.x * 8 + i] = tr_sum[i];
+    p.trace[blockIdx.x * 8 + 5] = tr_tiles;
+  }
+#endif
 }
 
 }  // namespace

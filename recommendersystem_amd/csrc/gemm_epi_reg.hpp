@@ -247,13 +247,19 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
         }
       }
     };
+    // software pipeline over the 8 row blocks: the operands of block i+1 are in flight while block i is finished.  (Two
+    // blocks of lookahead measured the same -- 31 K vs 33 K cycles per tile for the residual epilogue,
+    // tools/micro/gemm8p_trace.hip: with every CU in its epilogue at once these loads are bandwidth-, not latency-bound
+    // -- and cost 16 more registers.)  The memory clobbers keep each request ahead of the stores that follow it in
+    // program order: the persistent kernel counts on "the stores of the last row block follow the last load".
     Pre pa, pb;
     request(std::integral_constant<int, 0>{}, pa);
     static_for<4>([&](auto H) __attribute__((always_inline))  {
       constexpr int i = decltype(H)::value * 2;
       request(std::integral_constant<int, i + 1>{}, pb);
+      asm volatile("" ::: "memory");
       finish(std::integral_constant<int, i>{}, pa);
-      if constexpr (i + 2 < 8) request(std::integral_constant<int, i + 2>{}, pa);
+      if constexpr (i + 2 < 8) { request(std::integral_constant<int, i + 2>{}, pa); asm volatile("" ::: "memory"); }
       finish(std::integral_constant<int, i + 1>{}, pb);
     });
   };
