@@ -161,7 +161,7 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
 int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev);
 /* attention fwd+bwd on caller-provided device buffers (T-typed): qkv [B*T][(H+2KV)*hd] post-RoPE, dO [B*T][H*hd],
- * uid/tm [B*T] int32, rope tables [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32,
+ * uid/tm [B*T] int32 with 0 <= uid < 2^19 and 0 <= tm < 4096, rope tables [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32,
  * dqkv [B*T][(H+2KV)*hd] (gradients w.r.t. the un-rotated q, k and v) */
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,

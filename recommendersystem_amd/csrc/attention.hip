@@ -21,6 +21,9 @@ namespace rsys {
 
 #define SENT_Q (-2147483647)
 #define SENT_K (-2147483646)
+// token keys (uid << 12 | tm) of tokens past the end of a row: never equal to each other or to a real key (uid < 2^19)
+#define KEY_NO_Q ((int)0xFFFFE000u)
+#define KEY_NO_K ((int)0xFFFFFFFFu)
 constexpr float LOG2E = 1.4426950408889634f;
 // v_exp_f32 directly (exp2f adds range scaling the softmax arguments never need: they are <= 0 or hugely negative)
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -202,22 +205,25 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   return RSYS_OK;
 }
 
-// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS, the lane's own ids (u, tmv).
-// allowed(q, kv) = uid equal AND (tm[kv] == 0 OR tm equal)  <=>  ((uq ^ uk) | ((tq ^ tk) & mk)) == 0 with mk = tm[kv] ? ~0 : 0.
-// LANE_IS_Q: the lane is the query and the rows are keys (ms = the keys' mk, staged with the tile); else the lane is
-// the key (lane_m = its own mk) and the rows are queries.  Five vector ops per score.
+// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS against the lane's own ids.
+// allowed(q, kv) = uid equal AND (tm[kv] == 0 OR tm equal).  With the token key a = uid << 12 | tm (host-checked:
+// 0 <= uid < 2^19, 0 <= tm < 4096) this is  a[kv] == (a[q] & ~4095)  OR  a[kv] == a[q]: two compares, one scalar OR
+// and the select -- three vector ops per score (the xor / and-or form took five).
+// LANE_IS_Q: the lane is the query (b0 = its key without tm, b1 = its key) and the rows are keys (ks = their keys,
+// staged with the tile); else the lane is the key (b0 holds its key) and the rows are queries (ks = their b0, ks2 = b1).
+__device__ __forceinline__ int token_key(int uid, int tm) { return (int)(((unsigned int)uid << 12) | (unsigned int)tm); }
 template <bool LANE_IS_Q>
-__device__ __forceinline__ void mask_tile(f32x4& S, const int* us, const int* ts, const int* ms, int tok0, int u, int tmv, int lane_m, int g, float fill) {
-  const int4 u4 = *(const int4*)(us + tok0 + 4 * g);
-  const int4 t4 = *(const int4*)(ts + tok0 + 4 * g);
-  const int uu[4] = {u4.x, u4.y, u4.z, u4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
-  int mm[4];
-  if (LANE_IS_Q) { const int4 m4 = *(const int4*)(ms + tok0 + 4 * g); mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w; }
-  else { mm[0] = mm[1] = mm[2] = mm[3] = lane_m; }
+__device__ __forceinline__ void mask_tile(f32x4& S, const int* ks, const int* ks2, int tok0, int b0, int b1, int g, float fill) {
+  const int4 a4 = *(const int4*)(ks + tok0 + 4 * g);
+  const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+  if (LANE_IS_Q) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int bad = (u ^ uu[r]) | ((tmv ^ tt[r]) & mm[r]);
-    S[r] = bad == 0 ? S[r] : fill;
+    for (int r = 0; r < 4; ++r) S[r] = (aa[r] == b0 || aa[r] == b1) ? S[r] : fill;
+  } else {
+    const int4 c4 = *(const int4*)(ks2 + tok0 + 4 * g);
+    const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[r] = (b0 == aa[r] || b0 == cc[r]) ? S[r] : fill;
   }
 }
 
@@ -245,9 +251,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ks = (T*)smem_raw;                       // [2][64][LDD]
   T* Vs = Ks + 2 * C::TILE;                   // [2][64][LDD]
-  int* uk = (int*)(Vs + 2 * C::TILE);         // [2][64]
-  int* tk = uk + 128;                         // [2][64]
-  int* mk = tk + 128;                         // [2][64]  tm[kv] ? ~0 : 0
+  int* ak = (int*)(Vs + 2 * C::TILE);         // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) qf[s] = frag_global<T>(qrow, s * C::KS, HD, l);
   }
-  const int uq = qv ? p.uid[tok0 + q] : SENT_Q, tq = qv ? p.tm[tok0 + q] : 0;
+  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   float m_run = -1e30f, l_run = 0.f;
   f32x4 oacc[HD / 16];
 #pragma unroll
@@ -274,17 +278,17 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
 
   TileRegs<T, HD> rk, rv;
-  int ru = 0, rt = 0;
+  int ra = 0;
   auto gload = [&](int kt) {
     const int nv = min(64, p.T - kt * 64);
     tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
     tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    if (t < 64) { ru = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; rt = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
+    if (t < 64) ra = t < nv ? token_key(p.uid[tok0 + kt * 64 + t], p.tm[tok0 + kt * 64 + t]) : KEY_NO_K;
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; mk[buf * 64 + t] = rt ? -1 : 0; }
+    if (t < 64) ak[buf * 64 + t] = ra;
   };
 
   int kt = next_bit(bits, 0);
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     first_stage<T, HD>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, mk + cur * 64, 16 * i, uq, tq, 0, g, -1e30f);
+      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], ak + cur * 64, nullptr, 16 * i, aq0, aq, g, -1e30f);
     }
     float tmax = -1e30f;
 #pragma unroll
@@ -470,8 +474,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   T* dOs = Qs + 2 * C::TILE;             // [2][64 q][LDD]
   float* lse2 = (float*)(dOs + 2 * C::TILE);   // [2][64]
   float* dls = lse2 + 128;                      // [2][64]
-  int* uqs = (int*)(dls + 128);                 // [2][64]
-  int* tqs = uqs + 128;                         // [2][64]
+  int* q0s = (int*)(dls + 128);                 // [2][64] query keys without tm
+  int* q1s = q0s + 128;                         // [2][64] query keys
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   int grp, kvt;
   attn_work(p.B * p.KV, nt, grp, kvt);
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) { kf[s] = frag_global<T>(krow, s * C::KS, HD, l); vf[s] = frag_global<T>(vrow, s * C::KS, HD, l); }
   }
-  const int ukv = kvv ? p.uid[tok0 + kv] : SENT_K, tkv = kvv ? p.tm[tok0 + kv] : 0;
+  const int akv = kvv ? token_key(p.uid[tok0 + kv], p.tm[tok0 + kv]) : KEY_NO_K;
   f32x4 dK[HD / 16], dV[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const unsigned int bits = p.kmap[b * nt + kvt], fullbits = p.kmap_full[b * nt + kvt];
 
   TileRegs<T, HD> rq, rdo;
-  float rl = 0.f, rd = 0.f; int ru = 0, rt = 0;
+  float rl = 0.f, rd = 0.f; int ra = 0;
   auto gload = [&](int it) {   // it = head-in-group * 32 + q tile
     const int h = kvh * rep + (it >> 5), qt = it & 31;
     const int nv = min(64, p.T - qt * 64);
@@ -506,13 +510,13 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
       const bool v = t < nv;
       const long long o = ((long long)b * p.H + h) * p.T + qt * 64 + (v ? t : 0);
       rl = v ? p.lse[o] * LOG2E : 0.f; rd = v ? p.delta[o] : 0.f;
-      ru = v ? p.uid[tok0 + qt * 64 + t] : SENT_Q; rt = v ? p.tm[tok0 + qt * 64 + t] : 0;
+      ra = v ? token_key(p.uid[tok0 + qt * 64 + t], p.tm[tok0 + qt * 64 + t]) : KEY_NO_Q;
     }
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rq, Qs + buf * C::TILE, t);
     tile_store<T, HD>(rdo, dOs + buf * C::TILE, t);
-    if (t < 64) { lse2[buf * 64 + t] = rl; dls[buf * 64 + t] = rd; uqs[buf * 64 + t] = ru; tqs[buf * 64 + t] = rt; }
+    if (t < 64) { lse2[buf * 64 + t] = rl; dls[buf * 64 + t] = rd; q0s[buf * 64 + t] = ra & ~4095; q1s[buf * 64 + t] = ra; }
   };
   auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
     int hh = from >> 5, qt = from & 31;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
       const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
       const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
       const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-      if (!fullt) mask_tile<false>(S[i], uqs + cur * 64, tqs + cur * 64, nullptr, 16 * i, ukv, tkv, tkv ? -1 : 0, g, -1e30f);
+      if (!fullt) mask_tile<false>(S[i], q0s + cur * 64, q1s + cur * 64, 16 * i, akv, 0, g, -1e30f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pv = fexp2(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
@@ -577,9 +581,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ks = (T*)smem_raw;                  // [2][64 kv][LDD]
   T* Vs = Ks + 2 * C::TILE;              // [2][64 kv][LDD]
-  int* uk = (int*)(Vs + 2 * C::TILE);    // [2][64]
-  int* tk = uk + 128;
-  int* mk = tk + 128;                    // [2][64]  tm[kv] ? ~0 : 0
+  int* ak = (int*)(Vs + 2 * C::TILE);    // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) { qf[s] = frag_global<T>(qrow, s * C::KS, HD, l); dof[s] = frag_global<T>(drow, s * C::KS, HD, l); }
   }
-  const int uq = qv ? p.uid[tok0 + q] : SENT_Q, tq = qv ? p.tm[tok0 + q] : 0;
+  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   const long long so = ((long long)b * p.H + h) * p.T + min(q, p.T - 1);
   const float lse2 = qv ? p.lse[so] * LOG2E : 0.f, dl = qv ? p.delta[so] : 0.f;
   f32x4 dQ[HD / 16];
@@ -607,17 +609,17 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
   const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
   TileRegs<T, HD> rk, rv;
-  int ru = 0, rt = 0;
+  int ra = 0;
   auto gload = [&](int kt) {
     const int nv = min(64, p.T - kt * 64);
     tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
     tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    if (t < 64) { ru = t < nv ? p.uid[tok0 + kt * 64 + t] : SENT_K; rt = t < nv ? p.tm[tok0 + kt * 64 + t] : 0; }
+    if (t < 64) ra = t < nv ? token_key(p.uid[tok0 + kt * 64 + t], p.tm[tok0 + kt * 64 + t]) : KEY_NO_K;
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) { uk[buf * 64 + t] = ru; tk[buf * 64 + t] = rt; mk[buf * 64 + t] = rt ? -1 : 0; }
+    if (t < 64) ak[buf * 64 + t] = ra;
   };
   int kt = next_bit(bits, 0), cur = 0;
   if (kt < nt) { gload(kt); lstore(0); }
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     const bool fullt = (fullbits >> kt) & 1u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!fullt) mask_tile<true>(S[i], uk + cur * 64, tk + cur * 64, mk + cur * 64, 16 * i, uq, tq, 0, g, -1e30f);
+      if (!fullt) mask_tile<true>(S[i], ak + cur * 64, nullptr, 16 * i, aq0, aq, g, -1e30f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pv = fexp2(fmaf(S[i][r], c2, -lse2));

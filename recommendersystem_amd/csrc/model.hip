@@ -435,6 +435,9 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   for (size_t i = 0; i < N; ++i) {
     int id = b->matchedid[i];
     ARG_CHECK(id >= -1 && id < m->V, "matchedid out of range");
+    // the attention kernels compare tokens through the key userid << 12 | token_mask_ids (attention.hip: mask_tile)
+    ARG_CHECK(b->userid[i] >= 0 && b->userid[i] < (1 << 19), "userid must be in [0, 2^19)");
+    ARG_CHECK(b->token_mask_ids[i] >= 0 && b->token_mask_ids[i] < 4096, "token_mask_ids must be in [0, 4096)");
     ARG_CHECK(b->status[i] >= -1 && b->status[i] <= m->cfg.vocab_status, "status out of range");
     ARG_CHECK(b->gender[i] >= -1 && b->gender[i] <= m->cfg.vocab_gender, "gender out of range");
     ARG_CHECK(b->source[i] >= -1 && b->source[i] <= m->cfg.vocab_source, "source out of range");
