@@ -166,7 +166,7 @@ __device__ __forceinline__ int next_bit(unsigned int bits, int from) {  // lowes
 // qmap / qmap_full [b][q tile]: bit j = kv tile j has some / only allowed pairs; kmap* is the transposed relation.
 __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   __shared__ int uq[64], tq[64];
-  __shared__ unsigned int any_bits;
+  __shared__ unsigned int any_bits, any16[4];
   __shared__ int cnt[32];
   const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const int nt = (p.T + 63) / 64;
@@ -176,13 +176,23 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
     uq[t] = v ? p.uid[base + qt * 64 + t] : SENT_Q; tq[t] = v ? p.tm[base + qt * 64 + t] : 0;
   }
   if (t == 0) any_bits = 0u;
+  if (t < 4) any16[t] = 0u;
   if (t < 32) cnt[t] = 0;
   __syncthreads();
   for (int kv = t; kv < p.T; kv += 256) {
     const int uk = p.uid[base + kv], tk = p.tm[base + kv];
     int n = 0;
-    for (int i = 0; i < 64; ++i) n += ((uq[i] == uk) && (tk == 0 || tq[i] == tk)) ? 1 : 0;
-    if (n) { atomicOr(&any_bits, 1u << (kv >> 6)); atomicAdd(&cnt[kv >> 6], n); }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      int ng = 0;
+      for (int i = 0; i < 16; ++i) ng += ((uq[gq * 16 + i] == uk) && (tk == 0 || tq[gq * 16 + i] == tk)) ? 1 : 0;
+      if (ng) atomicOr(&any16[gq], 1u << (kv >> 6));
+      n += ng;
+    }
+    if (n) {
+      atomicOr(&any_bits, 1u << (kv >> 6)); atomicAdd(&cnt[kv >> 6], n);
+      atomicOr(&p.kmap16[(b * nt + (kv >> 6)) * 4 + ((kv >> 4) & 3)], 1u << qt);
+    }
   }
   __syncthreads();
   if (t < nt) {
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
     if (full) atomicOr(&p.qmap_full[b * nt + qt], 1u << t);
   }
   if (t == 0) p.qmap[b * nt + qt] = any_bits;
+  if (t < 4) p.qmap16[(b * nt + qt) * 4 + t] = any16[t];
 }
 
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
@@ -200,6 +211,7 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(p.kmap, 0, bytes, s));
   HIP_CHECK(hipMemsetAsync(p.kmap_full, 0, bytes, s));
   HIP_CHECK(hipMemsetAsync(p.qmap_full, 0, bytes, s));
+  HIP_CHECK(hipMemsetAsync(p.kmap16, 0, bytes * 4, s));
   hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   for (int j = 0; j < HD / 16; ++j) oacc[j] = f32x4{0, 0, 0, 0};
   zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t);
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);   // kv tiles this wave's 16 queries take part in
   const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
   const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
 
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     if (nxt < nt) gload(nxt);
     const T* Kc = Ks + cur * C::TILE;
     const T* Vc = Vs + cur * C::TILE;
+    if ((wbits >> kt) & 1u) {   // (a wave whose 16 queries have no allowed key in this tile leaves its state untouched)
     f32x4 S[4];
     first_stage<T, HD>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
@@ -332,6 +346,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) oacc[j] *= alpha;
     acc_second_stage<T, HD>(oacc, S, Vc, l);
+    }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -498,6 +513,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Qs + i * C::TILE, t); zero_pad_cols<T, HD>(dOs + i * C::TILE, t); }
   const unsigned int bits = p.kmap[b * nt + kvt], fullbits = p.kmap_full[b * nt + kvt];
+  const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.kmap16[(b * nt + kvt) * 4 + w]);   // q tiles that may see this wave's 16 keys
 
   TileRegs<T, HD> rq, rdo;
   float rl = 0.f, rd = 0.f; int ra = 0;
@@ -536,6 +552,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     if (nxt < end) gload(nxt);
     const T* Qc = Qs + cur * C::TILE;
     const T* dOc = dOs + cur * C::TILE;
+    if ((wbits >> (it & 31)) & 1u) {   // (nothing to add for a wave whose 16 keys no query of this tile may see)
     f32x4 S[4], dP[4];
     first_stage<T, HD>(S, Qc, kf, l);      // S[q][kv]: rows q (registers), col kv (lane)
     first_stage<T, HD>(dP, dOc, vf, l);    // dP[q][kv]
@@ -555,6 +572,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     }
     acc_second_stage<T, HD>(dV, S, dOc, l);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
     acc_second_stage<T, HD>(dK, dP, Qc, l);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+    }
     if (nxt < end) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -606,6 +624,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   for (int j = 0; j < HD / 16; ++j) dQ[j] = f32x4{0, 0, 0, 0};
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
   const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
   const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
   TileRegs<T, HD> rk, rv;
@@ -629,6 +648,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     if (nxt < nt) gload(nxt);
     const T* Kc = Ks + cur * C::TILE;
     const T* Vc = Vs + cur * C::TILE;
+    if ((wbits >> kt) & 1u) {
     f32x4 S[4], dP[4];
     first_stage<T, HD>(S, Kc, qf, l);      // S^T[kv][q]
     first_stage<T, HD>(dP, Vc, dof, l);    // dP^T[kv][q]
@@ -643,6 +663,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
       }
     }
     acc_second_stage<T, HD>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
+    }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;

@@ -101,6 +101,9 @@ struct AttnParams {
   // [B][ceil(T/64)] bitmaps: qmap bit j = kv tile j has an allowed pair with this q tile, qmap_full = every pair allowed;
   // kmap / kmap_full: the transposed relation (bit j = q tile j)
   unsigned int *qmap, *kmap, *qmap_full, *kmap_full;
+  // [B][ceil(T/64)][4]: the same "some allowed pair" bits per group of 16 queries (qmap16: bit j = kv tile j) and per
+  // group of 16 keys (kmap16: bit j = q tile j): a wave owns one such group and skips the tiles it has nothing in
+  unsigned int *qmap16, *kmap16;
   // backward
   const void* dO; const float* delta;
   void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv

@@ -213,6 +213,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
   DALLOC(m->qmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
   DALLOC(m->qmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
+  DALLOC(m->qmap16, (int64_t)m->rows_max * ((m->T + 63) / 64) * 16); DALLOC(m->kmap16, (int64_t)m->rows_max * ((m->T + 63) / 64) * 16);
   m->la.resize(m->L);
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
@@ -571,7 +572,7 @@ static int forward_trunk(Model* m) {
   RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
-  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
   tic(m, "phase_trunk_fwd");
@@ -740,7 +741,7 @@ static int backward_trunk(Model* m) {
   RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
-  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full;
+  ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
   int bucket_top = m->L - 1;
   for (int l = m->L - 1; l >= 0; --l) {

@@ -86,7 +86,7 @@ struct Model {
   unsigned char *d_wm = nullptr, *d_rm = nullptr;
   int* d_rope_pos = nullptr;
   // activations (void* = T-typed)
-  void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap, *qmap_full, *kmap_full;
+  void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap, *qmap_full, *kmap_full, *qmap16, *kmap16;
   struct LayerAct { float* x; void* xn; void* xnd; void* La; void* qkv; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
   std::vector<LayerAct> la;
   float* xL; float* rstdf; void* out;
