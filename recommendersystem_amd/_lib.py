@@ -7,6 +7,10 @@ GPU returns an error from the library ("no HIP device visible").
 import ctypes as C
 import os
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's ncclCommInitRank fails with
+# "hipIpcGetMemHandle: invalid argument" otherwise); set before the HIP runtime is first loaded, never overriding the caller
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librsys_hip.so")
 
