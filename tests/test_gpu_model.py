@@ -221,6 +221,39 @@ def test_random_masks_and_properties_at_scale():
     model.close()
 
 
+@pytest.mark.parametrize("dtype,tol_loss,tol_act", [("fp32", 1e-4, 1e-4), ("bf16", 4e-2, 6e-2)])
+def test_production_sequence_length(dtype, tol_loss, tol_act):
+    """The reference's production row is S = 1024 interactions = 2048 tokens (train.py:551): 32 tiles per row, the widest
+    the tile bitmaps hold (bit 31 in use), 64-token tiles that straddle users, a row that ends in padding.  Narrow
+    model, one row, against the oracle; the second row is all padding (userid 0, no targets)."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("hd64", mask_rate=0.15, mask_topk=160, max_sequence_length=1024, num_layers=1)
+    rows, seed = 2, 77
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1, mu=np.log(150.0), sigma=0.7)
+    S = cfg["max_sequence_length"]
+    for k in d:                                     # row 0: real users, tail padded; row 1: padding only
+        d[k][S - 37:] = 0
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    y_ref, l_ref, G_ref, _ = _oracle(cfg, P, d, wm, rm)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    y = model.trunk_output(rows)
+    live = np.zeros(rows * S * 2, bool); live[:2 * (S - 37)] = True      # padded tokens attend among themselves only
+    assert relerr(y.reshape(-1, y.shape[-1])[live], y_ref.reshape(-1, y_ref.shape[-1])[live]) < tol_act
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, l_ref)
+    for n in ("transformers.layers.0.attn.q_proj.weight", "transformers.layers.0.attn.v_proj.weight",
+              "item_embedding.matchedid_embedding.embedding.weight"):
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-12)
+        assert np.abs(g - G_ref[n]).max() / scale < (2e-3 if dtype == "fp32" else 0.2), n
+    model.close()
+
+
 def test_rccl_communicator_world1(monkeypatch):
     """RCCL path on one GPU: ncclCommInitRank(world=1), the bucketed gradient all-reduce and the f64
     all-reduce really call RCCL (RSYS_FORCE_RCCL=1) and leave sums unchanged; hardware_check self test."""
