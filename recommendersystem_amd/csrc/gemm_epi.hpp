@@ -1,7 +1,7 @@
-// Fused GEMM epilogues shared by the two MFMA GEMM kernels (gemm.hip: 128x128 register-staged tiles for every
-// operand layout; gemm8p.hip: 256x256 LDS-DMA 8-phase tiles for row-major bf16 operands).  Both kernels stage the
-// accumulators through LDS and hand every lane W consecutive columns of one output row; epi_item applies the
-// epilogue to those W values and writes them with 16-byte accesses.
+// Fused GEMM epilogues, LDS-staged form: used by the 128x128 kernel (gemm.hip), which passes its accumulators through
+// LDS and hands every lane W consecutive columns of one output row; epi_item applies the epilogue to those W values and
+// writes them with 16-byte accesses.  (The 256-wide kernels write straight from registers: gemm_epi_reg.hpp.)
+// Also declares the launchers of the LDS-DMA kernels (gemm8p.hip, gemm4w.hip) for the dispatcher in gemm.hip.
 #pragma once
 #include <utility>
 
