@@ -224,15 +224,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
   };
+#ifndef T8_VARIANT
+#define T8_VARIANT 0   // tools/micro/gemm8p_trace.hip experiments: 1 = all LDS reads retired before the first MFMA of a phase, 2 = no s_setprio, 3 = both
+#endif
   auto mma_q = [&](auto IH, auto JH, const bf16x8(&bf)[2][2]) {
     constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (T8_VARIANT & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!(T8_VARIANT & 2)) __builtin_amdgcn_s_setprio(1);
     static_for<4>([&](auto i) { static_for<2>([&](auto j) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
         acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
     }); });
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(T8_VARIANT & 2)) __builtin_amdgcn_s_setprio(0);
   };
 
   // One K tile per trip; the buffer index is a run-time offset and the ends of the pipeline are handled by

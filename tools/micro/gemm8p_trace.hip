@@ -9,7 +9,10 @@
 #define RSYS_8P_TRACE 1
 #include "../../recommendersystem_amd/csrc/gemm8p.hip"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -21,7 +24,13 @@ static void run(int M, int N, int K, int epi, int c_f32, int stagger = 0) {
   hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2);
   hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&C2, (size_t)M * N * 2); hipMalloc(&R, (size_t)M * N * 4);
   hipMalloc(&tr, 8 * 8 * 1024);
-  hipMemset(A, 0x3c, (size_t)M * K * 2); hipMemset(B, 0x3c, (size_t)N * K * 2); hipMemset(R, 0, (size_t)M * N * 4);
+  {   // uniform random bf16 in [-1, 1): operand data sets the power draw and with it the clock (constant data reads 15-20 % high)
+    std::vector<unsigned short> h((size_t)std::max(M, N) * K);
+    unsigned int x = 0x1234567u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; const float f = (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f; unsigned int u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+    hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  }
+  hipMemset(R, 0, (size_t)M * N * 4);
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.epi = epi; p.c_f32 = c_f32;
   p.alpha = 1.f; p.splitk = 1; p.trace = tr;
@@ -51,15 +60,15 @@ static void run(int M, int N, int K, int epi, int c_f32, int stagger = 0) {
 int main() {
   using namespace rsys;
   const int NT = 65536;
-  for (int st : {0, 4, 8, 12}) {
-    run(NT, 1024, 512, EPI_STORE, 0, st);
-    run(NT, 2816, 512, EPI_SWIGLU, 0, st);
-    run(NT, 2816, 512, EPI_STORE, 0, st);
-    run(NT, 512, 1408, EPI_RESIDUAL, 1, st);
-    run(NT, 1408, 512, EPI_STORE, 0, st);
-  }
-  run(NT, 512, 512, EPI_RESIDUAL, 1);
-  run(NT, 512, 2816, EPI_STORE, 0);
-  run(8192, 8192, 8192, EPI_STORE, 0);
+  const int stagger = getenv("TRACE_STAGGER") ? atoi(getenv("TRACE_STAGGER")) : 0;   // 1 us-ish naps for every other workgroup
+  run(NT, 1024, 512, EPI_STORE, 0, stagger);
+  run(NT, 2816, 512, EPI_SWIGLU, 0, stagger);
+  run(NT, 2816, 512, EPI_STORE, 0, stagger);
+  run(NT, 512, 1408, EPI_RESIDUAL, 1, stagger);
+  run(NT, 1408, 512, EPI_STORE, 0, stagger);
+  run(NT, 512, 512, EPI_RESIDUAL, 1, stagger);
+  run(NT, 512, 2816, EPI_STORE, 0, stagger);
+  run(4096, 4096, 4096, EPI_STORE, 0, stagger);
+  run(8192, 8192, 8192, EPI_STORE, 0, stagger);
   return 0;
 }
