@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     }
   };
 #ifndef T8_VARIANT
-#define T8_VARIANT 0   // tools/micro/gemm8p_trace.hip experiments: 1 = all LDS reads retired before the first MFMA of a phase, 2 = no s_setprio, 3 = both
+#define T8_VARIANT 0   // tools/micro/gemm8p_trace.hip experiments: bit 0 = all LDS reads retired before the first MFMA of a phase, bit 1 = no s_setprio, bit 2 = two half-tiles less in flight at the waits
 #endif
   auto mma_q = [&](auto IH, auto JH, const bf16x8(&bf)[2][2]) {
     constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     read_b(bf1, bo, 1);
     if (kt > 0 && kt + 1 < nt) stage_a(bn, I1{}, 1);
     if (kt < 2 && pend) { if (kt + 1 < nt) wait_vm(W8{}, pend); else wait_vm(W0{}, pend); }
-    else if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nt) { if constexpr (T8_VARIANT & 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     T8_BARRIER();
     mma_q(I0{}, I1{}, bf1);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     // P4
     if (kt + 2 < nt) stage_a(bo, I0{}, 2);
     if (kt == 0 && pend) { if (kt + 2 < nt) wait_vm(W6{}, pend); else wait_vm(W2{}, pend); }
-    else if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (kt + 2 < nt) { if constexpr (T8_VARIANT & 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     T8_BARRIER();
     mma_q(I1{}, I0{}, bf0);
