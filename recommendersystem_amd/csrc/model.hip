@@ -452,23 +452,20 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
 }
 
 // ------------------------------------------------------------------ GEMM helper
-// K splits of a weight-gradient GEMM on the 128x128 kernel (2 workgroups per CU -> 512 slots): a multiple of 8 (one split
-// never straddles XCDs) that fills whole rounds of slots while a workgroup's K range stays long against its fixed cost
-// (first tiles from HBM + 64 KB of atomics, about 4 K tiles).  E.g. dW2 (44 tiles): 32 splits = 1408 workgroups (92 % of
-// three rounds) instead of 24 = 1056 (69 %).
+// K splits of a weight-gradient GEMM on the 128x128 kernel: the smallest multiple of 8 (one split never straddles XCDs)
+// that gives every CU two workgroups.  Measured on the trunk's shapes (tools/scan_splitk.py, K = 65536): two co-resident
+// workgroups per CU hide each other's latencies, and beyond that every further split only adds its fixed cost (first
+// tiles from HBM + 64 KB of atomics) -- dW13 (88 tiles) 8 splits 690 TFLOP/s vs 632 at 32, dW2 (44) 16: 620 vs 569 at 32,
+// dWqkv (32) 16: 627 vs 561 at 32, dWo (16) 32: 464.
 static int pick_splitk(int M, int N, int K, int bk) {
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
   const int kt = (K + bk - 1) / bk;
   if (kt < 16) return 1;
-  int best = 1; double best_score = -1.0;
-  for (int s = 8; s <= 128 && s * 4 <= kt; s += 8) {
-    const long long wgs = tiles * s;
-    const double eff = (double)wgs / (double)(((wgs + 511) / 512) * 512);
-    const int per = (kt + s - 1) / s;
-    const double score = eff * per / (per + 4.0);
-    if (score > best_score) { best_score = score; best = s; }
-  }
-  return best;
+  long long s = (512 + tiles - 1) / tiles;
+  s = (s + 7) / 8 * 8;
+  if (s > 128) s = 128;
+  while (s > 8 && s * 4 > kt) s -= 8;   // keep at least 4 K tiles per split
+  return (int)s;
 }
 
 template <typename T>
