@@ -476,17 +476,18 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
   const int ktiles = (p.K + T8_BK - 1) / T8_BK;
   // K splits (a multiple of 8: one split never straddles XCDs): fill whole rounds of the 256 CUs while keeping the
-  // K range of a workgroup long against its fixed cost (first tiles from HBM + 256 KB of atomics ~ 8 K tiles)
+  // K range of a workgroup long against its fixed cost (first tiles from HBM + 256 KB of atomics ~ 16 K tiles)
   int best = 8; double best_score = -1.0;
   for (int sk = 8; sk <= 256; sk += 8) {
     const int per = (ktiles + sk - 1) / sk;
     if (per < 2 && sk > 8) break;
     const long long wgs = (long long)tiles * sk;
     const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
-    const double score = eff * per / (per + 8.0);
+    const double score = eff * per / (per + 16.0);   // (tools/scan_splitk_8t.py: 24 splits 694 TFLOP/s, 40 splits 660 on the dWp shape)
     if (score > best_score) { best_score = score; best = sk; }
   }
-  p.splitk = best;
+  static const int force = getenv("RSYS_DEBUG_8T_SPLITK") ? atoi(getenv("RSYS_DEBUG_8T_SPLITK")) : 0;   // scans (tools/)
+  p.splitk = force > 0 ? (force + 7) / 8 * 8 : best;
   hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
