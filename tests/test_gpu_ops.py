@@ -201,10 +201,13 @@ def _attn_ref(q, k, v, uid, tm, dO, H, KV, hd):
 
 
 @pytest.mark.parametrize("dtype,tol", [(0, 2e-5), (1, 3e-2)])
-@pytest.mark.parametrize("B,T,H,KV,hd", [(2, 128, 2, 1, 64), (3, 32, 2, 1, 16), (2, 96, 4, 2, 16), (1, 200, 2, 2, 32), (2, 64, 2, 1, 64)])
-def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd):
+@pytest.mark.parametrize("B,T,H,KV,hd,wide_ids", [(2, 128, 2, 1, 64, False), (3, 32, 2, 1, 16, False), (2, 96, 4, 2, 16, False),
+                                                  (1, 200, 2, 2, 32, False), (2, 64, 2, 1, 64, False), (2, 192, 2, 1, 64, True)])
+def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd, wide_ids):
     """Block-sparse masked attention vs numpy: ragged T (not a multiple of the 64-token tile), packed users,
-    token-mask ids, GQA, all supported head dims.  Identity RoPE tables so grads compare directly."""
+    token-mask ids, GQA, all supported head dims.  Identity RoPE tables so grads compare directly.
+    wide_ids: user ids up to 2^19 - 1, users that are NOT contiguous in the row, and token-mask ids up to 4095 (the
+    ranges of the kernels' token key uid << 12 | tm; ranking requests use one mask id per candidate)."""
     from recommendersystem_amd import _lib
     lib = _lib.lib()
     bf = dtype == 1
@@ -220,6 +223,9 @@ def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd):
         uid[b] = np.searchsorted(cuts, np.arange(T), side="right") + 1 + 10 * b
         uid[b, -5:] = 0
     tm = (rng.random((B, T)) < 0.15).astype(np.int32)
+    if wide_ids:
+        uid = rng.choice(np.array([0, 1, 2 ** 12, 2 ** 19 - 1, 2 ** 19 - 2, 77777], np.int32), size=(B, T))
+        tm = np.where(rng.random((B, T)) < 0.3, rng.choice(np.array([1, 2, 4094, 4095], np.int32), size=(B, T)), 0).astype(np.int32)
     q = qkv[:, :H * hd]; k = qkv[:, H * hd:(H + KV) * hd]; v = qkv[:, (H + KV) * hd:]
     cos = np.ones((T, hd // 2), np.float32); sin = np.zeros((T, hd // 2), np.float32)
     dev = lambda a: _to_dev(lib, a)
