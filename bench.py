@@ -126,6 +126,8 @@ def main():
         assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
     hg = rdist.HostGroup(rank, world)
     device = local_rank if world > 1 else 0
+    if os.environ.get("RSYS_BENCH_DEVICE") is not None:   # rehearsal of the N-rank path on a box with fewer GPUs
+        device = int(os.environ["RSYS_BENCH_DEVICE"])
     over = {} if args.layers is None else {"num_layers": args.layers}
     cfg = synth.make_config(args.config, **over)
     S = cfg["max_sequence_length"]
