@@ -33,7 +33,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 }
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false> (256x256 LDS-DMA, persistent, row-major bf16)", "8t": "gemm8p_kernel<true> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r1h_pmc_traffic.json"
+TRAFFIC_FILE = "r1i_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
