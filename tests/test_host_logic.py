@@ -154,3 +154,26 @@ def test_train_loop_checkpoints_and_stops(tmp_path):
     stopper = T.make_early_stopper(cfg)
     assert len(hist) < 16 and len(hist) == 2 + stopper.patience          # two improving epochs, then `patience` flat ones
     assert os.path.exists(tmp_path / "transformer.masked.1.rating.finetune.npz")
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line under profiles/ (written by `python bench.py` on an MI355X) carries every field the driver's
+    contract names, and its numbers are consistent with each other."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sorted(glob.glob(os.path.join(root, "profiles", "r1*_bench_cfg3.json")))[-1]
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "interactions/sec" and d["unit"] == "interactions/sec" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rows, S = d["config"]["global_rows"], 512
+    assert abs(d["value"] - rows * S / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
