@@ -24,14 +24,16 @@ HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
 KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
-    "8p": "gemm8p_kernel<false>",                         # 256x256 LDS-DMA, persistent, row-major operands (gemm8p.hip)
-    "8t": "gemm8p_kernel<true>",                          # the same pipeline, K-major operands + split-K atomics
+    "8p": "gemm8p_kernel<false, false>",                  # 256x256 LDS-DMA, persistent, row-major operands (gemm8p.hip)
+    "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
+    "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
     "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
-KERNEL_LABEL = {"8p": "gemm8p_kernel<false> (256x256 LDS-DMA, persistent, row-major bf16)", "8t": "gemm8p_kernel<true> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
+                "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 TRAFFIC_FILE = "r1i_pmc_traffic.json"
 

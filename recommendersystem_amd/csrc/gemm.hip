@@ -457,6 +457,12 @@ static bool use_8p_tn(const GemmParams& p) {
   return (e && atoi(e) == 2) || t256 >= 32;
 }
 
+// row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
+static bool use_8p_nt_splitk(const GemmParams& p) {
+  if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
+  return (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 32;
+}
+
 const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km) {
   GemmParams p = p0;
   if (p.splitk < 1) p.splitk = 1;
@@ -466,6 +472,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
     if (k == 3) return "4w";
   }
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
+  if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return "8s";
   return a_km ? "tn" : (b_km ? "nn" : "nt");
 }
 
@@ -495,6 +502,7 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   if (p.epi == EPI_QKV_ROPE) ARG_CHECK((p.hd & (p.hd - 1)) == 0, "gemm: head_dim must be a power of two");
   if constexpr (!is_bf16<CT>::value) { a_f32 = false; b_f32 = false; }
   if constexpr (is_bf16<CT>::value) {
+    if (!a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return launch_gemm8p_nt_splitk(p, s);
     if (!a_km && !b_km && !a_f32 && !b_f32) {
       const int k = pick_rowmajor_kernel(p);
       if (k == 2) return launch_gemm8p(p, s);

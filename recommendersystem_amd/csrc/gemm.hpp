@@ -53,7 +53,7 @@ struct GemmParams {
 template <typename CT>
 int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s);
 
-// short name of the kernel launch_gemm picks for this problem ("8p", "8t", "4w", "nt", "nn", "tn"): timing tags
+// short name of the kernel launch_gemm picks for this problem ("8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
 }  // namespace rsys

@@ -67,8 +67,13 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // the epilogue and the epilogue's stores drain behind the next tile's first MFMAs; the counted vmcnt waits of the
 // first K tiles allow for those stores (vector memory operations retire in issue order).  A device-side row count
 // (*m_dev, the head GEMMs) just shortens the tile run: no idle workgroups.
-template <bool KM>
+// SK (row-major operands only): split-K with the work mapping and the LDS-staged fp32-atomic epilogue of the K-major
+// form instead of the persistent tile run -- for products with few output tiles and a very long K whose operands exist
+// as row-major (K-contiguous) copies: the metadata-projection gradient on transposed copies of dF and Meta.
+template <bool KM, bool SK = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+  static_assert(!(KM && SK), "the K-major form is always split-K");
+  constexpr bool PERSIST = !KM && !SK;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l0 = t & 63;
   int l = l0;   // refreshed per tile through an opaque move: nothing derived from it is carried across an epilogue
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // through the XCD's private L2
   const int tiles_n = (p.N + T8_BN - 1) / T8_BN;
   int tile, tile_first = 0, tile_end = 0, tile_step = 1, kt0 = 0, nt;
-  if constexpr (!KM) {
+  if constexpr (PERSIST) {
     const int rows = p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M;
     const int ntiles = ((rows + T8_BM - 1) / T8_BM) * tiles_n;
     const int xcd = blockIdx.x & 7, G = gridDim.x;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #endif
   auto run_tiles = [&](auto FULLC) __attribute__((always_inline)) {
   constexpr bool WANT = decltype(FULLC)::value;
-  if constexpr (!KM) {
+  if constexpr (PERSIST) {
     tile = tile_first;
     while (tile < tile_end && is_full(tile) != WANT) tile += tile_step;
     if (tile >= tile_end) return;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     tile_offsets();
   }
   pend = 0;
-  if constexpr (!KM) {
+  if constexpr (PERSIST) {
     if (p.flags & 4) {   // timing experiment: every other workgroup of an XCD starts p.T microsecond-ish naps late
       if ((blockIdx.x >> 3) & 1) for (int k = 0; k < p.T; ++k) __builtin_amdgcn_s_sleep(32);
     }
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // ---- next tile: its first two K tiles are requested before this tile's results are written
   const int em0 = m0, en0 = n0;
   bool more = false;
-  if constexpr (!KM) {
+  if constexpr (PERSIST) {
     tile += tile_step;
     while (tile < tile_end && is_full(tile) != WANT) tile += tile_step;
     more = tile < tile_end;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   TR_MARK(2);
   // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; if (!more) return; l = l0; asm volatile("" : "+v"(l)); fq = l >> 4; fr = l & 15; lane_offsets(); tile_offsets(); continue; }   // timing experiment: no epilogue
-  if constexpr (!KM) {
+  if constexpr (PERSIST) {
     epilogue_regs<WANT ? 1 : 0>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
     // A lower bound on the vector memory instructions of the epilogue that follow its last load: all stores where the
     // epilogue has no loads, else the stores of its last two row blocks (the last operand request precedes them).  A
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   TR_MARK(4);
   }
   };
-  if constexpr (KM) run_tiles(std::true_type{});
+  if constexpr (!PERSIST) run_tiles(std::true_type{});
   else { run_tiles(std::true_type{}); run_tiles(std::false_type{}); }
 #ifdef RSYS_8P_TRACE
   if (p.trace != nullptr && t == 0) {
@@ -489,6 +494,33 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
   static const int force = getenv("RSYS_DEBUG_8T_SPLITK") ? atoi(getenv("RSYS_DEBUG_8T_SPLITK")) : 0;   // scans (tools/)
   p.splitk = force > 0 ? (force + 7) / 8 * 8 : best;
   hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// row-major operands + split-K atomics (see the SK template parameter)
+bool gemm8p_nt_splitk_eligible(const GemmParams& p) {
+  if (p.epi != EPI_ATOMIC || !p.c_f32 || p.k_dev != nullptr || p.m_dev != nullptr) return false;
+  if (p.K % T8_BK != 0 || p.K < 16 * T8_BK || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0) return false;
+  if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldb * 2 >= (1ull << 32)) return false;
+  return true;
+}
+
+int launch_gemm8p_nt_splitk(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  const int ktiles = p.K / T8_BK;
+  int best = 8; double best_score = -1.0;   // as launch_gemm8p_tn
+  for (int sk = 8; sk <= 256; sk += 8) {
+    const int per = (ktiles + sk - 1) / sk;
+    if (per < 2 && sk > 8) break;
+    const long long wgs = (long long)tiles * sk;
+    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    const double score = eff * per / (per + 16.0);
+    if (score > best_score) { best_score = score; best = sk; }
+  }
+  p.splitk = best;
+  hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

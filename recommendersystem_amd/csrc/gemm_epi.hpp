@@ -143,6 +143,9 @@ int launch_gemm8p(const GemmParams& p, hipStream_t s);
 // the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
 bool gemm8p_tn_eligible(const GemmParams& p);
 int launch_gemm8p_tn(const GemmParams& p, hipStream_t s);
+// the row-major pipeline with the same split-K mapping and atomic epilogue (long K, few output tiles, K-contiguous operands)
+bool gemm8p_nt_splitk_eligible(const GemmParams& p);
+int launch_gemm8p_nt_splitk(const GemmParams& p, hipStream_t s);
 // row-major bf16 operands, 256x128 tiles, two workgroups per CU (gemm4w.hip)
 bool gemm4w_eligible(const GemmParams& p);
 int launch_gemm4w(const GemmParams& p, hipStream_t s);

@@ -178,6 +178,11 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   if (m->bf16_mode) { DALLOC(m->Sh, m->n_total * 2); DALLOC(m->ShT, m->n_total * 2); } else { m->Sh = m->P; }
   DALLOC(m->Meta, (int64_t)(m->V + 1) * m->Mp * e);
   DALLOC(m->F32, (int64_t)(m->V + 1) * D * 4); DALLOC(m->FT, (int64_t)(m->V + 1) * D * e);
+  if (m->bf16_mode) {
+    m->Vp = ((int64_t)m->V + 1 + 63) / 64 * 64;
+    DALLOC(m->MetaT, (int64_t)m->Mp * m->Vp * 2); DALLOC(m->dFT, (int64_t)D * m->Vp * 2);
+    HIP_CHECK(hipMemset(m->MetaT, 0, (size_t)m->Mp * m->Vp * 2)); HIP_CHECK(hipMemset(m->dFT, 0, (size_t)D * m->Vp * 2));
+  }
   // RoPE tables (model.py:173-179), fp32 like torch; the host may overwrite them (rsys_model_set_rope)
   {
     const int half = hd / 2;
@@ -305,6 +310,17 @@ int model_init_random(Model* m, uint64_t seed) {
   return RSYS_OK;
 }
 
+// bf16 mode: MetaT = Meta^T ([Mp][Vp], rows >= M and columns > V stay zero) for the row-major form of dWp = dF^T Meta
+static int build_meta_t(Model* m) {
+  if (!m->bf16_mode) return RSYS_OK;
+  TransposeBatch b; b.n = 1;
+  b.job[0].src = (const bf16*)m->Meta; b.job[0].dst = (bf16*)m->MetaT; b.job[0].rows = m->V + 1; b.job[0].cols = m->Mp;
+  b.job[0].ld_src = m->Mp; b.job[0].ld_dst = m->Vp;
+  RC(launch_transpose_bf16(b, m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  return RSYS_OK;
+}
+
 int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
   ARG_CHECK(V == m->V && Mdim == m->M, "metadata table shape must be (V, metadata_dim)");  // model.py:387
   HIP_CHECK(hipSetDevice(m->device));
@@ -334,7 +350,7 @@ int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
     void* dst = (unsigned char*)m->Meta + (size_t)r0 * m->Mp * m->esz;
     HIP_CHECK(hipMemcpy(dst, m->bf16_mode ? (void*)hosth.data() : (void*)hostf.data(), (size_t)nr * m->Mp * m->esz, hipMemcpyHostToDevice));
   }
-  return RSYS_OK;
+  return build_meta_t(m);
 }
 
 int model_random_metadata(Model* m, uint64_t seed) {
@@ -344,7 +360,7 @@ int model_random_metadata(Model* m, uint64_t seed) {
   if (m->bf16_mode) RC(launch_fill_normal_t<bf16>((bf16*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
   else RC(launch_fill_normal_t<float>((float*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
-  return RSYS_OK;
+  return build_meta_t(m);
 }
 
 int model_set_rope(Model* m, const float* c, const float* s, int64_t n_pos) {
@@ -910,13 +926,23 @@ static int finalize_grads_t(Model* m, int stage) {
       if (m->bf16_mode) RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
       RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
     }
+    if (m->bf16_mode) {   // K-contiguous copy of dF for the row-major pipeline: dFT[d][v]
+      TransposeBatch b; b.n = 1;
+      b.job[0].src = (const bf16*)m->FT; b.job[0].dst = (bf16*)m->dFT; b.job[0].rows = m->V + 1; b.job[0].cols = m->D;
+      b.job[0].ld_src = m->D; b.job[0].ld_dst = m->Vp;
+      RC(launch_transpose_bf16(b, m->stream));
+    }
   }
   if (stage != 1) {
     GemmParams p{};
-    p.A = m->bf16_mode ? (const void*)m->FT : (const void*)(m->G + m->o_E);
-    p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1;
-    p.M = m->D; p.N = m->Mp; p.K = m->V + 1; p.epi = EPI_ATOMIC;
-    RC(gemm<T>(m, "gemm_table_dw", p, false, true, true));
+    p.C = m->G + m->o_Wp; p.ldc = m->Mp; p.c_f32 = 1; p.M = m->D; p.N = m->Mp; p.epi = EPI_ATOMIC;
+    if (m->bf16_mode) {   // dWp[d][c] += sum_v dFT[d][v] MetaT[c][v]  (both operands K-contiguous, padding columns are zero)
+      p.A = m->dFT; p.lda = m->Vp; p.B = m->MetaT; p.ldb = m->Vp; p.K = (int)m->Vp;
+      RC(gemm<T>(m, "gemm_table_dw", p, false, false, false));
+    } else {
+      p.A = m->G + m->o_E; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.K = m->V + 1;
+      RC(gemm<T>(m, "gemm_table_dw", p, false, true, true));
+    }
   }
   toc(m);
   return RSYS_OK;

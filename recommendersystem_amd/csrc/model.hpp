@@ -75,6 +75,10 @@ struct Model {
   void* Meta = nullptr;      // [V+1][Mp] T
   float* F32 = nullptr;      // [V+1][D]
   void* FT = nullptr;        // [V+1][D] T
+  // bf16 mode: K-contiguous (transposed) operand copies for the metadata-projection gradient dWp = dF^T Meta, which then
+  // runs on the row-major LDS-DMA pipeline: MetaT [Mp][Vp] (built when the table is loaded), dFT [D][Vp] (per step);
+  // Vp = V + 1 rounded up to 64, the padding stays zero
+  void* MetaT = nullptr; void* dFT = nullptr; int64_t Vp = 0;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int rope_npos = 0;
   std::vector<void*> allocs;

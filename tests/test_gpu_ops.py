@@ -126,6 +126,15 @@ def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 6208, 4096), (520, 8192, 8192), (2048, 4104, 1024)])
+def test_gemm_rowmajor_splitk_lds_dma_kernel(M, N, K):
+    """Row-major operands with split-K fp32 atomics on the LDS-DMA pipeline (gemm8p_kernel<false, true>: the
+    metadata-projection gradient on transposed operand copies): exact on asymmetric integer data, ragged M / N, and it
+    accumulates into what C already holds."""
+    out, ref = run_gemm(1, M, N, K, False, False, c_f32=True, splitk=8, integer=True, seed=M + N + K)
+    np.testing.assert_array_equal(out, ref.astype(np.float32))
+
+
 @pytest.mark.parametrize("rows", [0, 1, 256, 300, 717, 1280, 2048, 5000])
 @pytest.mark.parametrize("kern", ["1", "2"])
 def test_gemm_device_side_row_count(monkeypatch, rows, kern):
