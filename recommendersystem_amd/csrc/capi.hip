@@ -117,6 +117,7 @@ int32_t rsys_zero_grad(rsys_model* h) {
   HIP_CHECK(hipSetDevice(h->m->device));
   HIP_CHECK(hipMemsetAsync(h->m->G, 0, h->m->n_total * 4, h->m->stream));
   h->m->table_grads_pending = false;
+  h->m->gE_clean[0] = h->m->gE_clean[1] = true;
   return RSYS_OK;
 }
 

@@ -699,7 +699,8 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
         if (!m->cfg.finetune) {
           GemmParams p{};  // dF[s:e] += dlogits^T . Ew
           p.A = m->logits; p.lda = m->ldl; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_E + (int64_t)vs * D; p.ldc = D; p.c_f32 = 1;
-          p.M = Vm; p.N = D; p.K = KB; p.epi = EPI_ACCUM; p.k_dev = np;
+          p.M = Vm; p.N = D; p.K = KB; p.epi = m->gE_clean[medium] ? EPI_STORE : EPI_ACCUM; p.k_dev = np;
+          m->gE_clean[medium] = false;
           RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
         }
         if (!m->cfg.finetune) m->table_grads_pending = true;
@@ -1089,6 +1090,7 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
     rc = launch_adamw<float>(m->P, m->G, o->mom, o->var, nullptr, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                              o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
   toc(m);
+  if (rc == RSYS_OK && !m->cfg.finetune) m->gE_clean[0] = m->gE_clean[1] = true;   // the kernel zeroed the gradients it consumed
   return rc;
 }
 

@@ -102,6 +102,9 @@ struct Model {
   void *dLa, *dxl;   // finetune workspaces
   float* sumsq;
   bool table_grads_pending = false;
+  // the item-table gradient rows of medium m are known to be zero (just zeroed by zero_grad / AdamW and not written since):
+  // the first head GEMM of a step then stores dF instead of reading 245 MB of zeros to add to
+  bool gE_clean[2] = {false, false};
   bool drop_active = false; unsigned long long drop_seed = 0, drop_step = 0;   // LoRA dropout of the current pass
   bool last_evaluate = false;
   PhaseTimer timer;
