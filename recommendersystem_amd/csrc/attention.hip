@@ -71,6 +71,13 @@ __device__ __forceinline__ typename AMma<T>::Frag frag_global(const T* rowptr, i
     return k < kmax ? rowptr[k] : 0.f;
   }
 }
+__device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)b[i];
+  return s;
+}
+__device__ __forceinline__ float frag_dot(float a, float b) { return a * b; }
 // bf16: transposed fragment of a row-major [token][d] tile for the contraction over 32 tokens tok0..tok0+31 in the
 // ACCUMULATOR slot order (slot j<4 -> token tok0 + 4g + j, j>=4 -> tok0 + 16 + 4g + j-4); MFMA row = d0 + (l&15).
 __device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int ld, int tok0, int d0, int l) {
@@ -408,43 +415,6 @@ int launch_attn_fwd(const AttnParams& p, hipStream_t s) {
 template int launch_attn_fwd<bf16>(const AttnParams&, hipStream_t);
 template int launch_attn_fwd<float>(const AttnParams&, hipStream_t);
 
-// ------------------------------------------------------------------------ delta = rowsum(dO * O) per head
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
-  // one wave per token row; each lane owns 16-byte chunks; lanes of one head reduce with shuffles
-  constexpr int E = 16 / sizeof(T);
-  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int l = threadIdx.x & 63;
-  if (row >= (long long)p.B * p.T) return;
-  const int D = p.H * p.hd;
-  const int lph = p.hd / E;                 // lanes per head (2..32, power of two)
-  const long long b = row / p.T; const int t = (int)(row % p.T);
-  for (int c0 = 0; c0 < D / E; c0 += 64) {
-    const int c = c0 + l;
-    float acc = 0.f;
-    if (c < D / E) {
-      uint4 ra = *(const uint4*)((const T*)p.dO + row * p.ldo + c * E);
-      uint4 rb = *(const uint4*)((const T*)p.o + row * p.ldo + c * E);
-      const T* a = (const T*)&ra; const T* o = (const T*)&rb;
-#pragma unroll
-      for (int k = 0; k < E; ++k) acc += to_f32(a[k]) * to_f32(o[k]);
-    }
-    for (int off = 1; off < lph; off <<= 1) acc += __shfl_xor(acc, off, 64);
-    if (c < D / E && (l & (lph - 1)) == 0) {
-      const int h = (c * E) / p.hd;
-      ((float*)p.delta)[(b * p.H + h) * p.T + t] = acc;
-    }
-  }
-}
-template <typename T>
-int launch_attn_delta(const AttnParams& p, hipStream_t s) {
-  long long rows = (long long)p.B * p.T;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
-  HIP_CHECK(hipGetLastError());
-  return RSYS_OK;
-}
-template int launch_attn_delta<bf16>(const AttnParams&, hipStream_t);
-template int launch_attn_delta<float>(const AttnParams&, hipStream_t);
 
 // gradient tile (rows d = 16j+4g+r, col = token on the lane) -> un-rotate (inverse of transformer.model.py:182-190; the
 // pair (d, d+1) is two consecutive registers of the lane), transpose through LDS, store rows with 16-byte accesses
@@ -618,7 +588,19 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   }
   const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   const long long so = ((long long)b * p.H + h) * p.T + min(q, p.T - 1);
-  const float lse2 = qv ? p.lse[so] * LOG2E : 0.f, dl = qv ? p.delta[so] : 0.f;
+  // delta = rowsum(dO * O) of this lane's query: the four lanes that share a query hold disjoint quarters of d in their
+  // fragments.  Written out for the dK/dV kernel, which runs after this one.
+  float dl = 0.f;
+  {
+    const T* orow = (const T*)p.o + (tok0 + min(q, p.T - 1)) * p.ldo + h * HD;
+#pragma unroll
+    for (int s = 0; s < C::NDS; ++s) dl += frag_dot(dof[s], frag_global<T>(orow, s * C::KS, HD, l));
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (!qv) dl = 0.f;
+    if (g == 0 && qv) p.delta[so] = dl;
+  }
+  const float lse2 = qv ? p.lse[so] * LOG2E : 0.f;
   f32x4 dQ[HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) dQ[j] = f32x4{0, 0, 0, 0};
@@ -689,9 +671,10 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
     set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), sm_kv, s, p);
-  HIP_CHECK(hipGetLastError());
+  // the dQ kernel also produces delta = rowsum(dO * O), which the dK/dV kernel reads
   hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
+  HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), sm_kv, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -446,8 +446,7 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   int rc = launch_attn_tilemap(p, nullptr);
   if (!rc) rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_fwd<bf16>(p, nullptr) : launch_attn_fwd<float>(p, nullptr);
   if (!rc && dO) {
-    rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_delta<bf16>(p, nullptr) : launch_attn_delta<float>(p, nullptr);
-    if (!rc) rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_bwd<bf16>(p, nullptr) : launch_attn_bwd<float>(p, nullptr);
+    rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_bwd<bf16>(p, nullptr) : launch_attn_bwd<float>(p, nullptr);
   }
   hipError_t e2 = hipDeviceSynchronize();
   hipFree(maps); hipFree(delta);

@@ -105,13 +105,12 @@ struct AttnParams {
   // group of 16 keys (kmap16: bit j = q tile j): a wave owns one such group and skips the tiles it has nothing in
   unsigned int *qmap16, *kmap16;
   // backward
-  const void* dO; const float* delta;
+  const void* dO; float* delta;   // delta [B][H][T] = rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv
   const float *rope_cos, *rope_sin; const int* rope_pos;
 };
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s);
 template <typename T> int launch_attn_fwd(const AttnParams& p, hipStream_t s);
-template <typename T> int launch_attn_delta(const AttnParams& p, hipStream_t s);
 template <typename T> int launch_attn_bwd(const AttnParams& p, hipStream_t s);
 
 // ---- optimizer (optim.hip)

@@ -809,7 +809,6 @@ static int backward_trunk(Model* m) {
     ap.dO = m->dO; ap.delta = m->delta;
     ap.dq = m->dqkv; ap.dk = AT<T>(m->dqkv) + m->H * hd; ap.dv = AT<T>(m->dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
     tic(m, "attn_bwd");
-    RC(launch_attn_delta<T>(ap, s));
     RC(launch_attn_bwd<T>(ap, s));
     toc(m);
     if (!ft) {
