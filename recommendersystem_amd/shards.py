@@ -10,6 +10,8 @@ the reference also has in Python (Finetune/embed.py:39-71, see serve.py).
     save_data           transformer.jl:202-240   users -> {datadir}/{split}/{shard}/{p}.h5, num_tokens.txt
     pad_splits          transformer.jl:181-200   pad.h5 so that every shard holds the same number of tokens
     save_media_embeddings  transformer.jl:56-77  media_embeddings.h5 ("metadata": text | image | 4 date features)
+    get_finetune_data / save_finetune_data   notebooks/Finetune/transformer.jl:52-166   one user per row of 1024 tokens:
+                        history, then the held-out test event, which alone carries targets (weights normalised per task)
 
 The random choices (mini subsample, duplicate users to fill the last round of shards, shuffles) use a numpy generator;
 they are statistically, not bitwise, those of the Julia run.
@@ -195,3 +197,97 @@ def save_data(datadir, datasplit, transdir, num_items_0, mini=False, num_shards=
     with open(os.path.join(splitdir, "num_tokens.txt"), "w") as f:
         f.write(str(total))
     return total
+
+
+# ---- finetune shards (notebooks/Finetune/transformer.jl) -----------------------------------------------------------
+
+FINETUNE_SEQ_LEN = 1024                 # Finetune/transformer.jl:21
+NUM_TEST_ITEMS = 1                      # :55
+
+
+def get_finetune_data(data, userid, num_items_0, max_seq_len=FINETUNE_SEQ_LEN):
+    """Finetune/transformer.jl:52-133.  `data` = {"user", "items": history events, "test_items": [<= 1 held-out event]}.
+    One row of `max_seq_len` tokens: the newest max_seq_len - 1 projected history tokens, then the test event; only the
+    test event gets targets (same rules as the pretraining writer), and every task's weights are normalised to sum 1."""
+    assert len(data["test_items"]) <= NUM_TEST_ITEMS
+    items = project(tokenize(data["items"]))
+    if len(items) > max_seq_len - NUM_TEST_ITEMS:
+        items = items[len(items) - (max_seq_len - NUM_TEST_ITEMS):]
+    u = data["user"]
+    N = max_seq_len
+    d = {k: np.zeros(N, np.int32) for k in _INT_KEYS}
+    d["time"] = np.zeros(N, np.float64)
+    d["rating"] = np.zeros(N, np.float32)
+    d["progress"] = np.zeros(N, np.float32)
+    for m in MEDIUMS:
+        for metric in METRICS:
+            d[f"{m}.{metric}.label"] = np.zeros(N, np.float32)
+            d[f"{m}.{metric}.weight"] = np.zeros(N, np.float32)
+            d[f"{m}.{metric}.position"] = np.zeros(N, np.int32)
+    i = 0
+    for source, istest in ((items, False), (data["test_items"], True)):
+        for x in source:
+            m = x["medium"]
+            d["userid"][i] = userid
+            d["time"][i] = x["history_max_ts"]
+            d["gender"][i] = 0 if u["gender"] is None else u["gender"] + 1
+            d["source"][i] = u["source"]
+            d["matchedid"][i] = x["matchedid"] + (num_items_0 if m == 1 else 0)
+            d["status"][i] = x["status"]
+            d["rating"][i] = x["rating"]
+            d["progress"][i] = x["progress"]
+            if istest:
+                hs, hr = x["history_status"], x["history_rating"]
+                inferred_watch = x["status"] == 0 and hs is None
+                new_watch = x["status"] > PLANNED_STATUS and (hs is None or 0 < hs <= PLANNED_STATUS)
+                if inferred_watch or new_watch:
+                    d[f"{m}.watch.label"][i] = 1
+                    d[f"{m}.watch.weight"][i] = 1
+                    d[f"{m}.watch.position"][i] = x["matchedid"]
+                if x["rating"] > 0 and x["rating"] != hr:
+                    d["token_mask_ids"][i] = 1
+                    d[f"{m}.rating.label"][i] = x["rating"]
+                    d[f"{m}.rating.weight"][i] = 1
+                    d[f"{m}.rating.position"][i] = x["matchedid"]
+                if x["status"] > 0 and x["status"] != hs:
+                    d[f"{m}.status.label"][i] = x["status"]
+                    d[f"{m}.status.weight"][i] = 1
+                    d[f"{m}.status.position"][i] = x["matchedid"]
+            i += 1
+    for m in MEDIUMS:
+        for metric in METRICS:
+            wsum = d[f"{m}.{metric}.weight"].sum()
+            if wsum > 0:
+                d[f"{m}.{metric}.weight"] /= wsum
+    return d
+
+
+def save_finetune_data(datadir, datasplit, num_items_0, num_shards=1, users_per_part=USERS_PER_PART, max_seq_len=FINETUNE_SEQ_LEN,
+                       seed=0, load=None):
+    """Finetune/transformer.jl:135-166: `{datadir}/users/{datasplit}/*/*.msgpack` -> `{datadir}/transformer/{datasplit}/{shard}/{p}.h5`
+    with every dataset of shape (users, max_seq_len) as h5py shows it (Julia stacks the users as columns)."""
+    if load is None:
+        import msgpack
+
+        def load(fn):
+            with open(fn, "rb") as f:
+                return msgpack.unpackb(f.read(), raw=False, strict_map_key=False)
+    rng = np.random.default_rng(seed)
+    users = sorted(glob.glob(os.path.join(datadir, "users", datasplit, "*", "*.msgpack")))
+    assert users, f"no user files under {datadir}/users/{datasplit}"
+    while len(users) % num_shards != 0:
+        users.append(users[rng.integers(len(users))])
+    users = [users[i] for i in rng.permutation(len(users))]
+    n_rows = 0
+    for shard in range(1, num_shards + 1):
+        dest = os.path.join(datadir, "transformer", datasplit, str(shard))
+        os.makedirs(dest, exist_ok=True)
+        files = [x for i, x in enumerate(users, start=1) if i % num_shards + 1 == shard]
+        files = [files[i] for i in rng.permutation(len(files))]
+        for p, lo in enumerate(range(0, len(files), users_per_part), start=1):
+            part = files[lo:lo + users_per_part]
+            rows = [get_finetune_data(load(fn), i, num_items_0, max_seq_len) for i, fn in enumerate(part, start=1)]
+            rows = [rows[i] for i in rng.permutation(len(rows))]
+            h5.write_h5(os.path.join(dest, f"{p}.h5"), {k: np.stack([r[k] for r in rows]) for k in rows[0]}, blosc=3)
+            n_rows += len(rows)
+    return n_rows
