@@ -8,4 +8,4 @@ from .model import ALL_MEDIUMS, ALL_METRICS, RecommenderModel, synchronize  # no
 from .optim import create_optimizer  # noqa: F401
 from .train import (ConstantScheduler, EarlyStopper, WSDScheduler, evaluate_metrics, make_early_stopper,  # noqa: F401
                     make_task_weights, minimize_quadratic, train_epoch, wsum)
-from . import checkpoint, data, dist, h5, serve, shards, train, workload  # noqa: F401,E402  (ra.data.FinetuneDataset, ra.train.train, ...)
+from . import checkpoint, cli, data, dist, h5, serve, shards, train, workload  # noqa: F401,E402  (ra.data.FinetuneDataset, ra.train.train, ...)

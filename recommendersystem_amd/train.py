@@ -61,12 +61,12 @@ class LambdaLR:
         self._factor = self.fn(self.last_epoch)
 
 
-def create_learning_rate_schedule(tokens_per_epoch, tokens_per_batch, epochs, finetune=False):
-    """train.py:331-347."""
+def create_learning_rate_schedule(tokens_per_epoch, tokens_per_batch, epochs, finetune=False, warmup_steps=2000):
+    """train.py:331-347 (the reference's warm-up is fixed at 2000 steps, which a run needs at least 2223 steps for)."""
     if finetune:
         return LambdaLR(ConstantScheduler())
     total_steps = int(round(tokens_per_epoch * epochs / tokens_per_batch))
-    return LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=total_steps, decay_ratio=0.1, final_ratio=0.1))
+    return LambdaLR(WSDScheduler(warmup_steps=warmup_steps, total_steps=total_steps, decay_ratio=0.1, final_ratio=0.1))
 
 
 class EarlyStopper:  # train.py:350-372

@@ -485,6 +485,39 @@ def test_hdf5_shards_and_embeddings_feed_the_step(tmp_path):
     assert np.isfinite(out[0][0]).all() and np.abs(out[0][1]).max() > 0
 
 
+def test_cli_trains_from_a_data_directory(tmp_path):
+    """the command line of transformer.py over a data directory in the reference's layout (csv files,
+    list_tag, blosc HDF5 shards + num_tokens.txt, media_embeddings.h5): two epochs at a tiny size, the metrics CSV in the
+    reference's format, a checkpoint, and a resumed --prod run that continues after the last epoch."""
+    from recommendersystem_amd import cli, data, h5, workload
+    if not os.path.exists(h5.LIB_PATH):
+        pytest.skip("librsys_h5.so not built (no libhdf5 on this host)")
+    cfg = workload.make_config("tiny")
+    V0, V1, S, M = cfg["vocab_sizes"]["0_matchedid"], cfg["vocab_sizes"]["1_matchedid"], cfg["max_sequence_length"], cfg["metadata_emb_size"]
+    d = str(tmp_path)
+    open(f"{d}/manga.csv", "w").write("matchedid\n" + "\n".join(str(i) for i in range(V0)) + "\n")
+    open(f"{d}/anime.csv", "w").write("matchedid\n" + "\n".join(str(i) for i in range(V1)) + "\n")
+    open(f"{d}/list_tag", "w").write("20260101")
+    cfg["max_ts"] = __import__("datetime").datetime(2026, 1, 1).timestamp()
+    rows_per_batch = 4
+    for split, nb, seed in (("training", 6, 1), ("test", 2, 2)):
+        stream = workload.make_stream(cfg, nb * rows_per_batch * S, seed, mu=np.log(8.0), sigma=0.6)
+        data.write_shards(f"{d}/transformer/{split}", [[stream]], 1, fmt="h5")
+    table = np.random.default_rng(3).standard_normal((V0 + V1, M)).astype(np.float32) / np.sqrt(M)
+    h5.write_h5(f"{d}/media_embeddings.h5", {"metadata": table}, blosc=3)
+    argv = ["--datadir", d, "--model", "tiny", "--metadata_emb_size", str(M), "--dtype", "fp32", "--local_batch_size", str(rows_per_batch),
+            "--global_batch_size", str(2 * rows_per_batch), "--num_epochs", "2", "--warmup_steps", "2", "--prod"]
+    hist = cli.main(argv)
+    assert [e for e, _, _ in hist] == [0, 1] and all(np.isfinite(l).all() for _, tr, te in hist for l in (tr, te))
+    lines = open(f"{d}/transformer.masked.csv").read().strip().split("\n")
+    assert lines[0] == "epoch,training_loss,test_loss,0.watch,0.rating,1.watch,1.rating" and [l.split(",")[0] for l in lines[1:]] == ["-1", "0", "1"]
+    assert os.path.exists(f"{d}/transformer.masked.finished")
+    saved = os.path.exists(f"{d}/transformer.masked.npz")   # written when the early stopper saw the test loss improve
+    argv[argv.index("--num_epochs") + 1] = "3"
+    hist2 = cli.main(argv)                                   # --prod resumes after the checkpointed epoch, else starts over
+    assert hist2[-1][0] == 2 and (hist2[0][0] > 0) == saved
+
+
 def test_serving_predict_end_to_end():
     """Request -> response through `serve.predict` (embed.py:74-161) on the HIP inference forward: retrieval returns the
     trunk output at the query item token, ranking the rating head at each candidate's action token; compared with the

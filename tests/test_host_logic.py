@@ -177,3 +177,20 @@ def test_committed_bench_line_follows_the_contract():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+def test_cli_training_config(tmp_path):
+    """transformer.py:513-567: vocabulary sizes from the csv files, max_ts from list_tag, --mini halves the layers."""
+    from recommendersystem_amd import cli
+    (tmp_path / "manga.csv").write_text("matchedid,title\n0,a\n41,b\n7,c\n")
+    (tmp_path / "anime.csv").write_text("title,matchedid\nx,12\ny,99\n")
+    (tmp_path / "list_tag").write_text("20250301\n")
+    ns = type("A", (), dict(datadir=str(tmp_path), finetune=None, finetune_metric=None, mini=True, model="prod", metadata_emb_size=6148))
+    c = cli.get_training_config(ns)
+    assert c["vocab_sizes"] == {"0_matchedid": 42, "1_matchedid": 100, "status": 9, "gender": 4, "source": 4}
+    assert c["num_layers"] == 4 and c["embed_dim"] == 2048 and c["mask_topk"] == 128 and c["max_sequence_length"] == 1024
+    import datetime
+    assert c["max_ts"] == datetime.datetime(2025, 3, 1).timestamp() and c["min_ts"] == datetime.datetime(2000, 1, 1).timestamp()
+    ns.model, ns.mini = "cfg3", False
+    c3 = cli.get_training_config(ns)
+    assert (c3["embed_dim"], c3["num_layers"], c3["max_sequence_length"], c3["mask_topk"]) == (512, 8, 512, 64)
