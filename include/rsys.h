@@ -104,6 +104,9 @@ int32_t rsys_losses_get(rsys_model* m, float losses_out[12], float weight_sums_o
 /* number of positive-weight positions selected per task in the last forward (they bound the head GEMMs) */
 int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
 /* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
+/* ItemEmbedding.forward over all items (model.py:139-145), the table Finetune/register.py:27-33 exports as the watch-head
+ * weights of the serving registry: out [V][embed_dim] f32, V = vocab_0 + vocab_1 (manga rows first) */
+int32_t rsys_item_table(rsys_model* m, float* out, int64_t n);
 int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
 /* debug/parity: trunk output of the last forward (rows*2S*D floats) */
 int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);

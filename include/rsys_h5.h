@@ -46,7 +46,8 @@ int rsys_h5_dataset_info(void* file, const char* name, int32_t* dtype, int32_t* 
 int rsys_h5_read(void* file, const char* name, void* dst, int64_t dst_bytes);
 
 /* `file[k, blosc = level] = v` (transformer.jl:75, 198, 230): chunked, byte-shuffled, blosclz at `level`;
- * level < 0 writes a contiguous uncompressed dataset.  Empty datasets are always written contiguous. */
+ * level < 0 writes a contiguous uncompressed dataset.  Empty datasets and rank-0 (scalar) datasets are always written
+ * contiguous; ndim = 0 stores one value (h5py's `create_dataset(k, data=python_float)`, Finetune/register.py:34-36). */
 int rsys_h5_write(void* file, const char* name, int32_t dtype, int32_t ndim, const int64_t* dims, const void* src,
                   int32_t blosc_level);
 

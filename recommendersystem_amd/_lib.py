@@ -67,6 +67,7 @@ _SIGS = [
     ("rsys_forward_backward", C.c_int32, [_P, C.c_int32, C.POINTER(C.c_float * 4), C.c_float, C.c_uint64, C.c_uint64]),
     ("rsys_losses_get", C.c_int32, [_P, C.POINTER(C.c_float * 12), C.POINTER(C.c_float * 4)]),
     ("rsys_head_rows_get", C.c_int32, [_P, C.POINTER(C.c_int32 * 4)]),
+    ("rsys_item_table", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_infer", C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
     ("rsys_trunk_output_get", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_clip_grad_norm", C.c_int32, [_P, C.c_float, C.POINTER(C.c_float)]),

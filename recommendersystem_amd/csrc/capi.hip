@@ -152,6 +152,7 @@ int32_t rsys_head_rows_get(rsys_model* h, int32_t out[4]) {
   return RSYS_OK;
 }
 
+int32_t rsys_item_table(rsys_model* h, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_item_table(h->m, out, n); }
 int32_t rsys_infer(rsys_model* h, int32_t task, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_infer(h->m, task, out, n); }
 
 int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {

@@ -186,7 +186,7 @@ int rsys_h5_read(void* file, const char* name, void* dst, int64_t dst_bytes) {
 
 int rsys_h5_write(void* file, const char* name, int32_t dtype, int32_t ndim, const int64_t* dims, const void* src,
                   int32_t blosc_level) {
-  if (!file || !name || !dims || ndim < 1 || ndim > RSYS_H5_MAX_DIMS || native_type(dtype) < 0 || blosc_level > 9)
+  if (!file || !name || (!dims && ndim > 0) || ndim < 0 || ndim > RSYS_H5_MAX_DIMS || native_type(dtype) < 0 || blosc_level > 9)
     return fail(RSYS_H5_BADARG, "rsys_h5_write: bad argument");
   h5file* f = (h5file*)file;
   if (!f->writable) return fail(RSYS_H5_BADARG, "file was opened read-only");
@@ -198,10 +198,10 @@ int rsys_h5_write(void* file, const char* name, int32_t dtype, int32_t ndim, con
     count *= hd[i];
   }
   if (count && !src) return fail(RSYS_H5_BADARG, "rsys_h5_write: null source");
-  hid_t space = H5Screate_simple(ndim, hd, NULL);
+  hid_t space = ndim == 0 ? H5Screate(H5S_SCALAR) : H5Screate_simple(ndim, hd, NULL);   /* rank 0: one value, as h5py stores a Python float */
   hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
   int rc = 0;
-  if (blosc_level >= 0 && count > 0) {
+  if (blosc_level >= 0 && count > 0 && ndim > 0) {
     /* whole trailing dimensions, as many leading rows as fit the chunk target */
     for (int i = 1; i < ndim; ++i) inner *= hd[i];
     for (int i = 0; i < ndim; ++i) chunk[i] = hd[i];

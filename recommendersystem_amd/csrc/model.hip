@@ -1043,6 +1043,25 @@ static int infer_t(Model* m, int task, float* out, int64_t n) {
   return RSYS_OK;
 }
 
+// ItemEmbedding.forward over every item id (model.py:139-145; what register.py:27-29 stores as the watch-head weights):
+// F[id] = E[id] + Wp Meta[id] + bp for id in [0, V), fp32.
+template <typename T>
+static int item_table_t(Model* m, float* out, int64_t n) {
+  ARG_CHECK(n == (int64_t)m->V * m->D, "item table: expected V * embed_dim values");
+  GemmParams p{};
+  p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
+  p.M = m->V + 1; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
+  p.C2 = m->FT; p.ldc2 = m->D;
+  RC(gemm<T>(m, "gemm_table_fwd", p, false, false, false));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  HIP_CHECK(hipMemcpy(out, m->F32, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return RSYS_OK;
+}
+int model_item_table(Model* m, float* out, int64_t n) {
+  HIP_CHECK(hipSetDevice(m->device));
+  return m->bf16_mode ? item_table_t<bf16>(m, out, n) : item_table_t<float>(m, out, n);
+}
+
 int model_infer(Model* m, int task, float* out, int64_t n) {
   ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
   ARG_CHECK(task == 0 || task == 1, "task: 0 retrieval, 1 ranking");

@@ -129,6 +129,7 @@ int model_refresh_shadow(Model* m);
 int model_batch_upload(Model* m, const rsys_batch* b);
 int model_forward_backward(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step);
 int model_infer(Model* m, int task, float* out, int64_t n);
+int model_item_table(Model* m, float* out, int64_t n);
 int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);

@@ -106,10 +106,12 @@ class File:
         return out
 
     def write(self, name, arr, blosc=3):
-        a = np.ascontiguousarray(arr)
+        a = np.asarray(arr)
+        if a.ndim:
+            a = np.ascontiguousarray(a)
         if a.dtype not in _CODE:
             raise H5Error(f"{name}: dtype {a.dtype} has no HDF5 mapping here")
-        if a.ndim < 1 or a.ndim > 4:
+        if a.ndim > 4:
             raise H5Error(f"{name}: rank {a.ndim} not supported")
         dims = (ctypes.c_int64 * 4)(*a.shape)
         _check(lib().rsys_h5_write(self._h, name.encode(), _CODE[a.dtype], a.ndim, dims,

@@ -272,6 +272,13 @@ class RecommenderModel:
             return out
         raise AssertionError(task)
 
+    def item_embeddings(self):
+        """`model.item_embedding(torch.arange(0, n_0 + n_1))` (register.py:27-29): the (V, D) table E + Wp.Meta + bp."""
+        V = self.config["vocab_sizes"]["0_matchedid"] + self.config["vocab_sizes"]["1_matchedid"]
+        out = np.empty((V, self.config["embed_dim"]), np.float32)
+        check(lib().rsys_item_table(self._h, out.ctypes.data, out.size))
+        return out
+
     def trunk_output(self, rows):
         S = self.config["max_sequence_length"]; D = self.config["embed_dim"]
         out = np.empty((rows, 2 * S, D), np.float32)

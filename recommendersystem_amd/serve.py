@@ -113,3 +113,13 @@ def predict(model, users, task, medium, max_user_len=None, max_ranking_items=Non
     d = build_batch(users, task, medium, model.config["vocab_sizes"]["0_matchedid"], max_user_len, max_ranking_items)
     embs = model.inference_forward(d, task)
     return extract(embs, users, task, medium, max_user_len)
+
+
+def register_transformer(model, path):
+    """Finetune/register.py:14-36: the serving registry `model.registry.h5` -- the item table split by medium (the
+    retrieval scores are softmax(table . user embedding), Finetune/embed.jl:86-90) and the rating offset of each medium."""
+    from . import h5
+    n0 = model.config["vocab_sizes"]["0_matchedid"]
+    embs = model.item_embeddings()
+    mean = np.float64(model.config["rating_mean"])
+    h5.write_h5(path, {"0.watch.weight": embs[:n0], "1.watch.weight": embs[n0:], "0.rating_mean": mean, "1.rating_mean": mean}, blosc=None)

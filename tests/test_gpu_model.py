@@ -518,6 +518,31 @@ def test_cli_trains_from_a_data_directory(tmp_path):
     assert hist2[-1][0] == 2 and (hist2[0][0] > 0) == saved
 
 
+def test_registry_export_matches_the_item_embedding(tmp_path):
+    """Finetune/register.py:14-36: `model.registry.h5` holds ItemEmbedding.forward over every item, split by medium, and the
+    rating offsets -- checked against the oracle's fused table (fp32 1e-5, bf16 table arithmetic 2e-2)."""
+    import recommendersystem_amd as ra
+    from oracle import model_np
+    from recommendersystem_amd import h5, serve
+    if not os.path.exists(h5.LIB_PATH):
+        pytest.skip("librsys_h5.so not built (no libhdf5 on this host)")
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    n0, n1 = cfg["vocab_sizes"]["0_matchedid"], cfg["vocab_sizes"]["1_matchedid"]
+    ref = model_np.OracleModel(cfg, P, np.float64).fused_table()[:n0 + n1]
+    for dtype, tol in (("fp32", 1e-5), ("bf16", 2e-2)):
+        model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+        model.load_state_dict(P)
+        path = str(tmp_path / f"model.registry.{dtype}.h5")
+        serve.register_transformer(model, path)
+        model.close()
+        got = h5.read_h5(path)
+        assert sorted(got) == ["0.rating_mean", "0.watch.weight", "1.rating_mean", "1.watch.weight"]
+        assert got["0.watch.weight"].shape == (n0, cfg["embed_dim"]) and got["1.watch.weight"].shape == (n1, cfg["embed_dim"])
+        assert got["0.rating_mean"].shape == () and float(got["1.rating_mean"]) == pytest.approx(cfg["rating_mean"])
+        assert relerr(np.concatenate([got["0.watch.weight"], got["1.watch.weight"]]), ref) < tol, dtype
+
+
 def test_serving_predict_end_to_end():
     """Request -> response through `serve.predict` (embed.py:74-161) on the HIP inference forward: retrieval returns the
     trunk output at the query item token, ranking the rating head at each candidate's action token; compared with the
