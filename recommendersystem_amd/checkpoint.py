@@ -121,6 +121,28 @@ def to_reference(blob, scheduler_state=None):
     return ckpt
 
 
+def dedup_finetune_models(blobs):
+    """Finetune/register.py:38-63 on `.npz`-layout dicts: the four finetuned checkpoints share one frozen trunk, so it is
+    stored once (`base`) and every checkpoint keeps only its LoRA tensors.  Returns (base, [lora-only blobs]); raises like
+    the reference when a checkpoint has no LoRA keys, no trunk keys, or a trunk that differs from the first one's."""
+    base, out = None, []
+    for i, blob in enumerate(blobs):
+        trunk = {k: v for k, v in blob.items() if k.startswith("model/") and "lora_" not in k}
+        lora = {k: v for k, v in blob.items() if k.startswith("model/") and "lora_" in k}
+        assert lora, f"checkpoint {i}: no lora keys found"
+        assert trunk, f"checkpoint {i}: no trunk keys found; is this a full checkpoint?"
+        if base is None:
+            base = trunk
+        else:
+            assert set(trunk) == set(base), f"checkpoint {i}: key mismatch"
+            for k, v in trunk.items():
+                assert np.array_equal(v, base[k]), f"checkpoint {i}: {k} differs from base"
+        rest = {k: v for k, v in blob.items() if not k.startswith("model/")}
+        rest.update(lora)
+        out.append(rest)
+    return base, out
+
+
 def main(argv):
     if len(argv) != 4 or argv[1] not in ("pt2npz", "npz2pt"):
         print(__doc__)

@@ -62,3 +62,26 @@ def test_committed_conversion_is_current():
     assert sorted(z.files) == sorted(blob.keys())
     for k in z.files:
         np.testing.assert_array_equal(z[k], blob[k], err_msg=k)
+
+
+def test_dedup_finetune_models():
+    """register.py:38-63: one shared trunk + per-checkpoint LoRA tensors; a trunk that differs is refused."""
+    from recommendersystem_amd.checkpoint import dedup_finetune_models
+    rng = np.random.default_rng(0)
+    trunk = {"model/transformers.layers.0.attn.q_proj.weight": rng.standard_normal((4, 4)).astype(np.float32),
+             "model/rating_head.0.bias": rng.standard_normal(4).astype(np.float32)}
+    blobs = []
+    for i in range(4):
+        b = dict(trunk)
+        b["model/transformers.layers.0.attn.q_proj_lora_A.weight"] = np.full((2, 4), i, np.float32)
+        b["epoch"] = np.array([i])
+        blobs.append(b)
+    base, loras = dedup_finetune_models(blobs)
+    assert sorted(base) == sorted(trunk) and len(loras) == 4
+    for i, l in enumerate(loras):
+        assert sorted(l) == ["epoch", "model/transformers.layers.0.attn.q_proj_lora_A.weight"] and l["epoch"][0] == i
+    blobs[2]["model/rating_head.0.bias"] = blobs[2]["model/rating_head.0.bias"] + 1
+    with pytest.raises(AssertionError):
+        dedup_finetune_models(blobs)
+    with pytest.raises(AssertionError):
+        dedup_finetune_models([trunk])
