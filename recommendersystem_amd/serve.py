@@ -123,3 +123,26 @@ def register_transformer(model, path):
     embs = model.item_embeddings()
     mean = np.float64(model.config["rating_mean"])
     h5.write_h5(path, {"0.watch.weight": embs[:n0], "1.watch.weight": embs[n0:], "0.rating_mean": mean, "1.rating_mean": mean}, blosc=None)
+
+
+def compute_retrieval(registry, medium, user, idxs=None):
+    """Finetune/embed.jl:86-90: p = softmax(table_m . u) over the medium's items (optionally at `idxs`), times the
+    registry's retrieval coefficient when it has one (`{m}.retrieval.coefs`, fitted by Finetune/regress.jl)."""
+    logits = np.asarray(registry[f"{medium}.watch.weight"], np.float64) @ np.asarray(user[f"{medium}.retrieval"], np.float64)
+    p = np.exp(logits - logits.max())
+    p /= p.sum()
+    if idxs is not None:
+        p = p[np.asarray(idxs)]
+    coefs = registry.get(f"{medium}.retrieval.coefs")
+    return (p * np.asarray(coefs).reshape(-1)[0] if coefs is not None else p).astype(np.float32)
+
+
+def compute_ranking(registry, medium, user):
+    """Finetune/embed.jl:92-96: blend of the medium's mean rating and the model's rating predictions with the registry's
+    coefficients (`{m}.rating.coefs` = [baseline, model]); without coefficients the model's prediction alone."""
+    r_masked = np.asarray(user[f"{medium}.ranking"], np.float64)
+    coefs = registry.get(f"{medium}.rating.coefs")
+    if coefs is None:
+        return r_masked.astype(np.float32)
+    c = np.asarray(coefs, np.float64).reshape(-1)
+    return (c[0] * float(np.asarray(registry[f"{medium}.rating_mean"])) + c[1] * r_masked).astype(np.float32)

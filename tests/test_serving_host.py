@@ -37,3 +37,23 @@ def test_tokenize_and_project_properties():
     assert [(t["medium"], t["matchedid"], t["status"], t["rating"]) for t in tok] == [(0, 5, 2, 7), (1, 5, 3, 0), (0, 5, 2, 7)]
     assert tok[0]["history_status"] == -1                    # identity of the first event of the span, state of the last
     assert len(serve.project(tok)) == 2                      # the last token changed nothing
+
+
+def test_registry_scores():
+    """Finetune/embed.jl:86-96 on a small registry."""
+    from recommendersystem_amd import serve
+    rng = np.random.default_rng(4)
+    table = rng.standard_normal((7, 5)).astype(np.float32)
+    u = rng.standard_normal(5).astype(np.float32)
+    reg = {"1.watch.weight": table, "1.rating_mean": np.float64(7.5)}
+    p = serve.compute_retrieval(reg, 1, {"1.retrieval": u})
+    z = table.astype(np.float64) @ u
+    ref = np.exp(z) / np.exp(z).sum()
+    assert p.shape == (7,) and np.allclose(p, ref, rtol=1e-6) and abs(p.sum() - 1) < 1e-6
+    assert np.allclose(serve.compute_retrieval(reg, 1, {"1.retrieval": u}, idxs=[2, 0]), ref[[2, 0]], rtol=1e-6)
+    reg["1.retrieval.coefs"] = np.array([0.5])
+    assert np.allclose(serve.compute_retrieval(reg, 1, {"1.retrieval": u}), 0.5 * ref, rtol=1e-6)
+    r = np.array([0.3, -1.0], np.float32)
+    assert np.allclose(serve.compute_ranking(reg, 1, {"1.ranking": r}), r)
+    reg["1.rating.coefs"] = np.array([1.0, 0.8])
+    assert np.allclose(serve.compute_ranking(reg, 1, {"1.ranking": r}), 7.5 + 0.8 * r)
