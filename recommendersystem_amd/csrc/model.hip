@@ -524,6 +524,18 @@ template <typename T> static inline T* W(Model* m, int64_t off) { return (T*)m->
 template <typename T> static inline T* AT(void* p) { return (T*)p; }
 template <typename T> static inline T* WT(Model* m, int64_t off) { return (T*)m->ShT + off; }
 
+// Fused item table F = E + Meta Wp^T + bp over all V + 1 rows (model.py:120-133): f32 copy for the token gather, T copy as the
+// tied watch-head operand.  (At cfg-3 this is 782 x 2 tiles of 256 x 256 = 6.1 per CU; sending the rows beyond whole rounds
+// to the 128 x 128 kernel in a second launch was measured: 1.32 -> 1.18 + 0.12 ms, not worth the second code path.)
+template <typename T>
+static int table_forward(Model* m) {
+  GemmParams p{};
+  p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
+  p.M = m->V + 1; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
+  p.C2 = m->FT; p.ldc2 = m->D;
+  return gemm<T>(m, "gemm_table_fwd", p, false, false, false);
+}
+
 // bf16 mode: the dx GEMMs of the trunk (dX = dY . W, W stored [out][in]) read W^T as a row-major [in][out] operand
 static int ensure_transposes(Model* m) {
   if (!m->bf16_mode || !m->wt_dirty) return RSYS_OK;
@@ -567,13 +579,7 @@ static int forward_trunk(Model* m) {
   const int* rpos = b.rope_pos;
   // fused item table F = E + Meta Wp^T + bp
   tic(m, "phase_embed");
-  {
-    GemmParams p{};
-    p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = D; p.c_f32 = 1;
-    p.M = m->V + 1; p.N = D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
-    p.C2 = m->FT; p.ldc2 = D;
-    RC(gemm<T>(m, "gemm_table_fwd", p, false, false, false));
-  }
+  RC(table_forward<T>(m));
   SmallParams sp = small_params(m);
   RC(launch_action_features<T>(b, sp, AT<T>(m->feat), s));
   {
@@ -1048,11 +1054,7 @@ static int infer_t(Model* m, int task, float* out, int64_t n) {
 template <typename T>
 static int item_table_t(Model* m, float* out, int64_t n) {
   ARG_CHECK(n == (int64_t)m->V * m->D, "item table: expected V * embed_dim values");
-  GemmParams p{};
-  p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
-  p.M = m->V + 1; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
-  p.C2 = m->FT; p.ldc2 = m->D;
-  RC(gemm<T>(m, "gemm_table_fwd", p, false, false, false));
+  RC(table_forward<T>(m));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   HIP_CHECK(hipMemcpy(out, m->F32, (size_t)n * 4, hipMemcpyDeviceToHost));
   return RSYS_OK;
