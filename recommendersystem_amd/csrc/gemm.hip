@@ -453,7 +453,8 @@ static bool use_8p_tn(const GemmParams& p) {
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   // measured (tools/bench_gemm_tn.py and in the step): the two transposed reads per fragment make this pipeline ~35 %
   // slower per FLOP than its row-major form, so it wins only where the 128x128 kernel needs many K splits per output
-  // tile AND the output is large: the metadata-projection gradient (50 tiles); the per-layer gradients (4..22 tiles) stay
+  // tile AND the output is large (>= 32 tiles of 256 x 256; the per-layer gradients, 4..22 tiles, stay on the 128 x 128 kernel).
+  // (The step's one such product, the metadata-projection gradient, has moved to row-major operand copies: use_8p_nt_splitk.)
   return (e && atoi(e) == 2) || t256 >= 32;
 }
 
