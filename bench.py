@@ -47,6 +47,18 @@ def traffic_of(db, variant):
     return None
 
 
+HBM_KERNEL_SYMBOL = {"hbm_gather": "gather_items_kernel", "hbm_scatter": "embedding_scatter", "hbm_rmsnorm_fwd": "rmsnorm_fwd_kernel",
+                     "hbm_rmsnorm_bwd": "rmsnorm_bwd_kernel", "adamw": "adamw_kernel", "sumsq": "sumsq_kernel"}
+
+
+def traffic_of_name(db, sym):
+    """PMC HBM bytes per launch of the first kernel of the committed summary whose name contains `sym`"""
+    for name, k in (db or {}).items():
+        if sym and sym in name:
+            return k["hbm_bytes_per_launch"]
+    return None
+
+
 def flops_per_interaction(cfg, B):
     """fwd+bwd, dense-attention upper bound, metadata projection once per step."""
     L, D, I, S = cfg["num_layers"], cfg["embed_dim"], cfg["intermediate_dim"], cfg["max_sequence_length"]
@@ -55,45 +67,42 @@ def flops_per_interaction(cfg, B):
     return 36 * L * (D * D + D * I) + 56 * S * D * L + 6 * K * V * D / S + 4 * V * M * D / (B * S) + 6 * (D * D + D) * 2 * K / S
 
 
-def cpu_baseline(cfg, seed, budget_rows=2):
-    """The numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample:
-    one fp32 training step at `budget_rows` rows, split into the per-step fixed part (fused item table
-    fwd+bwd, AdamW/clip over all parameters) and the per-row part, then scaled to the 64-row step."""
+def cpu_baseline(cfg, seed, rows=8):
+    """The numpy oracle (oracle/, kind "port": fp32, OpenBLAS on every host core) timed on this box on a bounded
+    sample of the same workload: ONE whole training step (fused item table, forward, backward incl. the metadata
+    projection gradient, clip, AdamW over all 129 M parameters) at `rows` rows of S interactions, measured directly --
+    value = rows * S / that time, nothing extrapolated.  (The per-step fixed work -- table projection both ways, the
+    optimizer pass -- is amortised over `rows` rows here, over 64 in the GPU step; the split is in `sample`.)"""
     from oracle import model_np, synth, train_np
+    blas = []
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        blas = [(p_.get("internal_api"), p_.get("num_threads", 1)) for p_ in threadpool_info() if p_.get("user_api") == "blas"]
     except Exception:
-        threads = os.cpu_count() or 1
+        pass
+    threads = max([n for _, n in blas] or [os.cpu_count() or 1])
     S = cfg["max_sequence_length"]
-    small = dict(cfg)
-    P = synth.make_params(small, seed, "init")
-    P = {k: v.astype(np.float32) for k, v in P.items()}
-    d = synth.make_batch(small, budget_rows, seed + 1)
-    wm, rm = synth.make_masks(small, budget_rows, seed + 2)
-    names = synth.trainable_names(small)
+    P = {k: v.astype(np.float32) for k, v in synth.make_params(cfg, seed, "init").items()}
+    d = synth.make_batch(cfg, rows, seed + 1, mu=4.6, sigma=1.0)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    names = synth.trainable_names(cfg)
     tw = train_np.make_task_weights()
-    model = model_np.OracleModel(small, P, np.float32)
+    model = model_np.OracleModel(cfg, P, np.float32)
+    opt = train_np.AdamW(model.P, names, 1e-4)
     t0 = time.time()
-    model.fused_table()
-    t_table_fwd = time.time() - t0
-    t0 = time.time()
-    dm = model_np.mask_tokens(small, model_np.reshape_batch(small, d), wm, rm)
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
     losses, G = model.forward(dm, False, True, tw)
-    t_rows = time.time() - t0          # includes the table forward and its backward GEMM (dF^T Meta)
-    t0 = time.time()
+    t_fb = time.time() - t0
+    t1 = time.time()
     G = {k: G[k] for k in names}
     G, norm = train_np.clip_grad_norm(G, 1.0)
-    opt = train_np.AdamW(model.P, names, 1e-4)
     P2 = dict(model.P); opt.step(P2, G)
-    t_opt = time.time() - t0
-    B = 64
-    fixed = 2 * t_table_fwd + t_opt           # per step: table fwd + its backward GEMM, clip + AdamW pass
-    per_row = max(t_rows - 2 * t_table_fwd, 1e-9) / budget_rows
-    est_step = fixed + B * per_row
-    return {"value": B * S / est_step, "unit": "interactions/sec", "cores": int(threads), "kind": "port",
-            "sample": f"numpy-oracle fp32, one train step at {budget_rows} rows x S={S} (measured {t_rows + t_opt:.1f}s: "
-                      f"table {t_table_fwd:.1f}s fwd, rows {t_rows:.1f}s, clip+AdamW {t_opt:.1f}s), scaled to the 64-row step"}
+    t_opt = time.time() - t1
+    total = time.time() - t0
+    assert all(np.isfinite(losses))
+    return {"value": rows * S / total, "unit": "interactions/sec", "cores": int(threads), "kind": "port",
+            "sample": f"numpy oracle fp32 ({blas or 'blas threads unknown'}), one whole train step at {rows} rows x S={S} measured "
+                      f"directly: {total:.1f}s = fwd+bwd {t_fb:.1f}s + clip+AdamW {t_opt:.1f}s; no extrapolation"}
 
 
 def main():
@@ -107,10 +116,18 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-train-loop", action="store_true", help="skip the train_epoch (upload + loss read-back per step) measurement")
+    ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the CPU-baseline step (numpy oracle)")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has made no GPU call (it has not even loaded the library); it starts
+        # N fresh ranks of itself, relays rank 0's JSON line (rank 0 inherits stdout) and exits with the first failure
+        from recommendersystem_amd.dist import launch_local
+        sys.exit(launch_local(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     # the contract is ONE JSON line on stdout: native libraries (RCCL prints a banner at communicator creation) write to
     # file descriptor 1 behind Python's back, so everything but that line is sent to stderr at the descriptor level
@@ -121,15 +138,23 @@ def main():
     import recommendersystem_amd as ra
     from recommendersystem_amd import workload as synth   # configurations + synthetic corpus (inputs only)
     from recommendersystem_amd import dist as rdist
-    from recommendersystem_amd.train import WSDScheduler, LambdaLR
+    from recommendersystem_amd.train import WSDScheduler, LambdaLR, train_epoch
 
     rank, world, local_rank = rdist.env_rank()
-    if args.gpus > 1:
-        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     hg = rdist.HostGroup(rank, world)
     device = local_rank if world > 1 else 0
     if os.environ.get("RSYS_BENCH_DEVICE") is not None:   # rehearsal of the N-rank path on a box with fewer GPUs
         device = int(os.environ["RSYS_BENCH_DEVICE"])
+    # every rank must own a GPU: agree BEFORE any collective that could leave the others waiting
+    have = 1.0 if device < ra.device_count() else 0.0
+    if hg.all_reduce([have], "min")[0] < 1.0:
+        print(f"bench.py rank {rank}: {ra.device_count()} GPU(s) visible, {world} ranks need one each" +
+              ("" if have else f" (this rank wanted device {device})"), file=sys.stderr)
+        hg.close()
+        sys.exit(3)
     over = {} if args.layers is None else {"num_layers": args.layers}
     cfg = synth.make_config(args.config, **over)
     S = cfg["max_sequence_length"]
@@ -149,6 +174,7 @@ def main():
     model.mask_seed = 0x3A5C ^ rank
     d = synth.make_batch(cfg, rows, 0xD47A ^ rank, mu=4.6, sigma=1.0)
     model.upload(d)                            # inputs resident in HBM before the timed region
+    tw = ra.make_task_weights()
 
     def step():
         if comm is not None:
@@ -172,8 +198,10 @@ def main():
     ra.synchronize()
     t0 = time.perf_counter()
     rep = {}
+    model.step_mark()
     for i in range(args.steps):
         step()
+        model.step_mark()                      # an event on the compute stream per step boundary, no host sync
         if n_instr and i + 1 == n_instr:
             rep = model.timing_report()
             model.timing(False)
@@ -181,6 +209,20 @@ def main():
     hg.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = hg.all_reduce([elapsed], "max")[0]
+    per_step = model.step_times_ms()
+    plain = per_step[n_instr:] if len(per_step) > n_instr else per_step     # steps without per-kernel events
+    # the reference's real loop (train.py:238-283) beside the resident-batch number: every step uploads its batch from an
+    # in-memory shard (to_device) and reads its losses back (the host sync train_epoch does), through train.train_epoch
+    loop_ms = None
+    if not args.no_train_loop:
+        shard = [synth.make_batch(cfg, rows, (0xD47A ^ rank) + 1 + i, mu=4.6, sigma=1.0) for i in range(4)]
+        loader = [shard[i % 4] for i in range(max(4, args.steps))]
+        train_epoch(model, loader[:2], opt, sched, tw, 1, comm)             # warm-up of this path
+        ra.synchronize(); hg.barrier()
+        t1 = time.perf_counter()
+        train_epoch(model, loader, opt, sched, tw, 1, comm)
+        ra.synchronize(); hg.barrier()
+        loop_ms = hg.all_reduce([(time.perf_counter() - t1) / len(loader) * 1e3], "max")[0]
     if rep:
         # the head GEMMs stop at the positive-weight rows (device-side limit): count the flops they really did
         npos = model.head_rows()
@@ -237,6 +279,25 @@ def main():
             "roofline": roofline,
             "losses": [round(float(x), 4) for x in losses],
         }
+        if len(plain):
+            q = lambda f: round(float(np.quantile(plain, f)), 3)
+            out["ms_per_step_stats"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": int(len(plain)),
+                                        "note": "HIP-event time between step boundaries on the compute stream, steps without per-kernel events"}
+        if loop_ms is not None:
+            out["train_loop_ms_per_step"] = round(loop_ms, 3)     # train_epoch: batch upload + loss read-back every step
+            out["train_loop_interactions_per_sec"] = round(world * rows * S / (loop_ms * 1e-3), 1)
+        hbm = {}
+        for tag, r in rep.items():                                # HBM-bound row kernels: algorithmic bytes / HIP-event time
+            if (tag.startswith("hbm_") or tag in ("adamw", "sumsq")) and r["ms"] > 0:
+                e = {"GBps": round(r["flops"] / (r["ms"] * 1e-3) / 1e9, 1), "ms_per_step": round(r["ms"] / n_instr, 4),
+                     "launches_per_step": r["count"] // n_instr, "algorithmic_MB_per_launch": round(r["flops"] / r["count"] / 1e6, 2)}
+                e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 3)
+                pm = traffic_of_name(traffic_db, HBM_KERNEL_SYMBOL.get(tag))
+                if pm:
+                    e["pmc_MB_per_launch"] = round(pm / 1e6, 2)
+                hbm[tag[4:] if tag.startswith("hbm_") else tag] = e
+        if hbm:
+            out["hbm_kernels"] = hbm
         if rep:
             phases = {k: round(v["ms"] / n_instr, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
             out["ms_per_step_by_phase"] = phases
@@ -246,7 +307,7 @@ def main():
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
                 print(f"  {k:22s} {v['ms'] / n_instr:8.3f} ms/step  {v['count'] // n_instr:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, 1)
+            out["cpu_baseline"] = cpu_baseline(cfg, 1, args.cpu_rows)
         print(json.dumps(out), file=json_out, flush=True)
     if comm is not None:
         comm.close()

@@ -111,6 +111,14 @@ int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
 /* debug/parity: trunk output of the last forward (rows*2S*D floats) */
 int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);
 
+/* debug/parity: integer and index paths of the last forward, read back bit-exactly (tests compare them with the
+ * reference's mask_tokens, model.py:417-462, and position selection, model.py:501-513).  Keys: "masked.token_mask_ids",
+ * "masked.matchedid", "masked.status" (int32 [rows*S]); "masked.rating", "masked.progress" (f32); "masked.<medium>.
+ * <watch|rating>.<label|weight|position>"; "idx.<task>" (int32 [mask_topk*rows], task = medium*2 + metric); "npos"
+ * (int32 [4]); "tokens.userid", "tokens.token_mask_ids" (int32 [rows*2S], model.py:468-469); "embed.x0" (f32
+ * [rows*2S*D]); "table.fused" (f32 [(V+1)*D]).  `bytes` must be the exact size of the array. */
+int32_t rsys_debug_get(rsys_model* m, const char* key, void* out, int64_t bytes);
+
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) -- train.py:273; norm_out may be NULL */
 int32_t rsys_clip_grad_norm(rsys_model* m, float max_norm, float* norm_out);
 
@@ -169,6 +177,10 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin);
+/* per-step time distribution (bench.py): rsys_step_mark records an event on the model's stream at an optimizer-step
+ * boundary; rsys_step_marks_get writes the milliseconds between consecutive marks (at most cap) and clears the marks */
+int32_t rsys_step_mark(rsys_model* m);
+int32_t rsys_step_marks_get(rsys_model* m, float* ms_out, int32_t cap, int32_t* n_out);
 int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-call-site HIP-event timings; 2: also run the side-stream GEMMs in line */
 int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
 

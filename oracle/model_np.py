@@ -140,6 +140,14 @@ def gelu_grad(x):
     return 0.5 * (1.0 + erf(x / math.sqrt(2.0))) + x * np.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi)
 
 
+def bf16_round(a):
+    """float -> nearest-even bfloat16 -> float (the storage rounding of the HIP path's T-typed operands)."""
+    a32 = np.ascontiguousarray(a, np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(a32.shape)
+
+
 def _remap(x, vocab):
     """model.py:23-24 MaskedEmbedding: -1 -> last row."""
     return np.where(x == -1, vocab, x)
@@ -150,9 +158,18 @@ class OracleModel:
     """Forward/backward of RecommenderModel (model.py:346-538) on numpy arrays.
     P: {state_dict key: array}.  Gradients for the trainable keys only."""
 
-    def __init__(self, cfg, P, dtype=np.float64):
+    def __init__(self, cfg, P, dtype=np.float64, operand_round=None):
+        """operand_round="bf16": every array the HIP path stores as a bf16 GEMM operand (weights' shadow copies,
+        normalised activations, q/k/v, attention probabilities and outputs, SwiGLU products, logits, and the matching
+        gradient operands of the backward) is rounded to bfloat16 at that point; accumulation stays in `dtype`.  This
+        is the reference's autocast arithmetic as the benchmarked mode computes it, for the tight bf16 parity check."""
         self.cfg = cfg
         self.dt = dtype
+        if operand_round is None:
+            self.q = lambda a: a
+        else:
+            assert operand_round == "bf16"
+            self.q = lambda a: bf16_round(a).astype(dtype)
         self.P = {k: np.asarray(v, dtype) for k, v in P.items()}
         D = cfg["embed_dim"]; H = cfg["num_heads"]
         self.hd = D // H
@@ -160,6 +177,10 @@ class OracleModel:
         self.V0 = cfg["vocab_sizes"]["0_matchedid"]
         self.V = self.V0 + cfg["vocab_sizes"]["1_matchedid"]
         self.lora = bool(cfg.get("finetune")) and any("lora_" in k for k in self.P)
+
+    def W(self, name):
+        """a weight as a GEMM operand (rounded like the bf16 shadow when operand rounding is on)"""
+        return self.q(self.P[name])
 
     # ---- embeddings
     def action_features(self, d):
@@ -195,7 +216,7 @@ class OracleModel:
         if "item_embedding.fused_embedding" in P:
             return P["item_embedding.fused_embedding"]
         return (P["item_embedding.matchedid_embedding.embedding.weight"]
-                + P["item_embedding.metadata_embedding.embedding.weight"] @ P["item_embedding.projection_layer.weight"].T
+                + self.W("item_embedding.metadata_embedding.embedding.weight") @ self.W("item_embedding.projection_layer.weight").T
                 + P["item_embedding.projection_layer.bias"])
 
     # ---- trunk
@@ -209,37 +230,43 @@ class OracleModel:
         for l in range(cfg["num_layers"]):
             p = f"transformers.layers.{l}."
             c = {}
+            Q = self.q
             xn, r1 = rmsnorm(x, P[p + "sa_norm.scale"])
-            q = xn @ P[p + "attn.q_proj.weight"].T
-            k = xn @ P[p + "attn.k_proj.weight"].T
-            v = xn @ P[p + "attn.v_proj.weight"].T
+            xn = Q(xn)
+            q = xn @ self.W(p + "attn.q_proj.weight").T
+            k = xn @ self.W(p + "attn.k_proj.weight").T
+            v = xn @ self.W(p + "attn.v_proj.weight").T
             if self.lora:                                               # model.py:263-271 (dropout = identity)
-                c["qa"] = xn @ P[p + "attn.q_proj_lora_A.weight"].T
-                c["va"] = xn @ P[p + "attn.v_proj_lora_A.weight"].T
-                q = q + 2.0 * (c["qa"] @ P[p + "attn.q_proj_lora_B.weight"].T)
-                v = v + 2.0 * (c["va"] @ P[p + "attn.v_proj_lora_B.weight"].T)
-            q = apply_rope(q.reshape(B, T, H, hd), cos, sin)
-            k = apply_rope(k.reshape(B, T, KV, hd), cos, sin)
-            v = v.reshape(B, T, KV, hd)
+                c["qa"] = Q(xn @ self.W(p + "attn.q_proj_lora_A.weight").T)
+                c["va"] = Q(xn @ self.W(p + "attn.v_proj_lora_A.weight").T)
+                q = q + 2.0 * (c["qa"] @ self.W(p + "attn.q_proj_lora_B.weight").T)
+                v = v + 2.0 * (c["va"] @ self.W(p + "attn.v_proj_lora_B.weight").T)
+            q = Q(apply_rope(q.reshape(B, T, H, hd), cos, sin))
+            k = Q(apply_rope(k.reshape(B, T, KV, hd), cos, sin))
+            v = Q(v.reshape(B, T, KV, hd))
             kk = np.repeat(k, rep, axis=2); vv = np.repeat(v, rep, axis=2)   # GQA: head h -> kv head h//rep
             qh = q.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)  # (B,H,T,hd)
             s = np.matmul(qh, kh.transpose(0, 1, 3, 2)) * scale + neg
             s = s - s.max(-1, keepdims=True)
-            pr = np.exp(s); pr /= pr.sum(-1, keepdims=True)
-            o = np.matmul(pr, vh).transpose(0, 2, 1, 3).reshape(B, T, H * hd)
-            h = x + o @ P[p + "attn.output_proj.weight"].T
+            pr = np.exp(s); den = pr.sum(-1, keepdims=True)
+            o = Q((np.matmul(Q(pr), vh) / den).transpose(0, 2, 1, 3).reshape(B, T, H * hd))   # (flash kernels round exp(s - max), not the quotient)
+            pr /= den
+            h = x + o @ self.W(p + "attn.output_proj.weight").T
             hn, r2 = rmsnorm(h, P[p + "mlp_norm.scale"])
-            a = hn @ P[p + "mlp.w1.weight"].T
-            b = hn @ P[p + "mlp.w3.weight"].T
+            hn = Q(hn)
+            a = hn @ self.W(p + "mlp.w1.weight").T
+            b = hn @ self.W(p + "mlp.w3.weight").T
             sig = 1.0 / (1.0 + np.exp(-a))
-            g = a * sig * b
-            out = h + g @ P[p + "mlp.w2.weight"].T
+            g = Q(a * sig * b)
+            a = Q(a); b = Q(b)                                          # (what the backward reads back; the product above used the accumulators)
+            sig = 1.0 / (1.0 + np.exp(-a))
+            out = h + g @ self.W(p + "mlp.w2.weight").T
             c.update(x=x, xn=xn, r1=r1, q=q, k=k, v=v, pr=pr, o=o, h=h, hn=hn, r2=r2, a=a, b=b, sig=sig, g=g)
             cache.append(c)
             x = out
         y, rf = rmsnorm(x, P["transformers.norm.scale"])
         cache.append(dict(x=x, rf=rf))
-        return y
+        return self.q(y)
 
     def trunk_bwd(self, gy, cos, sin, cache, G):
         cfg, P = self.cfg, self.P
@@ -254,18 +281,21 @@ class OracleModel:
             c = cache[l]
             B, T, D = c["x"].shape
             # out = h + g W2^T
-            G[p + "mlp.w2.weight"] = fl(gx).T @ fl(c["g"])
-            gg = gx @ P[p + "mlp.w2.weight"]
-            ga = gg * c["b"] * (c["sig"] * (1.0 + c["a"] * (1.0 - c["sig"])))
-            gb = gg * c["a"] * c["sig"]
+            Q = self.q
+            gxq = Q(gx)                                                 # the gradient as a GEMM operand
+            G[p + "mlp.w2.weight"] = fl(gxq).T @ fl(c["g"])
+            gg = gxq @ self.W(p + "mlp.w2.weight")
+            ga = Q(gg * c["b"] * (c["sig"] * (1.0 + c["a"] * (1.0 - c["sig"]))))
+            gb = Q(gg * c["a"] * c["sig"])
             G[p + "mlp.w1.weight"] = fl(ga).T @ fl(c["hn"])
             G[p + "mlp.w3.weight"] = fl(gb).T @ fl(c["hn"])
-            ghn = ga @ P[p + "mlp.w1.weight"] + gb @ P[p + "mlp.w3.weight"]
+            ghn = Q(ga @ self.W(p + "mlp.w1.weight") + gb @ self.W(p + "mlp.w3.weight"))
             dh, G[p + "mlp_norm.scale"] = rmsnorm_bwd(ghn, c["h"], P[p + "mlp_norm.scale"], c["r2"])
             gh = gx + dh
+            ghq = Q(gh)
             # h = x + o Wo^T
-            G[p + "attn.output_proj.weight"] = fl(gh).T @ fl(c["o"])
-            go = (gh @ P[p + "attn.output_proj.weight"]).reshape(B, T, H, hd)
+            G[p + "attn.output_proj.weight"] = fl(ghq).T @ fl(c["o"])
+            go = Q(ghq @ self.W(p + "attn.output_proj.weight")).reshape(B, T, H, hd)
             kk = np.repeat(c["k"], rep, axis=2); vv = np.repeat(c["v"], rep, axis=2)
             pr = c["pr"]
             goh = go.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)
@@ -278,18 +308,19 @@ class OracleModel:
             gkk = np.matmul(gs.transpose(0, 1, 3, 2), qh).transpose(0, 2, 1, 3)
             gk = gkk.reshape(B, T, KV, rep, hd).sum(3)
             gv = gvv.reshape(B, T, KV, rep, hd).sum(3)
-            gq = apply_rope_bwd(gq, cos, sin).reshape(B, T, H * hd)
-            gk = apply_rope_bwd(gk, cos, sin).reshape(B, T, KV * hd)
-            gv = gv.reshape(B, T, KV * hd)
-            gxn = gq @ P[p + "attn.q_proj.weight"] + gk @ P[p + "attn.k_proj.weight"] + gv @ P[p + "attn.v_proj.weight"]
+            gq = Q(apply_rope_bwd(gq, cos, sin).reshape(B, T, H * hd))
+            gk = Q(apply_rope_bwd(gk, cos, sin).reshape(B, T, KV * hd))
+            gv = Q(gv.reshape(B, T, KV * hd))
+            gxn = gq @ self.W(p + "attn.q_proj.weight") + gk @ self.W(p + "attn.k_proj.weight") + gv @ self.W(p + "attn.v_proj.weight")
             if self.lora:
                 G[p + "attn.q_proj_lora_B.weight"] = 2.0 * fl(gq).T @ fl(c["qa"])
                 G[p + "attn.v_proj_lora_B.weight"] = 2.0 * fl(gv).T @ fl(c["va"])
-                gqa = 2.0 * gq @ P[p + "attn.q_proj_lora_B.weight"]
-                gva = 2.0 * gv @ P[p + "attn.v_proj_lora_B.weight"]
+                gqa = Q(2.0 * gq @ self.W(p + "attn.q_proj_lora_B.weight"))
+                gva = Q(2.0 * gv @ self.W(p + "attn.v_proj_lora_B.weight"))
                 G[p + "attn.q_proj_lora_A.weight"] = fl(gqa).T @ fl(c["xn"])
                 G[p + "attn.v_proj_lora_A.weight"] = fl(gva).T @ fl(c["xn"])
-                gxn = gxn + gqa @ P[p + "attn.q_proj_lora_A.weight"] + gva @ P[p + "attn.v_proj_lora_A.weight"]
+                gxn = gxn + gqa @ self.W(p + "attn.q_proj_lora_A.weight") + gva @ self.W(p + "attn.v_proj_lora_A.weight")
+            gxn = Q(gxn)
             G[p + "attn.q_proj.weight"] = fl(gq).T @ fl(c["xn"])
             G[p + "attn.k_proj.weight"] = fl(gk).T @ fl(c["xn"])
             G[p + "attn.v_proj.weight"] = fl(gv).T @ fl(c["xn"])
@@ -303,7 +334,8 @@ class OracleModel:
         trunk output (B,2S,D) and a cache for backward."""
         cfg, P = self.cfg, self.P
         feat, fc = self.action_features(dm)
-        e_a = feat @ P["action_embedding.linear.weight"].T + P["action_embedding.linear.bias"]
+        feat = self.q(feat)
+        e_a = feat @ self.W("action_embedding.linear.weight").T + P["action_embedding.linear.bias"]
         Ft = self.fused_table()
         ids = _remap(dm["matchedid"], self.V)
         e_i = Ft[ids]
@@ -348,8 +380,8 @@ class OracleModel:
             if metric == "watch":
                 embed = e0[bp]
                 s, e = (0, self.V0) if medium == 0 else (self.V0, self.V)
-                items = Ft[s:e]
-                logits = embed @ items.T
+                items = self.q(Ft[s:e])
+                logits = self.q(embed @ items.T)
                 mx = logits.max(-1, keepdims=True)
                 lse = mx[:, 0] + np.log(np.exp(logits - mx).sum(-1))
                 ce = lse - logits[np.arange(len(bp)), positions]
@@ -358,7 +390,7 @@ class OracleModel:
                     coef = (tw * labels * weights / w_sum)[:, None]
                     gl = np.exp(logits - lse[:, None])
                     gl[np.arange(len(bp)), positions] -= 1.0
-                    gl *= coef
+                    gl = self.q(gl * coef)
                     tmp = np.zeros((B * S, D), dt)
                     np.add.at(tmp, bp, gl @ items)
                     gy[:, 0::2] += tmp.reshape(B, S, D)
@@ -367,8 +399,10 @@ class OracleModel:
                 embed = e1[bp]
                 W0, b0 = P["rating_head.0.weight"], P["rating_head.0.bias"]
                 W2, b2 = P["rating_head.2.weight"], P["rating_head.2.bias"]
+                W0 = self.q(W0)
                 z = embed @ W0.T + b0
-                hact = gelu(z)
+                hact = self.q(gelu(z))
+                z = self.q(z)
                 preds = (hact @ W2.T + b2).reshape(-1)
                 tgt = labels - dt(cfg["rating_mean"])
                 if evaluate:                                            # model.py:395-401 moments
@@ -379,7 +413,7 @@ class OracleModel:
                     gp = (tw * 2.0 * (preds - tgt) * weights / w_sum)[:, None]
                     G["rating_head.2.weight"] = G.get("rating_head.2.weight", 0) + gp.T @ hact
                     G["rating_head.2.bias"] = G.get("rating_head.2.bias", 0) + gp.sum(0)
-                    gz = (gp @ W2) * gelu_grad(z)
+                    gz = self.q((gp @ W2) * gelu_grad(z))
                     G["rating_head.0.weight"] = G.get("rating_head.0.weight", 0) + gz.T @ embed
                     G["rating_head.0.bias"] = G.get("rating_head.0.bias", 0) + gz.sum(0)
                     ge = gz @ W0
@@ -399,13 +433,14 @@ class OracleModel:
             np.add.at(gFt, ctx["ids"].reshape(-1), g_item)
             Meta = P["item_embedding.metadata_embedding.embedding.weight"]
             G["item_embedding.matchedid_embedding.embedding.weight"] = gFt
-            G["item_embedding.projection_layer.weight"] = gFt.T @ Meta
+            G["item_embedding.projection_layer.weight"] = self.q(gFt).T @ self.q(Meta)
             G["item_embedding.projection_layer.bias"] = gFt.sum(0)
         feat = ctx["feat"].reshape(-1, 32)
         pc, ps, gi, si, sti = ctx["fc"]
         G["action_embedding.linear.weight"] = g_act.T @ feat
         G["action_embedding.linear.bias"] = g_act.sum(0)
-        gf = g_act @ P["action_embedding.linear.weight"]                 # (N,32)
+        g_act = self.q(g_act)
+        gf = g_act @ self.W("action_embedding.linear.weight")                 # (N,32)
         pc = pc.reshape(-1, 2); ps = ps.reshape(-1, 2)
         G["action_embedding.periodic_time_cos"] = (-np.sin(pc) * gf[:, 1:3]).sum(0)
         G["action_embedding.periodic_time_sin"] = (np.cos(ps) * gf[:, 3:5]).sum(0)

@@ -70,6 +70,7 @@ _SIGS = [
     ("rsys_item_table", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_infer", C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
     ("rsys_trunk_output_get", C.c_int32, [_P, _P, C.c_int64]),
+    ("rsys_debug_get", C.c_int32, [_P, C.c_char_p, _P, C.c_int64]),
     ("rsys_clip_grad_norm", C.c_int32, [_P, C.c_float, C.POINTER(C.c_float)]),
     ("rsys_adamw_create", C.c_int32, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(_P)]),
     ("rsys_adamw_destroy", C.c_int32, [_P]),
@@ -97,6 +98,8 @@ _SIGS = [
     ("rsys_op_gemm_rows", C.c_int32, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int32, C.c_int32, _P]),
     ("rsys_op_attention", C.c_int32, [C.c_int32] + [C.c_int32] * 5 + [_P] * 9),
+    ("rsys_step_mark", C.c_int32, [_P]),
+    ("rsys_step_marks_get", C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("rsys_op_timing", C.c_int32, [_P, C.c_int32]),
     ("rsys_timing_get", C.c_int32, [_P, C.c_char_p, C.c_size_t]),
 ]

@@ -105,7 +105,14 @@ def main(argv=None):
     ap.add_argument("--global_batch_size", type=int, default=None, help="rows per optimizer step (transformer.py:593, 600: 32 / 512)")
     ap.add_argument("--num_epochs", type=int, default=None)
     ap.add_argument("--warmup_steps", type=int, default=2000, help="transformer.py:345 (fixed there; short rehearsal runs need fewer)")
+    ap.add_argument("--nproc_per_node", type=int, default=None,
+                    help="start this many ranks of this command (what `torchrun --standalone --nproc_per_node=N` does in "
+                         "entrypoint.sh:25); ignored when a launcher has already set WORLD_SIZE")
     args = ap.parse_args(argv)
+    if args.nproc_per_node and args.nproc_per_node > 1 and "WORLD_SIZE" not in os.environ:
+        # this process has made no GPU call: spawn the ranks as ordinary children and pass their verdict on
+        raw = list(sys.argv[1:] if argv is None else argv)
+        sys.exit(rdist.launch_local(args.nproc_per_node, [sys.executable, "-m", "recommendersystem_amd.cli"] + raw))
 
     rank, world, local_rank = rdist.env_rank()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))

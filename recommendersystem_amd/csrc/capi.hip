@@ -169,6 +169,57 @@ int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {
   return RSYS_OK;
 }
 
+// Parity read-back of the integer / index paths of the last forward (tests only; synchronises):
+//   "masked.token_mask_ids" | "masked.matchedid" | "masked.status"   int32 [rows*S]   mask_tokens outputs (model.py:417-462)
+//   "masked.rating" | "masked.progress"                              f32   [rows*S]
+//   "masked.<m>.<watch|rating>.<label|weight|position>"              f32 / f32 / int32 [rows*S]
+//   "idx.<task>"   int32 [mask_topk*rows]  flat positions chosen for task = medium*2 + metric (model.py:501-513)
+//   "npos"         int32 [4]               positive-weight positions per task
+//   "tokens.userid" | "tokens.token_mask_ids"   int32 [rows*2S]  interleaved per-token arrays (model.py:468-469)
+//   "embed.x0"     f32 [rows*2S*D]         interleaved input embeddings (even rows: gathered item rows)
+//   "table.fused"  f32 [(V+1)*D]           the fused item table the gather reads (row V = mask row)
+int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes) {
+  CHECK_HANDLE(h);
+  ARG_CHECK(key && out, "null");
+  Model* m = h->m;
+  ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
+  HIP_CHECK(hipSetDevice(m->device));
+  const int64_t N = (int64_t)m->cur_rows * m->S;
+  const std::string k(key);
+  const void* src = nullptr; int64_t n = 0;   // n: bytes
+  const BatchDev& b = m->bd;
+  if (k == "masked.token_mask_ids") { src = b.m_tmid; n = N * 4; }
+  else if (k == "masked.matchedid") { src = b.m_matchedid; n = N * 4; }
+  else if (k == "masked.status") { src = b.m_status; n = N * 4; }
+  else if (k == "masked.rating") { src = b.m_rating; n = N * 4; }
+  else if (k == "masked.progress") { src = b.m_progress; n = N * 4; }
+  else if (k == "npos") { src = m->npos; n = 16; }
+  else if (k == "tokens.userid") { src = m->uid_t; n = 2 * N * 4; }
+  else if (k == "tokens.token_mask_ids") { src = m->tm_t; n = 2 * N * 4; }
+  else if (k == "embed.x0") { src = m->x0; n = 2 * N * m->D * 4; }
+  else if (k == "table.fused") { src = m->F32; n = (int64_t)(m->V + 1) * m->D * 4; }
+  else if (k.size() == 5 && k.compare(0, 4, "idx.") == 0 && k[4] >= '0' && k[4] <= '3') { src = m->idx[k[4] - '0']; n = (int64_t)m->K * m->cur_rows * 4; }
+  else if (k.compare(0, 7, "masked.") == 0 && k.size() > 9 && (k[7] == '0' || k[7] == '1') && k[8] == '.') {
+    const int med = k[7] - '0';
+    const std::string rest = k.substr(9);
+    const size_t dot = rest.find('.');
+    if (dot != std::string::npos) {
+      const std::string metric = rest.substr(0, dot), field = rest.substr(dot + 1);
+      const int mi = metric == "watch" ? 0 : metric == "rating" ? 1 : -1;
+      if (mi >= 0) {
+        const int ti = med * 2 + mi;
+        if (field == "label") src = b.m_label[ti]; else if (field == "weight") src = b.m_weight[ti]; else if (field == "position") src = b.m_position[ti];
+        n = N * 4;
+      }
+    }
+  }
+  if (src == nullptr) { set_error(std::string("rsys_debug_get: unknown key ") + key); return RSYS_ERR_ARG; }
+  ARG_CHECK(bytes == n, "rsys_debug_get: buffer size does not match the array");
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  HIP_CHECK(hipMemcpy(out, src, (size_t)n, hipMemcpyDeviceToHost));
+  return RSYS_OK;
+}
+
 int32_t rsys_clip_grad_norm(rsys_model* h, float max_norm, float* norm_out) { CHECK_HANDLE(h); return model_clip(h->m, max_norm, norm_out); }
 
 int32_t rsys_adamw_create(rsys_model* h, float lr, float b1, float b2, float eps, float wd, rsys_optimizer** out) {
@@ -453,6 +504,35 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   hipFree(maps); hipFree(delta);
   if (rc) return rc;
   HIP_CHECK(e2);
+  return RSYS_OK;
+}
+
+// step boundaries on the model's stream: rsys_step_mark records an event, rsys_step_marks_get returns the elapsed time
+// between consecutive marks (ms) and clears them -- the per-step time distribution without a host sync per step
+int32_t rsys_step_mark(rsys_model* h) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipEventRecord(e, m->stream));
+  m->step_marks.push_back(e);
+  return RSYS_OK;
+}
+int32_t rsys_step_marks_get(rsys_model* h, float* ms_out, int32_t cap, int32_t* n_out) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  int n = 0;
+  for (size_t i = 1; i < m->step_marks.size() && n < cap; ++i, ++n) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, m->step_marks[i - 1], m->step_marks[i]));
+    if (ms_out) ms_out[n] = ms;
+  }
+  for (hipEvent_t e : m->step_marks) hipEventDestroy(e);
+  m->step_marks.clear();
+  if (n_out) *n_out = n;
   return RSYS_OK;
 }
 

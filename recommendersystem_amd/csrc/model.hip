@@ -257,6 +257,7 @@ int model_destroy(Model* m) {
   for (void* p : m->allocs) hipFree(p);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
   for (auto e : m->timer.pool) hipEventDestroy(e);
+  for (auto e : m->step_marks) hipEventDestroy(e);
   hipStreamDestroy(m->stream);
   delete m;
   return RSYS_OK;
@@ -422,33 +423,14 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   const size_t N = (size_t)b->rows * m->S;
   BatchDev& d = m->bd;
   hipStream_t s = m->stream;
-#define H2D(dst, src, bytes) HIP_CHECK(hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
   ARG_CHECK(b->userid && b->token_mask_ids && b->gender && b->source && b->matchedid && b->status && b->time && b->rating && b->progress,
             "batch arrays must not be null");
-  H2D(d.userid, b->userid, N * 4); H2D(d.tmid, b->token_mask_ids, N * 4); H2D(d.gender, b->gender, N * 4);
-  H2D(d.source, b->source, N * 4); H2D(d.matchedid, b->matchedid, N * 4); H2D(d.status, b->status, N * 4);
-  H2D(d.time, b->time, N * 8); H2D(d.rating, b->rating, N * 4); H2D(d.progress, b->progress, N * 4);
   for (int k = 0; k < 6; ++k) {
     if (k % 3 == 2 && b->label[k] == nullptr) continue;  // status targets are never used by the losses (model.py:448-449)
     ARG_CHECK(b->label[k] && b->weight[k] && b->position[k], "target arrays must not be null");
-    H2D(d.label[k], b->label[k], N * 4); H2D(d.weight[k], b->weight[k], N * 4); H2D(d.position[k], b->position[k], N * 4);
   }
-  m->has_masks = b->watch_mask != nullptr;
-  if (m->has_masks) {
-    ARG_CHECK(b->rating_mask != nullptr, "watch_mask and rating_mask come together");
-    H2D(m->d_wm, b->watch_mask, N); H2D(m->d_rm, b->rating_mask, N);
-  }
-  m->has_rope_pos = b->rope_input_pos != nullptr;
-  if (m->has_rope_pos) {
-    // model.py:470-476: token positions 2p, 2p+1
-    std::vector<int> pos(2 * N);
-    for (size_t i = 0; i < N; ++i) { pos[2 * i] = 2 * b->rope_input_pos[i]; pos[2 * i + 1] = 2 * b->rope_input_pos[i] + 1; }
-    for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
-    HIP_CHECK(hipMemcpy(m->d_rope_pos, pos.data(), 2 * N * 4, hipMemcpyHostToDevice));
-  }
-#undef H2D
-  HIP_CHECK(hipStreamSynchronize(s));
-  // index paths are checked on the host before any kernel may dereference them
+  ARG_CHECK(b->watch_mask == nullptr || b->rating_mask != nullptr, "watch_mask and rating_mask come together");
+  // index paths are checked on the host BEFORE anything is copied: a rejected batch leaves the resident one untouched
   for (size_t i = 0; i < N; ++i) {
     int id = b->matchedid[i];
     ARG_CHECK(id >= -1 && id < m->V, "matchedid out of range");
@@ -463,6 +445,28 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
     ARG_CHECK(b->position[3][i] >= 0 && b->position[3][i] < m->V1 && b->position[4][i] >= 0 && b->position[4][i] < m->V1,
               "anime target position out of range");
   }
+  std::vector<int> pos;
+  if (b->rope_input_pos != nullptr) {
+    // model.py:470-476: token positions 2p, 2p+1
+    pos.resize(2 * N);
+    for (size_t i = 0; i < N; ++i) { pos[2 * i] = 2 * b->rope_input_pos[i]; pos[2 * i + 1] = 2 * b->rope_input_pos[i] + 1; }
+    for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
+  }
+  m->cur_rows = 0;   // (a failing copy below must not leave a half-written batch marked as resident)
+#define H2D(dst, src, bytes) HIP_CHECK(hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
+  H2D(d.userid, b->userid, N * 4); H2D(d.tmid, b->token_mask_ids, N * 4); H2D(d.gender, b->gender, N * 4);
+  H2D(d.source, b->source, N * 4); H2D(d.matchedid, b->matchedid, N * 4); H2D(d.status, b->status, N * 4);
+  H2D(d.time, b->time, N * 8); H2D(d.rating, b->rating, N * 4); H2D(d.progress, b->progress, N * 4);
+  for (int k = 0; k < 6; ++k) {
+    if (k % 3 == 2 && b->label[k] == nullptr) continue;
+    H2D(d.label[k], b->label[k], N * 4); H2D(d.weight[k], b->weight[k], N * 4); H2D(d.position[k], b->position[k], N * 4);
+  }
+  m->has_masks = b->watch_mask != nullptr;
+  if (m->has_masks) { H2D(m->d_wm, b->watch_mask, N); H2D(m->d_rm, b->rating_mask, N); }
+  m->has_rope_pos = b->rope_input_pos != nullptr;
+  if (m->has_rope_pos) H2D(m->d_rope_pos, pos.data(), 2 * N * 4);
+#undef H2D
+  HIP_CHECK(hipStreamSynchronize(s));
   m->cur_rows = b->rows;
   return RSYS_OK;
 }
@@ -588,7 +592,9 @@ static int forward_trunk(Model* m) {
     p.M = N; p.N = D; p.K = 32; p.epi = EPI_BIAS; p.bias = m->P + m->o_lin_b;
     RC(gemm<T>(m, "gemm_action_fwd", p, false, false, false));
   }
+  tic(m, "hbm_gather", 8.0 * D * N);   // bytes: one fused-table row read + one embedding row written per interaction
   RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
+  toc(m);
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
@@ -598,7 +604,9 @@ static int forward_trunk(Model* m) {
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
     float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
+    tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
     RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s));
+    toc(m);
     const bool ft = m->cfg.finetune != 0;
     T* xnd = AT<T>(a.xn);   // LoRA input: dropout(x) in a training pass (model.py:265,269), else x itself
     if (ft) {
@@ -641,7 +649,9 @@ static int forward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
       RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
     }
+    tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
     RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
+    toc(m);
     {
       GemmParams p{};
       p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
@@ -655,7 +665,9 @@ static int forward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
     }
   }
+  tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
   RC(launch_rmsnorm_fwd<T>(m->xL, m->P + m->o_norm, AT<T>(m->out), m->rstdf, NT, D, s));
+  toc(m);
   toc(m);
   return RSYS_OK;
 }
@@ -758,7 +770,10 @@ static int backward_trunk(Model* m) {
   RC(ensure_transposes(m));
   const bool wt = m->bf16_mode;   // dx GEMMs: row-major W^T (bf16 mode) or the K-major read of W itself (fp32 parity mode)
   tic(m, "phase_trunk_bwd");
+  const double nb_bytes = (sizeof(T) + 4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT;   // g, x, residual gradient in; dx (+ its bf16 operand copy) out
+  tic(m, "hbm_rmsnorm_bwd", (4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT);
   RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
+  toc(m);
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
@@ -795,7 +810,9 @@ static int backward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
       RC(join_side(m));
     }
+    tic(m, "hbm_rmsnorm_bwd", nb_bytes);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
+    toc(m);
     if (!ft) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
@@ -874,7 +891,9 @@ static int backward_trunk(Model* m) {
         }
       }
     }
+    tic(m, "hbm_rmsnorm_bwd", nb_bytes);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
+    toc(m);
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
     if (m->grad_bucket_hook && !ft) {
@@ -896,8 +915,11 @@ static int backward_trunk(Model* m) {
   // gx = gradient w.r.t. the interleaved input embeddings (even rows: items, odd rows: actions)
   tic(m, "phase_embed_bwd");
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
+  tic(m, "hbm_scatter", 12.0 * D * N);   // bytes: one gradient row read + one table-gradient row read-modify-written per interaction
   RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
+  toc(m);
   m->table_grads_pending = true;
+  m->gE_clean[0] = m->gE_clean[1] = false;   // the rows now hold token gradients: a later head GEMM must add, not store
   {
     GemmParams p{};  // dWlin += g_act^T . feat
     p.A = gxt + D; p.lda = 2 * D; p.B = m->feat; p.ldb = 32; p.C = m->G + m->o_lin_w; p.ldc = 32; p.c_f32 = 1;
@@ -1094,13 +1116,13 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   const float* ss = nullptr;
   if (clip > 0.f) {
     HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
-    tic(m, "sumsq");
+    tic(m, "sumsq", 4.0 * m->n_opt);
     RC(launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream));
     toc(m);
     ss = m->sumsq;
   }
   o->step += 1;
-  tic(m, "adamw");
+  tic(m, "adamw", (m->bf16_mode ? 34.0 : 32.0) * m->n_opt);   // p, g, m, v read; p, m, v, zeroed g (+ bf16 shadow) written
   int rc;
   if (!m->cfg.finetune) m->wt_dirty = true;   // (finetune: only the LoRA segment moves, the base weights and their transposes stay)
   if (m->bf16_mode)

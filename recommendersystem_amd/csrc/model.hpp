@@ -108,6 +108,7 @@ struct Model {
   bool drop_active = false; unsigned long long drop_seed = 0, drop_step = 0;   // LoRA dropout of the current pass
   bool last_evaluate = false;
   PhaseTimer timer;
+  std::vector<hipEvent_t> step_marks;   // rsys_step_mark: one event per optimizer-step boundary (per-step time distribution)
 };
 
 struct Optimizer {

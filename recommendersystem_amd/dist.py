@@ -1,13 +1,20 @@
 """Data-parallel plumbing: one process per GPU (train.py:582-587), gradient all-reduce over RCCL/xGMI.
 
 The data path (gradient buckets) goes through the library's own RCCL communicator
-(rsys_comm_*, include/rsys.h).  The control plane -- exchanging the 128-byte RCCL id,
-barriers, the scalar max/sum of the benchmark and of reduce_mean -- uses the
-rendezvous the launcher already provides (torchrun env: RANK, WORLD_SIZE, LOCAL_RANK,
-MASTER_ADDR, MASTER_PORT) through torch.distributed's gloo backend on CPU tensors.
+(rsys_comm_*, include/rsys.h).  The control plane -- exchanging the 128-byte RCCL id
+(the reference leaves that to torchrun's store, train.py:582), barriers, the scalar
+max/sum of the benchmark and the agreement on failures -- is a small TCP star around
+rank 0 (`HostGroup`, plain sockets): a rank never imports torch, so the HIP runtime and
+RCCL it binds are the ones librsys_hip.so was built against (/opt/rocm).  The launcher
+only has to provide the usual environment: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR,
+MASTER_PORT (torchrun, or bench.py's / cli.py's own spawner).
 """
 import ctypes as C
+import json
 import os
+import socket
+import struct
+import time
 
 import numpy as np
 
@@ -19,46 +26,197 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-class HostGroup:
-    """CPU-side process group (gloo).  world == 1 needs no torch at all."""
+class RendezvousError(RuntimeError):
+    pass
 
-    def __init__(self, rank=None, world=None):
+
+def _send_frame(sock, header, raw=b""):
+    head = json.dumps(dict(header, raw=len(raw))).encode()
+    sock.sendall(struct.pack("!II", len(head), len(raw)) + head + raw)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise RendezvousError("peer closed the connection (another rank exited)")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_frame(sock):
+    nh, nr = struct.unpack("!II", _recv_exact(sock, 8))
+    header = json.loads(_recv_exact(sock, nh).decode())
+    return header, (_recv_exact(sock, nr) if nr else b"")
+
+
+def rendezvous_ports():
+    """Candidate ports of rank 0's listener.  RSYS_RDZV_PORT names one (bench.py's own spawner sets it); under torchrun
+    MASTER_PORT itself is held by the agent's store, so the candidates are the 16 ports after it and the handshake
+    (session token + world size) tells the right listener from anything else that may sit on one of them."""
+    if os.environ.get("RSYS_RDZV_PORT"):
+        return [int(os.environ["RSYS_RDZV_PORT"])]
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    return [base + 1 + k for k in range(16)]
+
+
+class HostGroup:
+    """CPU-side process group over TCP: rank 0 listens, every other rank holds one connection to it; each collective is
+    one request per rank and one reply (star).  Messages carry an operation counter, so ranks that fall out of step
+    fail with an error instead of exchanging the wrong values; a rank that dies closes its socket, which every other
+    rank sees as an error in its next collective (nobody is left waiting).  world == 1 opens nothing."""
+
+    def __init__(self, rank=None, world=None, timeout=None):
         r, w, _ = env_rank()
         self.rank = r if rank is None else rank
         self.world = w if world is None else world
-        self.pg = None
+        self.timeout = float(os.environ.get("RSYS_RDZV_TIMEOUT", "600")) if timeout is None else timeout
+        self.seq = 0
+        self.peers = []      # rank 0: sockets of ranks 1 .. world-1, by rank
+        self.sock = None     # other ranks: the connection to rank 0
+        self.listener = None
         if self.world > 1:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29500")
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.pg = dist
+            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            token = f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}:{os.environ.get('MASTER_PORT', '')}:{self.world}"
+            (self._serve if self.rank == 0 else self._join)(addr, token)
+
+    # ---- connection set-up
+    def _serve(self, addr, token):
+        err = None
+        for port in rendezvous_ports():
+            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                ls.bind(("", port))
+            except OSError as e:
+                err = e
+                ls.close()
+                continue
+            ls.listen(self.world)
+            self.listener = ls
+            break
+        if self.listener is None:
+            raise RendezvousError(f"rank 0 cannot bind any rendezvous port {rendezvous_ports()}: {err}")
+        peers = {}
+        deadline = time.monotonic() + self.timeout
+        while len(peers) < self.world - 1:
+            self.listener.settimeout(max(0.1, deadline - time.monotonic()))
+            try:
+                conn, _ = self.listener.accept()
+            except socket.timeout:
+                raise RendezvousError(f"rendezvous timed out: {len(peers) + 1} of {self.world} ranks arrived") from None
+            conn.settimeout(10.0)
+            try:
+                hello, _ = _recv_frame(conn)
+                ok = hello.get("token") == token and 0 < int(hello.get("rank", -1)) < self.world and hello["rank"] not in peers
+                _send_frame(conn, {"ok": bool(ok)})
+            except (OSError, ValueError, RendezvousError, struct.error):
+                ok = False
+            if not ok:
+                conn.close()
+                continue
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.settimeout(self.timeout)
+            peers[int(hello["rank"])] = conn
+        self.peers = [peers[r] for r in range(1, self.world)]
+
+    def _join(self, addr, token):
+        deadline = time.monotonic() + self.timeout
+        while True:
+            for port in rendezvous_ports():
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(10.0)
+                    _send_frame(s, {"token": token, "rank": self.rank})
+                    reply, _ = _recv_frame(s)
+                    if reply.get("ok"):
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        s.settimeout(self.timeout)
+                        self.sock = s
+                        return
+                except (OSError, ValueError, RendezvousError, struct.error):
+                    pass
+                s.close()
+            if time.monotonic() > deadline:
+                raise RendezvousError(f"rank {self.rank}: no rendezvous listener of rank 0 on {addr}:{rendezvous_ports()}")
+            time.sleep(0.2)
+
+    # ---- one collective = gather at rank 0, combine, scatter the result
+    def _collective(self, op, header, raw, combine):
+        self.seq += 1
+        header = dict(header, op=op, seq=self.seq)
+        try:
+            if self.rank != 0:
+                _send_frame(self.sock, header, raw)
+                out, out_raw = _recv_frame(self.sock)
+                if "error" in out:
+                    raise RendezvousError(out["error"])
+                return out, out_raw
+            parts = [(header, raw)]
+            for r, conn in enumerate(self.peers, start=1):
+                h, b = _recv_frame(conn)
+                if h.get("op") != op or h.get("seq") != self.seq:
+                    msg = f"ranks out of step: rank 0 is in {op}#{self.seq}, rank {r} in {h.get('op')}#{h.get('seq')}"
+                    for c in self.peers:
+                        _send_frame(c, {"error": msg})
+                    raise RendezvousError(msg)
+                parts.append((h, b))
+            out, out_raw = combine(parts)
+            for conn in self.peers:
+                _send_frame(conn, out, out_raw)
+            return out, out_raw
+        except (OSError, struct.error) as e:
+            raise RendezvousError(f"rank {self.rank}: {op} failed: {e}") from None
 
     def barrier(self):
-        if self.pg is not None:
-            self.pg.barrier()
+        if self.world > 1:
+            self._collective("barrier", {}, b"", lambda parts: ({}, b""))
 
     def broadcast_bytes(self, data, src=0):
-        if self.pg is None:
+        if self.world == 1:
             return data
-        import torch
-        t = torch.tensor(list(data), dtype=torch.uint8) if self.rank == src else torch.zeros(len(data), dtype=torch.uint8)
-        self.pg.broadcast(t, src)
-        return bytes(t.tolist())
+        _, raw = self._collective("bcast", {"src": src}, bytes(data) if self.rank == src else b"",
+                                  lambda parts: ({}, parts[src][1]))
+        return raw
 
     def all_reduce(self, values, op="sum"):
-        if self.pg is None:
-            return [float(v) for v in values]
-        import torch
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-        self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM if op == "sum" else self.pg.ReduceOp.MAX)
-        return t.tolist()
+        """element-wise sum / max / min of a short list of floats over the ranks (float64, summed in rank order)"""
+        vals = [float(v) for v in values]
+        if self.world == 1:
+            return vals
+        red = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+
+        def combine(parts):
+            m = np.array([h["v"] for h, _ in parts], np.float64)
+            return {"v": [float(x) for x in red(m, axis=0)]}, b""
+        out, _ = self._collective("reduce_" + op, {"v": vals}, b"", combine)
+        return out["v"]
+
+    def all_reduce_array(self, arr):
+        """in-place float32 sum over the ranks through host memory (debugging aid: HostComm)"""
+        if self.world == 1:
+            return arr
+
+        def combine(parts):
+            acc = np.frombuffer(parts[0][1], np.float32).copy()
+            for _, b in parts[1:]:
+                acc += np.frombuffer(b, np.float32)
+            return {}, acc.tobytes()
+        _, raw = self._collective("reduce_array", {"n": int(arr.size)}, np.ascontiguousarray(arr, np.float32).tobytes(), combine)
+        arr[...] = np.frombuffer(raw, np.float32).reshape(arr.shape)
+        return arr
 
     def close(self):
-        if self.pg is not None and self.pg.is_initialized():
-            self.pg.destroy_process_group()
-            self.pg = None
+        for c in self.peers + [x for x in (self.sock, self.listener) if x is not None]:
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock, self.listener = [], None, None
 
 
 class Comm:
@@ -105,9 +263,9 @@ class Comm:
 
 
 class HostComm:
-    """Gradient all-reduce through host memory over gloo (same surface as Comm): a debugging aid for machines whose RCCL
-    cannot initialise.  Never chosen silently: `make_comm` raises unless RSYS_ALLOW_HOST_ALLREDUCE=1 is set, and the
-    class says what it is on stderr (it is orders of magnitude slower than RCCL over xGMI)."""
+    """Gradient all-reduce through host memory over the TCP control plane (same surface as Comm): a debugging aid for
+    machines whose RCCL cannot initialise.  Never chosen silently: `make_comm` raises unless RSYS_ALLOW_HOST_ALLREDUCE=1
+    is set, and the class says what it is on stderr (it is orders of magnitude slower than RCCL over xGMI)."""
 
     def __init__(self, host_group, reason=""):
         import sys
@@ -115,7 +273,7 @@ class HostComm:
         self.rank, self.world = host_group.rank, host_group.world
         if self.rank == 0:
             print(f"[recommendersystem_amd.dist] RCCL communicator unavailable ({reason}); "
-                  "falling back to a HOST all-reduce over gloo", file=sys.stderr)
+                  "falling back to a HOST all-reduce over TCP", file=sys.stderr)
 
     def self_test(self):
         assert self.hg.all_reduce([1.0], "sum")[0] == float(self.world)
@@ -124,13 +282,11 @@ class HostComm:
         pass
 
     def all_reduce_grads(self, model):
-        import torch
         ptr = C.c_void_p(); n = C.c_int64()
         check(lib().rsys_grad_buffer(model._h, C.byref(ptr), C.byref(n)))
         host = np.empty(n.value, np.float32)
         check(lib().rsys_dev_d2h(host.ctypes.data, ptr, host.nbytes))
-        t = torch.from_numpy(host)
-        self.hg.pg.all_reduce(t)
+        self.hg.all_reduce_array(host)
         check(lib().rsys_dev_h2d(ptr, host.ctypes.data, host.nbytes))
 
     def all_reduce_sum(self, values):
@@ -144,12 +300,12 @@ def _no_rccl(host_group, reason):
     if os.environ.get("RSYS_ALLOW_HOST_ALLREDUCE") == "1":
         return HostComm(host_group, reason)
     raise RuntimeError(f"RCCL communicator unavailable on at least one rank ({reason}); the gradient all-reduce has no "
-                       "silent host path (set RSYS_ALLOW_HOST_ALLREDUCE=1 to debug with a gloo all-reduce)")
+                       "silent host path (set RSYS_ALLOW_HOST_ALLREDUCE=1 to debug with an all-reduce through host memory)")
 
 
 def make_comm(host_group, device):
     """RCCL communicator of this rank; every rank takes the same branch (the outcome of the RCCL attempt is agreed on
-    with a MIN reduction over gloo, so a failure raises on all ranks instead of leaving some inside a collective)."""
+    with a MIN reduction over the control plane, so a failure raises on all ranks instead of leaving some inside a collective)."""
     if host_group.world == 1:
         return None
     comm, err = None, ""
@@ -181,3 +337,42 @@ def shard_for_rank(shards, local_rank, local_world_size):
     """train.py:46-51: shard directory i goes to rank i % world; the count must divide evenly."""
     assert len(shards) % local_world_size == 0
     return [x for i, x in enumerate(shards) if i % local_world_size == local_rank]
+
+
+def launch_local(nproc, argv, env=None, poll=0.2, grace=10.0):
+    """`torchrun --standalone --nproc_per_node=N` (entrypoint.sh:25) for one node, without torch: start `nproc` fresh
+    processes of `argv` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / RSYS_RDZV_PORT set, rank 0 on
+    this process's stdout and the other ranks' stdout on stderr.  The caller must not have touched the GPU (the children
+    are ordinary child processes, nothing is exec'd over a process that has).  As soon as one rank exits non-zero the
+    others are terminated (no orphan is left inside a collective); returns the first non-zero exit code, else 0."""
+    import subprocess
+    import sys
+    ls = socket.socket(); ls.bind(("127.0.0.1", 0)); port = ls.getsockname()[1]; ls.close()
+    procs = []
+    for r in range(nproc):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RSYS_RDZV_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(poll)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+    if rc != 0:
+        for p in live:
+            p.terminate()
+        deadline = time.monotonic() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc

@@ -285,6 +285,26 @@ class RecommenderModel:
         check(lib().rsys_trunk_output_get(self._h, out.ctypes.data, out.size))
         return out
 
+    def debug_get(self, key, rows):
+        """Bit-exact read-back of an index-path array of the last forward (rsys_debug_get; parity tests)."""
+        S = self.config["max_sequence_length"]; D = self.config["embed_dim"]; n = rows * S
+        V = self.config["vocab_sizes"]["0_matchedid"] + self.config["vocab_sizes"]["1_matchedid"]
+        if key == "npos":
+            out = np.empty(4, np.int32)
+        elif key.startswith("idx."):
+            out = np.empty(self.config["mask_topk"] * rows, np.int32)
+        elif key.startswith("tokens."):
+            out = np.empty(2 * n, np.int32)
+        elif key == "embed.x0":
+            out = np.empty((2 * n, D), np.float32)
+        elif key == "table.fused":
+            out = np.empty((V + 1, D), np.float32)
+        else:
+            is_f32 = key in ("masked.rating", "masked.progress") or key.endswith(".label") or key.endswith(".weight")
+            out = np.empty(n, np.float32 if is_f32 else np.int32)
+        check(lib().rsys_debug_get(self._h, key.encode(), out.ctypes.data, out.nbytes))
+        return out
+
     def head_rows(self):
         """positive-weight positions per task in the last forward (the head GEMMs stop there)."""
         out = (C.c_int32 * 4)()
@@ -296,6 +316,16 @@ class RecommenderModel:
         """HIP-event timing of every kernel call site.  serialize=True additionally runs the side-stream GEMMs in
         line, so that each kernel is measured without a concurrent neighbour (bench.py --detail)."""
         check(lib().rsys_op_timing(self._h, (2 if serialize else 1) if enable else 0))
+
+    def step_mark(self):
+        """record a step boundary on the model's stream (no host sync)"""
+        check(lib().rsys_step_mark(self._h))
+
+    def step_times_ms(self, cap=65536):
+        """milliseconds between consecutive step_mark() calls since the last read (synchronises)"""
+        out = np.empty(cap, np.float32); n = C.c_int32()
+        check(lib().rsys_step_marks_get(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].astype(np.float64)
 
     def timing_report(self):
         buf = C.create_string_buffer(1 << 16)

@@ -4,38 +4,53 @@ Same names, argument meaning and behaviour as the reference functions; each cite
 the lines it restates.  Arithmetic on the device goes through RecommenderModel /
 AdamW (C ABI); nothing here touches a CPU compute fallback.
 """
+import dataclasses
+import math
+
 import numpy as np
 
 from .model import ALL_MEDIUMS, ALL_METRICS
 from .optim import clip_grad_norm_
 
 
-class ConstantScheduler:  # train.py:301-307
-    def __init__(self):
-        self.steps = 0
+class ConstantScheduler:
+    """Finetune schedule (train.py:301-307): the factor is 1 on every call; `steps` counts the calls."""
+    steps = 0
 
-    def __call__(self, epoch):
+    def __call__(self, _step=None):
         self.steps += 1
         return 1
 
 
-class WSDScheduler:  # train.py:310-328
+class WSDScheduler:
+    """Warm-up / stable / decay learning-rate factor (train.py:310-328) as a piecewise-linear curve through the knots
+    (0, 0) - (warmup, 1) - (total - decay, 1) - (total, final_ratio), decay = int(total * decay_ratio); steps outside
+    [0, total] take the value of the nearest end."""
+
     def __init__(self, warmup_steps, total_steps, decay_ratio, final_ratio):
-        self.warmup_steps = warmup_steps
-        self.total_steps = total_steps
-        self.final_ratio = final_ratio
-        self.decay_steps = int(total_steps * decay_ratio)
-        self.stable_steps = total_steps - warmup_steps - self.decay_steps
-        assert self.stable_steps >= 0
+        decay = int(total_steps * decay_ratio)
+        plateau_end = total_steps - decay
+        if plateau_end < warmup_steps:
+            raise AssertionError("warm-up and decay overlap: total_steps is too small")
+        self.warmup_steps, self.total_steps, self.final_ratio = warmup_steps, total_steps, final_ratio
+        # (first step, length, factor at the start, factor at the end) of the two ramps
+        self._ramps = ((0, max(1, warmup_steps), 0.0, 1.0), (plateau_end, max(1, decay), 1.0, final_ratio))
 
     def __call__(self, step):
-        s = max(0, min(int(step), self.total_steps))
+        s = min(max(int(step), 0), self.total_steps)
+        (w0, wn, wa, wb), (d0, dn, da, db) = self._ramps
         if s <= self.warmup_steps:
-            return s / max(1, self.warmup_steps)
-        if s <= (self.warmup_steps + self.stable_steps):
+            return wa + (wb - wa) * ((s - w0) / wn) if self.warmup_steps else 0.0
+        if s <= d0:
             return 1.0
-        decay_progress = (s - self.warmup_steps - self.stable_steps) / max(1, self.decay_steps)
-        return 1.0 - (1.0 - self.final_ratio) * decay_progress
+        return da + (db - da) * ((s - d0) / dn)
+
+    def reference_state(self):
+        """The attribute dict of the reference's scheduler object (what torch's LambdaLR.state_dict() stores in
+        `lr_lambdas`; checkpoint interchange, checkpoint.py)."""
+        d0 = self._ramps[1][0]
+        return {"warmup_steps": self.warmup_steps, "total_steps": self.total_steps, "final_ratio": self.final_ratio,
+                "decay_steps": self.total_steps - d0, "stable_steps": d0 - self.warmup_steps}
 
 
 class LambdaLR:
@@ -69,69 +84,71 @@ def create_learning_rate_schedule(tokens_per_epoch, tokens_per_batch, epochs, fi
     return LambdaLR(WSDScheduler(warmup_steps=warmup_steps, total_steps=total_steps, decay_ratio=0.1, final_ratio=0.1))
 
 
-class EarlyStopper:  # train.py:350-372
-    def __init__(self, patience, rtol):
-        self.patience = patience
-        self.rtol = rtol
-        self.counter = 0
-        self.stop_score = float("inf")
-        self.early_stop = False
-        self.saved_score = float("inf")
-        self.save_model = False
+@dataclasses.dataclass
+class EarlyStopper:
+    """Two running minima over the epoch scores (train.py:350-372).  `early_stop` turns on once `patience` epochs in a
+    row failed to beat the best score by the relative margin `rtol`; `save_model` says whether the latest score is the
+    lowest seen so far (the checkpoint is written only then)."""
+    patience: float
+    rtol: float
+    counter: int = 0                      # consecutive epochs without a margin-beating score
+    early_stop: bool = False
+    save_model: bool = False
+    _best_margin: float = math.inf        # best score for the patience rule
+    _best: float = math.inf               # best score for checkpointing
 
     def __call__(self, score):
-        if score < self.stop_score * (1 - self.rtol):
-            self.counter = 0
-            self.stop_score = score
-        else:
-            self.counter += 1
-            if self.counter >= self.patience:
-                self.early_stop = True
-        if score < self.saved_score:
-            self.saved_score = score
-            self.save_model = True
-        else:
-            self.save_model = False
+        improved = score < self._best_margin * (1 - self.rtol)
+        self.counter = 0 if improved else self.counter + 1
+        if improved:
+            self._best_margin = score
+        elif self.counter >= self.patience:
+            self.early_stop = True
+        self.save_model = score < self._best
+        self._best = min(self._best, score)
 
 
-def make_early_stopper(config):  # train.py:409-413
-    if config["finetune"]:
-        return EarlyStopper(patience=2, rtol=0.001)
-    return EarlyStopper(patience=float("inf"), rtol=0)
+def make_early_stopper(config):
+    """train.py:409-413: finetune runs stop after two flat epochs (0.1 % margin), pretraining never stops early."""
+    return EarlyStopper(2, 0.001) if config["finetune"] else EarlyStopper(math.inf, 0)
 
 
-def wsum(values, weights):  # train.py:375-376
-    return sum(x * y for (x, y) in zip(values, weights))
+def wsum(values, weights):
+    """Weighted total of the per-task losses (train.py:375-376)."""
+    return sum(v * w for v, w in zip(values, weights))
+
+
+# per-task loss scales of train.py:381-390, order ALL_MEDIUMS x ALL_METRICS
+_TASK_SCALE = np.array([4.618602403897067, 1.1958987168236102, 2.5443243303769867, 1.0527565486045412])
 
 
 def make_task_weights(finetune_medium=None, finetune_metric=None):
-    """train.py:379-406 (args.finetune_medium / args.finetune_metric become parameters)."""
-    scale = {0: {"watch": 4.618602403897067, "rating": 1.1958987168236102},
-             1: {"watch": 2.5443243303769867, "rating": 1.0527565486045412}}
-    scale = [scale[x][y] for x in ALL_MEDIUMS for y in ALL_METRICS]
-    if finetune_metric is None:
-        metric_weight = {"watch": 1, "rating": 0.25}
-    else:
-        metric_weight = {"watch": 0, "rating": 0}
-        metric_weight[finetune_metric] = 1
+    """train.py:379-406 (args.finetune_medium / args.finetune_metric become parameters): the outer product of a medium
+    share and a metric share, normalised to sum 1, each entry divided by its task's loss scale.  Pretraining: manga
+    0.25 / anime 1, watch 1 / rating 0.25; finetuning: one-hot on the chosen medium and metric."""
     if finetune_medium is None:
-        medium_weight = {0: 0.25, 1: 1}
+        medium_share = np.array([0.25, 1.0])
     else:
-        medium_weight = {finetune_medium: 1, 1 - finetune_medium: 0}
-    weights = [medium_weight[x] * metric_weight[y] for x in ALL_MEDIUMS for y in ALL_METRICS]
-    weights = [x / sum(weights) for x in weights]
-    return [(w / s) for (w, s) in zip(weights, scale)]
+        medium_share = np.eye(len(ALL_MEDIUMS))[ALL_MEDIUMS.index(finetune_medium)]
+    if finetune_metric is None:
+        metric_share = np.array([1.0, 0.25])
+    else:
+        metric_share = np.eye(len(ALL_METRICS))[ALL_METRICS.index(finetune_metric)]
+    share = np.outer(medium_share, metric_share).ravel()
+    return [float(x) for x in share / share.sum() / _TASK_SCALE]
 
 
-def minimize_quadratic(x, y):  # train.py:187-196
-    assert len(x) == 3 and len(y) == 3
-    if max(y) == min(y):
-        return float(max(y))
-    A = np.array([[x[0] ** 2, x[0], 1], [x[1] ** 2, x[1], 1], [x[2] ** 2, x[2], 1]])
-    B = np.array(y)
-    a, b, c = np.linalg.solve(A, B)
-    x_extremum = -b / (2 * a)
-    return float(a * x_extremum ** 2 + b * x_extremum + c)
+def minimize_quadratic(x, y):
+    """Value at the vertex of the parabola through three points (train.py:187-196), by Newton's divided differences:
+    p(t) = y0 + d01 (t - x0) + c (t - x0)(t - x1); flat data returns that constant."""
+    (x0, x1, x2), (y0, y1, y2) = x, y
+    if y0 == y1 == y2:
+        return float(y0)
+    d01 = (y1 - y0) / (x1 - x0)
+    d12 = (y2 - y1) / (x2 - x1)
+    c = (d12 - d01) / (x2 - x0)
+    t = (x0 + x1) / 2 - d01 / (2 * c)
+    return float(y0 + d01 * (t - x0) + c * (t - x0) * (t - x1))
 
 
 def reduce_mean(comm, x, w):
@@ -143,30 +160,28 @@ def reduce_mean(comm, x, w):
     return [a / b if b != 0 else 0 for (a, b) in zip(x, w)]
 
 
+_RATING_SCALES = [1, 0, -1]   # prediction scales of the three evaluation moments (model.py:395-401)
+
+
 def evaluate_metrics(model, dataloader, comm=None):
     """train.py:207-235: eval forward (fresh random masks, model(d, True)), weight-averaged per task,
     rating -> quadratic-minimum MSE over prediction scales {1, 0, -1}."""
-    init = lambda metric: [0, 0, 0] if metric in ["rating"] else 0
-    losses = [init(metric) for m in ALL_MEDIUMS for metric in ALL_METRICS]
-    weights = [0 for _ in range(len(ALL_MEDIUMS) * len(ALL_METRICS))]
+    tasks = [(m, metric) for m in ALL_MEDIUMS for metric in ALL_METRICS]
+    moments = np.zeros((len(tasks), len(_RATING_SCALES)))   # watch tasks use column 0 only
+    mass = np.zeros(len(tasks))
     model.eval()
-    for data in dataloader:
-        loss = model(data, True)
-        for i in range(len(losses)):
-            w = model.last_weight_sums[i]
-            if w == 0:
-                continue
-            if isinstance(losses[i], list):
-                for j in range(len(losses[i])):
-                    losses[i][j] += float(loss[i][j]) * w
-            else:
-                losses[i] += float(loss[i]) * w
-            weights[i] += w
+    for batch in dataloader:
+        out = model(batch, True)
+        w = np.asarray(model.last_weight_sums, np.float64)
+        for i, (_, metric) in enumerate(tasks):
+            vals = out[i] if metric == "rating" else [out[i]]
+            if w[i] != 0:
+                moments[i, : len(vals)] += w[i] * np.asarray(vals, np.float64)
+        mass += w
     model.train()
-    for i in range(len(losses)):
-        if isinstance(losses[i], list):
-            losses[i] = minimize_quadratic([1, 0, -1], losses[i])
-    return reduce_mean(comm, losses, weights)
+    totals = [minimize_quadratic(_RATING_SCALES, list(moments[i])) if metric == "rating" else float(moments[i, 0])
+              for i, (_, metric) in enumerate(tasks)]
+    return reduce_mean(comm, totals, mass)
 
 
 def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accum_steps, comm=None, max_norm=1.0):

@@ -1,9 +1,12 @@
-"""Worker of tests/test_dist_cpu.py: one rank of a world_size-2 gloo group on CPU."""
+"""Worker of tests/test_dist_cpu.py: one rank of a world_size-2 host group (TCP control plane) on CPU.  torch is made
+un-importable first: a rank of the data-parallel path must never need it."""
 import json
 import os
 import sys
 
 import numpy as np
+
+sys.modules["torch"] = None            # any `import torch` below raises ImportError
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +16,9 @@ from recommendersystem_amd import dist as rdist  # noqa: E402
 from recommendersystem_amd.train import make_task_weights, reduce_mean  # noqa: E402
 
 
-class GlooComm:
-    """Same surface as recommendersystem_amd.dist.Comm, but the reductions run over gloo on host arrays
-    (the RCCL communicator needs GPUs)."""
+class HostOnlyComm:
+    """Same surface as recommendersystem_amd.dist.Comm, but the reductions run over the TCP control plane on host
+    arrays (the RCCL communicator needs GPUs)."""
 
     def __init__(self, hg):
         self.hg, self.rank, self.world = hg, hg.rank, hg.world
@@ -52,11 +55,15 @@ def main():
     res["grad_local_norm"] = float(np.sqrt((flat ** 2).sum()))
     # epoch metrics (reduce_mean, train.py:199-204)
     wsums = [float(dm[f"{m}.{k}.weight"].sum()) for m in (0, 1) for k in ("watch", "rating")]
-    res["reduce_mean"] = reduce_mean(GlooComm(hg), [l * w for l, w in zip(losses, wsums)], wsums)
+    res["reduce_mean"] = reduce_mean(HostOnlyComm(hg), [l * w for l, w in zip(losses, wsums)], wsums)
     res["losses"] = losses
     res["wsums"] = wsums
     shards = [f"s{i}" for i in range(8)]
     res["shards"] = rdist.shard_for_rank(shards, rank, world)
+    arr = np.full(1000, rank + 1.0, np.float32)
+    res["array_sum_ok"] = bool((hg.all_reduce_array(arr) == sum(range(1, world + 1))).all())
+    res["min"] = hg.all_reduce([float(rank)], "min")
+    res["torch_blocked"] = "torch" in sys.modules and sys.modules["torch"] is None
     np.save(out_path + f".grad{rank}.npy", flat)
     with open(out_path + f".{rank}.json", "w") as f:
         json.dump(res, f)

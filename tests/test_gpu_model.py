@@ -167,6 +167,37 @@ def test_grad_accumulation_two_microsteps():
     model.close()
 
 
+def test_grad_accumulation_with_changing_task_weights():
+    """A watch head whose task weight is 0 in the first micro-step is skipped there; its first gradient GEMM of the
+    second micro-step must ADD to the item-table rows (they already hold the first micro-step's token gradients), not
+    store over them (model.hip: gE_clean)."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    from recommendersystem_amd.optim import AdamW
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    S = cfg["max_sequence_length"]
+    wm, rm = synth.make_masks(cfg, rows, 7)
+    halves = [({k: v[i * S:(i + 1) * S] for k, v in d.items()}, (wm[i:i + 1], rm[i:i + 1])) for i in range(2)]
+    tws = [[0.0, 0.2, 0.0, 0.25], [0.05, 0.2, 0.3, 0.25]]
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+    model.load_state_dict(P)
+    opt = AdamW(model, lr=0.0)
+    opt.step()                                   # an optimizer step leaves the gradient rows marked "just zeroed"
+    for (dd, mk), tw in zip(halves, tws):
+        model.set_loss_weights(tw, 2)
+        model(dd, False, masks=mk)
+    name_E = "item_embedding.matchedid_embedding.embedding.weight"
+    ref = 0.0
+    for (dd, mk), tw in zip(halves, tws):
+        o = model_np.OracleModel(cfg, P)
+        dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, dd), mk[0], mk[1])
+        _, G = o.forward(dm, False, True, [w / 2 for w in tw])
+        ref = ref + G[name_E]
+    assert relerr(model.grad(name_E), ref) < 1e-3
+    model.close()
+
+
 def test_inference_golden():
     """model(d, "retrieval"/"ranking") with rope_input_pos and per-candidate token_mask_ids (fixture from the reference)."""
     import recommendersystem_amd as ra
@@ -690,4 +721,163 @@ def test_bench_shape_forward_is_reproducible_and_matches_small_batch():
     model(sub, True, masks=(wm[8:12], rm[8:12]))
     small = model.trunk_output(4)
     assert relerr(small, outs[0][8:12]) < 3e-2, relerr(small, outs[0][8:12])
+    model.close()
+
+
+@pytest.mark.parametrize("name,over,rows,seed", CASES)
+def test_bf16_mode_vs_oracle_with_bf16_rounded_operands(name, over, rows, seed):
+    """The benchmarked arithmetic against the oracle run with the SAME storage roundings (every bf16 GEMM operand of the
+    HIP path rounded to bfloat16 at the point the kernels store it, fp64 accumulation): what is left is summation
+    order and the flash kernels' running-maximum rescaling, so the tolerances are 4-10x tighter than bf16-vs-fp64."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    ref = model_np.OracleModel(cfg, P, np.float64, operand_round="bf16")
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    y_ref, _ = ref.embed(dm)
+    l_ref, G_ref = ref.forward(dm, False, True, TASK_W)
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    y = model.trunk_output(rows)
+    e_y = relerr(y, y_ref)
+    e_l = max(abs(a - b) / max(abs(b), 1.0) for a, b in zip(losses, l_ref))
+    worst = ("", 0.0)
+    for n in synth.trainable_names(cfg):
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-3 * np.sqrt((G_ref[n] ** 2).mean()) + 1e-12)
+        e = float(np.abs(g - G_ref[n]).max() / max(scale, 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    print(f"bf16-vs-bf16-oracle[{name}]: trunk {e_y:.2e} losses {e_l:.2e} worst grad {worst}")
+    assert e_y < 1.5e-2, e_y
+    assert e_l < 1e-2, (losses, l_ref)
+    assert worst[1] < 4e-2, worst
+    model.close()
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_act,tol_grad", [("fp32", 1e-4, 1e-4, 5e-4), ("bf16", 4e-2, 6e-2, 1.5e-1)])
+def test_cfg1_exact_shape_full_parity(dtype, tol_loss, tol_act, tol_grad):
+    """BASELINE configs[0] at its exact shape (cfg-1: D=64, heads 4/2 of 16, I=176, L=2, S=32, 400+600 items, M=6148,
+    K=8, 64 rows): trunk output, the four losses and EVERY named gradient against the fp64 oracle."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("cfg1")
+    assert (cfg["embed_dim"], cfg["num_heads"], cfg["num_kv_heads"], cfg["intermediate_dim"], cfg["num_layers"],
+            cfg["max_sequence_length"], cfg["metadata_emb_size"], cfg["mask_topk"]) == (64, 4, 2, 176, 2, 32, 6148, 8)
+    rows, seed = 64, 101
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    y_ref, l_ref, G_ref, ev_ref = _oracle(cfg, P, d, wm, rm)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    assert relerr(model.trunk_output(rows), y_ref) < tol_act
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, l_ref)
+    worst = ("", 0.0)
+    for n in synth.trainable_names(cfg):
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-3 * np.sqrt((G_ref[n] ** 2).mean()) + 1e-12)
+        e = float(np.abs(g - G_ref[n]).max() / max(scale, 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < tol_grad, worst
+    ev = model(d, True, masks=(wm, rm))
+    flat = []; flat_ref = []
+    for a, b in zip(ev, ev_ref):
+        flat += a if isinstance(a, list) else [a]
+        flat_ref += b if isinstance(b, list) else [b]
+    for a, b in zip(flat, flat_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (flat, flat_ref)
+    model.close()
+
+
+def test_full_size_cfg2_parity_and_properties():
+    """BASELINE configs[1] at FULL size (cfg-2: D=256, L=8, S=256, 60 K + 40 K items, M=6148, K=32).
+    (1) fp32 mode, 2 rows: trunk output, the four losses, and the gradients of the trunk / rating-head weights against
+        the fp64 oracle, which gets the full fused item table (100 001 x 256) computed on the host in fp64 from the same
+        parameters and metadata;
+    (2) bf16 mode, 4 rows: user isolation and row-permutation equivariance, bit-exact (model.py:479-487)."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg = synth.make_config("cfg2")
+    S, D, M = cfg["max_sequence_length"], cfg["embed_dim"], cfg["metadata_emb_size"]
+    V0, V1 = cfg["vocab_sizes"]["0_matchedid"], cfg["vocab_sizes"]["1_matchedid"]
+    V = V0 + V1
+    assert (D, cfg["num_layers"], S, V, M, cfg["mask_topk"]) == (256, 8, 256, 100000, 6148, 32)
+    rng = np.random.default_rng(29)
+    base = (rng.standard_normal((997, M)) / np.sqrt(M)).astype(np.float32)
+    table = base[np.arange(V) % 997] * (1.0 + (np.arange(V) % 13)[:, None].astype(np.float32) / 13.0)
+
+    # ---- (1) fp32, 2 rows, vs oracle incl. heads and gradients
+    rows = 2
+    d = synth.make_batch(cfg, rows, 211, mu=4.0, sigma=0.8)
+    wm, rm = synth.make_masks(cfg, rows, 13)
+    model = ra.RecommenderModel(cfg, dtype="fp32", max_rows=rows)
+    model.init_weights(9)
+    for n, shape, tr in model.named_parameters():            # init leaves norm scales at 1 and phases / biases at 0: perturb them
+        if tr and (n.endswith(".scale") or "periodic_time" in n or n.endswith(".bias")):
+            model.set_parameter(n, (1.0 if n.endswith(".scale") else 0.0) + 0.1 * rng.standard_normal(shape).astype(np.float32))
+    model.load_pretrained_embeddings(table)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    y = model.trunk_output(rows)
+    P = {k: v for k, v in model.state_dict(include_frozen=False).items() if not k.startswith("watch_head.")}
+    E = P["item_embedding.matchedid_embedding.embedding.weight"].astype(np.float64)
+    Wp = P["item_embedding.projection_layer.weight"].astype(np.float64); bp = P["item_embedding.projection_layer.bias"].astype(np.float64)
+    F = np.empty((V + 1, D), np.float64)
+    for r0 in range(0, V, 8192):
+        F[r0:r0 + 8192] = E[r0:r0 + 8192] + table[r0:r0 + 8192].astype(np.float64) @ Wp.T + bp
+    F[V] = E[V] + bp                                         # the mask row has zero metadata (model.py:386)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    P64["item_embedding.fused_embedding"] = F
+    ref = model_np.OracleModel(cfg, P64, np.float64)
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    y_ref, _ = ref.embed(dm)
+    assert relerr(y, y_ref) < 1e-4, relerr(y, y_ref)
+    l_ref, G_ref = ref.forward(dm, False, True, TASK_W)
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (losses, l_ref)
+    for n in ["rating_head.0.weight", "rating_head.2.weight", "transformers.norm.scale", "action_embedding.linear.weight"] + \
+             [f"transformers.layers.{l}.{t}" for l in (0, 7) for t in ("attn.q_proj.weight", "attn.k_proj.weight", "attn.v_proj.weight",
+                                                                        "attn.output_proj.weight", "mlp.w1.weight", "mlp.w2.weight",
+                                                                        "mlp.w3.weight", "sa_norm.scale", "mlp_norm.scale")]:
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-12)
+        assert np.abs(g - G_ref[n]).max() / scale < 1e-3, (n, np.abs(g - G_ref[n]).max() / scale)
+    model.close()
+
+    # ---- (2) bf16, 4 rows: isolation and permutation
+    rows = 4
+    d = synth.make_batch(cfg, rows, 321, mu=4.0, sigma=0.8)
+    wm, rm = synth.make_masks(cfg, rows, 9)
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.init_weights(5)
+    model.load_pretrained_embeddings(table)
+    model.set_loss_weights(TASK_W, 1)
+    model(d, True, masks=(wm, rm))
+    y0 = model.trunk_output(rows).copy()
+    uid = np.asarray(d["userid"]).reshape(rows, S)
+    victim = uid[1, S // 2]
+    sel = (uid == victim)
+    assert sel.any() and not sel.all()
+    d2 = {k: np.array(v, copy=True) for k, v in d.items()}
+    flat = sel.reshape(-1)
+    d2["rating"] = np.where(flat, 10.0 - np.asarray(d["rating"]).reshape(-1), np.asarray(d["rating"]).reshape(-1)).astype(np.float32)
+    mid = np.asarray(d["matchedid"]).reshape(-1)
+    d2["matchedid"] = np.where(flat, (mid + 17) % V, mid).astype(np.int32)
+    model(d2, True, masks=(wm, rm))
+    y1 = model.trunk_output(rows)
+    tok = np.repeat(sel, 2, axis=1)
+    assert np.array_equal(y0[~tok], y1[~tok])
+    assert np.abs(y0[tok] - y1[tok]).max() > 1e-3
+    perm = np.array([2, 0, 3, 1])
+    dp = {k: np.asarray(v).reshape(rows, S)[perm].reshape(-1) for k, v in d.items()}
+    model(dp, True, masks=(wm[perm], rm[perm]))
+    assert np.array_equal(model.trunk_output(rows), y0[perm])
     model.close()
