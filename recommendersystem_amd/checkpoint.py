@@ -8,7 +8,8 @@ The reference writes a torch pickle (transformer.py:456-466):
 reference's state-dict names under "model/", AdamW moments by parameter NAME, the scheduler's step counter.
 
     python -m recommendersystem_amd.checkpoint pt2npz transformer.masked.pt transformer.masked.npz
-    python -m recommendersystem_amd.checkpoint npz2pt transformer.masked.npz transformer.masked.pt
+    python -m recommendersystem_amd.checkpoint npz2pt transformer.masked.npz transformer.masked.pt [DATADIR | media_embeddings.h5]
+(the optional last argument supplies the frozen metadata table the reference's strict load expects)
 
 The conversion needs torch only to read / write the pickle (host side; nothing here touches the GPU path).
 Optimizer state is keyed by parameter INDEX in the reference: `create_optimizer` (transformer.py:285-298) puts the
@@ -69,16 +70,44 @@ def from_reference(ckpt):
     return blob
 
 
-def to_reference(blob, scheduler_state=None):
-    """`.npz`-layout dict -> reference checkpoint dict (torch tensors).  The frozen metadata table is included when the
-    blob has it (the reference's strict load wants it); `scheduler_state` (a LambdaLR.state_dict()) may be supplied,
-    otherwise only `last_epoch` / `_step_count` are filled in."""
+def schedule_factor(lam, step):
+    """learning-rate factor of the stored schedule parameters at `step` (WSD, transformer.py:310-328; a finetune
+    checkpoint's constant schedule has no such parameters and gives 1)"""
+    if "total_steps" not in lam:
+        return 1.0
+    s = max(0, min(int(step), lam["total_steps"]))
+    if s <= lam["warmup_steps"]:
+        return s / max(1, lam["warmup_steps"])
+    plateau_end = lam["warmup_steps"] + lam["stable_steps"]
+    if s <= plateau_end:
+        return 1.0
+    return 1.0 - (1.0 - lam["final_ratio"]) * ((s - plateau_end) / max(1, lam["decay_steps"]))
+
+
+def to_reference(blob, scheduler_state=None, metadata=None):
+    """`.npz`-layout dict -> reference checkpoint dict (torch tensors) that transformer.py:657-700 can resume from.
+
+    * model: the reference's state-dict keys in its order, `watch_head.` aliases included.  The reference's strict
+      `load_state_dict` also wants the frozen metadata table, which this package's checkpoints leave out (it is an input
+      file, 4.9 GB at 200 K items): pass `metadata` = the (V, M) array of media_embeddings.h5 and it is inserted with its
+      zero mask row (model.py:380-389); a blob that already holds the table keeps it.
+    * optimizer: AdamW.state_dict() with the two parameter groups of create_optimizer; when the blob carries the
+      schedule's parameters ("scheduler/lambda", written by train.checkpoint_model) the groups' `lr` is the SCHEDULED
+      rate base * factor(last_epoch) and `initial_lr` the base rate, as torch's LambdaLR leaves them.
+    * scheduler: a complete LambdaLR.state_dict() (`lr_lambdas` = the attribute dict of the reference's WSDScheduler per
+      group, `base_lrs`, `_last_lr`, `last_epoch`, `_step_count`): torch's load_state_dict pops `lr_lambdas`.
+      `scheduler_state` overrides it verbatim."""
     import torch
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32).copy())
     names = [k[len("model/"):] for k in blob if k.startswith("model/")]
-    model = {}
-    for n in names:
-        model[n] = T(blob["model/" + n])
+    model = {n: T(blob["model/" + n]) for n in names}
+    if metadata is not None and FROZEN not in model:
+        meta = np.asarray(metadata, np.float32)
+        table = np.zeros((meta.shape[0] + 1, meta.shape[1]), np.float32)
+        table[:-1] = meta
+        at = names.index("item_embedding.matchedid_embedding.embedding.weight") + 1
+        names = names[:at] + [FROZEN] + names[at:]
+        model[FROZEN] = torch.from_numpy(table)
     # state-dict order of the reference: aliases of the shared item embedding sit before the rating head
     ordered = {}
     for n in names:
@@ -93,32 +122,54 @@ def to_reference(blob, scheduler_state=None):
                 ordered[ALIAS + m_] = model[m_]
     ckpt = {"model": ordered}
     cfg = json.loads(bytes(np.asarray(blob["config"], np.uint8)).decode()) if "config" in blob else {}
+    lam = json.loads(bytes(np.asarray(blob["scheduler/lambda"], np.uint8)).decode()) if "scheduler/lambda" in blob else None
+    le = int(np.asarray(blob["scheduler/last_epoch"]).reshape(-1)[0]) if "scheduler/last_epoch" in blob else None
+    factor = schedule_factor(lam, le) if (lam is not None and le is not None and scheduler_state is None) else None
+    lr0 = float(np.asarray(blob.get("optimizer/lr", [cfg.get("learning_rate", 1e-4)])).reshape(-1)[0])
+    n_groups = 2
     if "optimizer/step" in blob:
-        shapes = {n: tuple(np.shape(blob["model/" + n])) for n in names}
-        decay, nodecay = trainable_order(names, shapes)
+        shapes = {n: tuple(np.shape(blob["model/" + n])) for n in names if n != FROZEN}
+        decay, nodecay = trainable_order([n for n in names if n != FROZEN], shapes)
         order = decay + nodecay
         step = float(np.asarray(blob["optimizer/step"]).reshape(-1)[0])
-        lr = float(np.asarray(blob.get("optimizer/lr", [cfg.get("learning_rate", 1e-4)])).reshape(-1)[0])
         state = {}
         for idx, n in enumerate(order):
             if "optimizer/exp_avg/" + n in blob:
                 state[idx] = {"step": torch.tensor(step), "exp_avg": T(blob["optimizer/exp_avg/" + n]),
                               "exp_avg_sq": T(blob["optimizer/exp_avg_sq/" + n])}
-        common = {"lr": lr, "betas": (0.9, 0.95), "eps": 1e-8, "amsgrad": False, "maximize": False, "foreach": None,
-                  "capturable": False, "differentiable": False, "fused": True, "decoupled_weight_decay": True}
+        common = {"lr": lr0 if factor is None else lr0 * factor, "betas": (0.9, 0.95), "eps": 1e-8, "amsgrad": False,
+                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": True,
+                  "decoupled_weight_decay": True}
+        if factor is not None:
+            common["initial_lr"] = lr0
         ckpt["optimizer"] = {"state": state, "param_groups": [
             dict(weight_decay=0.1, **common, params=list(range(len(decay)))),
             dict(weight_decay=0.0, **common, params=list(range(len(decay), len(order))))]}
     if scheduler_state is not None:
         ckpt["scheduler"] = scheduler_state
-    elif "scheduler/last_epoch" in blob:
-        le = int(np.asarray(blob["scheduler/last_epoch"]).reshape(-1)[0])
-        ckpt["scheduler"] = {"last_epoch": le, "_step_count": le + 1}
+    elif le is not None:
+        f = 1.0 if factor is None else factor
+        ckpt["scheduler"] = {"base_lrs": [lr0] * n_groups, "last_epoch": le, "_step_count": le + 1, "_is_initial": False,
+                             "_get_lr_called_within_step": False, "_last_lr": [lr0 * f] * n_groups,
+                             "lr_lambdas": [dict(lam) if lam is not None else None for _ in range(n_groups)]}
     ckpt["config"] = cfg
     ckpt["epoch"] = int(np.asarray(blob.get("epoch", [-1])).reshape(-1)[0])
     ckpt["training_loss"] = [float(x) for x in np.asarray(blob.get("training_loss", []))]
     ckpt["test_loss"] = [float(x) for x in np.asarray(blob.get("test_loss", []))]
     return ckpt
+
+
+def load_metadata_table(path):
+    """the (V, M) float32 `metadata` dataset of media_embeddings.h5 (transformer.jl:56-77), given as that file, the data
+    directory that holds it, or a `.npy` array"""
+    import os
+    if path.endswith(".npy"):
+        return np.load(path)
+    if os.path.isdir(path):
+        path = os.path.join(path, "media_embeddings.h5")
+    from . import h5
+    with h5.File(path) as f:
+        return np.asarray(f["metadata"], np.float32)
 
 
 def dedup_finetune_models(blobs):
@@ -144,7 +195,7 @@ def dedup_finetune_models(blobs):
 
 
 def main(argv):
-    if len(argv) != 4 or argv[1] not in ("pt2npz", "npz2pt"):
+    if len(argv) not in (4, 5) or argv[1] not in ("pt2npz", "npz2pt"):
         print(__doc__)
         return 2
     import torch
@@ -152,7 +203,8 @@ def main(argv):
         np.savez(argv[3], **from_reference(torch.load(argv[2], weights_only=False, map_location="cpu")))
     else:
         z = np.load(argv[2])
-        torch.save(to_reference({k: z[k] for k in z.files}), argv[3])
+        meta = load_metadata_table(argv[4]) if len(argv) == 5 else None
+        torch.save(to_reference({k: z[k] for k in z.files}, metadata=meta), argv[3])
     return 0
 
 

@@ -235,8 +235,12 @@ def checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, traini
             for n, s in osd["state"].items():
                 blob["optimizer/exp_avg/" + n] = s["exp_avg"]
                 blob["optimizer/exp_avg_sq/" + n] = s["exp_avg_sq"]
+            blob["optimizer/lr"] = np.array([float(osd.get("lr", config.get("learning_rate", 1e-4)))])
         if scheduler is not None:
             blob["scheduler/last_epoch"] = np.array([scheduler.state_dict()["last_epoch"]])
+            fn = getattr(scheduler, "fn", None)      # the schedule's own parameters: npz2pt rebuilds torch's LambdaLR state from them
+            lam = fn.reference_state() if hasattr(fn, "reference_state") else {"steps": int(getattr(fn, "steps", 0))}
+            blob["scheduler/lambda"] = np.frombuffer(json.dumps(lam).encode(), np.uint8)
         blob["config"] = np.frombuffer(json.dumps(config).encode(), np.uint8)
         blob["epoch"] = np.array([epoch])
         blob["training_loss"] = np.array(training_loss, np.float64)

@@ -752,9 +752,9 @@ def test_bf16_mode_vs_oracle_with_bf16_rounded_operands(name, over, rows, seed):
         if e > worst[1]:
             worst = (n, e)
     print(f"bf16-vs-bf16-oracle[{name}]: trunk {e_y:.2e} losses {e_l:.2e} worst grad {worst}")
-    assert e_y < 1.5e-2, e_y
-    assert e_l < 1e-2, (losses, l_ref)
-    assert worst[1] < 4e-2, worst
+    assert e_y < 1e-2, e_y                       # measured 4e-3 / 6e-3
+    assert e_l < 5e-3, (losses, l_ref)           # measured 2e-4 / 2e-3
+    assert worst[1] < 5e-2, worst                # measured 3e-2 (a phase parameter with a tiny gradient)
     model.close()
 
 
@@ -832,7 +832,8 @@ def test_full_size_cfg2_parity_and_properties():
     Wp = P["item_embedding.projection_layer.weight"].astype(np.float64); bp = P["item_embedding.projection_layer.bias"].astype(np.float64)
     F = np.empty((V + 1, D), np.float64)
     for r0 in range(0, V, 8192):
-        F[r0:r0 + 8192] = E[r0:r0 + 8192] + table[r0:r0 + 8192].astype(np.float64) @ Wp.T + bp
+        r1 = min(V, r0 + 8192)
+        F[r0:r1] = E[r0:r1] + table[r0:r1].astype(np.float64) @ Wp.T + bp
     F[V] = E[V] + bp                                         # the mask row has zero metadata (model.py:386)
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
     P64["item_embedding.fused_embedding"] = F
