@@ -177,6 +177,12 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin);
+/* embedding-gradient scatter of the backward (nn.Embedding backward, model.py:21) on caller-provided device buffers:
+ * gE[id'] += sum over tokens n of gx0[n*ldx .. +D) with id' = m_matchedid[n] (-1 -> row V); matchedid = the raw ids the
+ * token index is built from (m_matchedid differs from it only where it is -1).  One writer per table row, fixed summation
+ * order: bitwise reproducible.  atomic != 0: the float-atomic form (A/B reference; needs ldx == 2 D). */
+int32_t rsys_op_embedding_scatter(const float* gx0, int64_t ldx, const int32_t* matchedid, const int32_t* m_matchedid, int32_t N,
+                                  int32_t V, int32_t D, float* gE, int32_t atomic);
 /* per-step time distribution (bench.py): rsys_step_mark records an event on the model's stream at an optimizer-step
  * boundary; rsys_step_marks_get writes the milliseconds between consecutive marks (at most cap) and clears the marks */
 int32_t rsys_step_mark(rsys_model* m);

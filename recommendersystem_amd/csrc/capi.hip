@@ -507,6 +507,34 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   return RSYS_OK;
 }
 
+// the backward's embedding scatter on caller-provided device buffers: gE[id'] += sum_n gx0[n * ldx ..+D) over the tokens whose
+// masked id (m_matchedid, -1 -> row V) is id'; the token index is built from the raw ids (matchedid) as at batch upload.
+// atomic != 0 runs the float-atomic form instead (A/B reference).
+int32_t rsys_op_embedding_scatter(const float* gx0, int64_t ldx, const int32_t* matchedid, const int32_t* m_matchedid, int32_t N,
+                                  int32_t V, int32_t D, float* gE, int32_t atomic) {
+  ARG_CHECK(gx0 && matchedid && m_matchedid && gE && N >= 1 && ldx >= D, "rsys_op_embedding_scatter: arguments");
+  if (atomic) {
+    ARG_CHECK(ldx == 2LL * D, "the atomic form reads the interleaved layout (row stride 2 D)");
+    BatchDev b{}; b.N = N; b.m_matchedid = const_cast<int*>(m_matchedid);
+    int rc = launch_embedding_scatter_add(gx0, b, V, D, gE, nullptr);
+    if (rc) return rc;
+    HIP_CHECK(hipDeviceSynchronize());
+    return RSYS_OK;
+  }
+  unsigned long long* keys = nullptr; int *skey = nullptr, *sidx = nullptr; float* slab = nullptr;
+  HIP_CHECK(hipMalloc((void**)&keys, (size_t)token_index_capacity(N) * 8));
+  HIP_CHECK(hipMalloc((void**)&skey, (size_t)N * 4));
+  HIP_CHECK(hipMalloc((void**)&sidx, (size_t)N * 4));
+  HIP_CHECK(hipMalloc((void**)&slab, seg_scatter_slab_floats(N, D) * 4));
+  int rc = launch_token_index_build(matchedid, N, V, keys, skey, sidx, nullptr);
+  if (!rc) rc = launch_embedding_scatter_segmented(gx0, ldx, m_matchedid, skey, sidx, N, V, D, gE, slab, nullptr);
+  hipError_t e = hipDeviceSynchronize();
+  hipFree(keys); hipFree(skey); hipFree(sidx); hipFree(slab);
+  if (rc) return rc;
+  HIP_CHECK(e);
+  return RSYS_OK;
+}
+
 // step boundaries on the model's stream: rsys_step_mark records an event, rsys_step_marks_get returns the elapsed time
 // between consecutive marks (ms) and clears them -- the per-step time distribution without a host sync per step
 int32_t rsys_step_mark(rsys_model* h) {

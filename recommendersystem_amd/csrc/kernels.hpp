@@ -84,7 +84,16 @@ int launch_colsum_add(const float* src, long long ld, long long rows, int cols, 
 // dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 1024)
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s);
 
-int launch_embedding_scatter_add(const float* gx0, const BatchDev& b, int V, int D, float* gE, hipStream_t s);
+int launch_embedding_scatter_add(const float* gx0, const BatchDev& b, int V, int D, float* gE, hipStream_t s);   // float atomics (A/B reference only)
+
+// ---- deterministic embedding-gradient scatter (scatter.hip)
+// token index of a batch: tokens sorted by (item id with -1 -> V, token index); keys: workspace of token_index_capacity(N) u64
+int token_index_capacity(int N);
+int launch_token_index_build(const int* matchedid, int N, int V, unsigned long long* keys, int* skey, int* sidx, hipStream_t s);
+size_t seg_scatter_slab_floats(int N, int D);
+// gE[id'] += sum over the tokens n (ascending) with masked id' of gx0[n * ldx .. + D); one writer per table row, no atomics
+int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const int* m_matchedid, const int* skey, const int* sidx,
+                                       int N, int V, int D, float* gE, float* slab, hipStream_t s);
 
 int launch_action_small_bwd(const float* gf /*[N][32]*/, const BatchDev& b, const SmallParams& sp,
                             float* g_per_cos, float* g_per_sin, float* g_status, float* g_gender, float* g_source,

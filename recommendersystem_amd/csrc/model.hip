@@ -213,6 +213,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     for (int k = 0; k < 4; ++k) { b.m_label[k] = (float*)carve(N * 4); b.m_weight[k] = (float*)carve(N * 4); b.m_position[k] = (int*)carve(N * 4); }
     b.watch_mask = nullptr; b.rating_mask = nullptr; b.rope_pos = nullptr;
     DALLOC(m->d_wm, N); DALLOC(m->d_rm, N); DALLOC(m->d_rope_pos, NT * 4);
+    DALLOC(m->tok_keys, (size_t)token_index_capacity((int)N) * 8); DALLOC(m->tok_skey, N * 4); DALLOC(m->tok_sidx, N * 4);
+    DALLOC(m->scatter_slab, seg_scatter_slab_floats((int)N, m->D) * 4);
   }
   DALLOC(m->feat, N * 32 * e); DALLOC(m->x0, NT * D * 4);
   DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
@@ -466,6 +468,8 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   m->has_rope_pos = b->rope_input_pos != nullptr;
   if (m->has_rope_pos) H2D(m->d_rope_pos, pos.data(), 2 * N * 4);
 #undef H2D
+  // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only
+  if (!m->cfg.finetune) RC(launch_token_index_build(d.matchedid, (int)N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s));
   HIP_CHECK(hipStreamSynchronize(s));
   m->cur_rows = b->rows;
   return RSYS_OK;
@@ -916,7 +920,11 @@ static int backward_trunk(Model* m) {
   tic(m, "phase_embed_bwd");
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
   tic(m, "hbm_scatter", 12.0 * D * N);   // bytes: one gradient row read + one table-gradient row read-modify-written per interaction
-  RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
+  {
+    static const bool atomic_ab = getenv("RSYS_SCATTER_ATOMIC") != nullptr;   // A/B measurement against the float-atomic form only
+    if (atomic_ab) RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
+    else RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
+  }
   toc(m);
   m->table_grads_pending = true;
   m->gE_clean[0] = m->gE_clean[1] = false;   // the rows now hold token gradients: a later head GEMM must add, not store

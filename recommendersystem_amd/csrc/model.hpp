@@ -87,6 +87,8 @@ struct Model {
   void* batch_blob = nullptr;
   bool has_masks = false, has_rope_pos = false;
   int cur_rows = 0;
+  // token index of the resident batch (scatter.hip): sorted (item id, token) pairs + the partial-sum slab of the scatter
+  unsigned long long* tok_keys = nullptr; int *tok_skey = nullptr, *tok_sidx = nullptr; float* scatter_slab = nullptr;
   unsigned char *d_wm = nullptr, *d_rm = nullptr;
   int* d_rope_pos = nullptr;
   // activations (void* = T-typed)

@@ -260,3 +260,103 @@ def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd, wide_ids):
     assert err(G[:, (H + KV) * hd:], gv) < tol, ("dv", err(G[:, (H + KV) * hd:], gv))
     for p in (d_qkv, d_dO, d_uid, d_tm, d_cos, d_sin, d_O, d_lse, d_dqkv):
         lib.rsys_dev_free(p)
+
+
+# ---------------------------------------------------------------- embedding scatter (deterministic segmented reduction)
+SEG_TILE, MASK_CHUNK = 8, 256      # scatter.hip
+
+
+def _scatter_tree_reference(gx_rows, ids, m_ids, V, gE0):
+    """The kernel's summation tree in float32, step by step: tokens sorted by (raw id with -1 -> V, index); per tile of 8
+    sorted positions each run is summed left to right; a run that spans tiles adds its per-tile partial sums in tile
+    order; watch-masked tokens (m_id == -1) are summed by position in chunks of 256, the chunk sums in four contiguous
+    quarters, the four quarter sums in order.  Every table row receives ONE add of its total."""
+    N, D = gx_rows.shape
+    out = gE0.copy()
+    key = np.where(ids == -1, V, ids).astype(np.int64)
+    order = np.lexsort((np.arange(N), key))
+    skey = key[order]
+    totals = {}
+    for t0 in range(0, N, SEG_TILE):
+        p = t0
+        while p < min(N, t0 + SEG_TILE):
+            q = p
+            acc = np.zeros(D, np.float32)
+            while q < min(N, t0 + SEG_TILE) and skey[q] == skey[p]:
+                i = order[q]
+                if skey[q] != V and m_ids[i] != -1:
+                    acc = acc + gx_rows[i]
+                q += 1
+            if skey[p] != V:
+                totals[int(skey[p])] = acc if int(skey[p]) not in totals else totals[int(skey[p])] + acc
+            p = q
+    for k, v in totals.items():
+        out[k] = out[k] + v
+    NC = (N + MASK_CHUNK - 1) // MASK_CHUNK
+    parts = []
+    for c in range(NC):
+        acc = np.zeros(D, np.float32)
+        for i in range(c * MASK_CHUNK, min(N, (c + 1) * MASK_CHUNK)):
+            if m_ids[i] == -1:
+                acc = acc + gx_rows[i]
+        parts.append(acc)
+    q = (NC + 3) // 4
+    quarter = []
+    for w in range(4):
+        acc = np.zeros(D, np.float32)
+        for c in range(w * q, min(NC, (w + 1) * q)):
+            acc = acc + parts[c]
+        quarter.append(acc)
+    out[V] = out[V] + (((quarter[0] + quarter[1]) + quarter[2]) + quarter[3])
+    return out
+
+
+def _run_scatter(gx, ids, m_ids, V, gE0, atomic=0):
+    from recommendersystem_amd import _lib
+    lib = _lib.lib()
+    N, D = ids.size, gE0.shape[1]
+    d_gx = _to_dev(lib, gx); d_id = _to_dev(lib, ids.astype(np.int32)); d_m = _to_dev(lib, m_ids.astype(np.int32))
+    d_g = _to_dev(lib, gE0)
+    _lib.check(lib.rsys_op_embedding_scatter(d_gx, 2 * D, d_id, d_m, N, V, D, d_g, atomic))
+    out = np.empty_like(gE0)
+    assert lib.rsys_dev_d2h(out.ctypes.data, d_g, out.nbytes) == 0
+    for p in (d_gx, d_id, d_m, d_g):
+        lib.rsys_dev_free(p)
+    return out
+
+
+@pytest.mark.parametrize("case", ["zipf", "all_one_id", "all_masked", "all_distinct", "ragged_small", "wide_rows"])
+def test_embedding_scatter_is_exact_and_reproducible(case):
+    """nn.Embedding's backward (model.py:21) as the step runs it: bit-exact against the kernel's own summation tree
+    evaluated in float32 on the host, bit-identical between runs, and equal to the fp64 scatter-add within fp32
+    rounding.  Cases: a Zipf id stream with 10 % masked tokens (the bench's shape class), 100 % duplicate ids (one row
+    spans every tile), every token masked (only the mask row moves), all ids distinct, a ragged tiny batch, D = 2048."""
+    rng = np.random.default_rng(5)
+    V, D, N = 5000, 256, 4096
+    if case == "ragged_small":
+        V, D, N = 37, 32, 45
+    if case == "wide_rows":
+        V, D, N = 300, 2048, 700
+    ids = np.minimum(rng.zipf(1.3, N) - 1, V - 1).astype(np.int32)
+    mask = rng.random(N) < 0.1
+    if case == "all_one_id":
+        ids[:] = 17
+    if case == "all_distinct":
+        ids = rng.permutation(V)[:N].astype(np.int32)
+    if case == "all_masked":
+        mask[:] = True
+    ids[rng.random(N) < 0.01] = -1                              # raw -1 ids (MaskedEmbedding, model.py:23-24) land in row V too
+    m_ids = np.where(mask, -1, ids).astype(np.int32)
+    gx = rng.standard_normal((2 * N, D)).astype(np.float32)     # interleaved layout: even rows are the item tokens
+    gE0 = rng.standard_normal((V + 1, D)).astype(np.float32)
+    out = _run_scatter(gx, ids, m_ids, V, gE0)
+    out2 = _run_scatter(gx, ids, m_ids, V, gE0)
+    assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))                       # run to run
+    want = _scatter_tree_reference(gx[0::2], ids, m_ids, V, gE0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), np.abs(out - want).max()
+    exact = gE0.astype(np.float64)
+    np.add.at(exact, np.where(m_ids == -1, V, m_ids), gx[0::2].astype(np.float64))
+    assert np.abs(out - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
+    if case == "zipf":
+        ref = _run_scatter(gx, ids, m_ids, V, gE0, atomic=1)                               # the float-atomic form agrees to rounding
+        assert np.abs(ref - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
