@@ -44,6 +44,10 @@ typedef struct rsys_config {
   int32_t dtype;                        /* RSYS_DTYPE_* : arithmetic type of the dense contractions */
   int32_t max_rows;                     /* rows (of S interactions) per forward call = local batch size */
   float lora_dropout;                   /* finetune only: nn.Dropout(p) on the LoRA input (model.py:238); 0 disables */
+  /* row-sharded item table (beyond the reference): world 0 = replicated table (the reference's scheme,
+   * transformer.py:678-682); world >= 1: this rank owns table rows [rank*(V+1)/world, (rank+1)*(V+1)/world) of the item
+   * embedding, the metadata table, the fused table and their Adam moments; rsys_model_set_shard_comm gives the communicator */
+  int32_t table_shard_rank, table_shard_world;
 } rsys_config;
 
 /* the batch record of train.py:75-98 / transformer.jl:79-142: 27 parallel arrays of
@@ -144,6 +148,17 @@ int32_t rsys_comm_destroy(rsys_comm* c);
  * of per-layer weight gradients on the communicator's stream while it continues, and rsys_allreduce_grads reduces the
  * rest.  comm == NULL disarms.  (Micro-steps before the last one accumulate locally: DDP no_sync, train.py:268-271.) */
 int32_t rsys_set_grad_sync(rsys_model* m, rsys_comm* c);
+/* row-sharded table mode: the communicator the forward / backward use for the row exchange and the vocabulary-parallel
+ * cross entropy (world must equal cfg.table_shard_world; NULL only when that is 1) */
+int32_t rsys_model_set_shard_comm(rsys_model* m, rsys_comm* c);
+/* rows [lo, hi) of the (V + 1)-row item table this model holds (the whole table when it is replicated) */
+int32_t rsys_table_rows(rsys_model* m, int64_t* lo, int64_t* hi);
+/* in-process rank group (tests): `world` ranks of ONE process on one device, each driven by its own host thread; the
+ * collectives are device copies between the ranks' buffers.  Two RCCL ranks cannot share a GPU; this lets the multi-rank
+ * partition arithmetic run on a one-GPU box with the real kernels. */
+int32_t rsys_local_group_create(int32_t world, int32_t device, void** group);
+int32_t rsys_local_group_destroy(void* group);
+int32_t rsys_comm_init_local(void* group, int32_t rank, rsys_comm** out);
 /* sum-all-reduce of (the rest of) the flat gradient buffer in buckets (the mean is folded into rsys_adamw_step's
  * grad_div); *early_floats (optional query): how many gradient elements the last call found already reduced */
 int32_t rsys_allreduce_grads(rsys_model* m, rsys_comm* c);

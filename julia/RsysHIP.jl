@@ -19,6 +19,7 @@ struct RsysConfig              # mirrors rsys_config (field order and types as i
     mask_topk::Int32; finetune::Int32; finetune_metric::Int32
     dtype::Int32; max_rows::Int32
     lora_dropout::Float32
+    table_shard_rank::Int32; table_shard_world::Int32     # row-sharded item table (world 0 = replicated)
 end
 
 struct RsysBatch               # mirrors rsys_batch

@@ -30,6 +30,7 @@ class rsys_config(C.Structure):
         ("rating_mean", C.c_float), ("rating_std", C.c_float), ("mask_rate", C.c_float),
         ("mask_topk", C.c_int32), ("finetune", C.c_int32), ("finetune_metric", C.c_int32),
         ("dtype", C.c_int32), ("max_rows", C.c_int32), ("lora_dropout", C.c_float),
+        ("table_shard_rank", C.c_int32), ("table_shard_world", C.c_int32),
     ]
 
 
@@ -81,6 +82,11 @@ _SIGS = [
     ("rsys_comm_init", C.c_int32, [C.POINTER(C.c_uint8 * 128), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("rsys_comm_destroy", C.c_int32, [_P]),
     ("rsys_set_grad_sync", C.c_int32, [_P, _P]),
+    ("rsys_model_set_shard_comm", C.c_int32, [_P, _P]),
+    ("rsys_table_rows", C.c_int32, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("rsys_local_group_create", C.c_int32, [C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("rsys_local_group_destroy", C.c_int32, [_P]),
+    ("rsys_comm_init_local", C.c_int32, [_P, C.c_int32, C.POINTER(_P)]),
     ("rsys_allreduce_grads", C.c_int32, [_P, _P]),
     ("rsys_grad_sync_early", C.c_int32, [_P, C.POINTER(C.c_int64)]),
     ("rsys_allreduce_f64", C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32]),

@@ -7,10 +7,12 @@
 
 #include <sstream>
 
+#include "comm.hpp"
 #include "model.hpp"
 
 namespace rsys {
 static thread_local std::string g_err;
+#define RC(expr) do { int _rc = (expr); if (_rc != RSYS_OK) return _rc; } while (0)
 void set_error(const std::string& msg) { g_err = msg; }
 }  // namespace rsys
 
@@ -18,52 +20,6 @@ using namespace rsys;
 
 struct rsys_model { Model* m; };
 struct rsys_optimizer { Optimizer o; };
-
-// ---------------------------------------------------------------- RCCL, bound at run time (librccl.so.1)
-typedef struct { char internal[128]; } ncclUniqueId_t;
-typedef void* ncclComm_t_;
-struct RcclApi {
-  void* lib = nullptr;
-  int (*GetUniqueId)(ncclUniqueId_t*) = nullptr;
-  int (*CommInitRank)(ncclComm_t_*, int, ncclUniqueId_t, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t_) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
-static RcclApi g_rccl;
-static int load_rccl() {
-  if (g_rccl.lib) return RSYS_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
-  if (!g_rccl.lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return RSYS_ERR_COMM; }
-  g_rccl.GetUniqueId = (int (*)(ncclUniqueId_t*))dlsym(g_rccl.lib, "ncclGetUniqueId");
-  g_rccl.CommInitRank = (int (*)(ncclComm_t_*, int, ncclUniqueId_t, int))dlsym(g_rccl.lib, "ncclCommInitRank");
-  g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(g_rccl.lib, "ncclCommDestroy");
-  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
-  g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
-    set_error("librccl is missing a required symbol"); return RSYS_ERR_COMM;
-  }
-  return RSYS_OK;
-}
-#define NCCL_CHECK(expr)                                                                          \
-  do {                                                                                            \
-    int _r = (expr);                                                                              \
-    if (_r != 0) {                                                                                \
-      set_error(std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error")); \
-      return RSYS_ERR_COMM;                                                                       \
-    }                                                                                             \
-  } while (0)
-enum { NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
-
-struct rsys_comm {
-  ncclComm_t_ comm = nullptr;
-  int rank = 0, world = 1, device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-  double* scratch = nullptr;
-  bool force = false;   // RSYS_FORCE_RCCL=1: run the collectives even at world == 1 (exercises RCCL on one GPU)
-};
 
 #define CHECK_HANDLE(h) do { if ((h) == nullptr) { set_error("null handle"); return RSYS_ERR_ARG; } } while (0)
 
@@ -197,7 +153,7 @@ int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes)
   else if (k == "tokens.userid") { src = m->uid_t; n = 2 * N * 4; }
   else if (k == "tokens.token_mask_ids") { src = m->tm_t; n = 2 * N * 4; }
   else if (k == "embed.x0") { src = m->x0; n = 2 * N * m->D * 4; }
-  else if (k == "table.fused") { src = m->F32; n = (int64_t)(m->V + 1) * m->D * 4; }
+  else if (k == "table.fused") { src = m->F32; n = (int64_t)m->TR * m->D * 4; }
   else if (k.size() == 5 && k.compare(0, 4, "idx.") == 0 && k[4] >= '0' && k[4] <= '3') { src = m->idx[k[4] - '0']; n = (int64_t)m->K * m->cur_rows * 4; }
   else if (k.compare(0, 7, "masked.") == 0 && k.size() > 9 && (k[7] == '0' || k[7] == '1') && k[8] == '.') {
     const int med = k[7] - '0';
@@ -284,42 +240,26 @@ int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* m
 }
 
 // ---------------------------------------------------------------- communicator
-int32_t rsys_comm_unique_id(uint8_t id_buf[128]) {
-  int rc = load_rccl();
-  if (rc) return rc;
-  ncclUniqueId_t id;
-  NCCL_CHECK(g_rccl.GetUniqueId(&id));
-  memcpy(id_buf, id.internal, 128);
-  return RSYS_OK;
-}
+int32_t rsys_comm_unique_id(uint8_t id_buf[128]) { return comm_unique_id(id_buf); }
 int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, int32_t device, rsys_comm** out) {
-  ARG_CHECK(world >= 1 && rank >= 0 && rank < world, "rank/world");
-  int rc = load_rccl();
-  if (rc) return rc;
-  HIP_CHECK(hipSetDevice(device));
-  rsys_comm* c = new rsys_comm();
-  c->rank = rank; c->world = world; c->device = device;
-  ncclUniqueId_t id;
-  memcpy(id.internal, id_buf, 128);
-  NCCL_CHECK(g_rccl.CommInitRank(&c->comm, world, id, rank));
-  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  HIP_CHECK(hipMalloc((void**)&c->scratch, 64 * sizeof(double)));
-  { const char* f = getenv("RSYS_FORCE_RCCL"); c->force = f && f[0] == '1'; }
-  *out = c;
+  ARG_CHECK(id_buf && out, "null");
+  return comm_init_rccl(id_buf, rank, world, device, out);
+}
+int32_t rsys_comm_destroy(rsys_comm* c) { return comm_destroy(c); }
+
+// in-process rank group (tests of the multi-rank partition arithmetic on one GPU): `world` ranks of THIS process on one
+// device, each driven by its own host thread; rsys_comm_init_local gives rank r its communicator
+int32_t rsys_local_group_create(int32_t world, int32_t device, void** out) {
+  ARG_CHECK(out && world >= 1 && world <= 16, "in-process group: 1..16 ranks");
+  LocalGroup* g = new LocalGroup();
+  g->world = world; g->device = device; g->slot.resize(world);
+  *out = g;
   return RSYS_OK;
 }
-int32_t rsys_comm_destroy(rsys_comm* c) {
-  if (!c) return RSYS_OK;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  if (c->comm) g_rccl.CommDestroy(c->comm);
-  hipFree(c->scratch);
-  hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done);
-  hipStreamDestroy(c->stream);
-  delete c;
-  return RSYS_OK;
+int32_t rsys_local_group_destroy(void* group) { delete (LocalGroup*)group; return RSYS_OK; }
+int32_t rsys_comm_init_local(void* group, int32_t rank, rsys_comm** out) {
+  ARG_CHECK(group && out, "null");
+  return comm_init_local((LocalGroup*)group, rank, out);
 }
 
 // DDP's bucketed gradient all-reduce (train.py:678-682, 272) on the communicator's own stream.
@@ -333,7 +273,7 @@ static int reduce_range(Model* m, rsys_comm* c, int64_t lo, int64_t hi) {
   const int64_t bucket = 16 * 1024 * 1024;  // floats
   for (int64_t o = lo; o < hi; o += bucket) {
     const int64_t n = std::min(bucket, hi - o);
-    NCCL_CHECK(g_rccl.AllReduce(m->G + o, m->G + o, (size_t)n, NCCL_FLOAT32, NCCL_SUM, c->comm, c->stream));
+    RC(comm_all_reduce_f32(c, m->G + o, (size_t)n, COMM_SUM, c->stream));
   }
   return RSYS_OK;
 }
@@ -344,7 +284,7 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
   m->reduced.clear();
   m->grad_bucket_hook = nullptr;
   m->gemm_flags &= ~2;
-  if (c == nullptr || (c->world == 1 && !c->force) || m->cfg.finetune) return RSYS_OK;
+  if (!comm_active(c) || m->cfg.finetune) return RSYS_OK;
   m->grad_bucket_hook = [m, c](int64_t lo, int64_t hi) -> int {
     hi = std::min(hi, m->n_opt);
     if (lo >= hi) return RSYS_OK;
@@ -358,6 +298,22 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
   return RSYS_OK;
 }
 
+int32_t rsys_model_set_shard_comm(rsys_model* h, rsys_comm* c) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  ARG_CHECK(m->sharded, "the model's item table is replicated (rsys_config.table_shard_world == 0)");
+  ARG_CHECK((c == nullptr && m->sh_world == 1) || (c != nullptr && c->world == m->sh_world && c->rank == m->sh_rank),
+            "the communicator's rank / world must equal the model's table_shard_rank / table_shard_world");
+  m->shard_comm = c;
+  return RSYS_OK;
+}
+int32_t rsys_table_rows(rsys_model* h, int64_t* lo, int64_t* hi) {
+  CHECK_HANDLE(h);
+  if (lo) *lo = h->m->row_lo;
+  if (hi) *hi = h->m->row_lo + h->m->TR;
+  return RSYS_OK;
+}
+
 int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   CHECK_HANDLE(h); CHECK_HANDLE(c);
   Model* m = h->m;
@@ -366,10 +322,13 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   m->gemm_flags &= ~2;             // the optimizer waits for the reduction: nothing after this call overlaps with it
   m->early_reduced = 0;
   for (auto& r : m->reduced) m->early_reduced += r.second - r.first;
-  if (c->world == 1 && !c->force) { m->reduced.clear(); return model_finalize_grads(m); }
+  if (!comm_active(c)) { m->reduced.clear(); return model_finalize_grads(m); }
   // what the early buckets have not covered, ascending
   std::vector<std::pair<int64_t, int64_t>> done = m->reduced, rem;
   m->reduced.clear();
+  // row-sharded table: a rank's table rows already hold the gradient of EVERY rank's loss (vocabulary-parallel head, row
+  // exchange of the token gradients): they are not part of the dense all-reduce
+  if (m->sharded) done.emplace_back(m->o_E, m->o_E + (int64_t)m->TR * m->D);
   std::sort(done.begin(), done.end());
   int64_t at = 0;
   for (auto& r : done) { if (r.first > at) rem.emplace_back(at, r.first); at = std::max(at, r.second); }
@@ -416,10 +375,10 @@ int32_t rsys_grad_sync_early(rsys_model* h, int64_t* n) { CHECK_HANDLE(h); ARG_C
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n) {
   CHECK_HANDLE(c);
   ARG_CHECK(n >= 1 && n <= 64 && x, "n in [1,64]");
-  if (c->world == 1 && !c->force) return RSYS_OK;
+  if (!comm_active(c)) return RSYS_OK;
   HIP_CHECK(hipSetDevice(c->device));
   HIP_CHECK(hipMemcpyAsync(c->scratch, x, n * 8, hipMemcpyHostToDevice, c->stream));
-  NCCL_CHECK(g_rccl.AllReduce(c->scratch, c->scratch, (size_t)n, NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream));
+  RC(comm_all_reduce_f64(c, c->scratch, (size_t)n, c->stream));
   HIP_CHECK(hipMemcpyAsync(x, c->scratch, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   return RSYS_OK;

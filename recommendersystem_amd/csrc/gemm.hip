@@ -461,6 +461,8 @@ static bool use_8p_tn(const GemmParams& p) {
 // row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
 static bool use_8p_nt_splitk(const GemmParams& p) {
   if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
+  static const char* e = getenv("RSYS_GEMM_KERNEL_NT_SPLITK");   // 2: force (tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
+  if (e && atoi(e) == 2) return true;
   return (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 32;
 }
 

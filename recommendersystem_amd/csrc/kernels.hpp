@@ -95,6 +95,27 @@ size_t seg_scatter_slab_floats(int N, int D);
 int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const int* m_matchedid, const int* skey, const int* sidx,
                                        int N, int V, int D, float* gE, float* slab, hipStream_t s);
 
+// ---- row-sharded item table (shard.hip): exchange plan, rows by id, vocabulary-parallel cross entropy
+int launch_plan_unique(const int* skey, const int* sidx, int N, int V, int* slot, int* uniq, int* tok2u, int* plan /*{U, uV}*/, hipStream_t s);
+int launch_plan_offsets(const int* uniq, const int* plan, const int* bound_dev, int nb, int* off, hipStream_t s);
+int launch_gather_rows_by_id(const float* src, long long ld, const int* ids, int sub, float* dst, int n, int D, hipStream_t s);
+int launch_add_rows_by_id(const float* src, const int* ids, int sub, float* dst, long long ld, int n, int D, hipStream_t s);
+int launch_gather_items_remote(const BatchDev& b, const float* Frem, const int* tok2u, const int* plan, int D, float* x0,
+                               int* uid_t, int* tm_t, hipStream_t s);
+int launch_vp_meta(const int* idx, const float* label, const float* weight, const int* position, const float* stats,
+                   const int* npos, float task_w, int KB, int KBmax, float* own /*[KBmax*4 + 4]*/, hipStream_t s);
+int launch_add_scalar(float* dst, const float* src, hipStream_t s);
+template <typename T>
+int launch_vp_compact(const T* EwAll, const float* metaAll, int W, int KB, int D, T* EwC, float* metaC, int* nlive, int* pre /*[W+1]*/, hipStream_t s);
+template <typename T>
+int launch_vp_rowmax(const T* logits, long long ldl, int Vloc, const int* nlive, float* rmax, int grid_rows, hipStream_t s);
+template <typename T>
+int launch_vp_sumexp(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const int* nlive,
+                     float* sums /*[2*cap]*/, int cap, int grid_rows, hipStream_t s);
+template <typename T>
+int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const float* sums, int cap,
+                     const int* nlive, const int* pre, int rank, float* loss_out, int grid_rows, hipStream_t s);
+
 int launch_action_small_bwd(const float* gf /*[N][32]*/, const BatchDev& b, const SmallParams& sp,
                             float* g_per_cos, float* g_per_sin, float* g_status, float* g_gender, float* g_source,
                             hipStream_t s);
@@ -134,8 +155,10 @@ struct TransposeJob { const void* src; void* dst; int rows, cols; long long ld_s
 struct TransposeBatch { TransposeJob job[64]; int n; };
 int launch_transpose_bf16(const TransposeBatch& b, hipStream_t s);
 int launch_scale(float* g, long long n, const float* sumsq, float grad_div, float max_norm, hipStream_t s);
-int launch_fill_normal(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, hipStream_t s);
+// dst[0, n) = elements [first, first + n) of the N(0, std) stream (seed, stream)
+int launch_fill_normal(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, hipStream_t s, long long first = 0);
+// rows [row0, row0 + rows) of a table generated row by row
 template <typename T>
-int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s);
+int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s, long long row0 = 0);
 
 }  // namespace rsys

@@ -77,7 +77,7 @@ static void build_layout(Model* m) {
   m->o_gender = take((m->cfg.vocab_gender + 1) * 4);
   m->o_source = take((m->cfg.vocab_source + 1) * 4);
   m->o_lin_w = take((int64_t)D * 32);
-  m->o_E = take((int64_t)(m->V + 1) * D);
+  m->o_E = take((int64_t)m->TR * D);
   m->o_Wp = take((int64_t)D * m->Mp);
   for (int l = 0; l < L; ++l) {
     m->lo[l].wqkv = take((int64_t)m->Nqkv * D);
@@ -105,8 +105,9 @@ static void build_layout(Model* m) {
   add_tensor(m, "action_embedding.source_embedding.embedding.weight", m->cfg.vocab_source + 1, 4, 2, m->o_source, 4, MAP_DIRECT, tr);
   add_tensor(m, "action_embedding.linear.weight", D, 32, 2, m->o_lin_w, 32, MAP_DIRECT, tr);
   add_tensor(m, "action_embedding.linear.bias", 1, D, 1, m->o_lin_b, D, MAP_DIRECT, tr);
-  add_tensor(m, "item_embedding.matchedid_embedding.embedding.weight", m->V + 1, D, 2, m->o_E, D, MAP_DIRECT, tr);
-  add_tensor(m, "item_embedding.metadata_embedding.embedding.weight", m->V + 1, m->M, 2, 0, m->Mp, MAP_DIRECT, false, true);
+  // (row-sharded table: these two tensors are the rank's rows [row_lo, row_lo + TR) of the (V + 1)-row tables)
+  add_tensor(m, "item_embedding.matchedid_embedding.embedding.weight", m->TR, D, 2, m->o_E, D, MAP_DIRECT, tr);
+  add_tensor(m, "item_embedding.metadata_embedding.embedding.weight", m->TR, m->M, 2, 0, m->Mp, MAP_DIRECT, false, true);
   add_tensor(m, "item_embedding.projection_layer.weight", D, m->M, 2, m->o_Wp, m->Mp, MAP_DIRECT, tr);
   add_tensor(m, "item_embedding.projection_layer.bias", 1, D, 1, m->o_bp, D, MAP_DIRECT, tr);
   for (int l = 0; l < L; ++l) {
@@ -140,6 +141,15 @@ static inline int64_t internal_row(const TensorInfo& t, int64_t r) {
   return r;
 }
 
+// rows of medium `med` (global ids [0, V0) / [V0, V)) that this rank holds: `len` rows, the first one is id `col0` inside the
+// medium and local table row `row` (replicated table: the whole medium)
+static void shard_medium_range(const Model* m, int med, int* len, int* col0, int* row) {
+  const int s = med == 0 ? 0 : m->V0, e = med == 0 ? m->V0 : m->V;
+  const int a = std::max(s, m->row_lo), b = std::min(e, m->row_lo + m->TR);
+  *len = std::max(0, b - a); *col0 = a - s; *row = a - m->row_lo;
+  if (*len == 0) { *col0 = 0; *row = 0; }
+}
+
 int model_create(const rsys_config* cfg, int device, Model** out) {
   ARG_CHECK(cfg != nullptr && out != nullptr, "null argument");
   ARG_CHECK(cfg->embed_dim % cfg->num_heads == 0, "embed_dim % num_heads");
@@ -167,6 +177,15 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   m->V0 = cfg->vocab_0; m->V1 = cfg->vocab_1; m->V = m->V0 + m->V1; m->M = cfg->metadata_dim;
   m->Mp = (m->M + 63) / 64 * 64; m->K = cfg->mask_topk; m->hd = hd;
   m->Nqkv = (m->H + 2 * m->KV) * hd; m->rows_max = cfg->max_rows;
+  m->sharded = cfg->table_shard_world >= 1;
+  m->sh_world = m->sharded ? cfg->table_shard_world : 1; m->sh_rank = m->sharded ? cfg->table_shard_rank : 0;
+  if (m->sh_world > 16 || m->sh_rank < 0 || m->sh_rank >= m->sh_world || (m->sharded && cfg->finetune)) {
+    delete m;
+    set_error("table_shard: rank must be in [0, world), world <= 16, and finetuning keeps the table replicated (it is frozen)");
+    return RSYS_ERR_ARG;
+  }
+  m->row_lo = (int)((int64_t)m->sh_rank * (m->V + 1) / m->sh_world);
+  m->TR = (int)((int64_t)(m->sh_rank + 1) * (m->V + 1) / m->sh_world) - m->row_lo;
   HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -176,10 +195,10 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   const size_t e = m->esz;
   DALLOC(m->P, m->n_total * 4); DALLOC(m->G, m->n_total * 4);
   if (m->bf16_mode) { DALLOC(m->Sh, m->n_total * 2); DALLOC(m->ShT, m->n_total * 2); } else { m->Sh = m->P; }
-  DALLOC(m->Meta, (int64_t)(m->V + 1) * m->Mp * e);
-  DALLOC(m->F32, (int64_t)(m->V + 1) * D * 4); DALLOC(m->FT, (int64_t)(m->V + 1) * D * e);
+  DALLOC(m->Meta, (int64_t)m->TR * m->Mp * e);
+  DALLOC(m->F32, (int64_t)m->TR * D * 4); DALLOC(m->FT, (int64_t)m->TR * D * e);
   if (m->bf16_mode) {
-    m->Vp = ((int64_t)m->V + 1 + 63) / 64 * 64;
+    m->Vp = ((int64_t)m->TR + 63) / 64 * 64;
     DALLOC(m->MetaT, (int64_t)m->Mp * m->Vp * 2); DALLOC(m->dFT, (int64_t)D * m->Vp * 2);
     HIP_CHECK(hipMemset(m->MetaT, 0, (size_t)m->Mp * m->Vp * 2)); HIP_CHECK(hipMemset(m->dFT, 0, (size_t)D * m->Vp * 2));
   }
@@ -236,7 +255,28 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   for (int k = 0; k < 4; ++k) DALLOC(m->idx[k], KB * 4);
   DALLOC(m->stats, 8 * 4); DALLOC(m->npos, 4 * 4); DALLOC(m->Ew, KB * D * e);
   m->ldl = pad8(std::max(m->V0, m->V1));
-  DALLOC(m->logits, KB * m->ldl * e); DALLOC(m->dE, KB * D * 4);
+  if (m->sharded) {
+    // vocabulary-parallel heads: the selected rows of ALL ranks against this rank's rows of each medium
+    const int W = m->sh_world;
+    int len_max = 0;
+    for (int med = 0; med < 2; ++med) { int len, col0, row; shard_medium_range(m, med, &len, &col0, &row); len_max = std::max(len_max, len); }
+    m->ldl_loc = pad8(std::max(len_max, 8));
+    const int64_t cap = (int64_t)W * KB;
+    DALLOC(m->logits, cap * m->ldl_loc * e); DALLOC(m->dEwC, cap * D * 4); m->dE = m->dEwC;
+    DALLOC(m->EwAll, cap * D * e); DALLOC(m->EwC, cap * D * e);
+    DALLOC(m->metaOwn, (KB * 4 + 4) * 4); DALLOC(m->metaAll, (int64_t)W * (KB * 4 + 4) * 4); DALLOC(m->metaC, cap * 4 * 4 + 4096);
+    DALLOC(m->vp_max, cap * 4); DALLOC(m->vp_sums, 2 * cap * 4); DALLOC(m->vp_nlive, 64); DALLOC(m->vp_pre, 64 * 4);
+    // exchange plan of the resident batch
+    DALLOC(m->u_slot, N * 4); DALLOC(m->u_ids, (N + 1) * 4); DALLOC(m->u_tok, N * 4); DALLOC(m->u_plan, 64);
+    DALLOC(m->u_bound, (W + 1) * 4); DALLOC(m->u_off, ((W + 1) + W + (int64_t)W * W) * 4 + 64);
+    DALLOC(m->Frem, (N + 1) * D * 4); DALLOC(m->sumsq_E, 64);
+    std::vector<int> bound(W + 1);
+    for (int r = 0; r <= W; ++r) bound[r] = (int)((int64_t)r * (m->V + 1) / W);
+    HIP_CHECK(hipMemcpy(m->u_bound, bound.data(), (W + 1) * 4, hipMemcpyHostToDevice));
+    m->need_off.assign(W + 1, 0); m->serve_off.assign(W + 1, 0); m->need_offD.assign(W + 1, 0); m->serve_offD.assign(W + 1, 0);
+  } else {
+    DALLOC(m->logits, KB * m->ldl * e); DALLOC(m->dE, KB * D * 4);
+  }
   DALLOC(m->z, KB * D * e); DALLOC(m->hact, KB * D * e); DALLOC(m->loss_acc, 16 * 4);
   DALLOC(m->gy, NT * D * 4); DALLOC(m->gxa, NT * D * 4); DALLOC(m->gxb, NT * D * 4); DALLOC(m->dh, NT * D * 4);
   if (m->bf16_mode) { DALLOC(m->gxa_t, NT * D * 2); DALLOC(m->gxb_t, NT * D * 2); DALLOC(m->dh_t, NT * D * 2); }
@@ -257,6 +297,8 @@ int model_destroy(Model* m) {
   hipStreamSynchronize(m->stream);
   hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
+  if (m->req_ids) hipFree(m->req_ids);
+  if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
   for (auto e : m->timer.pool) hipEventDestroy(e);
   for (auto e : m->step_marks) hipEventDestroy(e);
@@ -286,6 +328,16 @@ int model_init_random(Model* m, uint64_t seed) {
     if (t.map == MAP_W3) continue;  // filled together with w1 (same interleaved block)
     if (t.name.find("lora_B") != std::string::npos) continue;   // zeros (model.py:252,254)
     int64_t rows = t.map == MAP_W1 ? 2 * m->Ip : t.rows;
+    if (t.off == m->o_E && t.rows == m->TR && t.name.find("matchedid_embedding") != std::string::npos) {
+      // the item table: generated per chunk of 4096 GLOBAL rows (one Philox stream each), a rank fills the part it holds
+      const int64_t lo = m->row_lo, hi = lo + m->TR;
+      for (int64_t r0 = 0; r0 <= m->V; r0 += 4096, ++stream_id) {
+        const int64_t a = std::max(r0, lo), b = std::min<int64_t>(std::min<int64_t>(r0 + 4096, (int64_t)m->V + 1), hi);
+        if (a < b) RC(launch_fill_normal(m->P + t.off + (a - lo) * t.ld, (b - a) * t.ld, 0.006f, seed, stream_id, m->stream, (a - r0) * t.ld));
+      }
+      if (hi == (int64_t)m->V + 1) HIP_CHECK(hipMemsetAsync(m->P + t.off + (t.rows - 1) * t.ld, 0, t.cols * 4, m->stream));   // mask row (model.py:9-12)
+      continue;
+    }
     for (int64_t r0 = 0; r0 < rows; r0 += 4096) {  // rows*ld contiguous block incl. padding (re-zeroed below)
       int64_t nr = std::min<int64_t>(4096, rows - r0);
       RC(launch_fill_normal(m->P + t.off + r0 * t.ld, nr * t.ld, 0.006f, seed, stream_id++, m->stream));
@@ -317,25 +369,26 @@ int model_init_random(Model* m, uint64_t seed) {
 static int build_meta_t(Model* m) {
   if (!m->bf16_mode) return RSYS_OK;
   TransposeBatch b; b.n = 1;
-  b.job[0].src = (const bf16*)m->Meta; b.job[0].dst = (bf16*)m->MetaT; b.job[0].rows = m->V + 1; b.job[0].cols = m->Mp;
+  b.job[0].src = (const bf16*)m->Meta; b.job[0].dst = (bf16*)m->MetaT; b.job[0].rows = m->TR; b.job[0].cols = m->Mp;
   b.job[0].ld_src = m->Mp; b.job[0].ld_dst = m->Vp;
   RC(launch_transpose_bf16(b, m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   return RSYS_OK;
 }
 
-int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
-  ARG_CHECK(V == m->V && Mdim == m->M, "metadata table shape must be (V, metadata_dim)");  // model.py:387
+// rows [0, nrows) of the rank's part of the metadata table <- `rows` (nrows x M floats); the rest (mask row, padding) stays zero
+static int meta_write_rows(Model* m, const float* rows, int64_t nrows) {
+  const int64_t Mdim = m->M;
   HIP_CHECK(hipSetDevice(m->device));
   const int64_t chunk = 4096;
   std::vector<float> hostf((size_t)chunk * m->Mp);
   std::vector<unsigned short> hosth;
   if (m->bf16_mode) hosth.resize((size_t)chunk * m->Mp);
-  HIP_CHECK(hipMemset(m->Meta, 0, (size_t)(m->V + 1) * m->Mp * m->esz));  // mask row V and padding stay zero
-  for (int64_t r0 = 0; r0 < V; r0 += chunk) {
-    int64_t nr = std::min(chunk, V - r0);
+  HIP_CHECK(hipMemset(m->Meta, 0, (size_t)m->TR * m->Mp * m->esz));  // mask row V and padding stay zero
+  for (int64_t r0 = 0; r0 < nrows; r0 += chunk) {
+    int64_t nr = std::min(chunk, nrows - r0);
     for (int64_t r = 0; r < nr; ++r) {
-      const float* src = table + (r0 + r) * Mdim;
+      const float* src = rows + (r0 + r) * Mdim;
       if (m->bf16_mode) {
         unsigned short* d = hosth.data() + r * m->Mp;
         for (int64_t c = 0; c < Mdim; ++c) {
@@ -356,12 +409,20 @@ int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
   return build_meta_t(m);
 }
 
+// `table`: the FULL (V, M) array of media_embeddings.h5; a rank of a row-sharded table keeps its rows of it
+int model_load_metadata(Model* m, const float* table, int64_t V, int64_t Mdim) {
+  ARG_CHECK(V == m->V && Mdim == m->M, "metadata table shape must be (V, metadata_dim)");  // model.py:387
+  const int64_t nrows = std::max<int64_t>(0, std::min<int64_t>(m->row_lo + m->TR, m->V) - m->row_lo);
+  return meta_write_rows(m, table + (int64_t)m->row_lo * Mdim, nrows);
+}
+
 int model_random_metadata(Model* m, uint64_t seed) {
   HIP_CHECK(hipSetDevice(m->device));
-  HIP_CHECK(hipMemsetAsync(m->Meta, 0, (size_t)(m->V + 1) * m->Mp * m->esz, m->stream));
+  HIP_CHECK(hipMemsetAsync(m->Meta, 0, (size_t)m->TR * m->Mp * m->esz, m->stream));
   const float std_ = 1.0f / sqrtf((float)m->M);
-  if (m->bf16_mode) RC(launch_fill_normal_t<bf16>((bf16*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
-  else RC(launch_fill_normal_t<float>((float*)m->Meta, m->V, m->M, m->Mp, std_, seed, m->stream));
+  const long long nrows = std::max<long long>(0, std::min<long long>(m->row_lo + m->TR, m->V) - m->row_lo);   // (the mask row stays zero)
+  if (m->bf16_mode) RC(launch_fill_normal_t<bf16>((bf16*)m->Meta, nrows, m->M, m->Mp, std_, seed, m->stream, m->row_lo));
+  else RC(launch_fill_normal_t<float>((float*)m->Meta, nrows, m->M, m->Mp, std_, seed, m->stream, m->row_lo));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   return build_meta_t(m);
 }
@@ -386,8 +447,8 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   if (t.frozen_table) {
     ARG_CHECK(which == 0, "the metadata table is frozen (model.py:113-114)");
     if (in) {
-      // rows 0..V-1 come from the caller; the mask row is kept zero (model.py:386)
-      return model_load_metadata(m, in, m->V, m->M);
+      // the rows below the mask row come from the caller; the mask row is kept zero (model.py:386)
+      return meta_write_rows(m, in, std::max<int64_t>(0, std::min<int64_t>(m->row_lo + m->TR, m->V) - m->row_lo));
     }
     std::vector<unsigned char> host((size_t)t.rows * m->Mp * m->esz);
     HIP_CHECK(hipMemcpy(host.data(), m->Meta, host.size(), hipMemcpyDeviceToHost));
@@ -415,6 +476,44 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   if (which == 0 && m->bf16_mode)
     RC(launch_cast<bf16>(base, (bf16*)m->Sh + t.off, (int64_t)host.size(), m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
+  return RSYS_OK;
+}
+
+// Row-sharded table: which rows of which rank this batch reads.  Depends on the batch only (a watch-masked token reads
+// the mask row V instead of its item's row, and V is always part of the plan), so it is built once per upload:
+// distinct ids (sorted) -> contiguous runs per owner -> counts all-gathered -> id lists exchanged.  Every rank calls this
+// at the same point (it contains collectives).
+static int build_exchange_plan(Model* m, int N) {
+  const int W = m->sh_world;
+  hipStream_t s = m->stream;
+  ARG_CHECK(W == 1 || m->shard_comm != nullptr, "row-sharded table: call rsys_model_set_shard_comm before the first batch");
+  RC(launch_plan_unique(m->tok_skey, m->tok_sidx, N, m->V, m->u_slot, m->u_ids, m->u_tok, m->u_plan, s));
+  int* d_off = m->u_off; int* d_cnt = m->u_off + (W + 1); int* d_all = d_cnt + W;
+  RC(launch_plan_offsets(m->u_ids, m->u_plan, m->u_bound, W + 1, d_off, s));
+  int plan[2]; std::vector<int> off(W + 1), cnt(W), all((size_t)W * W);
+  HIP_CHECK(hipMemcpyAsync(plan, m->u_plan, 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(off.data(), d_off, (W + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  m->U = plan[0]; m->uV = plan[1];
+  ARG_CHECK(off[W] == m->U && m->U >= 1 && m->U <= N + 1, "exchange plan: inconsistent unique-id list");
+  for (int q = 0; q <= W; ++q) { m->need_off[q] = off[q]; m->need_offD[q] = (long long)off[q] * m->D; }
+  for (int q = 0; q < W; ++q) cnt[q] = off[q + 1] - off[q];
+  HIP_CHECK(hipMemcpyAsync(d_cnt, cnt.data(), W * 4, hipMemcpyHostToDevice, s));
+  RC(comm_all_gather(m->shard_comm, d_cnt, d_all, (size_t)W * 4, s));
+  HIP_CHECK(hipMemcpyAsync(all.data(), d_all, (size_t)W * W * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  long long acc = 0;
+  for (int q = 0; q < W; ++q) { m->serve_off[q] = acc; m->serve_offD[q] = acc * m->D; acc += all[(size_t)q * W + m->sh_rank]; }
+  m->serve_off[W] = acc; m->serve_offD[W] = acc * m->D; m->R = acc;
+  if (acc > m->req_cap) {
+    if (m->req_ids) HIP_CHECK(hipFree(m->req_ids));
+    if (m->rows_xchg) HIP_CHECK(hipFree(m->rows_xchg));
+    m->req_cap = acc + acc / 4 + 1024;
+    HIP_CHECK(hipMalloc((void**)&m->req_ids, (size_t)m->req_cap * 4));
+    HIP_CHECK(hipMalloc((void**)&m->rows_xchg, (size_t)m->req_cap * m->D * 4));
+  }
+  RC(comm_exchange(m->shard_comm, m->u_ids, m->need_off.data(), m->req_ids, m->serve_off.data(), 4, s));
+  HIP_CHECK(hipStreamSynchronize(s));
   return RSYS_OK;
 }
 
@@ -471,6 +570,7 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only
   if (!m->cfg.finetune) RC(launch_token_index_build(d.matchedid, (int)N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  if (m->sharded) RC(build_exchange_plan(m, (int)N));
   m->cur_rows = b->rows;
   return RSYS_OK;
 }
@@ -539,7 +639,7 @@ template <typename T>
 static int table_forward(Model* m) {
   GemmParams p{};
   p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
-  p.M = m->V + 1; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
+  p.M = m->TR; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
   p.C2 = m->FT; p.ldc2 = m->D;
   return gemm<T>(m, "gemm_table_fwd", p, false, false, false);
 }
@@ -596,9 +696,21 @@ static int forward_trunk(Model* m) {
     p.M = N; p.N = D; p.K = 32; p.epi = EPI_BIAS; p.bias = m->P + m->o_lin_b;
     RC(gemm<T>(m, "gemm_action_fwd", p, false, false, false));
   }
-  tic(m, "hbm_gather", 8.0 * D * N);   // bytes: one fused-table row read + one embedding row written per interaction
-  RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
-  toc(m);
+  if (m->sharded) {
+    // sparse row exchange: every owner sends the rows of F its peers' batches read (plan of the resident batch), then the
+    // token gather reads the fetched rows (one per distinct id)
+    tic(m, "shard_row_exchange");
+    RC(launch_gather_rows_by_id(m->F32, D, m->req_ids, m->row_lo, m->rows_xchg, (int)m->R, D, s));
+    RC(comm_exchange(m->shard_comm, m->rows_xchg, m->serve_offD.data(), m->Frem, m->need_offD.data(), 4, s));
+    toc(m);
+    tic(m, "hbm_gather", 8.0 * D * N);
+    RC(launch_gather_items_remote(b, m->Frem, m->u_tok, m->u_plan, D, m->x0, m->uid_t, m->tm_t, s));
+    toc(m);
+  } else {
+    tic(m, "hbm_gather", 8.0 * D * N);   // bytes: one fused-table row read + one embedding row written per interaction
+    RC(launch_gather_items(b, m->F32, m->V, D, m->x0, m->uid_t, m->tm_t, s));
+    toc(m);
+  }
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
@@ -676,6 +788,68 @@ static int forward_trunk(Model* m) {
   return RSYS_OK;
 }
 
+// ------------------------------------------------------------------ watch head over a row-sharded table (cfg-4)
+// Vocabulary-parallel form of model.py:153-170 + 514-519: the selected rows of ALL ranks against this rank's rows of the
+// medium.  all-gather (rows, row meta) -> pack the live rows -> local logits -> all-reduce(max) -> all-reduce(sum-exp,
+// target logit) -> loss of the own rows, dlogits of every row over the local columns -> dF of the local rows (complete:
+// no all-reduce) and the gradient of the selected rows (partial over the vocabulary: all-reduced, own rows scattered).
+template <typename T>
+static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd, float tw) {
+  const int D = m->D, rows = m->cur_rows, KB = m->K * rows, W = m->sh_world, KBmax = m->K * m->rows_max;
+  hipStream_t s = m->stream;
+  rsys_comm* c = m->shard_comm;
+  int len, col0, lrow;
+  shard_medium_range(m, medium, &len, &col0, &lrow);
+  T* Fm = AT<T>(m->FT) + (int64_t)lrow * D;
+  float* st = m->stats + 2 * ti;
+  int* np = m->npos + ti;
+  // every rank contributes a block of KBmax rows (ranks may hold batches of different row counts: the tail is dead rows)
+  RC(launch_vp_meta(m->idx[ti], m->bd.m_label[ti], m->bd.m_weight[ti], m->bd.m_position[ti], st, np, train ? tw : 0.f, KB, KBmax, m->metaOwn, s));
+  RC(comm_all_gather(c, m->Ew, m->EwAll, (size_t)KBmax * D * m->esz, s));
+  RC(comm_all_gather(c, m->metaOwn, m->metaAll, ((size_t)KBmax * 4 + 4) * 4, s));
+  RC(launch_vp_compact<T>(AT<T>(m->EwAll), m->metaAll, W, KBmax, D, AT<T>(m->EwC), m->metaC, m->vp_nlive, m->vp_pre, s));
+  std::vector<int> pre(W + 1);
+  HIP_CHECK(hipMemcpyAsync(pre.data(), m->vp_pre, (W + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));   // (the one host sync of the step: the sizes of the collectives below)
+  const int nlive = pre[W], cap = W * KBmax, own0 = pre[m->sh_rank], nown = pre[m->sh_rank + 1] - own0;
+  if (nlive == 0) return RSYS_OK;
+  const int npad = std::min(cap, (nlive + 255) & ~255);
+  if (len > 0) {
+    GemmParams p{};
+    p.A = m->EwC; p.lda = D; p.B = Fm; p.ldb = D; p.C = m->logits; p.ldc = m->ldl_loc;
+    p.M = cap; p.N = len; p.K = D; p.epi = EPI_STORE; p.m_dev = m->vp_nlive;
+    RC(gemm<T>(m, "gemm_logits", p, false, false, false));
+  }
+  tic(m, "ce");
+  RC(launch_vp_rowmax<T>(AT<T>(m->logits), m->ldl_loc, len, m->vp_nlive, m->vp_max, nlive, s));
+  RC(comm_all_reduce_f32(c, m->vp_max, (size_t)nlive, COMM_MAX, s));
+  RC(launch_vp_sumexp<T>(AT<T>(m->logits), m->ldl_loc, len, col0, m->metaC, m->vp_max, m->vp_nlive, m->vp_sums, cap, nlive, s));
+  RC(comm_all_reduce_f32(c, m->vp_sums, (size_t)nlive, COMM_SUM, s));
+  RC(comm_all_reduce_f32(c, m->vp_sums + cap, (size_t)nlive, COMM_SUM, s));
+  RC(launch_vp_finish<T>(AT<T>(m->logits), m->ldl_loc, len, col0, m->metaC, m->vp_max, m->vp_sums, cap, m->vp_nlive, m->vp_pre,
+                         m->sh_rank, m->loss_acc + 3 * ti, npad, s));
+  toc(m);
+  if (!bwd) return RSYS_OK;   // (the task weights are the same on every rank: all ranks leave here together)
+  HIP_CHECK(hipMemsetAsync(m->dEwC, 0, (size_t)nlive * D * 4, s));
+  if (len > 0) {
+    GemmParams p{};  // d(selected rows) = dlogits . F[local rows]   (partial over the vocabulary)
+    p.A = m->logits; p.lda = m->ldl_loc; p.B = Fm; p.ldb = D; p.C = m->dEwC; p.ldc = D; p.c_f32 = 1;
+    p.M = cap; p.N = D; p.K = len; p.epi = EPI_ATOMIC; p.m_dev = m->vp_nlive;
+    RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
+  }
+  RC(comm_all_reduce_f32(c, m->dEwC, (size_t)nlive * D, COMM_SUM, s));
+  if (nown > 0) RC(launch_scatter_rows_add(m->dEwC + (size_t)own0 * D, m->idx[ti], 0, m->gy, D, nown, D, s));
+  if (len > 0) {
+    GemmParams p{};  // dF[local rows of the medium] (+)= dlogits^T . (selected rows of all ranks): complete, no all-reduce
+    p.A = m->logits; p.lda = m->ldl_loc; p.B = m->EwC; p.ldb = D; p.C = m->G + m->o_E + (int64_t)lrow * D; p.ldc = D; p.c_f32 = 1;
+    p.M = len; p.N = D; p.K = cap; p.epi = m->gE_clean[medium] ? EPI_STORE : EPI_ACCUM; p.k_dev = m->vp_nlive;
+    m->gE_clean[medium] = false;
+    RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
+  }
+  m->table_grads_pending = true;
+  return RSYS_OK;
+}
+
 // ------------------------------------------------------------------ heads, fwd + bwd fused per task (model.py:501-528)
 template <typename T>
 static int heads(Model* m, int evaluate, const float tw[4]) {
@@ -696,7 +870,9 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
     int* np = m->npos + ti;   // positive-weight rows come first: the head GEMMs and the CE kernel stop there
     RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
     const bool bwd = train && tw[ti] != 0.f;
-    if (metric == 0) {
+    if (metric == 0 && m->sharded) {
+      RC(watch_head_sharded<T>(m, ti, medium, train, bwd, tw[ti]));
+    } else if (metric == 0) {
       const int vs = medium == 0 ? 0 : m->V0, Vm = medium == 0 ? m->V0 : m->V1;
       T* Fm = AT<T>(m->FT) + (int64_t)vs * D;
       {
@@ -922,7 +1098,17 @@ static int backward_trunk(Model* m) {
   tic(m, "hbm_scatter", 12.0 * D * N);   // bytes: one gradient row read + one table-gradient row read-modify-written per interaction
   {
     static const bool atomic_ab = getenv("RSYS_SCATTER_ATOMIC") != nullptr;   // A/B measurement against the float-atomic form only
-    if (atomic_ab) RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
+    if (m->sharded) {
+      // one gradient row per distinct id of the batch (keys = the ids' slots in the exchange plan, mask row = slot uV), sent
+      // to the rows' owners; an owner adds what it receives requester by requester (the ids of one requester are distinct)
+      HIP_CHECK(hipMemsetAsync(m->Frem, 0, (size_t)m->U * D * 4, s));
+      RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->u_slot, m->tok_sidx, N, m->uV, D, m->Frem, m->scatter_slab, s));
+      RC(comm_exchange(m->shard_comm, m->Frem, m->need_offD.data(), m->rows_xchg, m->serve_offD.data(), 4, s));
+      for (int q = 0; q < m->sh_world; ++q) {
+        const long long o = m->serve_off[q], n = m->serve_off[q + 1] - o;
+        RC(launch_add_rows_by_id(m->rows_xchg + o * D, m->req_ids + o, m->row_lo, m->G + m->o_E, D, (int)n, D, s));
+      }
+    } else if (atomic_ab) RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
     else RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
   }
   toc(m);
@@ -957,14 +1143,14 @@ static int finalize_grads_t(Model* m, int stage) {
   if (stage != 2) {
     const bool fused = m->bf16_mode && m->D <= 1024 && 1024 % (m->D >> 2) == 0;
     if (fused) {   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it) + bias gradient, one pass
-      RC(launch_cast_colsum(m->G + m->o_E, (bf16*)m->FT, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+      RC(launch_cast_colsum(m->G + m->o_E, (bf16*)m->FT, m->TR, m->D, m->G + m->o_bp, m->stream));
     } else {
-      if (m->bf16_mode) RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)(m->V + 1) * m->D, m->stream));
-      RC(launch_colsum_add(m->G + m->o_E, m->D, m->V + 1, m->D, m->G + m->o_bp, m->stream));
+      if (m->bf16_mode) RC(launch_cast<bf16>(m->G + m->o_E, (bf16*)m->FT, (long long)m->TR * m->D, m->stream));
+      RC(launch_colsum_add(m->G + m->o_E, m->D, m->TR, m->D, m->G + m->o_bp, m->stream));
     }
     if (m->bf16_mode) {   // K-contiguous copy of dF for the row-major pipeline: dFT[d][v]
       TransposeBatch b; b.n = 1;
-      b.job[0].src = (const bf16*)m->FT; b.job[0].dst = (bf16*)m->dFT; b.job[0].rows = m->V + 1; b.job[0].cols = m->D;
+      b.job[0].src = (const bf16*)m->FT; b.job[0].dst = (bf16*)m->dFT; b.job[0].rows = m->TR; b.job[0].cols = m->D;
       b.job[0].ld_src = m->D; b.job[0].ld_dst = m->Vp;
       RC(launch_transpose_bf16(b, m->stream));
     }
@@ -976,7 +1162,7 @@ static int finalize_grads_t(Model* m, int stage) {
       p.A = m->dFT; p.lda = m->Vp; p.B = m->MetaT; p.ldb = m->Vp; p.K = (int)m->Vp;
       RC(gemm<T>(m, "gemm_table_dw", p, false, false, false));
     } else {
-      p.A = m->G + m->o_E; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.K = m->V + 1;
+      p.A = m->G + m->o_E; p.lda = m->D; p.B = m->Meta; p.ldb = m->Mp; p.K = m->TR;
       RC(gemm<T>(m, "gemm_table_dw", p, false, true, true));
     }
   }
@@ -1083,6 +1269,7 @@ static int infer_t(Model* m, int task, float* out, int64_t n) {
 // F[id] = E[id] + Wp Meta[id] + bp for id in [0, V), fp32.
 template <typename T>
 static int item_table_t(Model* m, float* out, int64_t n) {
+  ARG_CHECK(!m->sharded, "item table: export from a model with a replicated table");
   ARG_CHECK(n == (int64_t)m->V * m->D, "item table: expected V * embed_dim values");
   RC(table_forward<T>(m));
   HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1101,11 +1288,24 @@ int model_infer(Model* m, int task, float* out, int64_t n) {
   return m->bf16_mode ? infer_t<bf16>(m, task, out, n) : infer_t<float>(m, task, out, n);
 }
 
+// sum of squares of all gradients into m->sumsq.  Row-sharded table: the replicated gradients are identical on every rank
+// (after the all-reduce), the table rows differ: their sum of squares is all-reduced and added.
+static int grad_sumsq(Model* m) {
+  HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
+  if (!m->sharded || !comm_active(m->shard_comm)) return launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream);
+  const int64_t e0 = m->o_E, e1 = m->o_E + (int64_t)m->TR * m->D;
+  RC(launch_sumsq(m->G, e0, m->sumsq, m->stream));
+  RC(launch_sumsq(m->G + e1, m->n_opt - e1, m->sumsq, m->stream));
+  HIP_CHECK(hipMemsetAsync(m->sumsq_E, 0, 4, m->stream));
+  RC(launch_sumsq(m->G + e0, e1 - e0, m->sumsq_E, m->stream));
+  RC(comm_all_reduce_f32(m->shard_comm, m->sumsq_E, 1, COMM_SUM, m->stream));
+  return launch_add_scalar(m->sumsq, m->sumsq_E, m->stream);
+}
+
 int model_clip(Model* m, float max_norm, float* norm_out) {
   HIP_CHECK(hipSetDevice(m->device));
   RC(model_finalize_grads(m));
-  HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
-  RC(launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream));
+  RC(grad_sumsq(m));
   RC(launch_scale(m->G, m->n_opt, m->sumsq, 1.0f, max_norm, m->stream));
   if (norm_out) {
     float ss;
@@ -1123,9 +1323,8 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   if (grad_div <= 0.f) grad_div = 1.f;
   const float* ss = nullptr;
   if (clip > 0.f) {
-    HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
     tic(m, "sumsq", 4.0 * m->n_opt);
-    RC(launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream));
+    RC(grad_sumsq(m));
     toc(m);
     ss = m->sumsq;
   }

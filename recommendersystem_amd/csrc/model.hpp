@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/rsys.h"
+#include "comm.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
 
@@ -79,6 +80,20 @@ struct Model {
   // runs on the row-major LDS-DMA pipeline: MetaT [Mp][Vp] (built when the table is loaded), dFT [D][Vp] (per step);
   // Vp = V + 1 rounded up to 64, the padding stays zero
   void* MetaT = nullptr; void* dFT = nullptr; int64_t Vp = 0;
+  // ---- row-sharded item table (cfg-4, shard.hip): this rank holds table rows [row_lo, row_lo + TR) of E / Meta / F
+  bool sharded = false; int sh_rank = 0, sh_world = 1;
+  int row_lo = 0, TR = 0;                // TR = V + 1 when the table is replicated
+  rsys_comm* shard_comm = nullptr;
+  // exchange plan of the resident batch: distinct ids (sorted) and who owns / asks for them
+  int *u_slot = nullptr, *u_ids = nullptr, *u_tok = nullptr, *u_plan = nullptr /*{U, uV}*/, *u_bound = nullptr, *u_off = nullptr;
+  int U = 0, uV = 0;
+  std::vector<long long> need_off, serve_off, need_offD, serve_offD;   // per-rank element offsets (ids; rows of D floats)
+  int* req_ids = nullptr; long long req_cap = 0, R = 0;                  // ids the peers ask this rank for, by requester
+  float *Frem = nullptr; float* rows_xchg = nullptr; long long xchg_cap = 0;   // [U][D] fetched rows / gradient sums; [R][D] served rows / received gradients
+  // vocabulary-parallel head workspaces: gathered selected rows of all ranks, packed live rows, row statistics
+  void *EwAll = nullptr, *EwC = nullptr; float *metaOwn = nullptr, *metaAll = nullptr, *metaC = nullptr, *vp_max = nullptr, *vp_sums = nullptr;
+  int *vp_nlive = nullptr, *vp_pre = nullptr; float* dEwC = nullptr;
+  int64_t ldl_loc = 0; float* sumsq_E = nullptr;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int rope_npos = 0;
   std::vector<void*> allocs;

@@ -120,48 +120,51 @@ __device__ __forceinline__ void normal4(const Philox& ph, unsigned long long ctr
   out[2] = rb * cosf(6.2831853f * u3); out[3] = rb * sinf(6.2831853f * u3);
 }
 
-__global__ void fill_normal_kernel(float* dst, long long n, float std, unsigned long long seed, unsigned int stream) {
+// dst[0, n) = elements [first, first + n) of the normal stream (seed, stream); first % 4 == 0
+__global__ void fill_normal_kernel(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, long long first4) {
   Philox ph(seed);
   const long long n4 = (n + 3) >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float z[4];
-    normal4(ph, (unsigned long long)i, stream, z);
+    normal4(ph, (unsigned long long)(i + first4), stream, z);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (i * 4 + k < n) dst[i * 4 + k] = z[k] * std;
   }
 }
-int launch_fill_normal(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, hipStream_t s) {
+int launch_fill_normal(float* dst, long long n, float std, unsigned long long seed, unsigned int stream, hipStream_t s, long long first) {
+  ARG_CHECK(first % 4 == 0, "fill_normal: the start offset must be a multiple of 4");
   int grid = (int)std::min<long long>((((n + 3) >> 2) + 255) / 256, 8192);
-  hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(256), 0, s, dst, n, std, seed, stream);
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(grid), dim3(256), 0, s, dst, n, std, seed, stream, first >> 2);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
 template <typename T>
-__global__ void fill_normal_t_kernel(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed) {
+__global__ void fill_normal_t_kernel(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, long long row0) {
   Philox ph(seed);
   const int c4 = (cols + 3) >> 2;
   const long long total = rows * c4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     long long r = i / c4; int c = (int)(i % c4) * 4;
     float z[4];
-    normal4(ph, (unsigned long long)i, 7u, z);
+    normal4(ph, (unsigned long long)(i + row0 * c4), 7u, z);   // (row0: the rows are rows [row0, row0 + rows) of a larger table)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (c + k < cols) dst[r * ld + c + k] = from_f32<T>(z[k] * std);
   }
 }
 template <typename T>
-int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s) {
+int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s, long long row0) {
+  if (rows <= 0) return RSYS_OK;
   long long total = rows * ((cols + 3) >> 2);
   int grid = (int)std::min<long long>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL((fill_normal_t_kernel<T>), dim3(grid), dim3(256), 0, s, dst, rows, cols, ld, std, seed);
+  hipLaunchKernelGGL((fill_normal_t_kernel<T>), dim3(grid), dim3(256), 0, s, dst, rows, cols, ld, std, seed, row0);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_fill_normal_t<bf16>(bf16*, long long, int, long long, float, unsigned long long, hipStream_t);
-template int launch_fill_normal_t<float>(float*, long long, int, long long, float, unsigned long long, hipStream_t);
+template int launch_fill_normal_t<bf16>(bf16*, long long, int, long long, float, unsigned long long, hipStream_t, long long);
+template int launch_fill_normal_t<float>(float*, long long, int, long long, float, unsigned long long, hipStream_t, long long);
 
 
 // dst[c][r] = src[r][c] for a batch of bf16 matrices: 64x64 tiles through LDS, 16-byte global accesses on both sides

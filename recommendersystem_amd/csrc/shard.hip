@@ -1,0 +1,275 @@
+// Row-sharded item table (an extension beyond the reference, which replicates the table and
+// all-reduces its dense gradient, transformer.py:678-682).  Rank r owns the contiguous table rows [lo_r, hi_r) of
+// E / Meta / the fused table F and their Adam moments.  Kernels of the three places where a rank meets rows it
+// does not own:
+//  * token path: the batch's distinct item ids are fetched from their owners once per step (exchange plan built at
+//    batch upload from the sorted token index) and the token gradients go back the same way as one row per distinct
+//    id -- a sparse row exchange instead of the dense table gradient in the all-reduce;
+//  * watch head: vocabulary-parallel cross entropy.  The selected rows of every rank are all-gathered, each rank
+//    forms the logits against its own rows of F, and (max, sum-exp, target logit) are all-reduced: the gradient of
+//    the local rows of F is complete locally (no all-reduce), the gradient of the selected rows is summed over ranks.
+#include "kernels.hpp"
+
+namespace rsys {
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ exchange plan (once per uploaded batch)
+// skey sorted ascending (raw ids, -1 -> V).  slot[p] = rank of skey[p] among the distinct keys; uniq[slot] = key;
+// tok2u[token] = slot.  The mask row V always gets a slot (watch-masked tokens read it): plan = {U, uV}.
+__global__ __launch_bounds__(1024) void plan_unique_kernel(const int* __restrict__ skey, const int* __restrict__ sidx, int N, int V,
+                                                           int* slot, int* uniq, int* tok2u, int* plan) {
+  __shared__ int wave_tot[16];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int per = (N + 1023) / 1024;
+  const int p0 = t * per, p1 = min(N, p0 + per);
+  int cnt = 0;
+  for (int p = p0; p < p1; ++p) cnt += (p == 0 || skey[p] != skey[p - 1]);
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+  if (l == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int k = 0; k < 16; ++k) { int v = wave_tot[k]; if (k < wv) base += v; total += v; }
+  int s = base + inc - cnt - 1;   // slot of the last head before p0
+  for (int p = p0; p < p1; ++p) {
+    if (p == 0 || skey[p] != skey[p - 1]) { ++s; uniq[s] = skey[p]; }
+    slot[p] = s;
+    tok2u[sidx[p]] = s;
+  }
+  if (t == 0) {
+    int U = total, uV = total - 1;
+    if (skey[N - 1] != V) { uniq[total] = V; uV = total; U = total + 1; }
+    plan[0] = U; plan[1] = uV;
+  }
+}
+int launch_plan_unique(const int* skey, const int* sidx, int N, int V, int* slot, int* uniq, int* tok2u, int* plan, hipStream_t s) {
+  ARG_CHECK(N >= 1 && N <= (1 << 20), "exchange plan: token count");
+  hipLaunchKernelGGL(plan_unique_kernel, dim3(1), dim3(1024), 0, s, skey, sidx, N, V, slot, uniq, tok2u, plan);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// off[o] = first unique slot whose id is >= bound[o] (bound[world] = V + 1 -> U): ids owned by rank o are slots [off[o], off[o+1])
+__global__ void plan_offsets_kernel(const int* __restrict__ uniq, const int* __restrict__ plan, const int* __restrict__ bound, int nb, int* off) {
+  const int o = threadIdx.x;
+  if (o >= nb) return;
+  const int U = plan[0], b = bound[o];
+  int lo = 0, hi = U;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (uniq[mid] < b) lo = mid + 1; else hi = mid; }
+  off[o] = lo;
+}
+int launch_plan_offsets(const int* uniq, const int* plan, const int* bound_dev, int nb, int* off, hipStream_t s) {
+  ARG_CHECK(nb >= 2 && nb <= 64, "exchange plan: ranks");
+  hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(64), 0, s, uniq, plan, bound_dev, nb, off);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// ------------------------------------------------------------------ rows by id
+// dst[j] = src[(ids[j] - sub) * ld ..+D)   (owner side: the rows its peers asked for)
+__global__ void gather_rows_by_id_kernel(const float* __restrict__ src, long long ld, const int* __restrict__ ids, int sub, float* dst, int n, int D) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (j >= n) return;
+  const float4* s4 = (const float4*)(src + (long long)(ids[j] - sub) * ld);
+  float4* d4 = (float4*)(dst + (long long)j * D);
+  for (int c = l; c < (D >> 2); c += 64) d4[c] = s4[c];
+}
+int launch_gather_rows_by_id(const float* src, long long ld, const int* ids, int sub, float* dst, int n, int D, hipStream_t s) {
+  if (n == 0) return RSYS_OK;
+  hipLaunchKernelGGL(gather_rows_by_id_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, ld, ids, sub, dst, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+// dst[(ids[j] - sub)] += src[j]; the ids of one call are distinct (one requester's list): plain read-modify-write
+__global__ void add_rows_by_id_kernel(const float* __restrict__ src, const int* __restrict__ ids, int sub, float* dst, long long ld, int n, int D) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (j >= n) return;
+  const float4* s4 = (const float4*)(src + (long long)j * D);
+  float4* d4 = (float4*)(dst + (long long)(ids[j] - sub) * ld);
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 a = d4[c]; const float4 b = s4[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[c] = a;
+  }
+}
+int launch_add_rows_by_id(const float* src, const int* ids, int sub, float* dst, long long ld, int n, int D, hipStream_t s) {
+  if (n == 0) return RSYS_OK;
+  hipLaunchKernelGGL(add_rows_by_id_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, ids, sub, dst, ld, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// token gather from the fetched rows: x0[2n] = Frem[masked ? uV : tok2u[n]] (model.py:23-24,139-145) + per-token uid / tm
+__global__ void gather_items_remote_kernel(BatchDev b, const float* __restrict__ Frem, const int* __restrict__ tok2u,
+                                           const int* __restrict__ plan, int D, float* x0, int* uid_t, int* tm_t) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (wave >= b.N) return;
+  const int u = b.m_matchedid[wave] == -1 ? plan[1] : tok2u[wave];
+  const float4* src = (const float4*)(Frem + (long long)u * D);
+  float4* dst = (float4*)(x0 + (long long)(2 * wave) * D);
+  for (int c = l; c < (D >> 2); c += 64) dst[c] = src[c];
+  if (l == 0) {
+    const int uid = b.userid[wave], tmv = b.m_tmid[wave];
+    uid_t[2 * wave] = uid; uid_t[2 * wave + 1] = uid;
+    tm_t[2 * wave] = tmv; tm_t[2 * wave + 1] = tmv;
+  }
+}
+int launch_gather_items_remote(const BatchDev& b, const float* Frem, const int* tok2u, const int* plan, int D, float* x0,
+                               int* uid_t, int* tm_t, hipStream_t s) {
+  hipLaunchKernelGGL(gather_items_remote_kernel, dim3(div_up(b.N, 4)), dim3(256), 0, s, b, Frem, tok2u, plan, D, x0, uid_t, tm_t);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+__global__ void add_scalar_kernel(float* dst, const float* src) { if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] += src[0]; }
+int launch_add_scalar(float* dst, const float* src, hipStream_t s) {
+  hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, s, dst, src);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// ------------------------------------------------------------------ vocabulary-parallel cross entropy
+// meta of a selected row: {target id inside the medium, label * weight, gradient coefficient tw * label * weight / max(w_sum, 1e-8)}
+// own[KBmax][4] floats (target as int bits; rows >= KB, the batch's selected rows, are zero); own[KBmax * 4] = npos (int bits)
+__global__ void vp_meta_kernel(const int* __restrict__ idx, const float* __restrict__ label, const float* __restrict__ weight,
+                               const int* __restrict__ position, const float* __restrict__ stats, const int* __restrict__ npos,
+                               float task_w, int KB, int KBmax, float* own) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) own[(long long)KBmax * 4] = __int_as_float(*npos);
+  if (j >= KBmax) return;
+  if (j >= KB) { own[4 * j + 0] = 0.f; own[4 * j + 1] = 0.f; own[4 * j + 2] = 0.f; own[4 * j + 3] = 0.f; return; }
+  const int i = idx[j];
+  const float lw = label[i] * weight[i];
+  own[4 * j + 0] = __int_as_float(position[i]);
+  own[4 * j + 1] = lw;
+  own[4 * j + 2] = task_w * lw / fmaxf(stats[0], 1e-8f);
+  own[4 * j + 3] = 0.f;
+}
+int launch_vp_meta(const int* idx, const float* label, const float* weight, const int* position, const float* stats,
+                   const int* npos, float task_w, int KB, int KBmax, float* own, hipStream_t s) {
+  hipLaunchKernelGGL(vp_meta_kernel, dim3(div_up(KBmax, 256)), dim3(256), 0, s, idx, label, weight, position, stats, npos, task_w, KB, KBmax, own);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// live rows of every rank, packed: row (q, i) with i < npos_q goes to pre_q + i.  all[q] = one rank's block
+// ([KB][D] rows, [KB * 4 + 4] meta floats).  Rows [nlive, nlive rounded up to 256) get zero meta (GEMM tile padding).
+template <typename T>
+__global__ void vp_compact_kernel(const T* __restrict__ EwAll, const float* __restrict__ metaAll, int W, int KB, int D,
+                                  T* EwC, float* metaC, int* nlive_out, int* pre_out) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  const long long mstride = (long long)KB * 4 + 4;
+  int pre = 0, q = -1, i = 0, nlive = 0;
+  for (int r = 0; r < W; ++r) {
+    const int np = __float_as_int(metaAll[r * mstride + (long long)KB * 4]);
+    if (q < 0 && row < nlive + np) { q = r; i = row - nlive; pre = nlive; }
+    nlive += np;
+  }
+  if (row == 0 && l == 0) {
+    *nlive_out = nlive;
+    int acc = 0;
+    for (int r = 0; r < W; ++r) { pre_out[r] = acc; acc += __float_as_int(metaAll[r * mstride + (long long)KB * 4]); }
+    pre_out[W] = acc;
+  }
+  const int pad_end = (nlive + 255) & ~255;
+  if (row >= pad_end || row >= W * KB) return;
+  if (row >= nlive) { if (l < 4) metaC[4LL * row + l] = 0.f; return; }
+  constexpr int E = 16 / sizeof(T);
+  const uint4* s4 = (const uint4*)(EwAll + ((long long)q * KB + i) * D);
+  uint4* d4 = (uint4*)(EwC + (long long)row * D);
+  for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+  if (l < 4) metaC[4LL * row + l] = metaAll[q * mstride + 4LL * i + l];
+  (void)pre;
+}
+template <typename T>
+int launch_vp_compact(const T* EwAll, const float* metaAll, int W, int KB, int D, T* EwC, float* metaC, int* nlive, int* pre, hipStream_t s) {
+  hipLaunchKernelGGL((vp_compact_kernel<T>), dim3(div_up((long long)W * KB, 4)), dim3(256), 0, s, EwAll, metaAll, W, KB, D, EwC, metaC, nlive, pre);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_vp_compact<bf16>(const bf16*, const float*, int, int, int, bf16*, float*, int*, int*, hipStream_t);
+template int launch_vp_compact<float>(const float*, const float*, int, int, int, float*, float*, int*, int*, hipStream_t);
+
+// pass 1: local row maximum over the Vloc local columns (rows >= *nlive: -3e38, the neutral element of the max all-reduce)
+template <typename T>
+__global__ __launch_bounds__(256) void vp_rowmax_kernel(const T* __restrict__ logits, long long ldl, int Vloc, const int* __restrict__ nlive, float* rmax) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (row >= *nlive || Vloc <= 0) { if (t == 0) rmax[row] = -3.0e38f; return; }
+  const T* lr = logits + (long long)row * ldl;
+  float m = -3.0e38f;
+  for (int c = t; c < Vloc; c += 256) m = fmaxf(m, to_f32(lr[c]));
+  m = block_max(m, red);
+  if (t == 0) rmax[row] = m;
+}
+// pass 2: sums[row] = sum_c exp(x - gmax), sums[cap + row] = the target's logit if the target column is local, else 0
+template <typename T>
+__global__ __launch_bounds__(256) void vp_sumexp_kernel(const T* __restrict__ logits, long long ldl, int Vloc, int col0,
+                                                        const float* __restrict__ metaC, const float* __restrict__ gmax,
+                                                        const int* __restrict__ nlive, float* sums, int cap) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (row >= *nlive || Vloc <= 0) { if (t == 0) { sums[row] = 0.f; sums[cap + row] = 0.f; } return; }
+  const T* lr = logits + (long long)row * ldl;
+  const float gm = gmax[row];
+  float ssum = 0.f;
+  for (int c = t; c < Vloc; c += 256) ssum += __expf(to_f32(lr[c]) - gm);
+  ssum = block_sum(ssum, red);
+  if (t == 0) {
+    const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+    sums[row] = ssum;
+    sums[cap + row] = (tgt >= 0 && tgt < Vloc) ? to_f32(lr[tgt]) : 0.f;
+  }
+}
+// pass 3: own rows add (lse - target logit) * label * weight to the loss; every live row's logits become
+// dlogits = coef * (softmax - onehot) over the local columns; padding columns up to ldl are zeroed
+template <typename T>
+__global__ __launch_bounds__(256) void vp_finish_kernel(T* logits, long long ldl, int Vloc, int col0, const float* __restrict__ metaC,
+                                                        const float* __restrict__ gmax, const float* __restrict__ sums, int cap,
+                                                        const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
+                                                        float* loss_out) {
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (row >= ((*nlive + 255) & ~255)) return;
+  T* lr = logits + (long long)row * ldl;
+  if (row >= *nlive) { for (int c = t; c < (int)ldl; c += 256) lr[c] = from_f32<T>(0.f); return; }
+  const float lse = gmax[row] + logf(sums[row]);
+  const float lw = metaC[4LL * row + 1], coef = metaC[4LL * row + 2];
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  if (t == 0 && row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) atomicAdd(loss_out, (lse - sums[cap + row]) * lw);
+  for (int c = t; c < (int)ldl; c += 256) {
+    float g = 0.f;
+    if (c < Vloc) g = coef * (__expf(to_f32(lr[c]) - lse) - (c == tgt ? 1.f : 0.f));
+    lr[c] = from_f32<T>(g);
+  }
+}
+template <typename T>
+int launch_vp_rowmax(const T* logits, long long ldl, int Vloc, const int* nlive, float* rmax, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((vp_rowmax_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, nlive, rmax);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_vp_sumexp(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const int* nlive,
+                     float* sums, int cap, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((vp_sumexp_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, gmax, nlive, sums, cap);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const float* sums, int cap,
+                     const int* nlive, const int* pre, int rank, float* loss_out, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((vp_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, gmax, sums, cap, nlive, pre, rank, loss_out);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+#define INST(T)                                                                                                          \
+  template int launch_vp_rowmax<T>(const T*, long long, int, const int*, float*, int, hipStream_t);                       \
+  template int launch_vp_sumexp<T>(const T*, long long, int, int, const float*, const float*, const int*, float*, int, int, hipStream_t); \
+  template int launch_vp_finish<T>(T*, long long, int, int, const float*, const float*, const float*, int, const int*, const int*, int, float*, int, hipStream_t);
+INST(bf16)
+INST(float)
+#undef INST
+
+}  // namespace rsys

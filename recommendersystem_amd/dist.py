@@ -262,6 +262,30 @@ class Comm:
             self._h = C.c_void_p()
 
 
+class LocalGroup:
+    """`world` ranks of THIS process on one GPU, each driven by its own host thread (rsys_local_group_create): the
+    collectives are device copies between the ranks' buffers.  For tests of the multi-rank arithmetic on a one-GPU box
+    (two RCCL ranks cannot share a GPU); `LocalComm(group, rank)` is a rank's communicator, same surface as `Comm`."""
+
+    def __init__(self, world, device=0):
+        self.world = world
+        self._h = C.c_void_p()
+        check(lib().rsys_local_group_create(world, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rsys_local_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class LocalComm(Comm):
+    def __init__(self, group, rank):     # noqa: super().__init__ is RCCL's rendezvous
+        self.hg = None
+        self.rank, self.world = rank, group.world
+        self._h = C.c_void_p()
+        check(lib().rsys_comm_init_local(group._h, rank, C.byref(self._h)))
+
+
 class HostComm:
     """Gradient all-reduce through host memory over the TCP control plane (same surface as Comm): a debugging aid for
     machines whose RCCL cannot initialise.  Never chosen silently: `make_comm` raises unless RSYS_ALLOW_HOST_ALLREDUCE=1

@@ -47,6 +47,8 @@ def _c_config(config, dtype, max_rows):
     c.dtype = DTYPES[dtype]
     c.max_rows = int(max_rows)
     c.lora_dropout = float(config.get("lora_dropout", 0.1 if config.get("finetune") else 0.0))   # nn.Dropout(0.1), model.py:238
+    shard = config.get("table_shard")            # (rank, world): row-sharded item table (cfg-4); None = replicated
+    c.table_shard_rank, c.table_shard_world = (int(shard[0]), int(shard[1])) if shard else (0, 0)
     return c
 
 
@@ -116,6 +118,16 @@ class RecommenderModel:
 
     def random_pretrained_embeddings(self, seed=0x3E7A):
         check(lib().rsys_model_random_metadata(self._h, seed))
+
+    def set_shard_comm(self, comm):
+        """row-sharded table mode: the communicator of the row exchange and the vocabulary-parallel cross entropy"""
+        check(lib().rsys_model_set_shard_comm(self._h, comm._h if comm is not None else None))
+
+    def table_rows(self):
+        """[lo, hi) of the (V + 1)-row item table held by this model"""
+        lo = C.c_int64(); hi = C.c_int64()
+        check(lib().rsys_table_rows(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def named_parameters(self):
         """[(name, shape, trainable)] in state_dict order."""
