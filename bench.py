@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true", help="skip the train_epoch (upload + loss read-back per step) measurement")
     ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the CPU-baseline step (numpy oracle)")
+    ap.add_argument("--table-shard", action="store_true",
+                    help="row-sharded item table + vocabulary-parallel cross entropy (SURVEY 8(e) cfg-4; default for --config cfg4): "
+                         "rank r of N holds rows [r (V+1)/N, (r+1)(V+1)/N) of the item tables and their Adam moments")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
@@ -157,6 +160,9 @@ def main():
         sys.exit(3)
     over = {} if args.layers is None else {"num_layers": args.layers}
     cfg = synth.make_config(args.config, **over)
+    sharded = args.table_shard or args.config == "cfg4"
+    if sharded:
+        cfg["table_shard"] = (rank, world)
     S = cfg["max_sequence_length"]
     rows = args.rows
     model = ra.RecommenderModel(cfg, device=device, dtype=args.dtype, max_rows=rows)
@@ -167,6 +173,8 @@ def main():
     if comm is None and args.rehearse_comm:
         os.environ["RSYS_FORCE_RCCL"] = "1"
         comm = rdist.Comm(hg, device)
+    if sharded and comm is not None:
+        model.set_shard_comm(comm)             # row exchange + vocabulary-parallel head run on this communicator
     sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
     for _ in range(2000):
         sched.step()                           # bench at the stable learning rate
@@ -273,7 +281,7 @@ def main():
             "config": {"workload": f"{args.config}: train step fwd+bwd+allreduce+clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}" + (f" + item table row-sharded x{world} (vocab-parallel CE, sparse row exchange)" if sharded else "")},
             "model_flops_per_interaction": fpi,
             "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline,

@@ -108,10 +108,9 @@ int launch_add_scalar(float* dst, const float* src, hipStream_t s);
 template <typename T>
 int launch_vp_compact(const T* EwAll, const float* metaAll, int W, int KB, int D, T* EwC, float* metaC, int* nlive, int* pre /*[W+1]*/, hipStream_t s);
 template <typename T>
-int launch_vp_rowmax(const T* logits, long long ldl, int Vloc, const int* nlive, float* rmax, int grid_rows, hipStream_t s);
-template <typename T>
-int launch_vp_sumexp(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const int* nlive,
-                     float* sums /*[2*cap]*/, int cap, int grid_rows, hipStream_t s);
+int launch_vp_stats(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const int* nlive, float* lmax,
+                    float* sums /*[2*cap]*/, int cap, int grid_rows, hipStream_t s);
+int launch_vp_rebase(const float* lmax, const float* gmax, float* sums, int n, hipStream_t s);
 template <typename T>
 int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const float* sums, int cap,
                      const int* nlive, const int* pre, int rank, float* loss_out, int grid_rows, hipStream_t s);

@@ -265,7 +265,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     DALLOC(m->logits, cap * m->ldl_loc * e); DALLOC(m->dEwC, cap * D * 4); m->dE = m->dEwC;
     DALLOC(m->EwAll, cap * D * e); DALLOC(m->EwC, cap * D * e);
     DALLOC(m->metaOwn, (KB * 4 + 4) * 4); DALLOC(m->metaAll, (int64_t)W * (KB * 4 + 4) * 4); DALLOC(m->metaC, cap * 4 * 4 + 4096);
-    DALLOC(m->vp_max, cap * 4); DALLOC(m->vp_sums, 2 * cap * 4); DALLOC(m->vp_nlive, 64); DALLOC(m->vp_pre, 64 * 4);
+    DALLOC(m->vp_max, cap * 4); DALLOC(m->vp_lmax, cap * 4); DALLOC(m->vp_sums, 2 * cap * 4); DALLOC(m->vp_nlive, 64); DALLOC(m->vp_pre, 64 * 4);
     // exchange plan of the resident batch
     DALLOC(m->u_slot, N * 4); DALLOC(m->u_ids, (N + 1) * 4); DALLOC(m->u_tok, N * 4); DALLOC(m->u_plan, 64);
     DALLOC(m->u_bound, (W + 1) * 4); DALLOC(m->u_off, ((W + 1) + W + (int64_t)W * W) * 4 + 64);
@@ -821,9 +821,10 @@ static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd
     RC(gemm<T>(m, "gemm_logits", p, false, false, false));
   }
   tic(m, "ce");
-  RC(launch_vp_rowmax<T>(AT<T>(m->logits), m->ldl_loc, len, m->vp_nlive, m->vp_max, nlive, s));
+  RC(launch_vp_stats<T>(AT<T>(m->logits), m->ldl_loc, len, col0, m->metaC, m->vp_nlive, m->vp_lmax, m->vp_sums, cap, nlive, s));
+  HIP_CHECK(hipMemcpyAsync(m->vp_max, m->vp_lmax, (size_t)nlive * 4, hipMemcpyDeviceToDevice, s));
   RC(comm_all_reduce_f32(c, m->vp_max, (size_t)nlive, COMM_MAX, s));
-  RC(launch_vp_sumexp<T>(AT<T>(m->logits), m->ldl_loc, len, col0, m->metaC, m->vp_max, m->vp_nlive, m->vp_sums, cap, nlive, s));
+  RC(launch_vp_rebase(m->vp_lmax, m->vp_max, m->vp_sums, nlive, s));
   RC(comm_all_reduce_f32(c, m->vp_sums, (size_t)nlive, COMM_SUM, s));
   RC(comm_all_reduce_f32(c, m->vp_sums + cap, (size_t)nlive, COMM_SUM, s));
   RC(launch_vp_finish<T>(AT<T>(m->logits), m->ldl_loc, len, col0, m->metaC, m->vp_max, m->vp_sums, cap, m->vp_nlive, m->vp_pre,

@@ -91,7 +91,7 @@ struct Model {
   int* req_ids = nullptr; long long req_cap = 0, R = 0;                  // ids the peers ask this rank for, by requester
   float *Frem = nullptr; float* rows_xchg = nullptr; long long xchg_cap = 0;   // [U][D] fetched rows / gradient sums; [R][D] served rows / received gradients
   // vocabulary-parallel head workspaces: gathered selected rows of all ranks, packed live rows, row statistics
-  void *EwAll = nullptr, *EwC = nullptr; float *metaOwn = nullptr, *metaAll = nullptr, *metaC = nullptr, *vp_max = nullptr, *vp_sums = nullptr;
+  void *EwAll = nullptr, *EwC = nullptr; float *metaOwn = nullptr, *metaAll = nullptr, *metaC = nullptr, *vp_max = nullptr, *vp_lmax = nullptr, *vp_sums = nullptr;
   int *vp_nlive = nullptr, *vp_pre = nullptr; float* dEwC = nullptr;
   int64_t ldl_loc = 0; float* sumsq_E = nullptr;
   float *rope_cos = nullptr, *rope_sin = nullptr;

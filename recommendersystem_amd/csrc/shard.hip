@@ -192,68 +192,84 @@ int launch_vp_compact(const T* EwAll, const float* metaAll, int W, int KB, int D
 template int launch_vp_compact<bf16>(const bf16*, const float*, int, int, int, bf16*, float*, int*, int*, hipStream_t);
 template int launch_vp_compact<float>(const float*, const float*, int, int, int, float*, float*, int*, int*, hipStream_t);
 
-// pass 1: local row maximum over the Vloc local columns (rows >= *nlive: -3e38, the neutral element of the max all-reduce)
+// pass 1 (one read of the local logits, 16-byte loads): online local maximum and sum-exp relative to it, the target's
+// logit if the target column is local.  lmax[row] (rows >= *nlive / no local columns: -3e38, the neutral element of the max
+// all-reduce), sums[row] = local sum-exp, sums[cap + row] = target logit or 0.
 template <typename T>
-__global__ __launch_bounds__(256) void vp_rowmax_kernel(const T* __restrict__ logits, long long ldl, int Vloc, const int* __restrict__ nlive, float* rmax) {
+__global__ __launch_bounds__(256) void vp_stats_kernel(const T* __restrict__ logits, long long ldl, int Vloc, int col0,
+                                                       const float* __restrict__ metaC, const int* __restrict__ nlive,
+                                                       float* lmax, float* sums, int cap) {
   __shared__ float red[16];
+  constexpr int E = 16 / sizeof(T);
   const int row = blockIdx.x, t = threadIdx.x;
-  if (row >= *nlive || Vloc <= 0) { if (t == 0) rmax[row] = -3.0e38f; return; }
+  if (row >= *nlive || Vloc <= 0) { if (t == 0) { lmax[row] = -3.0e38f; sums[row] = 0.f; sums[cap + row] = 0.f; } return; }
   const T* lr = logits + (long long)row * ldl;
-  float m = -3.0e38f;
-  for (int c = t; c < Vloc; c += 256) m = fmaxf(m, to_f32(lr[c]));
-  m = block_max(m, red);
-  if (t == 0) rmax[row] = m;
-}
-// pass 2: sums[row] = sum_c exp(x - gmax), sums[cap + row] = the target's logit if the target column is local, else 0
-template <typename T>
-__global__ __launch_bounds__(256) void vp_sumexp_kernel(const T* __restrict__ logits, long long ldl, int Vloc, int col0,
-                                                        const float* __restrict__ metaC, const float* __restrict__ gmax,
-                                                        const int* __restrict__ nlive, float* sums, int cap) {
-  __shared__ float red[16];
-  const int row = blockIdx.x, t = threadIdx.x;
-  if (row >= *nlive || Vloc <= 0) { if (t == 0) { sums[row] = 0.f; sums[cap + row] = 0.f; } return; }
-  const T* lr = logits + (long long)row * ldl;
-  const float gm = gmax[row];
-  float ssum = 0.f;
-  for (int c = t; c < Vloc; c += 256) ssum += __expf(to_f32(lr[c]) - gm);
-  ssum = block_sum(ssum, red);
+  const int nchunks = (Vloc + E - 1) / E;
+  float m = -3.0e38f, ssum = 0.f;
+  for (int c = t; c < nchunks; c += 256) {
+    const uint4 raw = ((const uint4*)lr)[c];
+    const T* e = (const T*)&raw;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if (c * E + k < Vloc) {
+        const float x = to_f32(e[k]);
+        if (x > m) { ssum = ssum * __expf(m - x) + 1.f; m = x; }
+        else ssum += __expf(x - m);
+      }
+    }
+  }
+  const float gm = block_max(m, red);
+  ssum = block_sum(ssum * __expf(m - gm), red);
   if (t == 0) {
     const int tgt = __float_as_int(metaC[4LL * row]) - col0;
-    sums[row] = ssum;
+    lmax[row] = gm; sums[row] = ssum;
     sums[cap + row] = (tgt >= 0 && tgt < Vloc) ? to_f32(lr[tgt]) : 0.f;
   }
 }
-// pass 3: own rows add (lse - target logit) * label * weight to the loss; every live row's logits become
+// between the two all-reduces: the local sum-exp rebased from the local to the global maximum
+__global__ void vp_rebase_kernel(const float* __restrict__ lmax, const float* __restrict__ gmax, float* sums, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sums[i] *= __expf(lmax[i] - gmax[i]);
+}
+// pass 2: own rows add (lse - target logit) * label * weight to the loss; every live row's logits become
 // dlogits = coef * (softmax - onehot) over the local columns; padding columns up to ldl are zeroed
 template <typename T>
 __global__ __launch_bounds__(256) void vp_finish_kernel(T* logits, long long ldl, int Vloc, int col0, const float* __restrict__ metaC,
                                                         const float* __restrict__ gmax, const float* __restrict__ sums, int cap,
                                                         const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
                                                         float* loss_out) {
+  constexpr int E = 16 / sizeof(T);
   const int row = blockIdx.x, t = threadIdx.x;
   if (row >= ((*nlive + 255) & ~255)) return;
   T* lr = logits + (long long)row * ldl;
-  if (row >= *nlive) { for (int c = t; c < (int)ldl; c += 256) lr[c] = from_f32<T>(0.f); return; }
+  const int nchunks = (int)(ldl / E);
+  if (row >= *nlive) { for (int c = t; c < nchunks; c += 256) ((uint4*)lr)[c] = make_uint4(0, 0, 0, 0); return; }
   const float lse = gmax[row] + logf(sums[row]);
   const float lw = metaC[4LL * row + 1], coef = metaC[4LL * row + 2];
   const int tgt = __float_as_int(metaC[4LL * row]) - col0;
   if (t == 0 && row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) atomicAdd(loss_out, (lse - sums[cap + row]) * lw);
-  for (int c = t; c < (int)ldl; c += 256) {
-    float g = 0.f;
-    if (c < Vloc) g = coef * (__expf(to_f32(lr[c]) - lse) - (c == tgt ? 1.f : 0.f));
-    lr[c] = from_f32<T>(g);
+  for (int c = t; c < nchunks; c += 256) {
+    uint4 raw = ((const uint4*)lr)[c];
+    T* e = (T*)&raw;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int col = c * E + k;
+      const float g = col < Vloc ? coef * (__expf(to_f32(e[k]) - lse) - (col == tgt ? 1.f : 0.f)) : 0.f;
+      e[k] = from_f32<T>(g);
+    }
+    ((uint4*)lr)[c] = raw;
   }
 }
 template <typename T>
-int launch_vp_rowmax(const T* logits, long long ldl, int Vloc, const int* nlive, float* rmax, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((vp_rowmax_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, nlive, rmax);
+int launch_vp_stats(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const int* nlive, float* lmax,
+                    float* sums, int cap, int grid_rows, hipStream_t s) {
+  ARG_CHECK((ldl * sizeof(T)) % 16 == 0, "vocabulary-parallel ce: logits rows must be 16-byte multiples");
+  hipLaunchKernelGGL((vp_stats_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, nlive, lmax, sums, cap);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template <typename T>
-int launch_vp_sumexp(const T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const int* nlive,
-                     float* sums, int cap, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((vp_sumexp_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, gmax, nlive, sums, cap);
+int launch_vp_rebase(const float* lmax, const float* gmax, float* sums, int n, hipStream_t s) {
+  hipLaunchKernelGGL(vp_rebase_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, lmax, gmax, sums, n);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -265,8 +281,7 @@ int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* 
   return RSYS_OK;
 }
 #define INST(T)                                                                                                          \
-  template int launch_vp_rowmax<T>(const T*, long long, int, const int*, float*, int, hipStream_t);                       \
-  template int launch_vp_sumexp<T>(const T*, long long, int, int, const float*, const float*, const int*, float*, int, int, hipStream_t); \
+  template int launch_vp_stats<T>(const T*, long long, int, int, const float*, const int*, float*, float*, int, int, hipStream_t); \
   template int launch_vp_finish<T>(T*, long long, int, int, const float*, const float*, const float*, int, const int*, const int*, int, float*, int, hipStream_t);
 INST(bf16)
 INST(float)
