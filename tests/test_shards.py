@@ -252,3 +252,45 @@ def test_finetune_rows_and_dataset(h5, tmp_path):
     ds = data.FinetuneDataset(f"{datadir}/transformer/training", 0, 1, 2, False, 1)
     rows = sum(len(b["userid"]) for b in ds)
     assert rows == 2            # medium-1 users with a watch or rating target: users 1 and 3
+
+
+def test_event_pipeline_matches_the_reference_on_1200_users():
+    """tests/golden/tokenize_1k.npz (oracle/gen_tokenize_fixture.py): the reference's own tokenize / project
+    (Finetune/embed.py:39-71 = history_tools.jl:37-75) on 1 200 synthetic users with the importer's history annotation
+    (`nothing` on an item's first event).  The shard writer's event pipeline -- shards.tokenize / shards.project and the
+    pass-through columns of shards.get_data (matchedid with the anime offset, time, status, rating, progress, user columns)
+    -- must reproduce every kept token.  (The target rules of get_data, transformer.jl:120-139, exist only in Julia and
+    stay hand-derived: see test_get_data_label_rules.)"""
+    from recommendersystem_amd import shards
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tokenize_1k.npz"))
+    NONE = -99
+    fields = ("medium", "matchedid", "history_max_ts", "status", "rating", "progress", "history_status", "history_rating")
+
+    def users_of(prefix):
+        off = z[prefix + "/offsets"]
+        cols = {k: z[f"{prefix}/{k}"] for k in fields}
+        out = []
+        for a, b in zip(off[:-1], off[1:]):
+            ev = []
+            for i in range(a, b):
+                e = {k: (None if cols[k][i] == NONE else (int(cols[k][i]) if cols[k].dtype == np.int32 else float(cols[k][i]))) for k in fields}
+                ev.append(e)
+            out.append(ev)
+        return out
+
+    raw, want = users_of("in"), users_of("out")
+    assert len(raw) == 1200 and sum(map(len, raw)) > 40000
+    n0 = 300
+    for uid, (events, ref) in enumerate(zip(raw, want)):
+        got = shards.project(shards.tokenize([dict(e) for e in events]))
+        assert got == ref, uid
+        d = shards.get_data({"user": {"gender": None if uid % 3 == 0 else uid % 3 - 1, "source": uid % 4}, "items": [dict(e) for e in events]}, uid + 1, n0)
+        assert len(d["userid"]) == len(ref)
+        if not ref:
+            continue
+        np.testing.assert_array_equal(d["matchedid"], [e["matchedid"] + (n0 if e["medium"] == 1 else 0) for e in ref])
+        np.testing.assert_array_equal(d["status"], [e["status"] for e in ref])
+        np.testing.assert_array_equal(d["rating"], np.array([e["rating"] for e in ref], np.float32))
+        np.testing.assert_array_equal(d["progress"], np.array([e["progress"] for e in ref], np.float32))
+        np.testing.assert_array_equal(d["time"], [e["history_max_ts"] for e in ref])
+        assert (d["userid"] == uid + 1).all() and (d["source"] == uid % 4).all() and (d["gender"] == (0 if uid % 3 == 0 else uid % 3)).all()
