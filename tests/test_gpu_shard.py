@@ -183,3 +183,56 @@ def test_sharded_table_collectives_through_rccl_world1(monkeypatch, dtype, tol):
         assert np.abs(model.grad(n) - G_ref[n]).max() <= tol * max(np.abs(G_ref[n]).max(), 1e-12), n
     assert abs(clip_grad_norm_(model, 1e9) - n_ref) <= tol * n_ref
     model.close(); comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_data_parallel_step_with_early_buckets_on_concurrent_ranks(world):
+    """The reference-parity data-parallel scheme (replicated table, DDP bucketed all-reduce, train.py:678-682) on `world`
+    CONCURRENT ranks of one GPU (in-process rank group): armed with begin_grad_sync every rank's trunk backward hands its
+    finished per-layer gradient buckets to the communicator while it is still running, all_reduce_grads covers the rest
+    exactly once, and every rank ends with the SUM of the ranks' gradients and -- after the fused clip + mean + AdamW --
+    the parameters of the accumulated single-model step."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.optim import AdamW
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+    rows, seed = 2, 23
+    P = synth.make_params(cfg, seed, "test")
+    batches = [synth.make_batch(cfg, rows, seed + 1 + 10 * r) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, seed + 2 + 10 * r) for r in range(world)]
+    l_ref, G_ref, P_ref = _reference(cfg, P, batches, masks, "bf16", 1e-2)
+    names = synth.trainable_names(cfg)
+    group = rdist.LocalGroup(world)
+
+    def rank_fn(r):
+        comm = rdist.LocalComm(group, r)
+        comm.self_test()
+        assert comm.all_reduce_sum([r + 1.0, 2.0]) == [world * (world + 1) / 2, 2.0 * world]
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        comm.begin_grad_sync(model)
+        losses = model(batches[r], False, masks=masks[r])
+        comm.all_reduce_grads(model)
+        early = comm.early_reduced(model)
+        G = {n: model.grad(n) for n in names}
+        opt = AdamW(model, lr=1e-2)
+        opt.step(clip_max_norm=1.0, grad_div=float(world))
+        Pn = {n: model.get_parameter(n) for n in names}
+        model.close(); comm.close()
+        return losses, G, Pn, early
+
+    res = _run_ranks(world, rank_fn)
+    group.close()
+    D, I, L = cfg["embed_dim"], cfg["intermediate_dim"], cfg["num_layers"]
+    nqkv = (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * (D // cfg["num_heads"])
+    for r, (losses, G, Pn, early) in enumerate(res):
+        assert early >= L * (nqkv * D + D * D + 2 * I * D + D * I), early       # the trunk's weight matrices went early
+        for a, b in zip(losses, l_ref[r]):
+            assert abs(a - b) <= 2e-2 * max(abs(b), 1.0)
+        for n in names:
+            scale = max(np.abs(G_ref[n]).max(), 1e-12)
+            assert np.abs(G[n] - G_ref[n]).max() <= 5e-2 * scale, (r, n)
+            assert np.array_equal(G[n], res[0][1][n]), (r, n)                     # every rank holds the same reduced bits
+            assert np.abs(Pn[n] - P_ref[n]).mean() <= 2e-3, (r, n)
