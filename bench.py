@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--table-shard", action="store_true",
                     help="row-sharded item table + vocabulary-parallel cross entropy (SURVEY 8(e) cfg-4; default for --config cfg4): "
                          "rank r of N holds rows [r (V+1)/N, (r+1)(V+1)/N) of the item tables and their Adam moments")
+    ap.add_argument("--sampled-softmax", type=int, default=0,
+                    help="row-sharded table only: classes sampled per rank and medium for the watch heads (0 = full soft-max)")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
@@ -163,6 +165,8 @@ def main():
     sharded = args.table_shard or args.config == "cfg4"
     if sharded:
         cfg["table_shard"] = (rank, world)
+        if args.sampled_softmax:
+            cfg["sampled_softmax"] = args.sampled_softmax
     S = cfg["max_sequence_length"]
     rows = args.rows
     model = ra.RecommenderModel(cfg, device=device, dtype=args.dtype, max_rows=rows)
@@ -281,7 +285,8 @@ def main():
             "config": {"workload": f"{args.config}: train step fwd+bwd+allreduce+clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
-                       "parallelism": f"dp{world}" + (f" + item table row-sharded x{world} (vocab-parallel CE, sparse row exchange)" if sharded else "")},
+                       "parallelism": f"dp{world}" + (f" + item table row-sharded x{world} (vocab-parallel CE, sparse row exchange" +
+                                                                  (f", sampled soft-max {args.sampled_softmax}/rank/medium" if args.sampled_softmax else "") + ")" if sharded else "")},
             "model_flops_per_interaction": fpi,
             "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline,

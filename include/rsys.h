@@ -48,6 +48,10 @@ typedef struct rsys_config {
    * transformer.py:678-682); world >= 1: this rank owns table rows [rank*(V+1)/world, (rank+1)*(V+1)/world) of the item
    * embedding, the metadata table, the fused table and their Adam moments; rsys_model_set_shard_comm gives the communicator */
   int32_t table_shard_rank, table_shard_world;
+  /* row-sharded table only: > 0 replaces the full soft-max of the watch heads by a sampled one -- per step and medium every
+   * rank draws this many of its local classes (stratified uniform) and the partition function is estimated by importance
+   * weighting (log-Q correction), the target class always included.  0 = full soft-max (the reference, model.py:514-519). */
+  int32_t sampled_negatives;
 } rsys_config;
 
 /* the batch record of train.py:75-98 / transformer.jl:79-142: 27 parallel arrays of

@@ -20,6 +20,7 @@ struct RsysConfig              # mirrors rsys_config (field order and types as i
     dtype::Int32; max_rows::Int32
     lora_dropout::Float32
     table_shard_rank::Int32; table_shard_world::Int32     # row-sharded item table (world 0 = replicated)
+    sampled_negatives::Int32                               # sampled soft-max over the local classes (0 = full)
 end
 
 struct RsysBatch               # mirrors rsys_batch

@@ -30,7 +30,7 @@ class rsys_config(C.Structure):
         ("rating_mean", C.c_float), ("rating_std", C.c_float), ("mask_rate", C.c_float),
         ("mask_topk", C.c_int32), ("finetune", C.c_int32), ("finetune_metric", C.c_int32),
         ("dtype", C.c_int32), ("max_rows", C.c_int32), ("lora_dropout", C.c_float),
-        ("table_shard_rank", C.c_int32), ("table_shard_world", C.c_int32),
+        ("table_shard_rank", C.c_int32), ("table_shard_world", C.c_int32), ("sampled_negatives", C.c_int32),
     ]
 
 

@@ -115,6 +115,25 @@ template <typename T>
 int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const float* sums, int cap,
                      const int* nlive, const int* pre, int rank, float* loss_out, int grid_rows, hipStream_t s);
 
+// sampled softmax over the local classes (shard.hip)
+int launch_ss_sample(int len, int n_s, unsigned long long seed, unsigned int stream, int* cols, hipStream_t s);
+template <typename T> int launch_gather_rows_plain(const T* src, long long ld, const int* idx, int base, T* dst, int n, int D, hipStream_t s);
+int launch_add_rows_plain(const float* src, const int* idx, int base, float* dst, long long ld, int n, int D, hipStream_t s);
+template <typename T>
+int launch_ss_target_logit(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const int* nlive, float* tl, int grid_rows, hipStream_t s);
+template <typename T>
+int launch_ss_stats(const T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const int* nlive,
+                    float* lmax, float* lsum, int grid_rows, hipStream_t s);
+int launch_ss_max_with_target(const float* lmax, const float* tl, float* out, int n, hipStream_t s);
+int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, float inv_q, int n, hipStream_t s);
+template <typename T>
+int launch_ss_finish(T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const float* gmax,
+                     const float* sneg, const float* tl, float inv_q, const int* nlive, const int* pre, int rank, float* loss_out,
+                     float* dt, int grid_rows, hipStream_t s);
+template <typename T>
+int launch_ss_target_grad(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const float* dt, const int* nlive,
+                          float* gE_loc, float* dEwC, int grid_rows, hipStream_t s);
+
 int launch_action_small_bwd(const float* gf /*[N][32]*/, const BatchDev& b, const SmallParams& sp,
                             float* g_per_cos, float* g_per_sin, float* g_status, float* g_gender, float* g_source,
                             hipStream_t s);

@@ -163,6 +163,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   ARG_CHECK(cfg->mask_topk >= 1 && cfg->mask_topk <= cfg->max_sequence_length, "mask_topk");
   ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16, "dtype");
   ARG_CHECK(cfg->lora_dropout >= 0.f && cfg->lora_dropout < 1.f, "lora_dropout must be in [0,1)");
+  ARG_CHECK(cfg->sampled_negatives == 0 || (cfg->sampled_negatives > 0 && cfg->table_shard_world >= 1),
+            "sampled_negatives needs the row-sharded table (table_shard_world >= 1)");
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { set_error("no HIP device visible: the HIP path has no CPU fallback"); return RSYS_ERR_HIP; }
@@ -270,6 +272,11 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     DALLOC(m->u_slot, N * 4); DALLOC(m->u_ids, (N + 1) * 4); DALLOC(m->u_tok, N * 4); DALLOC(m->u_plan, 64);
     DALLOC(m->u_bound, (W + 1) * 4); DALLOC(m->u_off, ((W + 1) + W + (int64_t)W * W) * 4 + 64);
     DALLOC(m->Frem, (N + 1) * D * 4); DALLOC(m->sumsq_E, 64);
+    if (cfg->sampled_negatives > 0) {
+      const int64_t ns = std::min<int64_t>(cfg->sampled_negatives, std::max(len_max, 1));
+      DALLOC(m->ss_cols, ns * 4 + 64); DALLOC(m->ss_F, ns * D * e); DALLOC(m->ss_dF, ns * D * 4);
+      DALLOC(m->ss_tl, cap * 4); DALLOC(m->ss_dt, cap * 4);
+    }
     std::vector<int> bound(W + 1);
     for (int r = 0; r <= W; ++r) bound[r] = (int)((int64_t)r * (m->V + 1) / W);
     HIP_CHECK(hipMemcpy(m->u_bound, bound.data(), (W + 1) * 4, hipMemcpyHostToDevice));
@@ -788,6 +795,67 @@ static int forward_trunk(Model* m) {
   return RSYS_OK;
 }
 
+// ------------------------------------------------------------------ sampled soft-max watch head (cfg-4 option)
+// Called by watch_head_sharded after the selected rows of all ranks have been gathered and packed.  Per rank: n_s sampled
+// local classes (stratified uniform, fresh per step and medium) instead of all `len`; see shard.hip for the estimator.
+template <typename T>
+static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive, int npad, int own0, int nown, int len, int col0, int lrow) {
+  const int D = m->D, W = m->sh_world, cap = W * m->K * m->rows_max;
+  hipStream_t s = m->stream;
+  rsys_comm* c = m->shard_comm;
+  const int n_s = std::min(len, m->cfg.sampled_negatives);
+  const float inv_q = n_s > 0 ? (float)len / (float)n_s : 1.f;
+  const int64_t lds = pad8(std::max(n_s, 8));
+  T* Floc = AT<T>(m->FT) + (int64_t)lrow * D;
+  HIP_CHECK(hipMemsetAsync(m->ss_tl, 0, (size_t)nlive * 4, s));
+  if (n_s > 0) {
+    RC(launch_ss_sample(len, n_s, m->cur_seed ^ (0x5A3Dull + 977ull * (unsigned long long)m->sh_rank), (unsigned int)(m->cur_step * 2 + medium), m->ss_cols, s));
+    RC(launch_gather_rows_plain<T>(Floc, D, m->ss_cols, 0, AT<T>(m->ss_F), n_s, D, s));
+    GemmParams p{};
+    p.A = m->EwC; p.lda = D; p.B = m->ss_F; p.ldb = D; p.C = m->logits; p.ldc = lds;
+    p.M = cap; p.N = n_s; p.K = D; p.epi = EPI_STORE; p.m_dev = m->vp_nlive;
+    RC(gemm<T>(m, "gemm_logits", p, false, false, false));
+    RC(launch_ss_target_logit<T>(AT<T>(m->EwC), Floc, D, len, col0, m->metaC, m->vp_nlive, m->ss_tl, nlive, s));
+  }
+  tic(m, "ce");
+  RC(launch_ss_stats<T>(AT<T>(m->logits), lds, n_s, col0, m->ss_cols, m->metaC, m->vp_nlive, m->vp_lmax, m->vp_sums, nlive, s));
+  RC(comm_all_reduce_f32(c, m->ss_tl, (size_t)nlive, COMM_SUM, s));            // the target's owner has the only non-zero term
+  RC(launch_ss_max_with_target(m->vp_lmax, m->ss_tl, m->vp_max, nlive, s));
+  RC(comm_all_reduce_f32(c, m->vp_max, (size_t)nlive, COMM_MAX, s));
+  RC(launch_ss_rebase(m->vp_lmax, m->vp_max, m->vp_sums, inv_q, nlive, s));
+  RC(comm_all_reduce_f32(c, m->vp_sums, (size_t)nlive, COMM_SUM, s));
+  if (n_s > 0)
+    RC(launch_ss_finish<T>(AT<T>(m->logits), lds, n_s, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, inv_q, m->vp_nlive,
+                           m->vp_pre, m->sh_rank, m->loss_acc + 3 * ti, m->ss_dt, npad, s));
+  else
+    RC(launch_ss_finish<T>(AT<T>(m->logits), 8, 0, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, inv_q, m->vp_nlive,
+                           m->vp_pre, m->sh_rank, m->loss_acc + 3 * ti, m->ss_dt, npad, s));   // a rank without classes of this medium still owns loss rows
+  toc(m);
+  if (!bwd) return RSYS_OK;
+  HIP_CHECK(hipMemsetAsync(m->dEwC, 0, (size_t)nlive * D * 4, s));
+  if (n_s > 0) {
+    {
+      GemmParams p{};  // d(selected rows) = dlogits . F[sampled rows]
+      p.A = m->logits; p.lda = lds; p.B = m->ss_F; p.ldb = D; p.C = m->dEwC; p.ldc = D; p.c_f32 = 1;
+      p.M = cap; p.N = D; p.K = n_s; p.epi = EPI_ATOMIC; p.m_dev = m->vp_nlive;
+      RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
+    }
+    {
+      GemmParams p{};  // dF[sampled rows] = dlogits^T . (selected rows of all ranks), then added to the table gradient rows
+      p.A = m->logits; p.lda = lds; p.B = m->EwC; p.ldb = D; p.C = m->ss_dF; p.ldc = D; p.c_f32 = 1;
+      p.M = n_s; p.N = D; p.K = cap; p.epi = EPI_STORE; p.k_dev = m->vp_nlive;
+      RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
+      RC(launch_add_rows_plain(m->ss_dF, m->ss_cols, lrow, m->G + m->o_E, D, n_s, D, s));
+    }
+    RC(launch_ss_target_grad<T>(AT<T>(m->EwC), Floc, D, len, col0, m->metaC, m->ss_dt, m->vp_nlive, m->G + m->o_E + (int64_t)lrow * D, m->dEwC, nlive, s));
+  }
+  m->gE_clean[medium] = false;
+  RC(comm_all_reduce_f32(c, m->dEwC, (size_t)nlive * D, COMM_SUM, s));
+  if (nown > 0) RC(launch_scatter_rows_add(m->dEwC + (size_t)own0 * D, m->idx[ti], 0, m->gy, D, nown, D, s));
+  m->table_grads_pending = true;
+  return RSYS_OK;
+}
+
 // ------------------------------------------------------------------ watch head over a row-sharded table (cfg-4)
 // Vocabulary-parallel form of model.py:153-170 + 514-519: the selected rows of ALL ranks against this rank's rows of the
 // medium.  all-gather (rows, row meta) -> pack the live rows -> local logits -> all-reduce(max) -> all-reduce(sum-exp,
@@ -814,6 +882,8 @@ static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd
   const int nlive = pre[W], cap = W * KBmax, own0 = pre[m->sh_rank], nown = pre[m->sh_rank + 1] - own0;
   if (nlive == 0) return RSYS_OK;
   const int npad = std::min(cap, (nlive + 255) & ~255);
+  if (m->cfg.sampled_negatives > 0)
+    return watch_head_sampled<T>(m, ti, medium, bwd, nlive, npad, own0, nown, len, col0, lrow);
   if (len > 0) {
     GemmParams p{};
     p.A = m->EwC; p.lda = D; p.B = Fm; p.ldb = D; p.C = m->logits; p.ldc = m->ldl_loc;
@@ -1191,6 +1261,7 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   const int rows = m->cur_rows, N = rows * m->S;
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
   if (m->has_masks) { b.watch_mask = m->d_wm; b.rating_mask = m->d_rm; }
+  m->cur_seed = seed; m->cur_step = step;
   RC(launch_mask_tokens(b, m->cfg.finetune, m->cfg.finetune_metric, m->cfg.mask_rate, seed, step, m->stream));
   m->drop_active = m->cfg.finetune && !evaluate && m->cfg.lora_dropout > 0.f;   // nn.Dropout is active in train() mode only
   m->drop_seed = seed ^ 0xD409ull; m->drop_step = step;

@@ -94,6 +94,9 @@ struct Model {
   void *EwAll = nullptr, *EwC = nullptr; float *metaOwn = nullptr, *metaAll = nullptr, *metaC = nullptr, *vp_max = nullptr, *vp_lmax = nullptr, *vp_sums = nullptr;
   int *vp_nlive = nullptr, *vp_pre = nullptr; float* dEwC = nullptr;
   int64_t ldl_loc = 0; float* sumsq_E = nullptr;
+  // sampled softmax: sampled local classes, their rows of F, the rows' gradients, target logits and their gradients
+  int* ss_cols = nullptr; void* ss_F = nullptr; float *ss_dF = nullptr, *ss_tl = nullptr, *ss_dt = nullptr;
+  unsigned long long cur_seed = 0, cur_step = 0;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int rope_npos = 0;
   std::vector<void*> allocs;

@@ -280,9 +280,204 @@ int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* 
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
+// ------------------------------------------------------------------ sampled softmax (cfg-4 option; no reference counterpart)
+// Per (step, medium) a rank draws n_s of its `len` local classes by stratified uniform sampling (one per stratum of
+// len / n_s classes: distinct, sorted, inclusion probability q = n_s / len each).  The loss of a row with target t is the
+// full soft-max loss with the partition function estimated by importance weighting (the log-Q correction):
+//     Z ~= exp(l_t) + sum over ranks (1 / q_r) sum_{j in S_r, j != t} exp(l_j),     loss = log Z - l_t
+// so it stays on the scale of the full soft-max loss; a sampled class that IS the row's target is skipped (accidental hit).
+__global__ void ss_sample_kernel(int len, int n_s, unsigned long long seed, unsigned int stream, int* cols) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_s) return;
+  Philox ph(seed);
+  uint32_t r[4];
+  ph.gen((unsigned long long)j, stream, r);
+  const double w = (double)len / (double)n_s;
+  int c = (int)(((double)j + (double)u01(r[0])) * w);
+  const int lo = (int)((double)j * w), hi = max(lo, (int)((double)(j + 1) * w) - 1);   // keep the draw inside its own stratum
+  cols[j] = min(max(c, lo), min(hi, len - 1));
+}
+int launch_ss_sample(int len, int n_s, unsigned long long seed, unsigned int stream, int* cols, hipStream_t s) {
+  ARG_CHECK(n_s >= 1 && n_s <= len, "sampled softmax: 1 <= samples <= local classes");
+  hipLaunchKernelGGL(ss_sample_kernel, dim3(div_up(n_s, 256)), dim3(256), 0, s, len, n_s, seed, stream, cols);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// dst[j] = src[(base + idx[j]) * ld ..+D)  (T rows, 16-byte copies)
+template <typename T>
+__global__ void gather_rows_plain_kernel(const T* __restrict__ src, long long ld, const int* __restrict__ idx, int base, T* dst, int n, int D) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (j >= n) return;
+  constexpr int E = 16 / sizeof(T);
+  const uint4* s4 = (const uint4*)(src + (long long)(base + idx[j]) * ld);
+  uint4* d4 = (uint4*)(dst + (long long)j * D);
+  for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+}
+template <typename T>
+int launch_gather_rows_plain(const T* src, long long ld, const int* idx, int base, T* dst, int n, int D, hipStream_t s) {
+  hipLaunchKernelGGL((gather_rows_plain_kernel<T>), dim3(div_up(n, 4)), dim3(256), 0, s, src, ld, idx, base, dst, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+// dst[(base + idx[j])] += src[j]  (f32 rows; idx distinct)
+__global__ void add_rows_plain_kernel(const float* __restrict__ src, const int* __restrict__ idx, int base, float* dst, long long ld, int n, int D) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (j >= n) return;
+  const float4* s4 = (const float4*)(src + (long long)j * D);
+  float4* d4 = (float4*)(dst + (long long)(base + idx[j]) * ld);
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 a = d4[c]; const float4 b = s4[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[c] = a;
+  }
+}
+int launch_add_rows_plain(const float* src, const int* idx, int base, float* dst, long long ld, int n, int D, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_plain_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, idx, base, dst, ld, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// tl[row] = <selected row, F[target]> where the target class is local (one owner per row), else 0; one wave per row
+template <typename T>
+__global__ void ss_target_logit_kernel(const T* __restrict__ EwC, const T* __restrict__ Floc, int D, int len, int col0,
+                                       const float* __restrict__ metaC, const int* __restrict__ nlive, float* tl) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= *nlive) return;
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  float acc = 0.f;
+  if (tgt >= 0 && tgt < len) {
+    const T* a = EwC + (long long)row * D; const T* b = Floc + (long long)tgt * D;
+    for (int c = l; c < D; c += 64) acc += to_f32(a[c]) * to_f32(b[c]);
+    acc = wave_sum(acc);
+  }
+  if (l == 0) tl[row] = acc;
+}
+// local maximum / sum-exp over the sampled classes, the accidental hit (sampled class == the row's target) left out
+template <typename T>
+__global__ __launch_bounds__(256) void ss_stats_kernel(const T* __restrict__ logits, long long ldl, int n_s, int col0,
+                                                       const int* __restrict__ cols, const float* __restrict__ metaC,
+                                                       const int* __restrict__ nlive, float* lmax, float* lsum) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (row >= *nlive || n_s <= 0) { if (t == 0) { lmax[row] = -3.0e38f; lsum[row] = 0.f; } return; }
+  const T* lr = logits + (long long)row * ldl;
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  float m = -3.0e38f, ssum = 0.f;
+  for (int c = t; c < n_s; c += 256) {
+    if (cols[c] == tgt) continue;
+    const float x = to_f32(lr[c]);
+    if (x > m) { ssum = ssum * __expf(m - x) + 1.f; m = x; }
+    else ssum += __expf(x - m);
+  }
+  const float gm = block_max(m, red);
+  ssum = block_sum(ssum * __expf(m - gm), red);
+  if (t == 0) { lmax[row] = gm; lsum[row] = ssum; }
+}
+// lmax2 = max(lmax, tl): what the max all-reduce starts from (tl has been all-reduced: every rank knows the target logit)
+__global__ void ss_max_with_target_kernel(const float* __restrict__ lmax, const float* __restrict__ tl, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fmaxf(lmax[i], tl[i]);
+}
+// sneg = lsum * exp(lmax - gmax) / q: this rank's share of the negatives' partition sum (before the sum all-reduce)
+__global__ void ss_rebase_kernel(const float* __restrict__ lmax, const float* __restrict__ gmax, float* lsum, float inv_q, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lsum[i] = lsum[i] > 0.f ? lsum[i] * __expf(lmax[i] - gmax[i]) * inv_q : 0.f;
+}
+// lse = gmax + log(exp(tl - gmax) + sneg); own rows add (lse - tl) lw to the loss; dlogits over the sampled classes
+// (coef exp(l - lse) / q, 0 at an accidental hit); dt[row] = coef (exp(tl - lse) - 1) for the target's owner
+template <typename T>
+__global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl, int n_s, int col0, const int* __restrict__ cols,
+                                                        const float* __restrict__ metaC, const float* __restrict__ gmax,
+                                                        const float* __restrict__ sneg, const float* __restrict__ tl, float inv_q,
+                                                        const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
+                                                        float* loss_out, float* dt) {
+  const int row = blockIdx.x, t = threadIdx.x;
+  if (row >= ((*nlive + 255) & ~255)) return;
+  T* lr = logits + (long long)row * ldl;
+  if (row >= *nlive) { for (int c = t; c < (int)ldl; c += 256) lr[c] = from_f32<T>(0.f); if (t == 0) dt[row] = 0.f; return; }
+  const float gm = gmax[row];
+  const float lse = gm + logf(__expf(tl[row] - gm) + sneg[row]);
+  const float lw = metaC[4LL * row + 1], coef = metaC[4LL * row + 2];
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  if (t == 0) {
+    dt[row] = coef * (__expf(tl[row] - lse) - 1.f);
+    if (row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) atomicAdd(loss_out, (lse - tl[row]) * lw);
+  }
+  for (int c = t; c < (int)ldl; c += 256) {
+    float g = 0.f;
+    if (c < n_s && cols[c] != tgt) g = coef * __expf(to_f32(lr[c]) - lse) * inv_q;
+    lr[c] = from_f32<T>(g);
+  }
+}
+// target class gradients by the target's owner: dF[target] += dt * (selected row)  (rows may share a target: float atomics),
+// d(selected row) += dt * F[target]  (one owner per row: plain).  One wave per live row.
+template <typename T>
+__global__ void ss_target_grad_kernel(const T* __restrict__ EwC, const T* __restrict__ Floc, int D, int len, int col0,
+                                      const float* __restrict__ metaC, const float* __restrict__ dt, const int* __restrict__ nlive,
+                                      float* gE_loc, float* dEwC) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= *nlive) return;
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  const float g = dt[row];
+  if (tgt < 0 || tgt >= len || g == 0.f) return;
+  const T* a = EwC + (long long)row * D; const T* b = Floc + (long long)tgt * D;
+  float* gf = gE_loc + (long long)tgt * D; float* ge = dEwC + (long long)row * D;
+  for (int c = l; c < D; c += 64) { atomicAdd(&gf[c], g * to_f32(a[c])); ge[c] += g * to_f32(b[c]); }
+}
+
+template <typename T>
+int launch_ss_target_logit(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const int* nlive, float* tl, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((ss_target_logit_kernel<T>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, nlive, tl);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_ss_stats(const T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const int* nlive,
+                    float* lmax, float* lsum, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((ss_stats_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, col0, cols, metaC, nlive, lmax, lsum);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+int launch_ss_max_with_target(const float* lmax, const float* tl, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(ss_max_with_target_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, lmax, tl, out, n);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, float inv_q, int n, hipStream_t s) {
+  hipLaunchKernelGGL(ss_rebase_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, lmax, gmax, lsum, inv_q, n);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_ss_finish(T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const float* gmax,
+                     const float* sneg, const float* tl, float inv_q, const int* nlive, const int* pre, int rank, float* loss_out,
+                     float* dt, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((ss_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, col0, cols, metaC, gmax, sneg, tl, inv_q,
+                     nlive, pre, rank, loss_out, dt);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template <typename T>
+int launch_ss_target_grad(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const float* dt, const int* nlive,
+                          float* gE_loc, float* dEwC, int grid_rows, hipStream_t s) {
+  hipLaunchKernelGGL((ss_target_grad_kernel<T>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, dt, nlive, gE_loc, dEwC);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 #define INST(T)                                                                                                          \
   template int launch_vp_stats<T>(const T*, long long, int, int, const float*, const int*, float*, float*, int, int, hipStream_t); \
   template int launch_vp_finish<T>(T*, long long, int, int, const float*, const float*, const float*, int, const int*, const int*, int, float*, int, hipStream_t);
+INST(bf16)
+INST(float)
+#undef INST
+#define INST(T)                                                                                                          \
+  template int launch_gather_rows_plain<T>(const T*, long long, const int*, int, T*, int, int, hipStream_t);               \
+  template int launch_ss_target_logit<T>(const T*, const T*, int, int, int, const float*, const int*, float*, int, hipStream_t); \
+  template int launch_ss_stats<T>(const T*, long long, int, int, const int*, const float*, const int*, float*, float*, int, hipStream_t); \
+  template int launch_ss_finish<T>(T*, long long, int, int, const int*, const float*, const float*, const float*, const float*, float, const int*, const int*, int, float*, float*, int, hipStream_t); \
+  template int launch_ss_target_grad<T>(const T*, const T*, int, int, int, const float*, const float*, const int*, float*, float*, int, hipStream_t);
 INST(bf16)
 INST(float)
 #undef INST

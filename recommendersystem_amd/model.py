@@ -49,6 +49,7 @@ def _c_config(config, dtype, max_rows):
     c.lora_dropout = float(config.get("lora_dropout", 0.1 if config.get("finetune") else 0.0))   # nn.Dropout(0.1), model.py:238
     shard = config.get("table_shard")            # (rank, world): row-sharded item table (cfg-4); None = replicated
     c.table_shard_rank, c.table_shard_world = (int(shard[0]), int(shard[1])) if shard else (0, 0)
+    c.sampled_negatives = int(config.get("sampled_softmax", 0))   # classes sampled per rank and medium (0: full soft-max)
     return c
 
 
