@@ -35,7 +35,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r1k_pmc_traffic.json"
+TRAFFIC_FILE = "r2a_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
@@ -47,16 +47,20 @@ def traffic_of(db, variant):
     return None
 
 
-HBM_KERNEL_SYMBOL = {"hbm_gather": "gather_items_kernel", "hbm_scatter": "embedding_scatter", "hbm_rmsnorm_fwd": "rmsnorm_fwd_kernel",
-                     "hbm_rmsnorm_bwd": "rmsnorm_bwd_kernel", "adamw": "adamw_kernel", "sumsq": "sumsq_kernel"}
+HBM_KERNEL_SYMBOL = {"hbm_gather": ["gather_items_kernel"], "hbm_scatter": ["seg_scatter_kernel", "seg_fixup_kernel"],   # (one call site, two launches)
+                     "hbm_rmsnorm_fwd": ["rmsnorm_fwd_kernel"], "hbm_rmsnorm_bwd": ["rmsnorm_bwd_kernelIDF16b"], "adamw": ["adamw_kernel"],
+                     "sumsq": ["sumsq_kernel"]}
 
 
-def traffic_of_name(db, sym):
-    """PMC HBM bytes per launch of the first kernel of the committed summary whose name contains `sym`"""
-    for name, k in (db or {}).items():
-        if sym and sym in name:
-            return k["hbm_bytes_per_launch"]
-    return None
+def traffic_of_name(db, syms):
+    """PMC HBM bytes per call site from the committed summary: for every symbol, the first kernel whose name contains it"""
+    total = 0.0
+    for sym in syms or []:
+        hit = [k["hbm_bytes_per_launch"] for name, k in (db or {}).items() if sym in name]
+        if not hit:
+            return None
+        total += hit[0]
+    return total or None
 
 
 def flops_per_interaction(cfg, B):

@@ -8,10 +8,11 @@
 //  * per step, one wave per tile of SEG_TILE consecutive sorted positions adds its tokens' gradient rows in order and
 //    writes each finished table row ONCE with a plain read-modify-write (one writer per row: no atomics, the sum is
 //    bitwise reproducible).  A row whose tokens straddle tiles leaves per-tile partial sums in a slab; a second
-//    launch adds the partials of each such row in tile order.
+//    launch adds the partials of each such row in a fixed tree (four contiguous quarters of the tile list, one wave
+//    each, then the four sums in order).
 //  * the mask row V is the one row whose member set changes every step (mask_tokens redirects ~mask_rate of the
 //    tokens to it, transformer.model.py:437-462): its tokens are summed by position -- one partial per 256 tokens,
-//    then the partials in order.  Watch-masked tokens are skipped in their own item's segment.
+//    then the partials in the same tree.  Watch-masked tokens are skipped in their own item's segment.
 // HBM-bound: algorithmic bytes = one gradient row read per token + one table row read and written per distinct id.
 #include "kernels.hpp"
 
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const float* __restric
   store_row<NJ>(mslab + (long long)c * D, D4, l, acc);
 }
 
-// waves [0, NT): the wave of the tile in which a straddling row's tokens BEGIN adds that row's partial sums in tile
-// order and writes the row; the last block adds the mask-row partials (4 waves, a contiguous quarter each, then the
-// four sums in order) into row V
+// block t < NT: if a straddling row's tokens BEGIN in tile t, the block adds that row's per-tile partial sums -- its four
+// waves a contiguous quarter of the list each, in tile order, then the four quarter sums in order -- and writes the row;
+// the last block does the same with the mask-row partials into row V
 template <int NJ>
 __global__ __launch_bounds__(256) void seg_fixup_kernel(const int* __restrict__ skey, int N, int V, int D, float* gE,
                                                         const float* __restrict__ slab, const float* __restrict__ mslab,
@@ -222,61 +223,49 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(const int* __restrict__ 
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int D4 = D >> 2;
   constexpr int G = NJ <= 2 ? 8 : (NJ <= 4 ? 4 : 2);
+  const int t = blockIdx.x;
+  int L, dest;                       // partial rows to add, destination table row
+  const float* first; const float* rest;   // partial 0; partial i >= 1 at rest + (i - 1) * rest_stride
+  long long rest_stride;
+  if (t == NT) {
+    L = NC; dest = V; first = mslab; rest = mslab + D; rest_stride = D;
+  } else {
+    const int p0 = t * SEG_TILE, p1 = p0 + SEG_TILE;
+    if (p1 >= N) return;
+    const int last = skey[p1 - 1];
+    if (last == V || skey[p1] != last) return;                          // no row leaves this tile open
+    if (skey[p0] == last && p0 > 0 && skey[p0 - 1] == last) return;     // the row began in an earlier tile: not the owner
+    int lo = p1, hi = N;                                                // first sorted position with a larger key
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (skey[mid] <= last) lo = mid + 1; else hi = mid; }
+    const int t_end = (lo - 1) / SEG_TILE;                              // the row's last tile: its partial is a head partial
+    L = 1 + (t_end - t); dest = last;
+    first = slab + (long long)(2 * t + 1) * D; rest = slab + (long long)(2 * (t + 1)) * D; rest_stride = 2LL * D;
+  }
+  const int q = (L + 3) / 4, i0 = wv * q, i1 = min(L, i0 + q);
   RowAcc<NJ> acc;
-  if (blockIdx.x == gridDim.x - 1) {
-    const int q = (NC + 3) / 4, c0 = wv * q, c1 = min(NC, c0 + q);
-    acc.zero();
-    for (int cb = c0; cb < c1; cb += G) {
-      float4 r[G][NJ];
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-        if (cb + g < c1) load_row<NJ>(mslab + (long long)(cb + g) * D, D4, l, r[g]);
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-        if (cb + g < c1) acc.add(r[g]);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) ((float4*)part[wv])[l + 64 * j] = acc.v[j];
-    __syncthreads();
-    if (wv == 0) {
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        float4 r[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) r[j] = ((const float4*)part[w])[l + 64 * j];
-        acc.add(r);
-      }
-      add_to_row<NJ>(gE + (long long)V * D, D4, l, acc);
-    }
-    return;
-  }
-  const int t = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
-  if (t >= NT) return;
-  const int p0 = t * SEG_TILE, p1 = p0 + SEG_TILE;
-  if (p1 >= N) return;
-  const int last = skey[p1 - 1];
-  if (last == V || skey[p1] != last) return;                    // no row leaves this tile open
-  if (skey[p0] == last && p0 > 0 && skey[p0 - 1] == last) return;   // the row began in an earlier tile: not the owner
-  // last sorted position of the row (the keys are sorted: binary search for the first position with a larger key)
-  int lo = p1, hi = N;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (skey[mid] <= last) lo = mid + 1; else hi = mid; }
-  const int t_end = (lo - 1) / SEG_TILE;                          // tile of the row's last token; its partial is a head partial
   acc.zero();
-  {
-    float4 r[NJ];
-    load_row<NJ>(slab + (long long)(2 * t + 1) * D, D4, l, r);
-    acc.add(r);
-  }
-  for (int tb = t + 1; tb <= t_end; tb += G) {
+  for (int ib = i0; ib < i1; ib += G) {
     float4 r[G][NJ];
 #pragma unroll
     for (int g = 0; g < G; ++g)
-      if (tb + g <= t_end) load_row<NJ>(slab + (long long)(2 * (tb + g)) * D, D4, l, r[g]);
+      if (ib + g < i1) load_row<NJ>(ib + g == 0 ? first : rest + (long long)(ib + g - 1) * rest_stride, D4, l, r[g]);
 #pragma unroll
     for (int g = 0; g < G; ++g)
-      if (tb + g <= t_end) acc.add(r[g]);
+      if (ib + g < i1) acc.add(r[g]);
   }
-  add_to_row<NJ>(gE + (long long)last * D, D4, l, acc);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ((float4*)part[wv])[l + 64 * j] = acc.v[j];
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      float4 r[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) r[j] = ((const float4*)part[w])[l + 64 * j];
+      acc.add(r);
+    }
+    add_to_row<NJ>(gE + (long long)dest * D, D4, l, acc);
+  }
 }
 
 size_t seg_scatter_slab_floats(int N, int D) {
@@ -290,7 +279,7 @@ int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const in
   const int NT = div_up(N, SEG_TILE), NC = div_up(N, MASK_CHUNK);
   float* mslab = slab + (size_t)2 * NT * D;
   const int nj = (D / 4 + 63) / 64;
-  const dim3 gridA(div_up(NT + NC, 4)), gridB(div_up(NT, 4) + 1), blk(256);
+  const dim3 gridA(div_up(NT + NC, 4)), gridB(NT + 1), blk(256);
 #define LAUNCH_SEG(NJ)                                                                                                  \
   do {                                                                                                                  \
     hipLaunchKernelGGL((seg_scatter_kernel<NJ>), gridA, blk, 0, s, gx0, ldx, m_matchedid, skey, sidx, N, V, D, gE, slab, mslab, NT, NC); \

@@ -268,15 +268,27 @@ SEG_TILE, MASK_CHUNK = 8, 256      # scatter.hip
 
 def _scatter_tree_reference(gx_rows, ids, m_ids, V, gE0):
     """The kernel's summation tree in float32, step by step: tokens sorted by (raw id with -1 -> V, index); per tile of 8
-    sorted positions each run is summed left to right; a run that spans tiles adds its per-tile partial sums in tile
-    order; watch-masked tokens (m_id == -1) are summed by position in chunks of 256, the chunk sums in four contiguous
-    quarters, the four quarter sums in order.  Every table row receives ONE add of its total."""
+    sorted positions each run is summed left to right; a run that spans tiles adds its per-tile partial sums in four
+    contiguous quarters of the tile list, then the four quarter sums in order; watch-masked tokens (m_id == -1) are summed by
+    position in chunks of 256 and the chunk sums the same way.  Every table row receives ONE add of its total."""
     N, D = gx_rows.shape
     out = gE0.copy()
     key = np.where(ids == -1, V, ids).astype(np.int64)
     order = np.lexsort((np.arange(N), key))
     skey = key[order]
-    totals = {}
+
+    def quarters(parts):
+        """four contiguous quarters of the list, each summed left to right from zero, then ((q0 + q1) + q2) + q3"""
+        q = (len(parts) + 3) // 4
+        sums = []
+        for w in range(4):
+            acc = np.zeros(D, np.float32)
+            for x in parts[w * q:(w + 1) * q]:
+                acc = acc + x
+            sums.append(acc)
+        return ((sums[0] + sums[1]) + sums[2]) + sums[3]
+
+    partials = {}                      # table row -> its per-tile partial sums in tile order
     for t0 in range(0, N, SEG_TILE):
         p = t0
         while p < min(N, t0 + SEG_TILE):
@@ -288,10 +300,10 @@ def _scatter_tree_reference(gx_rows, ids, m_ids, V, gE0):
                     acc = acc + gx_rows[i]
                 q += 1
             if skey[p] != V:
-                totals[int(skey[p])] = acc if int(skey[p]) not in totals else totals[int(skey[p])] + acc
+                partials.setdefault(int(skey[p]), []).append(acc)
             p = q
-    for k, v in totals.items():
-        out[k] = out[k] + v
+    for k, parts in partials.items():
+        out[k] = out[k] + (parts[0] if len(parts) == 1 else quarters(parts))
     NC = (N + MASK_CHUNK - 1) // MASK_CHUNK
     parts = []
     for c in range(NC):
@@ -300,14 +312,7 @@ def _scatter_tree_reference(gx_rows, ids, m_ids, V, gE0):
             if m_ids[i] == -1:
                 acc = acc + gx_rows[i]
         parts.append(acc)
-    q = (NC + 3) // 4
-    quarter = []
-    for w in range(4):
-        acc = np.zeros(D, np.float32)
-        for c in range(w * q, min(NC, (w + 1) * q)):
-            acc = acc + parts[c]
-        quarter.append(acc)
-    out[V] = out[V] + (((quarter[0] + quarter[1]) + quarter[2]) + quarter[3])
+    out[V] = out[V] + quarters(parts)
     return out
 
 
