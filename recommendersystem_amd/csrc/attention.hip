@@ -170,43 +170,60 @@ __device__ __forceinline__ int next_bit(unsigned int bits, int from) {  // lowes
 }
 
 // ------------------------------------------------------------------------ tile maps
-// qmap / qmap_full [b][q tile]: bit j = kv tile j has some / only allowed pairs; kmap* is the transposed relation.
+// qmap / qmap_full [b][q tile]: bit j = kv tile j has some / only allowed pairs; kmap* is the transposed relation; the
+// *16 maps say the same per group of 16 queries (keys).  One workgroup per (row, q tile); wave w owns the tile's 16
+// queries w*16 .. w*16+15 as SCALARS (v_readlane of the lane that loaded them), the lanes sweep the row's keys 64 at a
+// time: allowed(q, kv) <=> key[kv] == key[q] or key[kv] == key[q] without its tm bits (token_key below), so a (query,
+// 64 keys) step is two compares, an OR and a ballot.  Exact: "some" bits may not miss a pair, "only" bits may not claim one.
+__device__ __forceinline__ int token_key(int uid, int tm);
 __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
-  __shared__ int uq[64], tq[64];
-  __shared__ unsigned int any_bits, any16[4];
+  __shared__ unsigned int any_bits, any16[4], kany[32];   // kany[j]: bit kg = keys 16 kg .. +15 of kv tile j meet a query of this tile
   __shared__ int cnt[32];
-  const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x, l = t & 63, w = t >> 6;
   const int nt = (p.T + 63) / 64;
   const long long base = (long long)b * p.T;
-  if (t < 64) {
-    const bool v = qt * 64 + t < p.T;
-    uq[t] = v ? p.uid[base + qt * 64 + t] : SENT_Q; tq[t] = v ? p.tm[base + qt * 64 + t] : 0;
-  }
   if (t == 0) any_bits = 0u;
   if (t < 4) any16[t] = 0u;
-  if (t < 32) cnt[t] = 0;
-  __syncthreads();
-  for (int kv = t; kv < p.T; kv += 256) {
-    const int uk = p.uid[base + kv], tk = p.tm[base + kv];
-    int n = 0;
+  if (t < 32) { cnt[t] = 0; kany[t] = 0u; }
+  // lane i < 16 of wave w holds the key of query qt*64 + w*16 + i
+  int myq = KEY_NO_Q;
+  if (l < 16) { const int q = qt * 64 + w * 16 + l; if (q < p.T) myq = token_key(p.uid[base + q], p.tm[base + q]); }
+  int aq[16], aq0[16];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      int ng = 0;
-      for (int i = 0; i < 16; ++i) ng += ((uq[gq * 16 + i] == uk) && (tk == 0 || tq[gq * 16 + i] == tk)) ? 1 : 0;
-      if (ng) atomicOr(&any16[gq], 1u << (kv >> 6));
-      n += ng;
+  for (int i = 0; i < 16; ++i) { aq[i] = __builtin_amdgcn_readlane(myq, i); aq0[i] = aq[i] & ~4095; }
+  __syncthreads();
+  unsigned int wany = 0u;
+  for (int j = 0; j < nt; ++j) {
+    const int kv = j * 64 + l;
+    const int ak = kv < p.T ? token_key(p.uid[base + kv], p.tm[base + kv]) : KEY_NO_K;
+    bool mine = false;     // this key meets one of the wave's queries
+    int n = 0;             // allowed pairs of this (q group, kv tile), wave-uniform
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool hit = ak == aq[i] || ak == aq0[i];
+      mine |= hit;
+      n += __builtin_popcountll(__ballot(hit));
     }
     if (n) {
-      atomicOr(&any_bits, 1u << (kv >> 6)); atomicAdd(&cnt[kv >> 6], n);
-      atomicOr(&p.kmap16[(b * nt + (kv >> 6)) * 4 + ((kv >> 4) & 3)], 1u << qt);
+      wany |= 1u << j;
+      const unsigned long long km = __ballot(mine);
+      unsigned int kg = 0u;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) kg |= ((km >> (16 * g4)) & 0xFFFFull) ? (1u << g4) : 0u;
+      if (l == 0) { atomicAdd(&cnt[j], n); atomicOr(&kany[j], kg); }
     }
   }
+  if (l == 0) { any16[w] = wany; atomicOr(&any_bits, wany); }
   __syncthreads();
   if (t < nt) {
     const bool any = (any_bits >> t) & 1u, full = cnt[t] == 4096;
     if (any) atomicOr(&p.kmap[b * nt + t], 1u << qt);
     if (full) atomicOr(&p.kmap_full[b * nt + t], 1u << qt);
     if (full) atomicOr(&p.qmap_full[b * nt + qt], 1u << t);
+    const unsigned int kg = kany[t];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      if ((kg >> g4) & 1u) atomicOr(&p.kmap16[(b * nt + t) * 4 + g4], 1u << qt);
   }
   if (t == 0) p.qmap[b * nt + qt] = any_bits;
   if (t < 4) p.qmap16[(b * nt + qt) * 4 + t] = any16[t];
