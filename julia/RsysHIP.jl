@@ -97,6 +97,14 @@ allreduce_grads!(m::Model, c::Comm) = check(ccall((:rsys_allreduce_grads, LIB), 
 # arm the early gradient buckets for the next backward (the last micro-step of an optimizer step)
 begin_grad_sync!(m::Model, c::Comm) = check(ccall((:rsys_set_grad_sync, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
 
+# row-sharded item table (rsys_config.table_shard_world >= 1): the communicator of the row exchange and the vocabulary-parallel
+# cross entropy, and the table rows [lo, hi) this model holds
+set_shard_comm!(m::Model, c::Comm) = check(ccall((:rsys_model_set_shard_comm, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
+function table_rows(m::Model)
+    lo = Ref{Int64}(0); hi = Ref{Int64}(0)
+    check(ccall((:rsys_table_rows, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), m.h, lo, hi)); (lo[], hi[])
+end
+
 # One optimizer step of train_epoch (transformer.py:256-276) with grad_accum = 1
 function train_step!(m::Model, o::Optimizer, c::Union{Comm,Nothing}, task_w, lr_factor, seed, step)
     c === nothing || begin_grad_sync!(m, c)
