@@ -105,6 +105,9 @@ def main(argv=None):
     ap.add_argument("--global_batch_size", type=int, default=None, help="rows per optimizer step (transformer.py:593, 600: 32 / 512)")
     ap.add_argument("--num_epochs", type=int, default=None)
     ap.add_argument("--warmup_steps", type=int, default=2000, help="transformer.py:345 (fixed there; short rehearsal runs need fewer)")
+    ap.add_argument("--table_shard", action="store_true",
+                    help="row-sharded item table + vocabulary-parallel cross entropy over the ranks (SURVEY 8(e) cfg-4; beyond the reference)")
+    ap.add_argument("--sampled_softmax", type=int, default=0, help="with --table_shard: classes sampled per rank and medium (0 = full soft-max)")
     ap.add_argument("--nproc_per_node", type=int, default=None,
                     help="start this many ranks of this command (what `torchrun --standalone --nproc_per_node=N` does in "
                          "entrypoint.sh:25); ignored when a launcher has already set WORLD_SIZE")
@@ -142,6 +145,11 @@ def main(argv=None):
 
     dataloaders = {x: dataset(x) for x in ("training", "test")}
     hg = rdist.HostGroup()
+    if args.table_shard:
+        assert not config["finetune"], "finetuning keeps the (frozen) item table replicated"
+        config["table_shard"] = (rank, world)
+        if args.sampled_softmax:
+            config["sampled_softmax"] = args.sampled_softmax
     model = RecommenderModel(config, device=local_rank, dtype=args.dtype, max_rows=local_batch)
     model.load_pretrained_embeddings(args.datadir)
     checkpoint_fn = f"{args.datadir}/transformer.masked.npz"
@@ -157,6 +165,8 @@ def main(argv=None):
     n_train = sum(int(np.prod(s)) for _, s, t in model.named_parameters() if t)
     log(f"Created model with {n_all} parameters and {n_train} trainable parameters")
     comm = rdist.make_comm(hg, local_rank)
+    if args.table_shard and comm is not None:
+        model.set_shard_comm(comm)
     optimizer = create_optimizer(model, config)
     if config["finetune"]:
         scheduler = rtrain.create_learning_rate_schedule(0, 1, num_epochs, finetune=True)
@@ -174,7 +184,7 @@ def main(argv=None):
     task_weights = rtrain.make_task_weights(args.finetune_medium, args.finetune_metric) if config["finetune"] else rtrain.make_task_weights()
     basename = "transformer.masked" if not config["finetune"] else f"transformer.masked.{args.finetune_medium}.{args.finetune_metric}.finetune"
     history = rtrain.train(model, optimizer, scheduler, dataloaders, config, args.datadir, task_weights, num_epochs, grad_accum_steps,
-                           comm, rank, starting_epoch, basename, log)
+                           comm, rank, starting_epoch, basename, log, gather=hg if (args.table_shard and world > 1) else None)
     if comm is not None:
         comm.close()
     hg.close()

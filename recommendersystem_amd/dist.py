@@ -196,6 +196,20 @@ class HostGroup:
         out, _ = self._collective("reduce_" + op, {"v": vals}, b"", combine)
         return out["v"]
 
+    def all_gather_bytes(self, data):
+        """every rank's byte string, in rank order, on every rank (checkpoints of a row-sharded table: host plumbing)"""
+        data = bytes(data)
+        if self.world == 1:
+            return [data]
+
+        def combine(parts):
+            return {"sizes": [len(b) for _, b in parts]}, b"".join(b for _, b in parts)
+        out, raw = self._collective("all_gather", {}, data, combine)
+        chunks, at = [], 0
+        for n in out["sizes"]:
+            chunks.append(raw[at:at + n]); at += n
+        return chunks
+
     def all_reduce_array(self, arr):
         """in-place float32 sum over the ranks through host memory (debugging aid: HostComm)"""
         if self.world == 1:

@@ -171,23 +171,34 @@ class RecommenderModel:
         check(lib().rsys_grad_get(self._h, base.encode(), out.ctypes.data, out.size))
         return out
 
-    def state_dict(self, include_frozen=True):
+    TABLE_KEYS = ("item_embedding.matchedid_embedding.embedding.weight", "item_embedding.metadata_embedding.embedding.weight")
+
+    def state_dict(self, include_frozen=True, gather=None):
+        """The reference's state dict.  With a row-sharded item table the two table tensors are this rank's rows; pass
+        `gather` = the ranks' `dist.HostGroup` to get the full tables on every rank (checkpoints: the reference's layout)."""
         sd = {}
         for n, _, tr in self.named_parameters():
             if not include_frozen and "metadata_embedding" in n:
                 continue
             sd[n] = self.get_parameter(n)
+            if gather is not None and n in self.TABLE_KEYS and self.config.get("table_shard"):
+                sd[n] = gather_rows(gather, sd[n])
         for k in list(sd):
             if k.startswith("item_embedding."):       # watch_head shares item_embedding (model.py:354)
                 sd["watch_head." + k] = sd[k]
         return sd
 
     def load_state_dict(self, sd, strict=True):
+        """Table tensors may be given whole ((V + 1) rows, the reference's layout): a row-sharded model keeps its rows."""
         names = [n for n, _, _ in self.named_parameters()]
         assert "item_embedding.fused_embedding" not in sd          # model.py:135-137
+        lo, hi = self.table_rows()
         for n in names:
             if n in sd:
-                self.set_parameter(n, np.asarray(sd[n]))
+                v = np.asarray(sd[n])
+                if n in self.TABLE_KEYS and v.shape[0] != hi - lo:
+                    v = v[lo:hi]
+                self.set_parameter(n, v)
             elif strict:
                 raise KeyError(f"missing key {n}")
         if strict:
@@ -348,6 +359,13 @@ class RecommenderModel:
             name, ms, cnt, fl = line.split()
             rep[name] = {"ms": float(ms), "count": int(cnt), "flops": float(fl)}
         return rep
+
+
+def gather_rows(host_group, rows):
+    """the ranks' row blocks of a row-sharded table, concatenated in rank order (over the TCP control plane)"""
+    rows = np.ascontiguousarray(rows, np.float32)
+    parts = host_group.all_gather_bytes(rows.tobytes())
+    return np.concatenate([np.frombuffer(b, np.float32).reshape(-1, rows.shape[1]) for b in parts], axis=0)
 
 
 def synchronize():

@@ -26,22 +26,31 @@ class AdamW:
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad()
 
-    def state_dict(self):
+    def state_dict(self, gather=None):
+        """AdamW moments by parameter name.  `gather` (the ranks' HostGroup): moments of a row-sharded table whole."""
+        from .model import gather_rows
         st = C.c_int32()
         check(lib().rsys_adamw_state_get(self._h, None, None, None, 0, C.byref(st)))
         state = {}
+        sharded = bool(self.model.config.get("table_shard"))
         for n, shape, tr in self.model.named_parameters():
             if not tr:
                 continue
             m = np.empty(shape, np.float32); v = np.empty(shape, np.float32)
             check(lib().rsys_adamw_state_get(self._h, n.encode(), m.ctypes.data, v.ctypes.data, m.size, None))
+            if gather is not None and sharded and n in self.model.TABLE_KEYS:
+                m, v = gather_rows(gather, m), gather_rows(gather, v)
             state[n] = {"exp_avg": m, "exp_avg_sq": v}
         return {"step": st.value, "lr": self.lr, "state": state}
 
     def load_state_dict(self, sd):
         check(lib().rsys_adamw_state_set(self._h, None, None, None, 0, int(sd["step"])))
+        lo, hi = self.model.table_rows()
         for n, s in sd["state"].items():
-            m = np.ascontiguousarray(s["exp_avg"], np.float32); v = np.ascontiguousarray(s["exp_avg_sq"], np.float32)
+            m, v = np.asarray(s["exp_avg"]), np.asarray(s["exp_avg_sq"])
+            if n in self.model.TABLE_KEYS and m.shape[0] != hi - lo:      # whole-table moments: keep this rank's rows
+                m, v = m[lo:hi], v[lo:hi]
+            m = np.ascontiguousarray(m, np.float32); v = np.ascontiguousarray(v, np.float32)
             check(lib().rsys_adamw_state_set(self._h, n.encode(), m.ctypes.data, v.ctypes.data, m.size, -1))
 
     def close(self):

@@ -221,16 +221,19 @@ def train_step_unfused(model, optimizer, data, task_weights, masks=None, max_nor
 
 
 def checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, training_loss, test_loss, task_weights, save,
-                     basename="transformer.masked"):
+                     basename="transformer.masked", gather=None, write=True):
     """train.py:431-497 (rank-local-0 only is the caller's job).  The checkpoint is an `.npz` with the reference's
     state-dict key names + AdamW moments + scheduler state + config JSON (a torch-pickle converter is SURVEY N3);
     the metrics CSV has the reference's exact header and row format (train.py:483-494)."""
     import json
     import os
+    # (row-sharded table: EVERY rank calls this with `gather` = the ranks' HostGroup -- the table rows and their moments are
+    # collected over the control plane -- and `write` = whether this rank writes the files)
     if save:
-        blob = {"model/" + k: v for k, v in model.state_dict(include_frozen=False).items() if not k.startswith("watch_head.")}
+        gk = {"gather": gather} if gather is not None else {}
+        blob = {"model/" + k: v for k, v in model.state_dict(include_frozen=False, **gk).items() if not k.startswith("watch_head.")}
         if optimizer is not None:
-            osd = optimizer.state_dict()
+            osd = optimizer.state_dict(**gk)
             blob["optimizer/step"] = np.array([osd["step"]])
             for n, s in osd["state"].items():
                 blob["optimizer/exp_avg/" + n] = s["exp_avg"]
@@ -245,7 +248,10 @@ def checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, traini
         blob["epoch"] = np.array([epoch])
         blob["training_loss"] = np.array(training_loss, np.float64)
         blob["test_loss"] = np.array(test_loss, np.float64)
-        np.savez(os.path.join(datadir, basename + ".npz"), **blob)
+        if write:
+            np.savez(os.path.join(datadir, basename + ".npz"), **blob)
+    if not write:
+        return
     names = [f"{m}.{metric}" for m in ALL_MEDIUMS for metric in ALL_METRICS]
     csv_fn = os.path.join(datadir, basename + ".csv")
     if epoch < 0:
@@ -285,7 +291,7 @@ def get_run_config(finetune):
 
 
 def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weights, num_epochs, grad_accum_steps,
-          comm=None, rank=0, starting_epoch=0, basename="transformer.masked", log=print):
+          comm=None, rank=0, starting_epoch=0, basename="transformer.masked", log=print, gather=None):
     """The epoch loop of train() (train.py:697-757): initial evaluation (CSV row of epoch start-1), then per epoch
     train_epoch -> evaluate_metrics -> early stopper -> checkpoint when the stopper says the model improved; stops early
     when the stopper runs out of patience.  Returns the list of (epoch, training_loss, test_loss)."""
@@ -294,9 +300,9 @@ def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weight
     initial_loss = get_loss()
     log(f"Initial Loss: {wsum(initial_loss, task_weights)}, {initial_loss}")
     stopper(wsum(initial_loss, task_weights))
-    if rank == 0:
+    if rank == 0 or gather is not None:
         checkpoint_model(datadir, model, optimizer, scheduler, config, starting_epoch - 1, initial_loss, initial_loss,
-                         task_weights, bool(config.get("finetune")), basename)
+                         task_weights, bool(config.get("finetune")), basename, gather=gather, write=rank == 0)
     history = []
     for epoch in range(starting_epoch, num_epochs):
         training_loss = train_epoch(model, dataloaders["training"], optimizer, scheduler, task_weights, grad_accum_steps, comm)
@@ -304,9 +310,9 @@ def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weight
         test_loss = get_loss()
         log(f"Epoch: {epoch}, Test Loss: {wsum(test_loss, task_weights)} {test_loss}")
         stopper(wsum(test_loss, task_weights))
-        if rank == 0:
+        if rank == 0 or gather is not None:
             checkpoint_model(datadir, model, optimizer, scheduler, config, epoch, training_loss, test_loss, task_weights,
-                             stopper.save_model, basename)
+                             stopper.save_model, basename, gather=gather, write=rank == 0)
         history.append((epoch, training_loss, test_loss))
         if stopper.early_stop:
             break

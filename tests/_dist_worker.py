@@ -63,6 +63,7 @@ def main():
     arr = np.full(1000, rank + 1.0, np.float32)
     res["array_sum_ok"] = bool((hg.all_reduce_array(arr) == sum(range(1, world + 1))).all())
     res["min"] = hg.all_reduce([float(rank)], "min")
+    res["gathered"] = [len(b) for b in hg.all_gather_bytes(bytes([rank]) * (3 + 2 * rank))] + [hg.all_gather_bytes(b"ab" if rank else b"")[0] == b""]
     res["torch_blocked"] = "torch" in sys.modules and sys.modules["torch"] is None
     np.save(out_path + f".grad{rank}.npy", flat)
     with open(out_path + f".{rank}.json", "w") as f:

@@ -30,6 +30,7 @@ def test_world2_host_group_without_torch(tmp_path):
     g = [np.load(out + f".grad{r}.npy") for r in range(2)]
     for r in res:
         assert r["bcast_ok"] and r["array_sum_ok"] and r["torch_blocked"] and r["min"] == [0.0]
+        assert r["gathered"] == [3, 5, True]
         assert r["sum"] == [3.0, 30.0] and r["max"] == [1.0]
     mean = (g[0] + g[1]) / 2
     assert abs(res[0]["grad_mean_norm"] - np.sqrt((mean ** 2).sum())) < 1e-9

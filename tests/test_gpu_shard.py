@@ -320,3 +320,65 @@ def test_sampled_softmax_estimates_the_full_loss():
     touched = int((np.abs(gE).sum(axis=1) > 0).sum())
     assert 0 < touched <= 2 * 256 + 2 * cfg["mask_topk"] * rows + rows * cfg["max_sequence_length"] + 1
     samp.close()
+
+
+def test_sharded_checkpoint_is_the_reference_layout_and_reshards(tmp_path):
+    """Checkpoints of a row-sharded run hold the WHOLE tables (the reference's state-dict layout): the ranks' rows and Adam
+    moments are gathered over the control plane, one rank writes; the file loads into a replicated model and into a run with
+    a different number of shards (each rank keeps its rows)."""
+    import socket
+
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd import train as T
+    from recommendersystem_amd.optim import AdamW
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+    rows, seed, world = 2, 23, 2
+    P = synth.make_params(cfg, seed, "test")
+    batches = [synth.make_batch(cfg, rows, seed + 1 + 10 * r) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, seed + 2 + 10 * r) for r in range(world)]
+    _, _, P_ref = _reference(cfg, P, batches, masks, "fp32", 1e-2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import os
+    os.environ["RSYS_RDZV_PORT"] = str(port)
+    group = rdist.LocalGroup(world)
+    sched = T.LambdaLR(T.WSDScheduler(warmup_steps=2, total_steps=40, decay_ratio=0.1, final_ratio=0.1))
+
+    def rank_fn(r):
+        hg = rdist.HostGroup(r, world)
+        comm = rdist.LocalComm(group, r)
+        c = dict(cfg); c["table_shard"] = (r, world)
+        model = ra.RecommenderModel(c, dtype="fp32", max_rows=rows)
+        model.set_shard_comm(comm)
+        _load(model, P)
+        model.set_loss_weights(TASK_W, 1)
+        model(batches[r], False, masks=masks[r])
+        comm.all_reduce_grads(model)
+        opt = AdamW(model, lr=1e-2)
+        opt.step(clip_max_norm=1.0, grad_div=float(world))
+        T.checkpoint_model(str(tmp_path), model, opt, sched, cfg, 0, [1.0] * 4, [1.0] * 4, TASK_W, True, gather=hg, write=r == 0)
+        model.close(); comm.close(); hg.close()
+
+    _run_ranks(world, rank_fn)
+    group.close()
+    os.environ.pop("RSYS_RDZV_PORT", None)
+    z = np.load(tmp_path / "transformer.masked.npz")
+    V1 = P[E_NAME].shape[0]
+    assert z["model/" + E_NAME].shape == (V1, cfg["embed_dim"]) and z["optimizer/exp_avg/" + E_NAME].shape == (V1, cfg["embed_dim"])
+    assert np.abs(z["model/" + E_NAME] - P_ref[E_NAME]).mean() <= 2e-5               # = the replicated run's table after the step
+    assert np.abs(z["model/transformers.layers.0.mlp.w1.weight"] - P_ref["transformers.layers.0.mlp.w1.weight"]).mean() <= 2e-5
+    # resume into three shards and into a replicated model: every holder gets exactly its rows
+    for shard in (None, (0, 3), (2, 3)):
+        c = dict(cfg)
+        if shard:
+            c["table_shard"] = shard
+        m = ra.RecommenderModel(c, dtype="fp32", max_rows=rows)
+        P0 = {k: v for k, v in P.items()}
+        m.load_state_dict(P0)                                       # (frozen table etc.)
+        opt = AdamW(m, lr=1e-2)
+        epoch, _ = T.load_checkpoint(str(tmp_path / "transformer.masked.npz"), m, opt, None)
+        lo, hi = m.table_rows()
+        assert epoch == 0 and np.array_equal(m.get_parameter(E_NAME), z["model/" + E_NAME][lo:hi])
+        assert np.array_equal(opt.state_dict()["state"][E_NAME]["exp_avg_sq"], z["optimizer/exp_avg_sq/" + E_NAME][lo:hi])
+        m.close()
