@@ -28,6 +28,26 @@ constexpr float LOG2E = 1.4426950408889634f;
 // v_exp_f32 directly (exp2f adds range scaling the softmax arguments never need: they are <= 0 or hugely negative)
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max / sum over the four lanes that share a query (lane, lane ^ 16, lane ^ 32, lane ^ 48): two row swaps in the vector
+// ALU (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS pipeline, which put
+// ~5 index instructions and an LDS latency each into the soft-max's dependency chain.
+__device__ __forceinline__ float quad_rows_max(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__builtin_bit_cast(float, (unsigned int)a[0]), __builtin_bit_cast(float, (unsigned int)a[1]));
+  const unsigned int w = __builtin_bit_cast(unsigned int, v);
+  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned int)b[0]), __builtin_bit_cast(float, (unsigned int)b[1]));
+}
+__device__ __forceinline__ float quad_rows_sum(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, (unsigned int)a[0]) + __builtin_bit_cast(float, (unsigned int)a[1]);
+  const unsigned int w = __builtin_bit_cast(unsigned int, v);
+  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, (unsigned int)b[0]) + __builtin_bit_cast(float, (unsigned int)b[1]);
+}
+
 template <typename T> struct AMma;
 template <> struct AMma<bf16> {
   static constexpr int KS = 32;   // contraction per MFMA
@@ -349,8 +369,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, S[i][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = quad_rows_max(tmax);
     const float m_new = fmaxf(m_run, tmax * c2);
     const float mu_old = fmaxf(m_run, -1e20f), mu_new = fmaxf(m_new, -1e20f);
     const float alpha = fexp2(mu_old - mu_new);
@@ -363,8 +382,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
         S[i][r] = pv;
         psum += pv;
       }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum = quad_rows_sum(psum);
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll

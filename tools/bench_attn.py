@@ -1,11 +1,13 @@
 """Attention forward + backward alone at the benchmark's shape (cfg-3: 64 rows x 1024 tokens, 8 / 4 heads of 64) on the
 bench's synthetic users (the tile maps' sparsity is part of the cost), through rsys_op_attention.  Run under
-`rocprofv3 --kernel-trace --stats` and read the kernels' average durations; RSYS_ATTN_NG=1 selects the one-group-per-wave
-kernels for a same-box A/B."""
+`rocprofv3 --kernel-trace --stats` and read the kernels' average durations (tools/ab_attn.sh alternates the values of an
+environment variable, e.g. RSYS_LIB_PATH between two builds, on one box)."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recommendersystem_amd import _lib, workload
+if os.environ.get("RSYS_LIB_PATH"):            # an experimental build of the library (same-box A/B of compile-time variants)
+    _lib.LIB_PATH = os.environ["RSYS_LIB_PATH"]
 lib = _lib.lib()
 cfg = workload.make_config("cfg3")
 B, S, H, KV, hd = 64, cfg["max_sequence_length"], cfg["num_heads"], cfg["num_kv_heads"], cfg["embed_dim"] // cfg["num_heads"]
