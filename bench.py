@@ -35,7 +35,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r2a_pmc_traffic.json"
+TRAFFIC_FILE = "r2b_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
@@ -206,9 +206,9 @@ def main():
     ra.synchronize()
     first_losses = model.losses(False)
     hg.barrier()
-    # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first fifth of the timed steps: ~300 event
+    # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first tenth of the timed steps: ~300 event
     # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
-    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else max(1, args.steps // 5))
+    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else max(1, args.steps // 10))
     if n_instr:
         model.timing(True, serialize=True)
     ra.synchronize()
