@@ -71,42 +71,66 @@ def flops_per_interaction(cfg, B):
     return 36 * L * (D * D + D * I) + 56 * S * D * L + 6 * K * V * D / S + 4 * V * M * D / (B * S) + 6 * (D * D + D) * 2 * K / S
 
 
-def cpu_baseline(cfg, seed, rows=8):
-    """The numpy oracle (oracle/, kind "port": fp32, OpenBLAS on every host core) timed on this box on a bounded
-    sample of the same workload: ONE whole training step (fused item table, forward, backward incl. the metadata
-    projection gradient, clip, AdamW over all 129 M parameters) at `rows` rows of S interactions, measured directly --
-    value = rows * S / that time, nothing extrapolated.  (The per-step fixed work -- table projection both ways, the
-    optimizer pass -- is amortised over `rows` rows here, over 64 in the GPU step; the split is in `sample`.)"""
-    from oracle import model_np, synth, train_np
-    blas = []
-    try:
-        from threadpoolctl import threadpool_info
-        blas = [(p_.get("internal_api"), p_.get("num_threads", 1)) for p_ in threadpool_info() if p_.get("user_api") == "blas"]
-    except Exception:
-        pass
-    threads = max([n for _, n in blas] or [os.cpu_count() or 1])
+def cpu_baseline(cfg, seed, rows=0, budget_s=30.0):
+    """The package's own C++ / OpenMP restatement of the training step (oracle/cpu_step.cpp, kind "port": fp32, blocked SGEMM
+    with an AVX2 / AVX-512 micro kernel on every host core, per-user attention; pinned to the numpy oracle by
+    tests/test_cpu_step.py) timed on this box: ONE whole step (fused item table, forward, backward incl. the metadata
+    projection gradient, clip, AdamW over all parameters) measured directly, value = rows * S / that time.  rows = 0: the GPU
+    step's own 64 rows when a 4096^3 SGEMM probe predicts the step inside `budget_s`, else 16 (then the per-step fixed work --
+    table projection both ways, optimizer -- is amortised over fewer rows than on the GPU; the split is in `sample`)."""
+    from oracle import cpu_step, model_np, synth, train_np
+    L = cpu_step.lib()
+    threads = int(L.cpu_step_threads())
     S = cfg["max_sequence_length"]
-    P = {k: v.astype(np.float32) for k, v in synth.make_params(cfg, seed, "init").items()}
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((4096, 4096), dtype=np.float32)
+    gemm_rate = 0.0
+    for _ in range(3):                        # best of three: the first call also starts the thread team and faults its pages in
+        t0 = time.time(); cpu_step.sgemm_nt(A, A); gemm_rate = max(gemm_rate, 2 * 4096 ** 3 / (time.time() - t0))
+    del A
+    D, I, Lr, K = cfg["embed_dim"], cfg["intermediate_dim"], cfg["num_layers"], cfg["mask_topk"]
+    V = cfg["vocab_sizes"]["0_matchedid"] + cfg["vocab_sizes"]["1_matchedid"]
+    M = cfg["metadata_emb_size"]
+    fixed = 4.0 * V * M * D                                                   # table projection, forward + gradient
+    per_row = S * (36.0 * Lr * (D * D + D * I) + 56.0 * S * D * Lr * 0.5) + 6.0 * K * V * D   # SURVEY 8(d), attention at half density
+    if rows <= 0:
+        rows = 64 if (fixed + 64 * per_row) / gemm_rate * 1.4 <= budget_s else 16
+    P = {}
+    for name, shape in synth.param_shapes(cfg).items():    # reference init (model.py:5-12), drawn in float32
+        if name.endswith(".scale"):
+            w = np.ones(shape, np.float32)
+        elif name.endswith(".bias") or "periodic" in name:
+            w = np.zeros(shape, np.float32)
+        elif "metadata_embedding" in name:
+            # N(0,1)/sqrt(M) like synth.make_metadata, but 4096 distinct rows repeated: drawing 1.2 G normals would take longer
+            # than the step being timed, and the arithmetic does not depend on the values
+            blk = rng.standard_normal((4096, shape[1]), dtype=np.float32) / np.float32(np.sqrt(shape[1]))
+            w = np.zeros(shape, np.float32)
+            for r0 in range(0, shape[0] - 1, 4096):
+                n = min(4096, shape[0] - 1 - r0); w[r0:r0 + n] = blk[:n]
+        else:
+            w = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.006)
+            if "embedding.weight" in name:
+                w[-1] = 0
+        P[name] = w
     d = synth.make_batch(cfg, rows, seed + 1, mu=4.6, sigma=1.0)
     wm, rm = synth.make_masks(cfg, rows, seed + 2)
-    names = synth.trainable_names(cfg)
     tw = train_np.make_task_weights()
-    model = model_np.OracleModel(cfg, P, np.float32)
-    opt = train_np.AdamW(model.P, names, 1e-4)
+    model = cpu_step.CpuStep(cfg, P, lr=1e-4)
+    del P
     t0 = time.time()
     dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
-    losses, G = model.forward(dm, False, True, tw)
+    losses, _ = model.forward_backward(dm, tw)
     t_fb = time.time() - t0
     t1 = time.time()
-    G = {k: G[k] for k in names}
-    G, norm = train_np.clip_grad_norm(G, 1.0)
-    P2 = dict(model.P); opt.step(P2, G)
+    norm = model.clip_adamw()
     t_opt = time.time() - t1
     total = time.time() - t0
-    assert all(np.isfinite(losses))
-    return {"value": rows * S / total, "unit": "interactions/sec", "cores": int(threads), "kind": "port",
-            "sample": f"numpy oracle fp32 ({blas or 'blas threads unknown'}), one whole train step at {rows} rows x S={S} measured "
-                      f"directly: {total:.1f}s = fwd+bwd {t_fb:.1f}s + clip+AdamW {t_opt:.1f}s; no extrapolation"}
+    assert all(np.isfinite(losses)) and np.isfinite(norm)
+    return {"value": rows * S / total, "unit": "interactions/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle/cpu_step.cpp (C++/OpenMP fp32, {threads} threads, AVX{int(L.cpu_step_isa())} SGEMM {gemm_rate / 1e9:.0f} GFLOP/s at 4096^3), "
+                      f"one whole train step at {rows} rows x S={S} measured directly: {total:.1f}s = fwd+bwd {t_fb:.1f}s + clip+AdamW "
+                      f"{t_opt:.1f}s; no extrapolation"}
 
 
 def main():
@@ -121,7 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true", help="skip the train_epoch (upload + loss read-back per step) measurement")
-    ap.add_argument("--cpu-rows", type=int, default=8, help="rows of the CPU-baseline step (numpy oracle)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline step (oracle/cpu_step.cpp); 0 = 64 if a GEMM probe predicts <= 30 s, else 16")
     ap.add_argument("--table-shard", action="store_true",
                     help="row-sharded item table + vocabulary-parallel cross entropy (SURVEY 8(e) cfg-4; default for --config cfg4): "
                          "rank r of N holds rows [r (V+1)/N, (r+1)(V+1)/N) of the item tables and their Adam moments")
