@@ -205,6 +205,88 @@ struct Batch {
   const float* label[4]; const float* weight[4]; const int32_t* position[4];   // tasks (0,watch) (0,rating) (1,watch) (1,rating)
 };
 
+// exp over arrays, 8 lanes (Cephes expf polynomial, < 2 ulp; arguments below -87.3 -- the masked scores' -inf -- give exactly 0)
+inline __m256 exp256(__m256 x) {
+  const __m256 lo = _mm256_set1_ps(-87.3365447504f), hi = _mm256_set1_ps(88.3762626647949f);
+  const __m256 under = _mm256_cmp_ps(x, lo, _CMP_LT_OQ);
+  x = _mm256_max_ps(_mm256_min_ps(x, hi), lo);
+  __m256 fx = _mm256_floor_ps(_mm256_fmadd_ps(x, _mm256_set1_ps(1.44269504088896341f), _mm256_set1_ps(0.5f)));
+  x = _mm256_fnmadd_ps(fx, _mm256_set1_ps(0.693359375f), x);
+  x = _mm256_fnmadd_ps(fx, _mm256_set1_ps(-2.12194440e-4f), x);
+  const __m256 z = _mm256_mul_ps(x, x);
+  __m256 y = _mm256_set1_ps(1.9875691500e-4f);
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(1.3981999507e-3f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(8.3334519073e-3f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(4.1665795894e-2f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(1.6666665459e-1f));
+  y = _mm256_fmadd_ps(y, x, _mm256_set1_ps(5.0000001201e-1f));
+  y = _mm256_add_ps(_mm256_fmadd_ps(y, z, x), _mm256_set1_ps(1.0f));
+  const __m256i e = _mm256_slli_epi32(_mm256_add_epi32(_mm256_cvttps_epi32(fx), _mm256_set1_epi32(127)), 23);
+  return _mm256_andnot_ps(under, _mm256_mul_ps(y, _mm256_castsi256_ps(e)));
+}
+// x[i] = exp(x[i] - shift) * mul; returns the sum of the exponentials before `mul`
+inline float exp_inplace(float* x, int n, float shift, float mul) {
+  const __m256 sh = _mm256_set1_ps(shift), mu = _mm256_set1_ps(mul);
+  __m256 acc = _mm256_setzero_ps();
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const __m256 e = exp256(_mm256_sub_ps(_mm256_loadu_ps(x + i), sh));
+    acc = _mm256_add_ps(acc, e);
+    _mm256_storeu_ps(x + i, _mm256_mul_ps(e, mu));
+  }
+  alignas(32) float t[8];
+  _mm256_store_ps(t, acc);
+  float sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  for (; i < n; ++i) { const float e = expf(x[i] - shift); sum += e; x[i] = e * mul; }
+  return sum;
+}
+inline float exp_sum(const float* x, int n, float shift) {
+  const __m256 sh = _mm256_set1_ps(shift);
+  __m256 acc = _mm256_setzero_ps();
+  int i = 0;
+  for (; i + 8 <= n; i += 8) acc = _mm256_add_ps(acc, exp256(_mm256_sub_ps(_mm256_loadu_ps(x + i), sh)));
+  alignas(32) float t[8];
+  _mm256_store_ps(t, acc);
+  float sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  for (; i < n; ++i) sum += expf(x[i] - shift);
+  return sum;
+}
+// SwiGLU (model.py:205-213): g = silu(a) * b; and its gradient
+void swiglu_fwd(const float* a, const float* b, float* g, int64_t n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < (n + 4095) / 4096; ++c) {
+    const int64_t i0 = c * 4096, i1 = std::min(n, i0 + 4096);
+    int64_t i = i0;
+    const __m256 one = _mm256_set1_ps(1.0f), zero = _mm256_setzero_ps();
+    for (; i + 8 <= i1; i += 8) {
+      const __m256 z = _mm256_loadu_ps(a + i);
+      const __m256 sg = _mm256_div_ps(one, _mm256_add_ps(one, exp256(_mm256_sub_ps(zero, z))));
+      _mm256_storeu_ps(g + i, _mm256_mul_ps(_mm256_mul_ps(z, sg), _mm256_loadu_ps(b + i)));
+    }
+    for (; i < i1; ++i) g[i] = a[i] / (1.0f + expf(-a[i])) * b[i];
+  }
+}
+void swiglu_bwd(const float* gg, const float* a, const float* b, float* ga, float* gb, int64_t n) {
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < (n + 4095) / 4096; ++c) {
+    const int64_t i0 = c * 4096, i1 = std::min(n, i0 + 4096);
+    int64_t i = i0;
+    const __m256 one = _mm256_set1_ps(1.0f), zero = _mm256_setzero_ps();
+    for (; i + 8 <= i1; i += 8) {
+      const __m256 z = _mm256_loadu_ps(a + i), g = _mm256_loadu_ps(gg + i);
+      const __m256 sg = _mm256_div_ps(one, _mm256_add_ps(one, exp256(_mm256_sub_ps(zero, z))));
+      const __m256 ds = _mm256_mul_ps(sg, _mm256_fmadd_ps(z, _mm256_sub_ps(one, sg), one));   // d silu / dz
+      _mm256_storeu_ps(ga + i, _mm256_mul_ps(_mm256_mul_ps(g, _mm256_loadu_ps(b + i)), ds));
+      _mm256_storeu_ps(gb + i, _mm256_mul_ps(_mm256_mul_ps(g, z), sg));
+    }
+    for (; i < i1; ++i) {
+      const float zz = a[i], sg = 1.0f / (1.0f + expf(-zz));
+      ga[i] = gg[i] * b[i] * (sg * (1.0f + zz * (1.0f - sg)));
+      gb[i] = gg[i] * zz * sg;
+    }
+  }
+}
+
 void rmsnorm_fwd(const float* x, const float* sc, float* y, float* r, int64_t n, int D) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
@@ -257,10 +339,17 @@ void rope(float* x, int64_t n, int T, int heads, int hd, const float* cs, const 
 
 struct Layer { float *x, *xn, *r1, *q, *k, *v, *lse, *o, *h, *hn, *r2, *a, *b, *g; };
 
+// Work buffers are kept between calls (same configuration and rows -> the same request sequence): a training loop reuses its
+// activations' memory, and first-touch page faults of ~20 GB would otherwise be a third of the timed step.
+std::vector<std::pair<float*, size_t>> g_pool;
 struct Arena {
-  std::vector<float*> ptrs;
-  float* get(size_t n) { float* p = (float*)aligned_alloc(64, ((n * 4 + 63) / 64) * 64); ptrs.push_back(p); return p; }
-  ~Arena() { for (float* p : ptrs) free(p); }
+  size_t at = 0;
+  float* get(size_t n) {
+    if (at == g_pool.size()) g_pool.emplace_back(nullptr, 0);
+    auto& e = g_pool[at++];
+    if (e.second < n) { free(e.first); e.first = (float*)aligned_alloc(64, ((n * 4 + 63) / 64) * 64); e.second = n; }
+    return e.first;
+  }
 };
 
 inline bool allowed(int uq, int tq, int uk, int tk) { return uq == uk && (tk == 0 || tq == tk); }   // model.py:479-487
@@ -302,8 +391,7 @@ void attention_fwd(const Cfg& c, const float* q, const float* k, const float* v,
               si[j] = ok ? si[j] * scale : -INFINITY;
               mx = std::max(mx, si[j]);
             }
-            float den = 0.f;
-            for (int j = 0; j < nk; ++j) { si[j] = expf(si[j] - mx); den += si[j]; }
+            const float den = exp_inplace(si, nk, mx, 1.0f);
             const float inv = 1.0f / den;
             for (int j = 0; j < nk; ++j) si[j] *= inv;
             lse[((int64_t)b * H + h) * T + i0 + i] = mx + logf(den);
@@ -351,11 +439,9 @@ void attention_bwd(const Cfg& c, const float* q, const float* k, const float* v,
             const int uq = uid[base + i0 + i], tq = tm[base + i0 + i];
             const float l = lse[((int64_t)b * H + h) * T + i0 + i], dl = delta[((int64_t)b * H + h) * T + i0 + i];
             float *si = s + (size_t)i * nk, *di = dp + (size_t)i * nk;
-            for (int j = 0; j < nk; ++j) {
-              const bool ok = allowed(uq, tq, uid[base + ks + j], tm[base + ks + j]);
-              const float p = ok ? expf(si[j] * scale - l) : 0.f;
-              si[j] = p * (di[j] - dl) * scale;
-            }
+            for (int j = 0; j < nk; ++j) si[j] = allowed(uq, tq, uid[base + ks + j], tm[base + ks + j]) ? si[j] * scale : -INFINITY;
+            exp_inplace(si, nk, l, 1.0f);
+            for (int j = 0; j < nk; ++j) si[j] = si[j] * (di[j] - dl) * scale;
           }
           gemm_block(nq, hd, nk, s, nk, 1, kh, ldk, 1, gq + (base + i0) * ldq + h * hd, ldq, false);
         }
@@ -384,12 +470,10 @@ void attention_bwd(const Cfg& c, const float* q, const float* k, const float* v,
               float *sj = st + (size_t)j * nq, *dj = dpt + (size_t)j * nq;
               const float* lrow = lse + ((int64_t)b * H + h) * T + qs;
               const float* drow = delta + ((int64_t)b * H + h) * T + qs;
-              for (int i = 0; i < nq; ++i) {
-                const bool ok = allowed(uid[base + qs + i], tm[base + qs + i], uk, tk);
-                const float p = ok ? expf(sj[i] * scale - lrow[i]) : 0.f;
-                sj[i] = p;                                   // P^T
-                dj[i] = p * (dj[i] - drow[i]) * scale;       // dS^T
-              }
+              for (int i = 0; i < nq; ++i)
+                sj[i] = allowed(uid[base + qs + i], tm[base + qs + i], uk, tk) ? sj[i] * scale - lrow[i] : -INFINITY;
+              exp_inplace(sj, nq, 0.f, 1.0f);                                           // P^T
+              for (int i = 0; i < nq; ++i) dj[i] = sj[i] * (dj[i] - drow[i]) * scale;   // dS^T
             }
             gemm_block(nk, hd, nq, st, nq, 1, goh, ldq, 1, gv + (base + j0) * ldk + g * hd, ldk, r > 0);
             gemm_block(nk, hd, nq, dpt, nq, 1, qh, ldq, 1, gk + (base + j0) * ldk + g * hd, ldk, r > 0);
@@ -426,6 +510,8 @@ struct Phase {   // CPU_STEP_TIMING=1: seconds per phase on stderr
 extern "C" {
 
 int cpu_step_threads(void) { return omp_get_max_threads(); }
+void cpu_step_set_threads(int n) { if (n >= 1) omp_set_num_threads(n); }
+void cpu_step_release(void) { for (auto& e : g_pool) free(e.first); g_pool.clear(); }
 
 // One forward + backward of sum_i task_w[i] * loss_i (model.py:493-529 and its autograd).  params / grads: pointer tables in
 // the order of the P_* / L_* enums (oracle/cpu_step.py builds them from the state-dict names); grads[P_META] is ignored
@@ -531,8 +617,7 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
     rmsnorm_fwd(a.h, LP(l, L_MLP), a.hn, a.r2, NT, D);
     gemm_nt((int)NT, I, D, a.hn, D, LP(l, L_W1), D, a.a, I);
     gemm_nt((int)NT, I, D, a.hn, D, LP(l, L_W3), D, a.b, I);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < NT * (int64_t)I; ++i) { const float z = a.a[i]; a.g[i] = z / (1.0f + expf(-z)) * a.b[i]; }   // model.py:205-213
+    swiglu_fwd(a.a, a.b, a.g, NT * (int64_t)I);
     float* out = ar.get(NT * D);
     memcpy(out, a.h, (size_t)NT * D * 4);
     gemm_nt((int)NT, D, I, a.g, I, LP(l, L_W2), I, out, D, true);
@@ -580,13 +665,11 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
         float* lr = logits + (int64_t)r * Vm;
         float mx = lr[0];
         for (int j = 1; j < Vm; ++j) mx = std::max(mx, lr[j]);
-        float den = 0.f;
-        for (int j = 0; j < Vm; ++j) den += expf(lr[j] - mx);
-        const float lse = mx + logf(den);
+        const float lse = mx + logf(exp_sum(lr, Vm, mx));
         const int t = pos[bp[r]];
         loss += (double)((lse - lr[t]) * lab[bp[r]] * w[bp[r]]);
         const float coef = tw * lab[bp[r]] * w[bp[r]] / ws;
-        for (int j = 0; j < Vm; ++j) lr[j] = expf(lr[j] - lse) * coef;
+        exp_inplace(lr, Vm, lse, coef);
         lr[t] -= coef;
       }
       losses[ti] = (float)(loss / ws);
@@ -644,12 +727,7 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
     Layer& a = lay[l];
     gemm_tn(D, I, (int)NT, gx, D, a.g, I, LG(l, L_W2), I);
     gemm_nn((int)NT, I, D, gx, D, LP(l, L_W2), I, gg, I);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < NT * (int64_t)I; ++i) {
-      const float zz = a.a[i], sg = 1.0f / (1.0f + expf(-zz));
-      ga[i] = gg[i] * a.b[i] * (sg * (1.0f + zz * (1.0f - sg)));
-      gb[i] = gg[i] * zz * sg;
-    }
+    swiglu_bwd(gg, a.a, a.b, ga, gb, NT * (int64_t)I);
     gemm_tn(I, D, (int)NT, ga, I, a.hn, D, LG(l, L_W1), D);
     gemm_tn(I, D, (int)NT, gb, I, a.hn, D, LG(l, L_W3), D);
     gemm_nn((int)NT, D, I, ga, I, LP(l, L_W1), D, ghn, D);

@@ -44,8 +44,29 @@ def lib():
         L.cpu_step_clip_adamw.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float]
         L.cpu_step_sgemm_nt.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
         L.cpu_step_isa.restype = ctypes.c_int
+        L.cpu_step_set_threads.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
+
+
+def host_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (a container on a big host sees
+    every core in `nproc` but is throttled to its share; one thread per allowed CPU, not per visible one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def param_order(cfg):
@@ -68,6 +89,12 @@ def _table(arrays):
     for i, a in enumerate(arrays):
         t[i] = a.ctypes.data
     return t
+
+
+def release():
+    """free the work buffers the library keeps between steps"""
+    if _lib is not None:
+        _lib.cpu_step_release()
 
 
 class CpuStep:
