@@ -294,8 +294,12 @@ def main():
                 a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["launches"] += r["count"]
         roofline = None
         traffic_db = {}
-        try:   # PMC passes are separate runs (rocprofv3 --pmc); their per-launch summary is committed under profiles/
-            traffic_db = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels"]
+        # PMC passes are separate runs (rocprofv3 --pmc) of the default workload; their per-launch summary is committed under
+        # profiles/ and only describes that workload
+        pmc_applies = args.config == "cfg3" and rows == 64 and args.layers is None and args.dtype == "bf16" and not sharded
+        try:
+            if pmc_applies:
+                traffic_db = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels"]
         except Exception:
             pass
         if var:

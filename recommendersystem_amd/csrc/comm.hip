@@ -223,7 +223,10 @@ int comm_all_gather(rsys_comm* c, const void* send, void* recv, size_t bytes, hi
     int rc = local_begin(c, send, recv, nullptr, s);
     if (rc) return local_fail(g, rc);
     for (int q = 0; q < g->world; ++q)
-      HIP_CHECK(hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->slot[q].send, bytes, hipMemcpyDeviceToDevice, s));
+      if (hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->slot[q].send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        set_error("all-gather: device copy failed");
+        return local_fail(g, RSYS_ERR_HIP);    // (the peers must not wait for this rank at the closing barrier)
+      }
     rc = local_end(c, s);
     return rc ? local_fail(g, rc) : RSYS_OK;
   }
@@ -248,7 +251,10 @@ int comm_exchange(rsys_comm* c, const void* send, const long long* send_off, voi
       const long long* so = g->slot[q].send_off;
       const long long n = so[c->rank + 1] - so[c->rank];
       if (n != recv_off[q + 1] - recv_off[q]) { set_error("exchange: a peer's send size differs from this rank's receive size"); return local_fail(g, RSYS_ERR_COMM); }
-      if (n) HIP_CHECK(hipMemcpyAsync((char*)recv + recv_off[q] * eb, (const char*)g->slot[q].send + so[c->rank] * eb, n * eb, hipMemcpyDeviceToDevice, s));
+      if (n && hipMemcpyAsync((char*)recv + recv_off[q] * eb, (const char*)g->slot[q].send + so[c->rank] * eb, n * eb, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        set_error("exchange: device copy failed");
+        return local_fail(g, RSYS_ERR_HIP);
+      }
     }
     rc = local_end(c, s);
     return rc ? local_fail(g, rc) : RSYS_OK;

@@ -57,6 +57,8 @@ def make_config(name="tiny", **over):
         "cfg2":  (8, 4, 2, 256, 704, 256, 60000, 40000, 6148, 32),
         "cfg3":  (8, 8, 4, 512, 1408, 512, 120000, 80000, 6148, 64),
         "cfg4":  (8, 16, 8, 1024, 2816, 512, 120000, 80000, 6148, 64),
+        # the reference's production shape (transformer.py:535-560; vocabulary as in cfg-3, the real one comes from {manga,anime}.csv)
+        "prod":  (8, 32, 16, 2048, 5632, 1024, 120000, 80000, 6148, 128),
     }[name]
     L, H, KV, D, I, S, V0, V1, M, K = shapes
     cfg = dict(base)
