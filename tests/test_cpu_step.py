@@ -90,3 +90,13 @@ def test_bad_index_is_rejected():
     dm["matchedid"][0, 0] = 10 ** 6
     with pytest.raises(ValueError):
         cpu_step.CpuStep(cfg, P).forward_backward(dm, train_np.make_task_weights())
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_configuration():
+    """bench.py's cpu_baseline leg end to end (thread count from the cgroup quota, GEMM probe, two steps, buffers released)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.cpu_baseline(synth.make_config("tiny"), 1, rows=4)
+    assert out["kind"] == "port" and out["unit"] == "interactions/sec" and out["value"] > 0
+    assert 1 <= out["cores"] <= (os.cpu_count() or 1) and out["cores"] == cpu_step.host_cpus()
+    assert "4 rows" in out["sample"] and "no extrapolation" in out["sample"]
