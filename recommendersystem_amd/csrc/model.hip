@@ -192,6 +192,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  for (int k = 0; k < 4; ++k) HIP_CHECK(hipEventCreateWithFlags(&m->ev_dw[k], hipEventDisableTiming));
   build_layout(m);
   const int64_t D = m->D, N = (int64_t)m->rows_max * m->S, NT = 2 * N, KB = (int64_t)m->K * m->rows_max;
   const size_t e = m->esz;
@@ -307,6 +308,7 @@ int model_destroy(Model* m) {
   if (m->req_ids) hipFree(m->req_ids);
   if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
+  for (int k = 0; k < 4; ++k) if (m->ev_dw[k]) hipEventDestroy(m->ev_dw[k]);
   for (auto e : m->timer.pool) hipEventDestroy(e);
   for (auto e : m->step_marks) hipEventDestroy(e);
   hipStreamDestroy(m->stream);
@@ -611,13 +613,21 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
   return rc;
 }
 
-// Weight-gradient GEMM, optionally (RSYS_SIDE_STREAM=1) on the side stream beside whatever the main stream launches
-// until join_side(): the side stream first waits for everything the main stream has enqueued so far (the operands).  rsys_op_timing(2)
-// (bench.py --detail) runs it in line instead, so that every kernel's time is measured without a neighbour.
+// Weight-gradient GEMM, optionally on the side stream beside what the main stream launches next: the side stream first waits for
+// everything the main stream has enqueued so far (the operands).  RSYS_SIDE_STREAM=1: the main stream joins right behind the
+// paired dx GEMM (join_side).  RSYS_SIDE_STREAM=2: deferred joins -- the four products of a layer queue up on the side stream and
+// the main stream waits for product `slot` only where the buffer that product reads is about to be overwritten (join_dw), so the
+// MFMA-bound weight gradients run beside the HBM-bound RMSNorm backward and the VALU-bound attention backward.  rsys_op_timing(2)
+// (bench.py --detail) runs everything in line instead, so that every kernel's time is measured without a neighbour.
+enum { DW_W2 = 0, DW_W13 = 1, DW_O = 2, DW_QKV = 3 };
+static int side_mode() {
+  static const int mode = [] { const char* e = getenv("RSYS_SIDE_STREAM"); return e ? atoi(e) : 0; }();
+  return mode;
+}
 template <typename T>
-static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
-  static const bool on = getenv("RSYS_SIDE_STREAM") != nullptr;   // opt-in: measured +1 % on the step, but it makes per-kernel durations depend on a neighbour
-  if (!on || (m->timer.enabled && m->timer.serialize)) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
+static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km, int slot) {
+  const int mode = side_mode();
+  if (mode == 0 || (m->timer.enabled && m->timer.serialize)) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
@@ -626,12 +636,28 @@ static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a
   if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K, m->side);   // (events on the stream the kernel runs on)
   RC(launch_gemm<T>(p, a_f32, false, a_km, b_km, m->side));
   toc(m, m->side);
-  HIP_CHECK(hipEventRecord(m->ev_join, m->side));
-  m->side_pending = true;
+  if (mode >= 2) {
+    HIP_CHECK(hipEventRecord(m->ev_dw[slot], m->side));
+    m->dw_pending[slot] = true;
+  } else {
+    HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+    m->side_pending = true;
+  }
   return RSYS_OK;
 }
+// mode 1: wait for the product launched last
 static int join_side(Model* m) {
   if (m->side_pending) { HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_join, 0)); m->side_pending = false; }
+  return RSYS_OK;
+}
+// mode 2: the main stream is about to overwrite what product `slot` reads (the side stream runs in order: earlier products are done too)
+static int join_dw(Model* m, int slot) {
+  if (m->dw_pending[slot]) { HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_dw[slot], 0)); m->dw_pending[slot] = false; }
+  return RSYS_OK;
+}
+static int join_all(Model* m) {
+  RC(join_side(m));
+  for (int k = 3; k >= 0; --k) RC(join_dw(m, k));
   return RSYS_OK;
 }
 
@@ -1037,13 +1063,14 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm_side<T>(m, "gemm_w2_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_w2_dw", p, false, true, true, DW_W2));
     }
     {
       GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward: writes [da|db] directly
       p.A = gxt; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dab; p.ldc = 2 * Ip;
       if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
+      RC(join_dw(m, DW_W13));   // the layer above's dW13 reads dab
       RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
       RC(join_side(m));
     }
@@ -1051,7 +1078,7 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dW13 += dab^T . hn
       p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
       p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm_side<T>(m, "gemm_w13_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_w13_dw", p, false, true, true, DW_W13));
     }
     {
       GemmParams p{};  // dhn = dab . W13
@@ -1061,6 +1088,7 @@ static int backward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
       RC(join_side(m));
     }
+    RC(join_dw(m, DW_O));       // the layer above's dWo reads dht
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     toc(m);
@@ -1068,7 +1096,7 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm_side<T>(m, "gemm_o_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_o_dw", p, false, true, true, DW_O));
     }
     {
       GemmParams p{};  // dO = dh . Wo
@@ -1082,6 +1110,7 @@ static int backward_trunk(Model* m) {
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
     ap.dO = m->dO; ap.delta = m->delta;
     ap.dq = m->dqkv; ap.dk = AT<T>(m->dqkv) + m->H * hd; ap.dv = AT<T>(m->dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
+    RC(join_dw(m, DW_QKV));     // the layer above's dWqkv reads dqkv
     tic(m, "attn_bwd");
     RC(launch_attn_bwd<T>(ap, s));
     toc(m);
@@ -1089,7 +1118,7 @@ static int backward_trunk(Model* m) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
       p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
       p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
-      RC(gemm_side<T>(m, "gemm_qkv_dw", p, false, true, true));
+      RC(gemm_side<T>(m, "gemm_qkv_dw", p, false, true, true, DW_QKV));
     }
     {
       GemmParams p{};  // dxn = dqkv . Wqkv
@@ -1151,7 +1180,7 @@ static int backward_trunk(Model* m) {
       // weight gradients of layers l .. bucket_top are final (the four tensors of a layer are contiguous, layers ascending)
       const int64_t lo = m->lo[l].wqkv, hi = m->lo[bucket_top].w2 + pad8((int64_t)D * Ip);
       if (l == 0 || (hi - lo) * 4 >= (25ll << 20)) {
-        RC(join_side(m));
+        RC(join_all(m));
         RC(m->grad_bucket_hook(lo, hi));
         bucket_top = l - 1;
         // From here on all-reduce kernels share the CUs with the backward.  A persistent grid (one workgroup pinned per
@@ -1161,6 +1190,7 @@ static int backward_trunk(Model* m) {
       }
     }
   }
+  RC(join_all(m));   // every weight gradient is final (and the saved activations may be overwritten by the next forward)
   toc(m);
   if (m->cfg.finetune) return RSYS_OK;   // embeddings are frozen (model.py:361-369)
   // gx = gradient w.r.t. the interleaved input embeddings (even rows: items, odd rows: actions)

@@ -48,6 +48,10 @@ struct Model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  // deferred joins (RSYS_SIDE_STREAM=2): one event per weight-gradient product of a layer (W2, W13, Wo, Wqkv), recorded on the
+  // side stream behind it; the main stream waits for a product only where the buffer it reads is overwritten next
+  hipEvent_t ev_dw[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool dw_pending[4] = {false, false, false, false};
   // DDP-style early gradient reduction (train.py:678-682): when set, the trunk backward hands every finished bucket of
   // per-layer weight gradients [lo, hi) of the flat buffer to this hook (>= 25 MB each, reverse layer order); the hook
   // enqueues its all-reduce on the communicator's stream behind an event and records the range in `reduced`
