@@ -122,13 +122,15 @@ int launch_add_rows_plain(const float* src, const int* idx, int base, float* dst
 template <typename T>
 int launch_ss_target_logit(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const int* nlive, float* tl, int grid_rows, hipStream_t s);
 template <typename T>
-int launch_ss_stats(const T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const int* nlive,
+int launch_ss_stats(const T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* cols, const float* metaC, const int* nlive,
                     float* lmax, float* lsum, int grid_rows, hipStream_t s);
+int launch_ss_targets(const float* metaC, const int* nlive, int cap_rows, int len, int col0, unsigned int* bitmap, int* out, int* count, hipStream_t s);
+int launch_ss_drop_hits(int* cols, int n_s, const unsigned int* bitmap, hipStream_t s);
 int launch_ss_max_with_target(const float* lmax, const float* tl, float* out, int n, hipStream_t s);
-int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, float inv_q, int n, hipStream_t s);
+int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, int n, hipStream_t s);
 template <typename T>
-int launch_ss_finish(T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const float* gmax,
-                     const float* sneg, const float* tl, float inv_q, const int* nlive, const int* pre, int rank, float* loss_out,
+int launch_ss_finish(T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* cols, const float* metaC, const float* gmax,
+                     const float* sneg, const float* tl, const int* nlive, const int* pre, int rank, float* loss_out,
                      float* dt, int grid_rows, hipStream_t s);
 template <typename T>
 int launch_ss_target_grad(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const float* dt, const int* nlive,

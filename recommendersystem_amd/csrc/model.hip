@@ -265,6 +265,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     for (int med = 0; med < 2; ++med) { int len, col0, row; shard_medium_range(m, med, &len, &col0, &row); len_max = std::max(len_max, len); }
     m->ldl_loc = pad8(std::max(len_max, 8));
     const int64_t cap = (int64_t)W * KB;
+    // sampled soft-max: the class list of a step = the sampled classes + the in-batch targets (at most one per gathered row)
+    const int64_t ss_ns = std::min<int64_t>(cfg->sampled_negatives, std::max(len_max, 1)), ss_tmax = std::min<int64_t>(cap, len_max);
+    if (cfg->sampled_negatives > 0) m->ldl_loc = pad8(std::max<int64_t>(m->ldl_loc, ss_ns + ss_tmax));
     DALLOC(m->logits, cap * m->ldl_loc * e); DALLOC(m->dEwC, cap * D * 4); m->dE = m->dEwC;
     DALLOC(m->EwAll, cap * D * e); DALLOC(m->EwC, cap * D * e);
     DALLOC(m->metaOwn, (KB * 4 + 4) * 4); DALLOC(m->metaAll, (int64_t)W * (KB * 4 + 4) * 4); DALLOC(m->metaC, cap * 4 * 4 + 4096);
@@ -274,9 +277,10 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     DALLOC(m->u_bound, (W + 1) * 4); DALLOC(m->u_off, ((W + 1) + W + (int64_t)W * W) * 4 + 64);
     DALLOC(m->Frem, (N + 1) * D * 4); DALLOC(m->sumsq_E, 64);
     if (cfg->sampled_negatives > 0) {
-      const int64_t ns = std::min<int64_t>(cfg->sampled_negatives, std::max(len_max, 1));
+      const int64_t ns = ss_ns + ss_tmax;
       DALLOC(m->ss_cols, ns * 4 + 64); DALLOC(m->ss_F, ns * D * e); DALLOC(m->ss_dF, ns * D * 4);
       DALLOC(m->ss_tl, cap * 4); DALLOC(m->ss_dt, cap * 4);
+      DALLOC(m->ss_bitmap, (len_max / 32 + 2) * 4); DALLOC(m->ss_tcount, 64);
     }
     std::vector<int> bound(W + 1);
     for (int r = 0; r <= W; ++r) bound[r] = (int)((int64_t)r * (m->V + 1) / W);
@@ -823,38 +827,39 @@ static int forward_trunk(Model* m) {
 
 // ------------------------------------------------------------------ sampled soft-max watch head (cfg-4 option)
 // Called by watch_head_sharded after the selected rows of all ranks have been gathered and packed.  Per rank: n_s sampled
-// local classes (stratified uniform, fresh per step and medium) instead of all `len`; see shard.hip for the estimator.
+// local classes (one per stratum, fresh per step and medium, weighted by the stratum's size) instead of all `len`; see shard.hip.
 template <typename T>
-static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive, int npad, int own0, int nown, int len, int col0, int lrow) {
+static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive, int npad, int own0, int nown, int len, int col0, int lrow, int n_t) {
   const int D = m->D, W = m->sh_world, cap = W * m->K * m->rows_max;
   hipStream_t s = m->stream;
   rsys_comm* c = m->shard_comm;
   const int n_s = std::min(len, m->cfg.sampled_negatives);
-  const float inv_q = n_s > 0 ? (float)len / (float)n_s : 1.f;
-  const int64_t lds = pad8(std::max(n_s, 8));
+  const int n_tot = n_s + n_t;           // sampled classes, then the in-batch targets (listed by watch_head_sharded)
+  const int64_t lds = pad8(std::max(n_tot, 8));
   T* Floc = AT<T>(m->FT) + (int64_t)lrow * D;
   HIP_CHECK(hipMemsetAsync(m->ss_tl, 0, (size_t)nlive * 4, s));
   if (n_s > 0) {
     RC(launch_ss_sample(len, n_s, m->cur_seed ^ (0x5A3Dull + 977ull * (unsigned long long)m->sh_rank), (unsigned int)(m->cur_step * 2 + medium), m->ss_cols, s));
-    RC(launch_gather_rows_plain<T>(Floc, D, m->ss_cols, 0, AT<T>(m->ss_F), n_s, D, s));
+    if (n_t > 0) RC(launch_ss_drop_hits(m->ss_cols, n_s, m->ss_bitmap, s));
+    RC(launch_gather_rows_plain<T>(Floc, D, m->ss_cols, 0, AT<T>(m->ss_F), n_tot, D, s));
     GemmParams p{};
     p.A = m->EwC; p.lda = D; p.B = m->ss_F; p.ldb = D; p.C = m->logits; p.ldc = lds;
-    p.M = cap; p.N = n_s; p.K = D; p.epi = EPI_STORE; p.m_dev = m->vp_nlive;
+    p.M = cap; p.N = n_tot; p.K = D; p.epi = EPI_STORE; p.m_dev = m->vp_nlive;
     RC(gemm<T>(m, "gemm_logits", p, false, false, false));
     RC(launch_ss_target_logit<T>(AT<T>(m->EwC), Floc, D, len, col0, m->metaC, m->vp_nlive, m->ss_tl, nlive, s));
   }
   tic(m, "ce");
-  RC(launch_ss_stats<T>(AT<T>(m->logits), lds, n_s, col0, m->ss_cols, m->metaC, m->vp_nlive, m->vp_lmax, m->vp_sums, nlive, s));
+  RC(launch_ss_stats<T>(AT<T>(m->logits), lds, n_s, n_tot, len, col0, m->ss_cols, m->metaC, m->vp_nlive, m->vp_lmax, m->vp_sums, nlive, s));
   RC(comm_all_reduce_f32(c, m->ss_tl, (size_t)nlive, COMM_SUM, s));            // the target's owner has the only non-zero term
   RC(launch_ss_max_with_target(m->vp_lmax, m->ss_tl, m->vp_max, nlive, s));
   RC(comm_all_reduce_f32(c, m->vp_max, (size_t)nlive, COMM_MAX, s));
-  RC(launch_ss_rebase(m->vp_lmax, m->vp_max, m->vp_sums, inv_q, nlive, s));
+  RC(launch_ss_rebase(m->vp_lmax, m->vp_max, m->vp_sums, nlive, s));
   RC(comm_all_reduce_f32(c, m->vp_sums, (size_t)nlive, COMM_SUM, s));
   if (n_s > 0)
-    RC(launch_ss_finish<T>(AT<T>(m->logits), lds, n_s, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, inv_q, m->vp_nlive,
+    RC(launch_ss_finish<T>(AT<T>(m->logits), lds, n_s, n_tot, len, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, m->vp_nlive,
                            m->vp_pre, m->sh_rank, m->loss_acc + 3 * ti, m->ss_dt, npad, s));
   else
-    RC(launch_ss_finish<T>(AT<T>(m->logits), 8, 0, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, inv_q, m->vp_nlive,
+    RC(launch_ss_finish<T>(AT<T>(m->logits), 8, 0, 0, len, col0, m->ss_cols, m->metaC, m->vp_max, m->vp_sums, m->ss_tl, m->vp_nlive,
                            m->vp_pre, m->sh_rank, m->loss_acc + 3 * ti, m->ss_dt, npad, s));   // a rank without classes of this medium still owns loss rows
   toc(m);
   if (!bwd) return RSYS_OK;
@@ -863,15 +868,15 @@ static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive,
     {
       GemmParams p{};  // d(selected rows) = dlogits . F[sampled rows]
       p.A = m->logits; p.lda = lds; p.B = m->ss_F; p.ldb = D; p.C = m->dEwC; p.ldc = D; p.c_f32 = 1;
-      p.M = cap; p.N = D; p.K = n_s; p.epi = EPI_ATOMIC; p.m_dev = m->vp_nlive;
+      p.M = cap; p.N = D; p.K = n_tot; p.epi = EPI_ATOMIC; p.m_dev = m->vp_nlive;
       RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
     }
     {
       GemmParams p{};  // dF[sampled rows] = dlogits^T . (selected rows of all ranks), then added to the table gradient rows
       p.A = m->logits; p.lda = lds; p.B = m->EwC; p.ldb = D; p.C = m->ss_dF; p.ldc = D; p.c_f32 = 1;
-      p.M = n_s; p.N = D; p.K = cap; p.epi = EPI_STORE; p.k_dev = m->vp_nlive;
+      p.M = n_tot; p.N = D; p.K = cap; p.epi = EPI_STORE; p.k_dev = m->vp_nlive;
       RC(gemm<T>(m, "gemm_head_dw", p, false, true, true));
-      RC(launch_add_rows_plain(m->ss_dF, m->ss_cols, lrow, m->G + m->o_E, D, n_s, D, s));
+      RC(launch_add_rows_plain(m->ss_dF, m->ss_cols, lrow, m->G + m->o_E, D, n_tot, D, s));
     }
     RC(launch_ss_target_grad<T>(AT<T>(m->EwC), Floc, D, len, col0, m->metaC, m->ss_dt, m->vp_nlive, m->G + m->o_E + (int64_t)lrow * D, m->dEwC, nlive, s));
   }
@@ -902,14 +907,22 @@ static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd
   RC(comm_all_gather(c, m->Ew, m->EwAll, (size_t)KBmax * D * m->esz, s));
   RC(comm_all_gather(c, m->metaOwn, m->metaAll, ((size_t)KBmax * 4 + 4) * 4, s));
   RC(launch_vp_compact<T>(AT<T>(m->EwAll), m->metaAll, W, KBmax, D, AT<T>(m->EwC), m->metaC, m->vp_nlive, m->vp_pre, s));
+  // sampled soft-max (training passes only; an evaluation reports the exact loss): list the in-batch targets among this rank's
+  // classes behind the slots of the sampled ones -- unless every class is sampled anyway
+  const bool sampled = m->cfg.sampled_negatives > 0 && train;
+  const int ss_ns = sampled ? std::min(len, m->cfg.sampled_negatives) : 0;
+  const bool ss_targets = sampled && ss_ns > 0 && ss_ns < len;
+  if (ss_targets) RC(launch_ss_targets(m->metaC, m->vp_nlive, W * KBmax, len, col0, m->ss_bitmap, m->ss_cols + ss_ns, m->ss_tcount, s));
   std::vector<int> pre(W + 1);
+  int n_t = 0;
   HIP_CHECK(hipMemcpyAsync(pre.data(), m->vp_pre, (W + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (ss_targets) HIP_CHECK(hipMemcpyAsync(&n_t, m->ss_tcount, 4, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));   // (the one host sync of the step: the sizes of the collectives below)
   const int nlive = pre[W], cap = W * KBmax, own0 = pre[m->sh_rank], nown = pre[m->sh_rank + 1] - own0;
   if (nlive == 0) return RSYS_OK;
   const int npad = std::min(cap, (nlive + 255) & ~255);
-  if (m->cfg.sampled_negatives > 0)
-    return watch_head_sampled<T>(m, ti, medium, bwd, nlive, npad, own0, nown, len, col0, lrow);
+  if (sampled)
+    return watch_head_sampled<T>(m, ti, medium, bwd, nlive, npad, own0, nown, len, col0, lrow, n_t);
   if (len > 0) {
     GemmParams p{};
     p.A = m->EwC; p.lda = D; p.B = Fm; p.ldb = D; p.C = m->logits; p.ldc = m->ldl_loc;

@@ -100,6 +100,7 @@ struct Model {
   int64_t ldl_loc = 0; float* sumsq_E = nullptr;
   // sampled softmax: sampled local classes, their rows of F, the rows' gradients, target logits and their gradients
   int* ss_cols = nullptr; void* ss_F = nullptr; float *ss_dF = nullptr, *ss_tl = nullptr, *ss_dt = nullptr;
+  unsigned int* ss_bitmap = nullptr; int* ss_tcount = nullptr;   // in-batch targets: bitmap over the local classes of a medium, their number
   unsigned long long cur_seed = 0, cur_step = 0;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int rope_npos = 0;

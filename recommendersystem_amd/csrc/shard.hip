@@ -281,21 +281,23 @@ int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* 
   return RSYS_OK;
 }
 // ------------------------------------------------------------------ sampled softmax (cfg-4 option; no reference counterpart)
-// Per (step, medium) a rank draws n_s of its `len` local classes by stratified uniform sampling (one per stratum of
-// len / n_s classes: distinct, sorted, inclusion probability q = n_s / len each).  The loss of a row with target t is the
-// full soft-max loss with the partition function estimated by importance weighting (the log-Q correction):
-//     Z ~= exp(l_t) + sum over ranks (1 / q_r) sum_{j in S_r, j != t} exp(l_j),     loss = log Z - l_t
-// so it stays on the scale of the full soft-max loss; a sampled class that IS the row's target is skipped (accidental hit).
+// Per (step, medium) a rank draws n_s of its `len` local classes by stratified sampling: stratum j = classes
+// [floor(j len / n_s), floor((j + 1) len / n_s)), one class uniformly from each (distinct, sorted).  A class of a stratum of
+// s_j classes is included with probability exactly 1 / s_j, so the partition function of a row with target t is estimated by
+//     Z ~= exp(l_t) + sum over ranks sum_{j : c_j != t} s_j exp(l_{c_j}),     loss = log Z - l_t
+// (importance weighting = the log-Q correction with the TRUE inclusion probability of each sampled class; a sampled class that
+// IS the row's target is skipped: the target's term is exact).  The weights must be the strata's own sizes: one global factor
+// len / n_s over strata of unequal size leaves the classes of the larger strata under-weighted for good, and a peaked model
+// trained that way drifts (tools/converge_sampled.py).
+__device__ __forceinline__ int ss_stratum_lo(int j, int len, int n_s) { return (int)((long long)j * len / n_s); }
 __global__ void ss_sample_kernel(int len, int n_s, unsigned long long seed, unsigned int stream, int* cols) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_s) return;
   Philox ph(seed);
   uint32_t r[4];
   ph.gen((unsigned long long)j, stream, r);
-  const double w = (double)len / (double)n_s;
-  int c = (int)(((double)j + (double)u01(r[0])) * w);
-  const int lo = (int)((double)j * w), hi = max(lo, (int)((double)(j + 1) * w) - 1);   // keep the draw inside its own stratum
-  cols[j] = min(max(c, lo), min(hi, len - 1));
+  const int lo = ss_stratum_lo(j, len, n_s), size = ss_stratum_lo(j + 1, len, n_s) - lo;   // size >= 1 (n_s <= len)
+  cols[j] = lo + min(size - 1, (int)(u01(r[0]) * (float)size));
 }
 int launch_ss_sample(int len, int n_s, unsigned long long seed, unsigned int stream, int* cols, hipStream_t s) {
   ARG_CHECK(n_s >= 1 && n_s <= len, "sampled softmax: 1 <= samples <= local classes");
@@ -304,14 +306,68 @@ int launch_ss_sample(int len, int n_s, unsigned long long seed, unsigned int str
   return RSYS_OK;
 }
 
-// dst[j] = src[(base + idx[j]) * ld ..+D)  (T rows, 16-byte copies)
+// In-batch targets.  The classes that ARE some live row's target this step are the ones that receive a pull-up gradient; with
+// uniform sampling alone each of them would be pushed down only every 1/q-th step (with weight 1/q), and on a Zipf-shaped
+// vocabulary that variance is what makes a small-sample run drift.  So every local class that is a target of the gathered rows
+// joins the class list of the step deterministically (weight 1), behind the n_s sampled ones; a sampled class that is also in
+// that set is dropped (index -1: zero row, zero gradient), so the estimator stays unbiased:
+//     Z ~= exp(l_t) + sum_{c in T, c != t} exp(l_c) + sum_j s_j exp(l_{c_j}) [c_j not in T].
+__global__ void ss_mark_targets_kernel(const float* __restrict__ metaC, const int* __restrict__ nlive, int len, int col0, unsigned int* bitmap) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= *nlive) return;
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  if (tgt >= 0 && tgt < len) atomicOr(&bitmap[tgt >> 5], 1u << (tgt & 31));
+}
+// ascending list of the marked classes -> out[0 .. *count); one workgroup of 1024 threads, a contiguous run of words each
+__global__ __launch_bounds__(1024) void ss_list_targets_kernel(const unsigned int* __restrict__ bitmap, int words, int* out, int* count) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (words + 1023) / 1024, w0 = t * per, w1 = min(words, w0 + per);
+  int n = 0;
+  for (int w = w0; w < w1; ++w) n += __popc(bitmap[w]);
+  part[t] = n;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int at = part[t] - n;
+  for (int w = w0; w < w1; ++w) {
+    unsigned int b = bitmap[w];
+    while (b) { const int bit = __ffs(b) - 1; out[at++] = w * 32 + bit; b &= b - 1; }
+  }
+  if (t == 1023) *count = part[1023];
+}
+__global__ void ss_drop_hits_kernel(int* cols, int n_s, const unsigned int* __restrict__ bitmap) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_s) return;
+  const int c = cols[j];
+  if ((bitmap[c >> 5] >> (c & 31)) & 1u) cols[j] = -1;
+}
+int launch_ss_targets(const float* metaC, const int* nlive, int cap_rows, int len, int col0, unsigned int* bitmap, int* out, int* count, hipStream_t s) {
+  const int words = (len + 31) / 32;
+  HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)words * 4, s));
+  hipLaunchKernelGGL(ss_mark_targets_kernel, dim3(div_up(cap_rows, 256)), dim3(256), 0, s, metaC, nlive, len, col0, bitmap);
+  hipLaunchKernelGGL(ss_list_targets_kernel, dim3(1), dim3(1024), 0, s, bitmap, words, out, count);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+int launch_ss_drop_hits(int* cols, int n_s, const unsigned int* bitmap, hipStream_t s) {
+  hipLaunchKernelGGL(ss_drop_hits_kernel, dim3(div_up(n_s, 256)), dim3(256), 0, s, cols, n_s, bitmap);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+// dst[j] = src[(base + idx[j]) * ld ..+D)  (T rows, 16-byte copies); idx[j] < 0: zeros
 template <typename T>
 __global__ void gather_rows_plain_kernel(const T* __restrict__ src, long long ld, const int* __restrict__ idx, int base, T* dst, int n, int D) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
   if (j >= n) return;
   constexpr int E = 16 / sizeof(T);
-  const uint4* s4 = (const uint4*)(src + (long long)(base + idx[j]) * ld);
   uint4* d4 = (uint4*)(dst + (long long)j * D);
+  if (idx[j] < 0) { for (int c = l; c < D / E; c += 64) d4[c] = make_uint4(0, 0, 0, 0); return; }   // dropped entry: a zero row
+  const uint4* s4 = (const uint4*)(src + (long long)(base + idx[j]) * ld);
   for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
 }
 template <typename T>
@@ -320,10 +376,10 @@ int launch_gather_rows_plain(const T* src, long long ld, const int* idx, int bas
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-// dst[(base + idx[j])] += src[j]  (f32 rows; idx distinct)
+// dst[(base + idx[j])] += src[j]  (f32 rows; the non-negative idx are distinct, negative ones are skipped)
 __global__ void add_rows_plain_kernel(const float* __restrict__ src, const int* __restrict__ idx, int base, float* dst, long long ld, int n, int D) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
-  if (j >= n) return;
+  if (j >= n || idx[j] < 0) return;
   const float4* s4 = (const float4*)(src + (long long)j * D);
   float4* d4 = (float4*)(dst + (long long)(base + idx[j]) * ld);
   for (int c = l; c < (D >> 2); c += 64) {
@@ -353,20 +409,22 @@ __global__ void ss_target_logit_kernel(const T* __restrict__ EwC, const T* __res
   }
   if (l == 0) tl[row] = acc;
 }
-// local maximum / sum-exp over the sampled classes, the accidental hit (sampled class == the row's target) left out
+// local maximum / sum-exp over the sampled classes, each weighted by its stratum's size (l + log s_j), the accidental hit
+// (sampled class == the row's target) left out
 template <typename T>
-__global__ __launch_bounds__(256) void ss_stats_kernel(const T* __restrict__ logits, long long ldl, int n_s, int col0,
+__global__ __launch_bounds__(256) void ss_stats_kernel(const T* __restrict__ logits, long long ldl, int n_s, int n_tot, int len, int col0,
                                                        const int* __restrict__ cols, const float* __restrict__ metaC,
                                                        const int* __restrict__ nlive, float* lmax, float* lsum) {
   __shared__ float red[16];
   const int row = blockIdx.x, t = threadIdx.x;
-  if (row >= *nlive || n_s <= 0) { if (t == 0) { lmax[row] = -3.0e38f; lsum[row] = 0.f; } return; }
+  if (row >= *nlive || n_tot <= 0) { if (t == 0) { lmax[row] = -3.0e38f; lsum[row] = 0.f; } return; }
   const T* lr = logits + (long long)row * ldl;
   const int tgt = __float_as_int(metaC[4LL * row]) - col0;
   float m = -3.0e38f, ssum = 0.f;
-  for (int c = t; c < n_s; c += 256) {
-    if (cols[c] == tgt) continue;
-    const float x = to_f32(lr[c]);
+  for (int c = t; c < n_tot; c += 256) {
+    if (cols[c] == tgt || cols[c] < 0) continue;
+    float x = to_f32(lr[c]);
+    if (c < n_s) x += __logf((float)(ss_stratum_lo(c + 1, len, n_s) - ss_stratum_lo(c, len, n_s)));   // + log s_j (in-batch targets: weight 1)
     if (x > m) { ssum = ssum * __expf(m - x) + 1.f; m = x; }
     else ssum += __expf(x - m);
   }
@@ -379,17 +437,17 @@ __global__ void ss_max_with_target_kernel(const float* __restrict__ lmax, const 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fmaxf(lmax[i], tl[i]);
 }
-// sneg = lsum * exp(lmax - gmax) / q: this rank's share of the negatives' partition sum (before the sum all-reduce)
-__global__ void ss_rebase_kernel(const float* __restrict__ lmax, const float* __restrict__ gmax, float* lsum, float inv_q, int n) {
+// sneg = lsum * exp(lmax - gmax): this rank's share of the negatives' (weighted) partition sum (before the sum all-reduce)
+__global__ void ss_rebase_kernel(const float* __restrict__ lmax, const float* __restrict__ gmax, float* lsum, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) lsum[i] = lsum[i] > 0.f ? lsum[i] * __expf(lmax[i] - gmax[i]) * inv_q : 0.f;
+  if (i < n) lsum[i] = lsum[i] > 0.f ? lsum[i] * __expf(lmax[i] - gmax[i]) : 0.f;
 }
 // lse = gmax + log(exp(tl - gmax) + sneg); own rows add (lse - tl) lw to the loss; dlogits over the sampled classes
-// (coef exp(l - lse) / q, 0 at an accidental hit); dt[row] = coef (exp(tl - lse) - 1) for the target's owner
+// (coef s_j exp(l - lse), 0 at an accidental hit); dt[row] = coef (exp(tl - lse) - 1) for the target's owner
 template <typename T>
-__global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl, int n_s, int col0, const int* __restrict__ cols,
+__global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* __restrict__ cols,
                                                         const float* __restrict__ metaC, const float* __restrict__ gmax,
-                                                        const float* __restrict__ sneg, const float* __restrict__ tl, float inv_q,
+                                                        const float* __restrict__ sneg, const float* __restrict__ tl,
                                                         const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
                                                         float* loss_out, float* dt) {
   const int row = blockIdx.x, t = threadIdx.x;
@@ -406,7 +464,8 @@ __global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl
   }
   for (int c = t; c < (int)ldl; c += 256) {
     float g = 0.f;
-    if (c < n_s && cols[c] != tgt) g = coef * __expf(to_f32(lr[c]) - lse) * inv_q;
+    if (c < n_tot && cols[c] != tgt && cols[c] >= 0)
+      g = coef * __expf(to_f32(lr[c]) - lse) * (c < n_s ? (float)(ss_stratum_lo(c + 1, len, n_s) - ss_stratum_lo(c, len, n_s)) : 1.f);
     lr[c] = from_f32<T>(g);
   }
 }
@@ -433,9 +492,9 @@ int launch_ss_target_logit(const T* EwC, const T* Floc, int D, int len, int col0
   return RSYS_OK;
 }
 template <typename T>
-int launch_ss_stats(const T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const int* nlive,
+int launch_ss_stats(const T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* cols, const float* metaC, const int* nlive,
                     float* lmax, float* lsum, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((ss_stats_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, col0, cols, metaC, nlive, lmax, lsum);
+  hipLaunchKernelGGL((ss_stats_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, n_tot, len, col0, cols, metaC, nlive, lmax, lsum);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -444,16 +503,16 @@ int launch_ss_max_with_target(const float* lmax, const float* tl, float* out, in
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, float inv_q, int n, hipStream_t s) {
-  hipLaunchKernelGGL(ss_rebase_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, lmax, gmax, lsum, inv_q, n);
+int launch_ss_rebase(const float* lmax, const float* gmax, float* lsum, int n, hipStream_t s) {
+  hipLaunchKernelGGL(ss_rebase_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, lmax, gmax, lsum, n);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 template <typename T>
-int launch_ss_finish(T* logits, long long ldl, int n_s, int col0, const int* cols, const float* metaC, const float* gmax,
-                     const float* sneg, const float* tl, float inv_q, const int* nlive, const int* pre, int rank, float* loss_out,
+int launch_ss_finish(T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* cols, const float* metaC, const float* gmax,
+                     const float* sneg, const float* tl, const int* nlive, const int* pre, int rank, float* loss_out,
                      float* dt, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((ss_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, col0, cols, metaC, gmax, sneg, tl, inv_q,
+  hipLaunchKernelGGL((ss_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, n_tot, len, col0, cols, metaC, gmax, sneg, tl,
                      nlive, pre, rank, loss_out, dt);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
@@ -475,8 +534,8 @@ INST(float)
 #define INST(T)                                                                                                          \
   template int launch_gather_rows_plain<T>(const T*, long long, const int*, int, T*, int, int, hipStream_t);               \
   template int launch_ss_target_logit<T>(const T*, const T*, int, int, int, const float*, const int*, float*, int, hipStream_t); \
-  template int launch_ss_stats<T>(const T*, long long, int, int, const int*, const float*, const int*, float*, float*, int, hipStream_t); \
-  template int launch_ss_finish<T>(T*, long long, int, int, const int*, const float*, const float*, const float*, const float*, float, const int*, const int*, int, float*, float*, int, hipStream_t); \
+  template int launch_ss_stats<T>(const T*, long long, int, int, int, int, const int*, const float*, const int*, float*, float*, int, hipStream_t); \
+  template int launch_ss_finish<T>(T*, long long, int, int, int, int, const int*, const float*, const float*, const float*, const float*, const int*, const int*, int, float*, float*, int, hipStream_t); \
   template int launch_ss_target_grad<T>(const T*, const T*, int, int, int, const float*, const float*, const int*, float*, float*, int, hipStream_t);
 INST(bf16)
 INST(float)
