@@ -45,6 +45,9 @@ def lib():
         L.cpu_step_sgemm_nt.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
         L.cpu_step_isa.restype = ctypes.c_int
         L.cpu_step_set_threads.argtypes = [ctypes.c_int]
+        # one thread per CPU this process is GRANTED: OpenMP's default is one per visible core, and 256 spinning threads on a
+        # 16-CPU cgroup quota run the step ~10x slower (measured on the GPU box)
+        L.cpu_step_set_threads(host_cpus())
         _lib = L
     return _lib
 
