@@ -35,7 +35,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r2b_pmc_traffic.json"
+TRAFFIC_FILE = "r2c_pmc_traffic.json"
 
 
 def traffic_of(db, variant):
