@@ -882,3 +882,46 @@ def test_full_size_cfg2_parity_and_properties():
     model(dp, True, masks=(wm[perm], rm[perm]))
     assert np.array_equal(model.trunk_output(rows), y0[perm])
     model.close()
+
+
+ODD_SHAPES = [
+    # embed_dim, heads, kv heads, intermediate, seq, vocab 0 / 1, metadata, topk, rows
+    dict(D=192, H=3, KV=1, I=520, S=40, V0=777, V1=1234, M=37, K=5, rows=3),      # hd 64, 3 query heads per kv head, T = 80
+    dict(D=64, H=4, KV=4, I=72, S=24, V0=9, V1=11, M=3, K=3, rows=1),              # hd 16, no GQA sharing, tiny vocabularies
+    dict(D=320, H=5, KV=5, I=904, S=136, V0=2049, V1=513, M=129, K=17, rows=2),    # T = 272: 4 full + 1 partial attention tile
+]
+
+
+@pytest.mark.parametrize("shape", ODD_SHAPES)
+@pytest.mark.parametrize("dtype,tol_loss,tol_act,tol_grad", [("fp32", 1e-4, 1e-4, 5e-4), ("bf16", 4e-2, 6e-2, 1.5e-1)])
+def test_irregular_shapes_vs_oracle(shape, dtype, tol_loss, tol_act, tol_grad):
+    """Shapes no tile size divides (the reference accepts any configuration with head_dim 16 or 64 here): sequence lengths
+    that leave partial attention tiles, intermediate / vocabulary / metadata sizes that leave partial GEMM tiles and odd
+    leading dimensions, 1:1 and 3:1 query-to-kv head ratios, a single row."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("tiny", mask_rate=0.2, mask_topk=shape["K"], num_heads=shape["H"], num_kv_heads=shape["KV"],
+                            embed_dim=shape["D"], intermediate_dim=shape["I"], max_sequence_length=shape["S"],
+                            metadata_emb_size=shape["M"])
+    cfg["vocab_sizes"]["0_matchedid"] = shape["V0"]; cfg["vocab_sizes"]["1_matchedid"] = shape["V1"]
+    rows, seed = shape["rows"], 61
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1, mu=2.5, sigma=0.9)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    y_ref, l_ref, G_ref, ev_ref = _oracle(cfg, P, d, wm, rm)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    assert relerr(model.trunk_output(rows), y_ref) < tol_act
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, l_ref)
+    worst = ("", 0.0)
+    for n in synth.trainable_names(cfg):
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-3 * np.sqrt((G_ref[n] ** 2).mean()) + 1e-12)
+        e = float(np.abs(g - G_ref[n]).max() / max(scale, 1e-6))
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < tol_grad, worst
+    model.close()
