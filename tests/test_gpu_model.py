@@ -889,6 +889,8 @@ ODD_SHAPES = [
     dict(D=192, H=3, KV=1, I=520, S=40, V0=777, V1=1234, M=37, K=5, rows=3),      # hd 64, 3 query heads per kv head, T = 80
     dict(D=64, H=4, KV=4, I=72, S=24, V0=9, V1=11, M=3, K=3, rows=1),              # hd 16, no GQA sharing, tiny vocabularies
     dict(D=320, H=5, KV=5, I=904, S=136, V0=2049, V1=513, M=129, K=17, rows=2),    # T = 272: 4 full + 1 partial attention tile
+    dict(D=128, H=4, KV=2, I=344, S=36, V0=301, V1=222, M=20, K=4, rows=2),        # hd 32
+    dict(D=256, H=2, KV=1, I=696, S=68, V0=150, V1=333, M=41, K=7, rows=2),        # hd 128
 ]
 
 
