@@ -11,75 +11,63 @@ from . import model_np, synth
 
 
 def wsd_factor(step, warmup_steps, total_steps, decay_ratio=0.1, final_ratio=0.1):
-    """train.py:310-328 WSDScheduler.__call__."""
-    decay_steps = int(total_steps * decay_ratio)
-    stable_steps = total_steps - warmup_steps - decay_steps
-    assert stable_steps >= 0
-    s = max(0, min(int(step), total_steps))
-    if s <= warmup_steps:
-        return s / max(1, warmup_steps)
-    if s <= warmup_steps + stable_steps:
-        return 1.0
-    prog = (s - warmup_steps - stable_steps) / max(1, decay_steps)
-    return 1.0 - (1.0 - final_ratio) * prog
+    """train.py:310-328 WSDScheduler.__call__ as the lower envelope of two ramps: the warm-up line through the origin capped
+    at 1, and the line that leaves 1 at the start of the decay and reaches `final_ratio` at `total_steps`."""
+    n_decay = int(total_steps * decay_ratio)
+    decay_start = total_steps - n_decay
+    assert decay_start >= warmup_steps
+    s = min(max(int(step), 0), total_steps)
+    rising = min(1.0, s / max(1, warmup_steps))
+    falling = 1.0 - (1.0 - final_ratio) * max(0, s - decay_start) / max(1, n_decay)
+    return min(rising, falling)
+
+
+_LOSS_SCALE = np.array([4.618602403897067, 1.1958987168236102, 2.5443243303769867, 1.0527565486045412])   # train.py:395-400, TASKS order
 
 
 def make_task_weights(finetune_medium=None, finetune_metric=None):
-    """train.py:379-406."""
-    scale = {(0, "watch"): 4.618602403897067, (0, "rating"): 1.1958987168236102,
-             (1, "watch"): 2.5443243303769867, (1, "rating"): 1.0527565486045412}
-    if finetune_metric is None:
-        mw = {"watch": 1, "rating": 0.25}
-    else:
-        mw = {"watch": 0, "rating": 0}; mw[finetune_metric] = 1
-    if finetune_medium is None:
-        dw = {0: 0.25, 1: 1}
-    else:
-        dw = {finetune_medium: 1, 1 - finetune_medium: 0}
-    w = [dw[m] * mw[k] for (m, k) in model_np.TASKS]
-    tot = sum(w)
-    return [x / tot / scale[t] for x, t in zip(w, model_np.TASKS)]
+    """train.py:379-406: (medium weight x metric weight), normalised to sum 1, divided by each task's loss scale."""
+    per_medium = np.array([0.25, 1.0]) if finetune_medium is None else np.eye(2)[finetune_medium]
+    per_metric = np.array([1.0, 0.25]) if finetune_metric is None else np.eye(2)[model_np.ALL_METRICS.index(finetune_metric)]
+    w = np.array([per_medium[m] * per_metric[model_np.ALL_METRICS.index(k)] for (m, k) in model_np.TASKS])
+    return list(w / w.sum() / _LOSS_SCALE)
 
 
 def minimize_quadratic(x, y):
-    """train.py:187-196."""
-    if max(y) == min(y):
-        return float(max(y))
-    A = np.array([[xi ** 2, xi, 1] for xi in x], np.float64)
-    a, b, c = np.linalg.solve(A, np.array(y, np.float64))
-    xe = -b / (2 * a)
-    return float(a * xe ** 2 + b * xe + c)
+    """train.py:187-196: the value at the vertex of the parabola through three points (a constant when the points are level)."""
+    y = np.asarray(y, np.float64)
+    if np.ptp(y) == 0:
+        return float(y[0])
+    a, b, c = np.polyfit(np.asarray(x, np.float64), y, 2)
+    return float(c - b * b / (4 * a))
 
 
 def block_permutation_indices(userid, block_perm):
-    """train.py:53-68 get_index_permutation with the block permutation supplied:
-    split at userid change points, emit whole user blocks in `block_perm` order."""
+    """train.py:53-68 get_index_permutation with the block permutation supplied: cut the stream where the userid changes
+    and emit the users' index runs in `block_perm` order."""
     userid = np.asarray(userid)
-    change = np.where(userid[:-1] != userid[1:])[0] + 1
-    starts = np.concatenate([[0], change]); ends = np.concatenate([change, [len(userid)]])
-    return np.concatenate([np.arange(starts[b], ends[b]) for b in block_perm]).astype(np.int64)
+    runs = np.split(np.arange(len(userid), dtype=np.int64), np.flatnonzero(np.diff(userid)) + 1)
+    return np.concatenate([runs[b] for b in block_perm])
 
 
 class EarlyStopper:
-    """train.py:350-372."""
+    """train.py:350-372: patience counted against the best score seen by a relative margin; `save_model` whenever the score
+    beats the best SAVED score (any margin)."""
 
     def __init__(self, patience, rtol):
         self.patience, self.rtol = patience, rtol
         self.counter = 0
-        self.stop_score = float("inf"); self.saved_score = float("inf")
-        self.early_stop = False; self.save_model = False
+        self.early_stop = self.save_model = False
+        self._bar = self._saved = float("inf")
 
     def __call__(self, score):
-        if score < self.stop_score * (1 - self.rtol):
-            self.counter = 0; self.stop_score = score
-        else:
-            self.counter += 1
-            if self.counter >= self.patience:
-                self.early_stop = True
-        if score < self.saved_score:
-            self.saved_score = score; self.save_model = True
-        else:
-            self.save_model = False
+        improved = score < self._bar * (1 - self.rtol)
+        self.counter = 0 if improved else self.counter + 1
+        if improved:
+            self._bar = score
+        self.early_stop = self.early_stop or self.counter >= self.patience
+        self.save_model = score < self._saved
+        self._saved = min(self._saved, score)
 
 
 def clip_grad_norm(G, max_norm=1.0):
