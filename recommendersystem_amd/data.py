@@ -28,13 +28,16 @@ def load_shard(fn):
 
 
 def get_index_permutation(arr, rng):
-    """train.py:53-68: split at userid change points, permute the user blocks, keep order inside a block."""
+    """train.py:53-68: the stream is cut where the userid changes, the users' runs are drawn in a random order (one
+    `rng.permutation` over the runs, as the reference draws it), positions inside a run keep their order."""
     arr = np.asarray(arr)
-    change_indices = np.where(arr[:-1] != arr[1:])[0] + 1
-    starts = np.concatenate([[0], change_indices])
-    ends = np.concatenate([change_indices, [len(arr)]])
-    block_permutation = rng.permutation(len(starts))
-    return np.concatenate([np.arange(starts[b], ends[b]) for b in block_permutation]).astype(np.int64)
+    cuts = np.flatnonzero(arr[1:] != arr[:-1]) + 1
+    first = np.r_[0, cuts]
+    length = np.diff(np.r_[first, len(arr)])
+    order = rng.permutation(len(first))
+    # gather all runs at once: position i of the output belongs to run order[j], offset i - (start of slot j)
+    slot_start = np.cumsum(length[order]) - length[order]
+    return (np.repeat(first[order] - slot_start, length[order]) + np.arange(len(arr))).astype(np.int64)
 
 
 def block_shuffle(d, rng):
