@@ -41,16 +41,17 @@ def _run(dtype):
 
 
 def test_fp32_training_curve_follows_the_oracle_for_40_steps():
+    """fp32 mode: 1e-4 on every loss of 40 consecutive optimizer steps (north_star's tolerance, held along a trajectory)"""
     g, c, dev, norms = _run("fp32")
     assert c[-1, 0] < c[0, 0] - 0.3 and c[-1, 2] < c[0, 2] - 0.3, c[[0, -1]]        # the model does learn on this stream
     rel = np.abs(g - c) / np.maximum(np.abs(c), 1e-3)
-    assert rel[:5].max() <= 1e-4, rel[:5]                                           # the first steps: one-step parity
-    assert rel.max() <= 2e-3, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))
-    assert max(dev.values()) <= 2e-2, sorted(dev.items(), key=lambda kv: -kv[1])[:3]
+    assert rel[:5].max() <= 1e-5, rel[:5]                                           # measured 1.6e-7
+    assert rel.max() <= 1e-4, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))     # measured 8e-7 .. 9e-7 after 40 steps
+    assert max(dev.values()) <= 5e-3, sorted(dev.items(), key=lambda kv: -kv[1])[:3]     # measured 8e-4 of the tensor's magnitude
 
 
-def test_bf16_training_curve_stays_within_a_percent_of_the_fp32_oracle():
+def test_bf16_training_curve_stays_close_to_the_fp32_oracle():
     g, c, dev, norms = _run("bf16")
     rel = np.abs(g - c) / np.maximum(np.abs(c), 1e-3)
-    assert rel.max() <= 2e-2, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))
+    assert rel.max() <= 6e-3, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))     # measured 0.9e-3 .. 1.2e-3
     assert g[-1, 0] < g[0, 0] - 0.3 and g[-1, 2] < g[0, 2] - 0.3
