@@ -111,11 +111,15 @@ int32_t rsys_forward_backward(rsys_model* m, int32_t evaluate, const float task_
 int32_t rsys_losses_get(rsys_model* m, float losses_out[12], float weight_sums_out[4]);
 /* number of positive-weight positions selected per task in the last forward (they bound the head GEMMs) */
 int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
-/* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
 /* ItemEmbedding.forward over all items (model.py:139-145), the table Finetune/register.py:27-33 exports as the watch-head
  * weights of the serving registry: out [V][embed_dim] f32, V = vocab_0 + vocab_1 (manga rows first) */
 int32_t rsys_item_table(rsys_model* m, float* out, int64_t n);
+/* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
 int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
+/* the same forward, returning only the tokens a server reads (Finetune/embed.py:147-161 takes token 2n of a user for
+ * retrieval and the candidates' action tokens for ranking): token_index[n_tokens] = flat token indices in [0, rows*2S);
+ * out = n_tokens*D floats (retrieval: the trunk output rows) or n_tokens floats (ranking: the rating head on those rows only) */
+int32_t rsys_infer_select(rsys_model* m, int32_t task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n);
 /* debug/parity: trunk output of the last forward (rows*2S*D floats) */
 int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);
 

@@ -74,6 +74,14 @@ function losses(m::Model)
     lo, ws
 end
 
+# inference forward (model.py:531-538): task 0 = retrieval, 1 = ranking; `tokens` = flat token indices (0-based) to report
+function infer_select(m::Model, task::Integer, tokens::Vector{Int32}, D::Integer)
+    out = task == 0 ? Matrix{Float32}(undef, D, length(tokens)) : Vector{Float32}(undef, length(tokens))
+    GC.@preserve tokens out check(ccall((:rsys_infer_select, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}, Int64, Ptr{Float32}, Int64),
+                                        m.h, task, tokens, length(tokens), out, length(out)))
+    out
+end
+
 function create_optimizer(m::Model; lr = 1f-4, betas = (0.9f0, 0.95f0), eps = 1f-8, weight_decay = 0.1f0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:rsys_adamw_create, LIB), Int32, (Ptr{Cvoid}, Float32, Float32, Float32, Float32, Float32, Ref{Ptr{Cvoid}}),

@@ -70,6 +70,7 @@ _SIGS = [
     ("rsys_head_rows_get", C.c_int32, [_P, C.POINTER(C.c_int32 * 4)]),
     ("rsys_item_table", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_infer", C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
+    ("rsys_infer_select", C.c_int32, [_P, C.c_int32, _P, C.c_int64, _P, C.c_int64]),
     ("rsys_trunk_output_get", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_debug_get", C.c_int32, [_P, C.c_char_p, _P, C.c_int64]),
     ("rsys_clip_grad_norm", C.c_int32, [_P, C.c_float, C.POINTER(C.c_float)]),

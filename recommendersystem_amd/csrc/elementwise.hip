@@ -539,6 +539,41 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
 template int launch_rating_tail<bf16>(bf16*, const bf16*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
 template int launch_rating_tail<float>(float*, const float*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
 
+// --------------------------------------------------------------------- inference outputs (model.py:531-538)
+// dst[i] = (float)src[i]: the trunk output leaves the device as float32 in one copy
+template <typename T>
+__global__ void widen_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = to_f32(src[i]);
+}
+template <typename T>
+int launch_widen(const T* src, float* dst, long long n, hipStream_t s) {
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL((widen_kernel<T>), dim3(blocks), dim3(256), 0, s, src, dst, n);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_widen<bf16>(const bf16*, float*, long long, hipStream_t);
+template int launch_widen<float>(const float*, float*, long long, hipStream_t);
+// out[r] = <h[r, :], w> + b[0]  (second layer of the rating head over every token); one wave per row
+template <typename T>
+__global__ void rowdot_kernel(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b, float* out, int n, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n) return;
+  const T* hr = h + (long long)row * D;
+  float acc = 0.f;
+  for (int c = l; c < D; c += 64) acc += to_f32(hr[c]) * w[c];
+  acc = wave_sum(acc);
+  if (l == 0) out[row] = acc + b[0];
+}
+template <typename T>
+int launch_rowdot(const T* h, const float* w, const float* b, float* out, int n, int D, hipStream_t s) {
+  hipLaunchKernelGGL((rowdot_kernel<T>), dim3(div_up(n, 4)), dim3(256), 0, s, h, w, b, out, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_rowdot<bf16>(const bf16*, const float*, const float*, float*, int, int, hipStream_t);
+template int launch_rowdot<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
+
 // --------------------------------------------------------------------- column sums
 template <typename TS>
 __global__ void colsum_kernel(const TS* __restrict__ src, long long ld, long long rows, int cols, float* dst, int rows_per_block) {

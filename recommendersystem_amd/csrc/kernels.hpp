@@ -170,6 +170,8 @@ int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_
                  float lr, float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div,
                  float max_norm, int zero_grad, hipStream_t s);
 template <typename T> int launch_cast(const float* src, T* dst, long long n, hipStream_t s);
+template <typename T> int launch_widen(const T* src, float* dst, long long n, hipStream_t s);
+template <typename T> int launch_rowdot(const T* h, const float* w, const float* b, float* out, int n, int D, hipStream_t s);
 // batched 2-D transposes of bf16 matrices (the weight shadows the dx GEMMs read as row-major [in][out] operands)
 struct TransposeJob { const void* src; void* dst; int rows, cols; long long ld_src, ld_dst; };
 struct TransposeBatch { TransposeJob job[64]; int n; };

@@ -321,7 +321,7 @@ int model_destroy(Model* m) {
 }
 
 int model_refresh_shadow(Model* m) {
-  m->wt_dirty = true;
+  m->wt_dirty = true; m->table_dirty = true;
   if (m->bf16_mode) RC(launch_cast<bf16>(m->P, (bf16*)m->Sh, m->n_total, m->stream));
   return RSYS_OK;
 }
@@ -380,6 +380,7 @@ int model_init_random(Model* m, uint64_t seed) {
 
 // bf16 mode: MetaT = Meta^T ([Mp][Vp], rows >= M and columns > V stay zero) for the row-major form of dWp = dF^T Meta
 static int build_meta_t(Model* m) {
+  m->table_dirty = true;   // (called whenever the metadata rows have changed)
   if (!m->bf16_mode) return RSYS_OK;
   TransposeBatch b; b.n = 1;
   b.job[0].src = (const bf16*)m->Meta; b.job[0].dst = (bf16*)m->MetaT; b.job[0].rows = m->TR; b.job[0].cols = m->Mp;
@@ -485,7 +486,7 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   }
   for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + internal_row(t, r) * t.ld, in + r * t.cols, t.cols * 4);
   HIP_CHECK(hipMemcpy(base, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-  if (which == 0) m->wt_dirty = true;
+  if (which == 0) { m->wt_dirty = true; m->table_dirty = true; }
   if (which == 0 && m->bf16_mode)
     RC(launch_cast<bf16>(base, (bf16*)m->Sh + t.off, (int64_t)host.size(), m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -724,7 +725,7 @@ static int forward_trunk(Model* m) {
   const int* rpos = b.rope_pos;
   // fused item table F = E + Meta Wp^T + bp
   tic(m, "phase_embed");
-  RC(table_forward<T>(m));
+  if (m->table_dirty) { RC(table_forward<T>(m)); m->table_dirty = false; }
   SmallParams sp = small_params(m);
   RC(launch_action_features<T>(b, sp, AT<T>(m->feat), s));
   {
@@ -1255,6 +1256,7 @@ template <typename T>
 static int finalize_grads_t(Model* m, int stage) {
   tic(m, stage == 2 ? "phase_table_bwd_gemm" : "phase_table_bwd");
   if (stage != 2) {
+    m->table_dirty = true;   // (FT is borrowed below)
     const bool fused = m->bf16_mode && m->D <= 1024 && 1024 % (m->D >> 2) == 0;
     if (fused) {   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it) + bias gradient, one pass
       RC(launch_cast_colsum(m->G + m->o_E, (bf16*)m->FT, m->TR, m->D, m->G + m->o_bp, m->stream));
@@ -1325,12 +1327,21 @@ int model_forward_backward(Model* m, int evaluate, const float task_w[4], float 
                       : forward_backward_t<float>(m, evaluate, task_w, grad_scale, seed, step);
 }
 
-// inference forward (model.py:531-538): the batch is used as given (no masking), rope positions optional
+// inference forward (model.py:531-538): the batch is used as given (no masking), rope positions optional.  `sel` (n_sel flat
+// token indices, host) restricts the output to those tokens: the rows are gathered on the device, the rating head runs on them
+// only, and what crosses PCIe is n_sel rows instead of rows * 2S.
 template <typename T>
-static int infer_t(Model* m, int task, float* out, int64_t n) {
+static int infer_t(Model* m, int task, const int32_t* sel, int64_t n_sel, float* out, int64_t n) {
   const int rows = m->cur_rows, N = rows * m->S, NT = 2 * N, D = m->D;
   hipStream_t s = m->stream;
   BatchDev b = m->bd;
+  const int KB = m->K * m->rows_max;
+  if (sel != nullptr) {
+    ARG_CHECK(n_sel <= NT, "selection: more tokens than the batch holds");
+    for (int64_t i = 0; i < n_sel; ++i) ARG_CHECK(sel[i] >= 0 && sel[i] < NT, "selection: token index out of range");
+  }
+  const int64_t ntok = sel != nullptr ? n_sel : NT;
+  ARG_CHECK(n == (task == 0 ? ntok * D : ntok), task == 0 ? "retrieval output has tokens*D floats" : "ranking output has one float per token");
   HIP_CHECK(hipMemcpyAsync(b.m_tmid, b.tmid, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_matchedid, b.matchedid, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_status, b.status, N * 4, hipMemcpyDeviceToDevice, s));
@@ -1338,45 +1349,34 @@ static int infer_t(Model* m, int task, float* out, int64_t n) {
   HIP_CHECK(hipMemcpyAsync(b.m_progress, b.progress, N * 4, hipMemcpyDeviceToDevice, s));
   m->drop_active = false;
   RC(forward_trunk<T>(m));
-  std::vector<unsigned char> host((size_t)NT * D * m->esz);
+  // the rows to report: all of m->out, or the selected ones gathered into the (free) dx buffer of the backward
+  const T* src = AT<T>(m->out);
+  if (sel != nullptr) {
+    int* d_sel = (int*)m->gf;                       // N * 32 floats: room for NT indices
+    HIP_CHECK(hipMemcpyAsync(d_sel, sel, (size_t)n_sel * 4, hipMemcpyHostToDevice, s));
+    RC(launch_gather_rows_plain<T>(AT<T>(m->out), D, d_sel, 0, AT<T>(m->dhn), (int)n_sel, D, s));
+    src = AT<T>(m->dhn);
+  }
   if (task == 0) {
-    ARG_CHECK(n == (int64_t)NT * D, "retrieval output has rows*2S*D floats");
+    // float32 on the device (the head-gradient buffer is free in an inference pass), one copy out
+    const float* f = (const float*)src;
+    if (m->bf16_mode) { RC(launch_widen<T>(src, m->gy, ntok * D, s)); f = m->gy; }
+    HIP_CHECK(hipMemcpyAsync(out, f, (size_t)ntok * D * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    HIP_CHECK(hipMemcpy(host.data(), m->out, host.size(), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < (int64_t)NT * D; ++i) {
-      if (m->bf16_mode) { uint32_t u = (uint32_t)((unsigned short*)host.data())[i] << 16; memcpy(&out[i], &u, 4); }
-      else out[i] = ((float*)host.data())[i];
-    }
     return RSYS_OK;
   }
-  ARG_CHECK(n == NT, "ranking output has rows*2S floats");
-  // rating_head on every token, in chunks of the head workspace
-  const int KB = m->K * m->rows_max;
-  std::vector<float> w2(D), zbuf;
-  float b2;
-  HIP_CHECK(hipStreamSynchronize(s));
-  HIP_CHECK(hipMemcpy(w2.data(), m->P + m->o_r2w, D * 4, hipMemcpyDeviceToHost));
-  HIP_CHECK(hipMemcpy(&b2, m->P + m->o_r2b, 4, hipMemcpyDeviceToHost));
-  std::vector<unsigned char> hh((size_t)KB * D * m->esz);
-  for (int r0 = 0; r0 < NT; r0 += KB) {
-    int nr = std::min(KB, NT - r0);
+  // rating_head (model.py:355-359) in chunks of the head workspace; predictions gather in a device vector
+  float* pred = m->delta;   // (rows_max * H * T floats >= NT; only the attention backward uses it otherwise)
+  for (int64_t r0 = 0; r0 < ntok; r0 += KB) {
+    const int nr = (int)std::min<int64_t>(KB, ntok - r0);
     GemmParams p{};
-    p.A = (unsigned char*)m->out + (size_t)r0 * D * m->esz; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->z; p.ldc = D;
+    p.A = (const unsigned char*)src + (size_t)r0 * D * m->esz; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->z; p.ldc = D;
     p.M = nr; p.N = D; p.K = D; p.epi = EPI_GELU; p.bias = m->P + m->o_r0b; p.C2 = m->hact; p.ldc2 = D;
     RC(gemm<T>(m, "gemm_rating_fwd", p, false, false, false));
-    HIP_CHECK(hipStreamSynchronize(s));
-    HIP_CHECK(hipMemcpy(hh.data(), m->hact, (size_t)nr * D * m->esz, hipMemcpyDeviceToHost));
-    for (int r = 0; r < nr; ++r) {
-      double acc = b2;
-      for (int c = 0; c < D; ++c) {
-        float hv;
-        if (m->bf16_mode) { uint32_t u = (uint32_t)((unsigned short*)hh.data())[(size_t)r * D + c] << 16; memcpy(&hv, &u, 4); }
-        else hv = ((float*)hh.data())[(size_t)r * D + c];
-        acc += (double)hv * w2[c];
-      }
-      out[r0 + r] = (float)acc;
-    }
+    RC(launch_rowdot<T>(AT<T>(m->hact), m->P + m->o_r2w, m->P + m->o_r2b, pred + r0, nr, D, s));
   }
+  HIP_CHECK(hipMemcpyAsync(out, pred, (size_t)ntok * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
   return RSYS_OK;
 }
 
@@ -1386,7 +1386,7 @@ template <typename T>
 static int item_table_t(Model* m, float* out, int64_t n) {
   ARG_CHECK(!m->sharded, "item table: export from a model with a replicated table");
   ARG_CHECK(n == (int64_t)m->V * m->D, "item table: expected V * embed_dim values");
-  RC(table_forward<T>(m));
+  if (m->table_dirty) { RC(table_forward<T>(m)); m->table_dirty = false; }
   HIP_CHECK(hipStreamSynchronize(m->stream));
   HIP_CHECK(hipMemcpy(out, m->F32, (size_t)n * 4, hipMemcpyDeviceToHost));
   return RSYS_OK;
@@ -1396,11 +1396,11 @@ int model_item_table(Model* m, float* out, int64_t n) {
   return m->bf16_mode ? item_table_t<bf16>(m, out, n) : item_table_t<float>(m, out, n);
 }
 
-int model_infer(Model* m, int task, float* out, int64_t n) {
+int model_infer(Model* m, int task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n) {
   ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
   ARG_CHECK(task == 0 || task == 1, "task: 0 retrieval, 1 ranking");
   HIP_CHECK(hipSetDevice(m->device));
-  return m->bf16_mode ? infer_t<bf16>(m, task, out, n) : infer_t<float>(m, task, out, n);
+  return m->bf16_mode ? infer_t<bf16>(m, task, token_index, n_tokens, out, n) : infer_t<float>(m, task, token_index, n_tokens, out, n);
 }
 
 // sum of squares of all gradients into m->sumsq.  Row-sharded table: the replicated gradients are identical on every rank
@@ -1446,7 +1446,7 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   o->step += 1;
   tic(m, "adamw", (m->bf16_mode ? 34.0 : 32.0) * m->n_opt);   // p, g, m, v read; p, m, v, zeroed g (+ bf16 shadow) written
   int rc;
-  if (!m->cfg.finetune) m->wt_dirty = true;   // (finetune: only the LoRA segment moves, the base weights and their transposes stay)
+  if (!m->cfg.finetune) { m->wt_dirty = true; m->table_dirty = true; }   // (finetune: only the LoRA segment moves; base weights, their transposes and the fused table stay)
   if (m->bf16_mode)
     rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                             o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);

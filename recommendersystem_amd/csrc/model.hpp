@@ -77,6 +77,9 @@ struct Model {
   void* ShT = nullptr;       // bf16 mode: the trunk weight matrices of Sh, transposed ([in][out]), same offsets: the dx GEMMs then
                              // read row-major operands (256x256 LDS-DMA kernel); rebuilt lazily when wt_dirty
   bool wt_dirty = true;
+  bool table_dirty = true;     // the fused item table F / FT must be rebuilt before the next forward: set by everything that changes a
+                               // parameter or the metadata, and by the table-gradient pass (it borrows FT); clean between the
+                               // micro-steps of one optimizer step, across finetune steps (frozen table) and across inference calls
   void* Meta = nullptr;      // [V+1][Mp] T
   float* F32 = nullptr;      // [V+1][D]
   void* FT = nullptr;        // [V+1][D] T
@@ -154,7 +157,7 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
 int model_refresh_shadow(Model* m);
 int model_batch_upload(Model* m, const rsys_batch* b);
 int model_forward_backward(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step);
-int model_infer(Model* m, int task, float* out, int64_t n);
+int model_infer(Model* m, int task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n);   // token_index == nullptr: every token
 int model_item_table(Model* m, float* out, int64_t n);
 int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);

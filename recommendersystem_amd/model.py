@@ -296,6 +296,17 @@ class RecommenderModel:
             return out
         raise AssertionError(task)
 
+    def inference_select(self, d, task, token_index):
+        """The inference forward reporting only the tokens a server reads (embed.py:147-161): `token_index` = flat token indices
+        in [0, rows * 2S).  "retrieval" -> (n, D) trunk outputs, "ranking" -> (n,) rating-head values (computed on those rows only)."""
+        self.upload(d)
+        idx = np.ascontiguousarray(np.asarray(token_index).reshape(-1), np.int32)
+        D = self.config["embed_dim"]
+        t = {"retrieval": 0, "ranking": 1}[task]
+        out = np.empty((idx.size, D) if t == 0 else (idx.size,), np.float32)
+        check(lib().rsys_infer_select(self._h, t, idx.ctypes.data, idx.size, out.ctypes.data, out.size))
+        return out
+
     def item_embeddings(self):
         """`model.item_embedding(torch.arange(0, n_0 + n_1))` (register.py:27-29): the (V, D) table E + Wp.Meta + bp."""
         V = self.config["vocab_sizes"]["0_matchedid"] + self.config["vocab_sizes"]["1_matchedid"]

@@ -111,8 +111,23 @@ def predict(model, users, task, medium, max_user_len=None, max_ranking_items=Non
         max_ranking_items = S - max_user_len if max_ranking_items is None else max_ranking_items
         assert max_user_len + max_ranking_items == S
     d = build_batch(users, task, medium, model.config["vocab_sizes"]["0_matchedid"], max_user_len, max_ranking_items)
-    embs = model.inference_forward(d, task)
-    return extract(embs, users, task, medium, max_user_len)
+    if not hasattr(model, "inference_select"):           # (a model that only has the reference's call: the full tensor, then extract)
+        return extract(model.inference_forward(d, task), users, task, medium, max_user_len)
+    # only the tokens `extract` would read leave the device (one row per user for retrieval, the candidates' action tokens for
+    # ranking) instead of the (rows, 2S, D) tensor
+    index, counts = [], []
+    for row, u in enumerate(users):
+        n = len(_history(u, max_user_len))
+        toks = [2 * n] if task == "retrieval" else list(2 * (n + np.arange(len(u["ranking_items"]))) + 1)
+        index += [row * 2 * S + int(t) for t in toks]; counts.append(len(toks))
+    key = f"{medium}.{task}"
+    if not index:
+        return [{key: []} for _ in users]
+    vals = model.inference_select(d, task, index)
+    out, at = [], 0
+    for c in counts:
+        out.append({key: (vals[at].tolist() if task == "retrieval" else vals[at:at + c].tolist())}); at += c
+    return out
 
 
 def register_transformer(model, path):

@@ -927,3 +927,38 @@ def test_irregular_shapes_vs_oracle(shape, dtype, tol_loss, tol_act, tol_grad):
             worst = (n, e)
     assert worst[1] < tol_grad, worst
     model.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_inference_select_equals_the_full_forward_and_sees_parameter_changes(dtype):
+    """rsys_infer_select reports exactly the rows rsys_infer reports for the same tokens (retrieval: trunk rows; ranking: the
+    rating head evaluated on those rows only), and the fused item table cached between inference calls is rebuilt after a
+    parameter of it changes."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("hd64")
+    rows = 3
+    S = cfg["max_sequence_length"]
+    P = synth.make_params(cfg, 9, "test")
+    d = synth.make_batch(cfg, rows, 10)
+    d["rope_input_pos"] = np.tile(np.arange(S, dtype=np.int32), rows)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+    model.load_state_dict(P)
+    full_r = model(d, "retrieval"); full_k = model(d, "ranking")
+    rng = np.random.default_rng(3)
+    idx = rng.choice(rows * 2 * S, size=37, replace=False).astype(np.int32)
+    sel_r = model.inference_select(d, "retrieval", idx)
+    sel_k = model.inference_select(d, "ranking", idx)
+    assert np.array_equal(sel_r, full_r.reshape(-1, cfg["embed_dim"])[idx])
+    assert np.allclose(sel_k, full_k.reshape(-1)[idx], rtol=1e-6, atol=1e-6)
+    again = model(d, "retrieval")                      # cached table: same bits
+    assert np.array_equal(again, full_r)
+    name = "item_embedding.projection_layer.bias"
+    model.set_parameter(name, P[name] + np.float32(0.25))
+    moved = model(d, "retrieval")
+    assert np.abs(moved - full_r).max() > 1e-3          # the table was rebuilt with the new bias
+    model.set_parameter(name, P[name])
+    assert np.array_equal(model(d, "retrieval"), full_r)
+    with pytest.raises(Exception):
+        model.inference_select(d, "retrieval", [rows * 2 * S])
+    model.close()
