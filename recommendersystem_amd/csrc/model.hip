@@ -234,7 +234,10 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     b.m_rating = (float*)carve(N * 4); b.m_progress = (float*)carve(N * 4);
     for (int k = 0; k < 4; ++k) { b.m_label[k] = (float*)carve(N * 4); b.m_weight[k] = (float*)carve(N * 4); b.m_position[k] = (int*)carve(N * 4); }
     b.watch_mask = nullptr; b.rating_mask = nullptr; b.rope_pos = nullptr;
-    DALLOC(m->d_wm, N); DALLOC(m->d_rm, N); DALLOC(m->d_rope_pos, NT * 4);
+    m->raw_bytes = (size_t)N * (4 * 6 + 8 + 4 * 2 + 18 * 4 + 2 + 8) + 64 * 32;   // raw arrays + the two masks + 2N positions + padding
+    DALLOC(m->raw_blob, m->raw_bytes);
+    HIP_CHECK(hipHostMalloc((void**)&m->h_stage, m->raw_bytes, hipHostMallocDefault));
+    m->d_wm = nullptr; m->d_rm = nullptr; m->d_rope_pos = nullptr;   // (placed in raw_blob per upload)
     DALLOC(m->tok_keys, (size_t)token_index_capacity((int)N) * 8); DALLOC(m->tok_skey, N * 4); DALLOC(m->tok_sidx, N * 4);
     DALLOC(m->scatter_slab, seg_scatter_slab_floats((int)N, m->D) * 4);
   }
@@ -309,6 +312,7 @@ int model_destroy(Model* m) {
   hipStreamSynchronize(m->stream);
   hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
+  if (m->h_stage) hipHostFree(m->h_stage);
   if (m->req_ids) hipFree(m->req_ids);
   if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
@@ -568,21 +572,35 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
     for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
   }
   m->cur_rows = 0;   // (a failing copy below must not leave a half-written batch marked as resident)
-#define H2D(dst, src, bytes) HIP_CHECK(hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
-  H2D(d.userid, b->userid, N * 4); H2D(d.tmid, b->token_mask_ids, N * 4); H2D(d.gender, b->gender, N * 4);
-  H2D(d.source, b->source, N * 4); H2D(d.matchedid, b->matchedid, N * 4); H2D(d.status, b->status, N * 4);
-  H2D(d.time, b->time, N * 8); H2D(d.rating, b->rating, N * 4); H2D(d.progress, b->progress, N * 4);
-  for (int k = 0; k < 6; ++k) {
-    if (k % 3 == 2 && b->label[k] == nullptr) continue;
-    H2D(d.label[k], b->label[k], N * 4); H2D(d.weight[k], b->weight[k], N * 4); H2D(d.position[k], b->position[k], N * 4);
+  // pack (pinned staging) -> one H2D -> the device arrays sit back to back in raw_blob
+  HIP_CHECK(hipStreamSynchronize(s));   // (the previous upload's copy has left the staging buffer; kernels reading the old batch are done)
+  size_t off = 0;
+  auto place = [&](const void* src, size_t bytes) -> void* {
+    void* dev = m->raw_blob + off;
+    if (src != nullptr) memcpy(m->h_stage + off, src, bytes);
+    off += (bytes + 63) / 64 * 64;
+    return dev;
+  };
+  d.time = (const double*)place(b->time, N * 8);
+  d.userid = (const int*)place(b->userid, N * 4); d.tmid = (const int*)place(b->token_mask_ids, N * 4);
+  d.gender = (const int*)place(b->gender, N * 4); d.source = (const int*)place(b->source, N * 4);
+  d.matchedid = (const int*)place(b->matchedid, N * 4); d.status = (const int*)place(b->status, N * 4);
+  d.rating = (const float*)place(b->rating, N * 4); d.progress = (const float*)place(b->progress, N * 4);
+  for (int k = 0; k < 6; ++k) {   // (status targets may be absent: their slots stay unwritten, nothing reads them)
+    d.label[k] = (const float*)place(b->label[k], N * 4); d.weight[k] = (const float*)place(b->weight[k], N * 4);
+    d.position[k] = (const int*)place(b->position[k], N * 4);
   }
   m->has_masks = b->watch_mask != nullptr;
-  if (m->has_masks) { H2D(m->d_wm, b->watch_mask, N); H2D(m->d_rm, b->rating_mask, N); }
+  m->d_wm = (unsigned char*)place(b->watch_mask, N); m->d_rm = (unsigned char*)place(b->rating_mask, N);
   m->has_rope_pos = b->rope_input_pos != nullptr;
-  if (m->has_rope_pos) H2D(m->d_rope_pos, pos.data(), 2 * N * 4);
-#undef H2D
-  // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only
-  if (!m->cfg.finetune) RC(launch_token_index_build(d.matchedid, (int)N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s));
+  m->d_rope_pos = (int*)place(m->has_rope_pos ? pos.data() : nullptr, 2 * N * 4);
+  if (off > m->raw_bytes) { set_error("batch upload: staging buffer too small"); return RSYS_ERR_STATE; }
+  HIP_CHECK(hipMemcpyAsync(m->raw_blob, m->h_stage, off, hipMemcpyHostToDevice, s));
+  // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only; built here for
+  // the row-sharded table (its exchange plan needs it now), else by the first backward over this batch (an inference or
+  // evaluation pass never needs it)
+  m->tok_index_valid = false;
+  if (m->sharded) { RC(launch_token_index_build(d.matchedid, (int)N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s)); m->tok_index_valid = true; }
   HIP_CHECK(hipStreamSynchronize(s));
   if (m->sharded) RC(build_exchange_plan(m, (int)N));
   m->cur_rows = b->rows;
@@ -1224,7 +1242,13 @@ static int backward_trunk(Model* m) {
         RC(launch_add_rows_by_id(m->rows_xchg + o * D, m->req_ids + o, m->row_lo, m->G + m->o_E, D, (int)n, D, s));
       }
     } else if (atomic_ab) RC(launch_embedding_scatter_add(gx, b, m->V, D, m->G + m->o_E, s));
-    else RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
+    else {
+      if (!m->tok_index_valid) {   // first backward over this batch: tokens sorted by (item id, position)
+        RC(launch_token_index_build(b.matchedid, N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s));
+        m->tok_index_valid = true;
+      }
+      RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
+    }
   }
   toc(m);
   m->table_grads_pending = true;

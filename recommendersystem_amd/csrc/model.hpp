@@ -111,6 +111,10 @@ struct Model {
   // batch
   BatchDev bd;
   void* batch_blob = nullptr;
+  // one upload = one copy: the batch's arrays are packed back to back (for the rows it has) in a pinned staging buffer and
+  // land in `raw_blob` with a single H2D; the BatchDev pointers are re-pointed into it per upload
+  unsigned char* raw_blob = nullptr; unsigned char* h_stage = nullptr; size_t raw_bytes = 0;
+  bool tok_index_valid = false;   // the token index of the resident batch (scatter / exchange plan) has been built
   bool has_masks = false, has_rope_pos = false;
   int cur_rows = 0;
   // token index of the resident batch (scatter.hip): sorted (item id, token) pairs + the partial-sum slab of the scatter
