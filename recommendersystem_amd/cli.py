@@ -143,7 +143,7 @@ def main(argv=None):
             return rdata.FinetuneDataset(path, local_rank, local_world, local_batch, split == "training", args.finetune_medium)
         return rdata.PretrainDataset(path, local_rank, local_world, local_batch * config["max_sequence_length"], seed=rank)
 
-    dataloaders = {x: dataset(x) for x in ("training", "test")}
+    dataloaders = {x: rdata.Prefetch(dataset(x)) for x in ("training", "test")}   # (the DataLoader workers of train.py:162-165)
     hg = rdist.HostGroup()
     if args.table_shard:
         assert not config["finetune"], "finetuning keeps the (frozen) item table replicated"

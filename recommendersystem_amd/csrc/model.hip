@@ -572,8 +572,9 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
     for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
   }
   m->cur_rows = 0;   // (a failing copy below must not leave a half-written batch marked as resident)
-  // pack (pinned staging) -> one H2D -> the device arrays sit back to back in raw_blob
-  HIP_CHECK(hipStreamSynchronize(s));   // (the previous upload's copy has left the staging buffer; kernels reading the old batch are done)
+  // pack (pinned staging) -> one H2D -> the device arrays sit back to back in raw_blob.  No wait before packing: the previous
+  // upload synchronised after ITS copy, so the staging buffer is free, and the copy below is ordered on the stream behind the
+  // kernels that still read the old batch -- the host packs while the GPU finishes the previous step's optimizer pass.
   size_t off = 0;
   auto place = [&](const void* src, size_t bytes) -> void* {
     void* dev = m->raw_blob + off;

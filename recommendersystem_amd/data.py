@@ -47,6 +47,57 @@ def block_shuffle(d, rng):
         d[k] = d[k][p]
 
 
+class Prefetch:
+    """The reference feeds its loop through a torch DataLoader with worker processes (train.py:162-165, `num_workers`): shard
+    decode and block shuffle overlap the GPU step.  Here one producer thread runs the wrapped dataset's iterator `depth` batches
+    ahead (blosc / HDF5 decode and the device calls of the consumer both release the GIL); order and content are the
+    dataset's own, an exception in the producer is re-raised in the consumer, leaving the loop early stops the producer."""
+
+    def __init__(self, dataset, depth=3):
+        self.dataset, self.depth = dataset, max(1, int(depth))
+
+    def __getattr__(self, name):          # (`partition` of a FinetuneDataset and the like)
+        return getattr(self.dataset, name)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(self.depth)
+        stop = threading.Event()
+        END = object()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1); return True
+                except queue.Full:
+                    continue
+            return False
+
+        def produce():
+            try:
+                for item in self.dataset:
+                    if not put(item):
+                        return
+                put(END)
+            except BaseException as e:     # noqa: B902 -- handed to the consumer
+                put(e)
+
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            t.join(timeout=5.0)
+
+
 class PretrainDataset:
     """Iterates batches of `tokens_per_batch` interactions; users may straddle batch boundaries exactly as in
     the reference (train.py:91-98)."""

@@ -200,3 +200,43 @@ def test_cli_training_config(tmp_path):
     ns.model, ns.mini = "cfg3", False
     c3 = cli.get_training_config(ns)
     assert (c3["embed_dim"], c3["num_layers"], c3["max_sequence_length"], c3["mask_topk"]) == (512, 8, 512, 64)
+
+
+def test_prefetch_keeps_order_propagates_errors_and_stops_early():
+    import threading
+    import time
+
+    from recommendersystem_amd import data
+
+    class Slow:
+        partition = [1, 4]
+
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at, self.made = n, fail_at, 0
+
+        def __iter__(self):
+            for i in range(self.n):
+                if i == self.fail_at:
+                    raise ValueError("bad shard")
+                time.sleep(0.002); self.made += 1
+                yield {"i": i}
+
+    src = Slow(40)
+    assert [b["i"] for b in data.Prefetch(src, depth=3)] == list(range(40))
+    assert data.Prefetch(src).partition == [1, 4]                     # attributes of the wrapped dataset stay reachable
+    import pytest
+    with pytest.raises(ValueError):
+        list(data.Prefetch(Slow(10, fail_at=4)))
+    src = Slow(1000)
+    n_threads = threading.active_count()
+    for k, b in enumerate(data.Prefetch(src, depth=2)):
+        if k == 5:
+            break
+    time.sleep(0.3)
+    assert src.made < 20 and threading.active_count() <= n_threads    # the producer stopped with the consumer
+    # the producer really runs ahead: consuming 20 slow items while each step also takes 2 ms costs ~max, not the sum
+    src = Slow(20)
+    t0 = time.time()
+    for b in data.Prefetch(src, depth=4):
+        time.sleep(0.002)
+    assert time.time() - t0 < 0.075
