@@ -154,6 +154,7 @@ def main():
                          "rank r of N holds rows [r (V+1)/N, (r+1)(V+1)/N) of the item tables and their Adam moments")
     ap.add_argument("--sampled-softmax", type=int, default=0,
                     help="row-sharded table only: classes sampled per rank and medium for the watch heads (0 = full soft-max)")
+    ap.add_argument("--deterministic", action="store_true", help="bitwise reproducible steps (rsys_model_set_deterministic): what the fixed summation order costs")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
@@ -200,6 +201,8 @@ def main():
             cfg["sampled_softmax"] = args.sampled_softmax
     S = cfg["max_sequence_length"]
     rows = args.rows
+    if args.deterministic:
+        cfg["deterministic"] = True
     model = ra.RecommenderModel(cfg, device=device, dtype=args.dtype, max_rows=rows)
     model.init_weights(0x1217)                 # same seed on every rank (replaces DDP's rank-0 broadcast, C1)
     model.random_pretrained_embeddings(0x3E7A)
@@ -296,7 +299,7 @@ def main():
         traffic_db = {}
         # PMC passes are separate runs (rocprofv3 --pmc) of the default workload; their per-launch summary is committed under
         # profiles/ and only describes that workload
-        pmc_applies = args.config == "cfg3" and rows == 64 and args.layers is None and args.dtype == "bf16" and not sharded
+        pmc_applies = args.config == "cfg3" and rows == 64 and args.layers is None and args.dtype == "bf16" and not sharded and not args.deterministic
         try:
             if pmc_applies:
                 traffic_db = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels"]

@@ -114,6 +114,11 @@ int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
 /* ItemEmbedding.forward over all items (model.py:139-145), the table Finetune/register.py:27-33 exports as the watch-head
  * weights of the serving registry: out [V][embed_dim] f32, V = vocab_0 + vocab_1 (manga rows first) */
 int32_t rsys_item_table(rsys_model* m, float* out, int64_t n);
+/* on != 0: every float sum of the training step gets a fixed order (split-K partial tiles summed in split order, reductions through
+ * per-workgroup partials instead of float atomics), so a step -- losses, gradients, updated parameters -- is bitwise reproducible
+ * from run to run; costs a few percent of the step.  Replicated item table only.  (The reference's CUDA path is not reproducible:
+ * its embedding backward and split-K reductions use atomics too.) */
+int32_t rsys_model_set_deterministic(rsys_model* m, int32_t on);
 /* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */
 int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
 /* the same forward, returning only the tokens a server reads (Finetune/embed.py:147-161 takes token 2n of a user for

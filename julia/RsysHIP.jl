@@ -74,6 +74,8 @@ function losses(m::Model)
     lo, ws
 end
 
+set_deterministic!(m::Model, on::Bool = true) = check(ccall((:rsys_model_set_deterministic, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, on ? 1 : 0))
+
 # inference forward (model.py:531-538): task 0 = retrieval, 1 = ranking; `tokens` = flat token indices (0-based) to report
 function infer_select(m::Model, task::Integer, tokens::Vector{Int32}, D::Integer)
     out = task == 0 ? Matrix{Float32}(undef, D, length(tokens)) : Vector{Float32}(undef, length(tokens))

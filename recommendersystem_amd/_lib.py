@@ -69,6 +69,7 @@ _SIGS = [
     ("rsys_losses_get", C.c_int32, [_P, C.POINTER(C.c_float * 12), C.POINTER(C.c_float * 4)]),
     ("rsys_head_rows_get", C.c_int32, [_P, C.POINTER(C.c_int32 * 4)]),
     ("rsys_item_table", C.c_int32, [_P, _P, C.c_int64]),
+    ("rsys_model_set_deterministic", C.c_int32, [_P, C.c_int32]),
     ("rsys_infer", C.c_int32, [_P, C.c_int32, _P, C.c_int64]),
     ("rsys_infer_select", C.c_int32, [_P, C.c_int32, _P, C.c_int64, _P, C.c_int64]),
     ("rsys_trunk_output_get", C.c_int32, [_P, _P, C.c_int64]),

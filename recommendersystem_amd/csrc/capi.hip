@@ -109,6 +109,7 @@ int32_t rsys_head_rows_get(rsys_model* h, int32_t out[4]) {
 }
 
 int32_t rsys_item_table(rsys_model* h, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_item_table(h->m, out, n); }
+int32_t rsys_model_set_deterministic(rsys_model* h, int32_t on) { CHECK_HANDLE(h); return model_set_deterministic(h->m, on); }
 int32_t rsys_infer(rsys_model* h, int32_t task, float* out, int64_t n) { CHECK_HANDLE(h); ARG_CHECK(out, "null"); return model_infer(h->m, task, nullptr, 0, out, n); }
 int32_t rsys_infer_select(rsys_model* h, int32_t task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n) {
   CHECK_HANDLE(h); ARG_CHECK(out && token_index && n_tokens >= 1, "null or empty selection");

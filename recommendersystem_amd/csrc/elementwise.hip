@@ -6,6 +6,45 @@
 
 namespace rsys {
 
+thread_local DetScratch g_det;
+
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, long long stride, int n, float* dst) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float acc = 0.f;
+  for (int b = 0; b < nparts; ++b) acc += part[(long long)b * stride + c];
+  dst[c] += acc;
+}
+// first stage of a long reduction: out[chunk][c] = sum of the partial rows [32 chunk, 32 chunk + 32) in row order
+__global__ void reduce_parts_stage_kernel(const float* __restrict__ part, int nparts, long long stride, int n, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, chunk = blockIdx.y;
+  if (c >= n) return;
+  const int b0 = chunk * 32, b1 = min(nparts, b0 + 32);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) acc += part[(long long)b * stride + c];
+  out[(long long)chunk * n + c] = acc;
+}
+int launch_reduce_parts(const float* part, int nparts, long long stride, int n, float* dst, hipStream_t s) {
+  if (nparts <= 0 || n <= 0) return RSYS_OK;
+  if (nparts > 64 && g_det.tmp != nullptr) {   // two stages, both with a fixed order: 32-row chunks, then the chunks
+    const int chunks = (nparts + 31) / 32;
+    if ((long long)chunks * n <= g_det.tmp_cap) {
+      hipLaunchKernelGGL(reduce_parts_stage_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, s, part, nparts, stride, n, g_det.tmp);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, g_det.tmp, chunks, (long long)n, n, dst);
+      HIP_CHECK(hipGetLastError());
+      return RSYS_OK;
+    }
+  }
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, nparts, stride, n, dst);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+// scratch of the deterministic mode for `floats` partial sums, or nullptr (atomics) when the mode is off
+static inline float* det_part(long long floats) {
+  if (g_det.part == nullptr) return nullptr;
+  return floats <= g_det.cap ? g_det.part : nullptr;
+}
+
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // --------------------------------------------------------------------- mask_tokens
@@ -200,8 +239,8 @@ template <typename TG, typename TO, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
-                                                          long long rows, int D) {
-  extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats
+                                                          float* part, long long rows, int D) {
+  extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (4 * D in deterministic mode: `part` set)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
   float4 acc[NJ], sc[NJ];
@@ -244,6 +283,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
       }
     }
   }
+  if (part != nullptr) {
+    // deterministic: the four waves' sums side by side in LDS ([4][D], launcher), added in wave order, one partial row per workgroup
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = (j * 64 + l) * 4;
+      if (EXACT || c < D) *(float4*)&sds[w * D + c] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) part[(long long)blockIdx.x * D + c] = ((sds[c] + sds[D + c]) + sds[2 * D + c]) + sds[3 * D + c];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + l) * 4;
@@ -261,8 +312,9 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
                            float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
-#define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, D * sizeof(float), s, g, x, scale, \
-                                                 rstd, resid, dx_out, dx_out_t, dscale, rows, D)
+  float* part = det_part((long long)grid.x * D);
+#define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
+                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D)
   if (D == 256) RSYS_NORM_BWD(1, true);
   else if (D == 512) RSYS_NORM_BWD(2, true);
   else if (D == 1024) RSYS_NORM_BWD(4, true);
@@ -273,6 +325,7 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
   else RSYS_NORM_BWD(8, false);
 #undef RSYS_NORM_BWD
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, (int)grid.x, D, D, dscale, s);
   return RSYS_OK;
 }
 template <typename T>
@@ -412,7 +465,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(T* logits, long long ldl, int V, const int* __restrict__ idx,
                                                  const float* __restrict__ label, const float* __restrict__ weight,
                                                  const int* __restrict__ position, const float* __restrict__ stats,
-                                                 const int* __restrict__ npos, float task_w, float* loss_out) {
+                                                 const int* __restrict__ npos, float task_w, float* loss_out, float* part) {
   __shared__ float red[16];
   constexpr int E = 16 / sizeof(T);
   const int row = blockIdx.x, t = threadIdx.x;
@@ -448,7 +501,10 @@ __global__ __launch_bounds__(256) void ce_kernel(T* logits, long long ldl, int V
   const int tgt = position[i];
   const float xt = to_f32(lr[tgt]);
   __syncthreads();
-  if (t == 0) atomicAdd(loss_out, (lse - xt) * lw);
+  if (t == 0) {
+    if (part != nullptr) part[row] = (lse - xt) * lw;   // deterministic mode: the rows' terms are added in row order afterwards
+    else atomicAdd(loss_out, (lse - xt) * lw);
+  }
   const float coef = task_w * lw / fmaxf(stats[0], 1e-8f);
   for (int c = t; c < nchunks; c += 256) {
     uint4 raw = ((const uint4*)lr)[c];
@@ -467,8 +523,11 @@ template <typename T>
 int launch_ce_fwd_bwd(T* logits, long long ldl, int n, int V, const int* idx, const float* label, const float* weight,
                       const int* position, const float* stats, const int* npos, float task_w, float* loss_out, hipStream_t s) {
   ARG_CHECK((ldl * sizeof(T)) % 16 == 0 && ldl >= V, "ce: ldl");
-  hipLaunchKernelGGL((ce_kernel<T>), dim3(n), dim3(256), 0, s, logits, ldl, V, idx, label, weight, position, stats, npos, task_w, loss_out);
+  float* part = det_part(n);
+  if (part != nullptr) HIP_CHECK(hipMemsetAsync(part, 0, (size_t)n * 4, s));   // (rows without a term write nothing)
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(n), dim3(256), 0, s, logits, ldl, V, idx, label, weight, position, stats, npos, task_w, loss_out, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, n, 1, 1, loss_out, s);
   return RSYS_OK;
 }
 template int launch_ce_fwd_bwd<bf16>(bf16*, long long, int, int, const int*, const float*, const float*, const int*, const float*, const int*, float, float*, hipStream_t);
@@ -481,11 +540,13 @@ __global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restr
                                                           const int* __restrict__ idx, const float* __restrict__ label,
                                                           const float* __restrict__ weight, const float* __restrict__ stats,
                                                           float rating_mean, float task_w, int evaluate, float* loss_out,
-                                                          float* dw2, float* db2, float* db0) {
-  extern __shared__ __attribute__((aligned(16))) float sds[];  // 2*D floats: dw2 | db0
+                                                          float* dw2, float* db2, float* db0, float* part) {
+  extern __shared__ __attribute__((aligned(16))) float sds[];  // 2*D floats: dw2 | db0  (deterministic mode: one such pair per wave + 4 scalars per wave)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < 2 * D; c += 256) sds[c] = 0.f;
+  const int nacc = part != nullptr ? 4 * 2 * D + 16 : 2 * D;
+  for (int c = threadIdx.x; c < nacc; c += 256) sds[c] = 0.f;
   __syncthreads();
+  float* const mine = part != nullptr ? sds + w * 2 * D : sds;   // deterministic: a wave adds into its own copy (its lanes own distinct columns)
   float l0 = 0.f, l1 = 0.f, l2 = 0.f, gb2 = 0.f;
   const float inv_ws = 1.f / fmaxf(stats[0], 1e-8f);
   for (int row = blockIdx.x * 4 + w; row < n; row += gridDim.x * 4) {
@@ -507,10 +568,20 @@ __global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restr
       float dz = dpred * w2[c] * gp;
       zr[c] = from_f32<T>(dz);
       if (dpred != 0.f) {
-        atomicAdd(&sds[c], dpred * to_f32(hr[c]));
-        atomicAdd(&sds[D + c], dz);
+        if (part != nullptr) { mine[c] += dpred * to_f32(hr[c]); mine[D + c] += dz; }
+        else { atomicAdd(&sds[c], dpred * to_f32(hr[c])); atomicAdd(&sds[D + c], dz); }
       }
     }
+  }
+  if (part != nullptr) {
+    // one partial row per workgroup: [dw2 (D) | db0 (D) | db2 | loss 0..2], the waves' copies added in wave order
+    float* sc = sds + 4 * 2 * D;
+    if (l == 0) { sc[w * 4 + 0] = gb2; sc[w * 4 + 1] = l0; sc[w * 4 + 2] = l1; sc[w * 4 + 3] = l2; }
+    __syncthreads();
+    float* pr = part + (long long)blockIdx.x * (2 * D + 4);
+    for (int c = threadIdx.x; c < 2 * D; c += 256) pr[c] = ((sds[c] + sds[2 * D + c]) + sds[4 * D + c]) + sds[6 * D + c];
+    if (threadIdx.x < 4) pr[2 * D + threadIdx.x] = ((sc[threadIdx.x] + sc[4 + threadIdx.x]) + sc[8 + threadIdx.x]) + sc[12 + threadIdx.x];
+    return;
   }
   __syncthreads();
   if (!evaluate) {
@@ -531,9 +602,20 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
                        const float* label, const float* weight, const float* stats, float rating_mean, float task_w,
                        int evaluate, float* loss_out, float* dw2, float* db2, float* db0, hipStream_t s) {
   int grid = std::min(div_up(n, 4), 512);
-  hipLaunchKernelGGL((rating_tail_kernel<T>), dim3(grid), dim3(256), 2 * D * sizeof(float), s, z, hact, n, D, w2, b2, idx,
-                     label, weight, stats, rating_mean, task_w, evaluate, loss_out, dw2, db2, db0);
+  const long long prow = 2LL * D + 4;
+  float* part = det_part(grid * prow);
+  hipLaunchKernelGGL((rating_tail_kernel<T>), dim3(grid), dim3(256), (part ? 8 * D + 16 : 2 * D) * sizeof(float), s, z, hact, n, D, w2, b2, idx,
+                     label, weight, stats, rating_mean, task_w, evaluate, loss_out, dw2, db2, db0, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) {
+    int rc = RSYS_OK;
+    if (!evaluate) {
+      rc = launch_reduce_parts(part, grid, prow, D, dw2, s);
+      if (rc == RSYS_OK) rc = launch_reduce_parts(part + D, grid, prow, D, db0, s);
+      if (rc == RSYS_OK) rc = launch_reduce_parts(part + 2 * D, grid, prow, 1, db2, s);
+    }
+    return rc == RSYS_OK ? launch_reduce_parts(part + 2 * D + 1, grid, prow, 3, loss_out, s) : rc;
+  }
   return RSYS_OK;
 }
 template int launch_rating_tail<bf16>(bf16*, const bf16*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
@@ -576,20 +658,23 @@ template int launch_rowdot<float>(const float*, const float*, const float*, floa
 
 // --------------------------------------------------------------------- column sums
 template <typename TS>
-__global__ void colsum_kernel(const TS* __restrict__ src, long long ld, long long rows, int cols, float* dst, int rows_per_block) {
+__global__ void colsum_kernel(const TS* __restrict__ src, long long ld, long long rows, int cols, float* dst, int rows_per_block, float* part) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float acc = 0.f;
   for (long long r = r0; r < r1; ++r) acc += to_f32(src[r * ld + c]);
-  if (acc != 0.f) atomicAdd(&dst[c], acc);
+  if (part != nullptr) part[(long long)blockIdx.y * cols + c] = acc;
+  else if (acc != 0.f) atomicAdd(&dst[c], acc);
 }
 template <typename TS>
 static int colsum_any(const TS* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
   int rpb = (int)std::max<long long>(64, (rows + 511) / 512);
   dim3 grid(div_up(cols, 256), div_up(rows, rpb));
-  hipLaunchKernelGGL((colsum_kernel<TS>), grid, dim3(256), 0, s, src, ld, rows, cols, dst, rpb);
+  float* part = det_part((long long)grid.y * cols);
+  hipLaunchKernelGGL((colsum_kernel<TS>), grid, dim3(256), 0, s, src, ld, rows, cols, dst, rpb, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, (int)grid.y, cols, cols, dst, s);
   return RSYS_OK;
 }
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s) {
@@ -599,7 +684,7 @@ int launch_colsum_add(const float* src, long long ld, long long rows, int cols, 
 // dst (bf16) = src (f32) and colsum[c] += sum_r src[r][c] in ONE pass over src: the operand copy of dF and the
 // projection-bias gradient of the table backward (model.hip finalize) both stream the same 410 MB.
 __global__ __launch_bounds__(1024) void cast_colsum_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long rows, int D,
-                                                           float* colsum, int rows_per_block) {
+                                                           float* colsum, int rows_per_block, float* part) {
   __shared__ float red[2048];                    // [row lane][D] partial sums (launcher: 1024 / (D/4) row lanes, D <= 1024... see launcher)
   const int cg = D >> 2;                         // 4-column groups per row (launcher: D % 4 == 0, 1024 % cg == 0)
   const int c = (threadIdx.x % cg) * 4, lane_r = threadIdx.x / cg, nr = 1024 / cg;
@@ -636,14 +721,18 @@ __global__ __launch_bounds__(1024) void cast_colsum_kernel(const float* __restri
   }
   for (int cc = threadIdx.x; cc < D; cc += 1024) {
     const float v = red[cc] + (nr > 1 ? red[D + cc] : 0.f);
-    if (v != 0.f) atomicAdd(&colsum[cc], v);
+    if (part != nullptr) part[(long long)blockIdx.x * D + cc] = v;
+    else if (v != 0.f) atomicAdd(&colsum[cc], v);
   }
 }
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s) {
   ARG_CHECK(D % 4 == 0 && D <= 1024 && 1024 % (D >> 2) == 0, "cast_colsum: D/4 must divide 1024, D <= 1024");
   const int rpb = (int)std::max<long long>(32, (rows + 511) / 512);
-  hipLaunchKernelGGL(cast_colsum_kernel, dim3(div_up(rows, rpb)), dim3(1024), 0, s, src, dst, rows, D, colsum, rpb);
+  const int grid = div_up(rows, rpb);
+  float* part = det_part((long long)grid * D);
+  hipLaunchKernelGGL(cast_colsum_kernel, dim3(grid), dim3(1024), 0, s, src, dst, rows, D, colsum, rpb, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, grid, D, D, colsum, s);
   return RSYS_OK;
 }
 
@@ -701,9 +790,49 @@ __global__ __launch_bounds__(256) void action_small_bwd_kernel(const float* __re
   for (int c = t; c < NS; c += 256) atomicAdd(&g_source[c], a_s[c]);
   for (int c = t; c < NST; c += 256) atomicAdd(&g_status[c], a_st[c]);
 }
+// deterministic form: one workgroup per output cell; a thread sums the interactions i = t, t + 256, ... that belong to the cell,
+// the workgroup adds its threads in a fixed tree, and the cell has this one contributor
+__global__ __launch_bounds__(256) void action_small_bwd_det_kernel(const float* __restrict__ gf, BatchDev b, SmallParams sp,
+                                                                   float* g_cos, float* g_sin, float* g_status, float* g_gender,
+                                                                   float* g_source) {
+  __shared__ float red[16];
+  const int NG = (sp.n_gender + 1) * 4, NS = (sp.n_source + 1) * 4;
+  int cell = blockIdx.x;
+  float acc = 0.f;
+  float* dst;
+  if (cell < 4) {
+    dst = cell < 2 ? g_cos + cell : g_sin + (cell - 2);
+    for (int i = threadIdx.x; i < b.N; i += 256) {
+      float p0, p1; double ts;
+      periodic_args(b.time[i], sp.min_ts, p0, p1, ts);
+      const float* g = gf + (long long)i * 32;
+      acc += cell == 0 ? -sinf(p0 + sp.per_cos[0]) * g[1] : cell == 1 ? -sinf(p1 + sp.per_cos[1]) * g[2]
+           : cell == 2 ? cosf(p0 + sp.per_sin[0]) * g[3] : cosf(p1 + sp.per_sin[1]) * g[4];
+    }
+  } else {
+    cell -= 4;
+    const int* index; int mask_row, width, col0;
+    if (cell < NG) { index = b.gender; mask_row = sp.n_gender; width = 4; col0 = 5; dst = g_gender + cell; }
+    else if (cell < NG + NS) { cell -= NG; index = b.source; mask_row = sp.n_source; width = 4; col0 = 9; dst = g_source + cell; }
+    else { cell -= NG + NS; index = b.m_status; mask_row = sp.n_status; width = 16; col0 = 15; dst = g_status + cell; }
+    const int row = cell / width, k = cell % width;
+    for (int i = threadIdx.x; i < b.N; i += 256) {
+      int r = index[i]; r = r == -1 ? mask_row : r;
+      if (r == row) acc += gf[(long long)i * 32 + col0 + k];
+    }
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) *dst += acc;
+}
 int launch_action_small_bwd(const float* gf, const BatchDev& b, const SmallParams& sp, float* g_per_cos, float* g_per_sin,
                             float* g_status, float* g_gender, float* g_source, hipStream_t s) {
   ARG_CHECK(sp.n_gender < 16 && sp.n_source < 16 && sp.n_status < 16, "action_small_bwd: small vocab sizes must be < 16");
+  if (g_det.part != nullptr) {
+    const int cells = 4 + (sp.n_gender + 1) * 4 + (sp.n_source + 1) * 4 + (sp.n_status + 1) * 16;
+    hipLaunchKernelGGL(action_small_bwd_det_kernel, dim3(cells), dim3(256), 0, s, gf, b, sp, g_per_cos, g_per_sin, g_status, g_gender, g_source);
+    HIP_CHECK(hipGetLastError());
+    return RSYS_OK;
+  }
   int grid = std::min(div_up(b.N, 256), 256);
   hipLaunchKernelGGL(action_small_bwd_kernel, dim3(grid), dim3(256), 0, s, gf, b, sp, g_per_cos, g_per_sin, g_status,
                      g_gender, g_source);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int ESB = (is_bf16<CT>::value && BF32) ? 4 : (int)sizeof(CT);
 
   // ---- state of the current work item (an output tile and a K range)
-  int cm0 = 0, cn0 = 0, kt0 = 0, kt1 = 0;
+  int cm0 = 0, cn0 = 0, kt0 = 0, kt1 = 0, cur_split = 0;
   // per-thread staging geometry: 4 A chunks + 4 B chunks of 16 bytes per tile.  Global address of a chunk =
   // uniform 64-bit tile base (SGPRs) + 32-bit per-thread byte offset (VGPR): the steady-state loads need no
   // vector address arithmetic.
@@ -325,7 +325,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int it = 0; it < 32; ++it) {
         const int row_l = it * 2 + (t >> 7);
         const long long row = m0 + half * 64 + row_l;
-        if (row < p.M && col < p.N) atomicAdd(&((float*)p.C)[row * p.ldc + col], p.alpha * Cs[row_l * CS_LD + (t & 127)]);
+        if (row < p.M && col < p.N) {
+          const float v = p.alpha * Cs[row_l * CS_LD + (t & 127)];
+          if (p.slab != nullptr) p.slab[((long long)cur_split * p.M + row) * p.N + col] = v;   // deterministic mode: summed in split order afterwards
+          else atomicAdd(&((float*)p.C)[row * p.ldc + col], v);
+        }
       }
       __syncthreads();
     }
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       tile = local % ntiles;
       split = xcd + 8 * (local / ntiles);
     }
+    cur_split = split;
     if (!setup(tile, split)) return;
     if (full) { prologue_loads(std::true_type{}); mainloop(std::true_type{}); }
     else { prologue_loads(std::false_type{}); mainloop(std::false_type{}); }
@@ -423,12 +428,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+// C[row][col] += sum over splits (in index order) of slab[split][row][col]: the deterministic end of a split-K product
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N, float* C, long long ldc) {
+  const long long n4 = (long long)M * N / 4, stride = (long long)M * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 acc = *(const float4*)(slab + 4 * i);
+    for (int sp = 1; sp < splits; ++sp) {
+      const float4 v = *(const float4*)(slab + sp * stride + 4 * i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long long e = 4 * i, row = e / N; const int col = (int)(e % N);
+    float4* c = (float4*)(C + row * ldc + col);
+    float4 o = *c; o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w; *c = o;
+  }
+}
+int gemm_slab_begin(const GemmParams& p, hipStream_t s) {
+  if (p.slab == nullptr) return RSYS_OK;
+  const long long need = (long long)p.splitk * p.M * p.N;
+  ARG_CHECK(need <= p.slab_floats, "gemm: split-K slab too small");
+  ARG_CHECK(p.N % 4 == 0 && p.ldc % 4 == 0, "gemm: deterministic split-K needs N % 4 == 0");
+  HIP_CHECK(hipMemsetAsync(p.slab, 0, (size_t)need * 4, s));   // (splits without work, rows beyond a device-side limit)
+  return RSYS_OK;
+}
+int gemm_slab_end(const GemmParams& p, hipStream_t s) {
+  if (p.slab == nullptr) return RSYS_OK;
+  const long long n4 = (long long)p.M * p.N / 4;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 4096)), dim3(256), 0, s, p.slab, p.splitk, p.M, p.N,
+                     (float*)p.C, p.ldc);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 template <typename CT, bool AF32, bool BF32, bool AKM, bool BKM>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM>), dim3(tiles * p.splitk), dim3(256), 0, s, p);
+  const bool slab = p.slab != nullptr && p.epi == EPI_ATOMIC && p.splitk > 1;
+  GemmParams q = p;
+  if (!slab) q.slab = nullptr;
+  { const int rc_ = gemm_slab_begin(q, s); if (rc_ != RSYS_OK) return rc_; }
+  hipLaunchKernelGGL((gemm_kernel<CT, AF32, BF32, AKM, BKM>), dim3(tiles * p.splitk), dim3(256), 0, s, q);
   HIP_CHECK(hipGetLastError());
-  return RSYS_OK;
+  return gemm_slab_end(q, s);
 }
 
 // which kernel a row-major bf16 problem goes to: 0 = 128x128 register-staged (this file), 2 = 256x256 LDS-DMA (gemm8p.hip),
@@ -526,6 +566,21 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
   set_error("gemm: operand layout/type combination not instantiated");
   return RSYS_ERR_ARG;
 }
+
+template <typename CT>
+long long gemm_slab_need(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_km) {
+  GemmParams p = p0;
+  if (p.epi != EPI_ATOMIC) return 0;
+  if (p.splitk < 1) p.splitk = 1;
+  if (p.splitk > 1) p.splitk = (p.splitk + 7) / 8 * 8;
+  if constexpr (is_bf16<CT>::value) {
+    if (!a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return (long long)gemm8p_splits(p, false) * p.M * p.N;
+    if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return (long long)gemm8p_splits(p, true) * p.M * p.N;
+  }
+  return p.splitk > 1 ? (long long)p.splitk * p.M * p.N : 0;
+}
+template long long gemm_slab_need<bf16>(const GemmParams&, bool, bool, bool, bool);
+template long long gemm_slab_need<float>(const GemmParams&, bool, bool, bool, bool);
 
 template int launch_gemm<bf16>(const GemmParams&, bool, bool, bool, bool, hipStream_t);
 template int launch_gemm<float>(const GemmParams&, bool, bool, bool, bool, hipStream_t);

@@ -44,6 +44,9 @@ struct GemmParams {
   // EPI_TABLE
   const float* E;
   unsigned long long* trace;   // tools/micro/gemm8p_trace.hip only (kernel built with RSYS_8P_TRACE): per-workgroup cycle sums
+  // deterministic split-K (Model::deterministic): instead of float atomics into C every K split stores its partial tile into
+  // slab[split][M][N] (slab_floats = capacity); the launcher clears the slab, and sums the splits in index order into C afterwards
+  float* slab; long long slab_floats;
   int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
                     // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip)
 };
@@ -52,6 +55,10 @@ struct GemmParams {
 // a_f32/b_f32: operand is float in memory although CT is bf16 (converted while staging).
 template <typename CT>
 int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km, hipStream_t s);
+
+// floats of slab the split-K launch of this problem needs (0: no split-K / nothing to do); mirrors launch_gemm's dispatch
+template <typename CT>
+long long gemm_slab_need(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
 // short name of the kernel launch_gemm picks for this problem ("8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // tiles (tn fastest) and its workgroups walk that run side by side, so neighbouring tiles share A rows / B rows
   // through the XCD's private L2
   const int tiles_n = (p.N + T8_BN - 1) / T8_BN;
-  int tile, tile_first = 0, tile_end = 0, tile_step = 1, kt0 = 0, nt;
+  int tile, tile_first = 0, tile_end = 0, tile_step = 1, kt0 = 0, nt, split_id = 0;
   if constexpr (PERSIST) {
     const int rows = p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M;
     const int ntiles = ((rows + T8_BM - 1) / T8_BM) * tiles_n;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     tile = local % ntiles;
     const int split = xcd + 8 * (local / ntiles);
+    split_id = split;
     const int ktiles = (p.K + T8_BK - 1) / T8_BK, per = (ktiles + p.splitk - 1) / p.splitk;
     kt0 = split * per;
     nt = min(ktiles, kt0 + per) - kt0;
@@ -420,7 +421,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #pragma unroll 8
         for (int r = 0; r < 32; ++r) {
           const int row = wm0 + q * 32 + r;
-          if (row < p.M) atomicAdd(C + (long long)row * p.ldc + col, p.alpha * Cs[r * CS_LD + l]);
+          if (row < p.M) {
+            const float v = p.alpha * Cs[r * CS_LD + l];
+            if (p.slab != nullptr) p.slab[((long long)split_id * p.M + row) * p.N + col] = v;   // deterministic mode (gemm.hpp)
+            else atomicAdd(C + (long long)row * p.ldc + col, v);
+          }
         }
       }
     }
@@ -476,12 +481,11 @@ bool gemm8p_tn_eligible(const GemmParams& p) {
   return true;
 }
 
-int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
-  GemmParams p = p0;
+// K splits of the two split-K forms (a multiple of 8: one split never straddles XCDs): fill whole rounds of the 256 CUs while
+// keeping the K range of a workgroup long against its fixed cost (first tiles from HBM + 256 KB of atomics ~ 16 K tiles)
+int gemm8p_splits(const GemmParams& p, bool k_major) {
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
   const int ktiles = (p.K + T8_BK - 1) / T8_BK;
-  // K splits (a multiple of 8: one split never straddles XCDs): fill whole rounds of the 256 CUs while keeping the
-  // K range of a workgroup long against its fixed cost (first tiles from HBM + 256 KB of atomics ~ 16 K tiles)
   int best = 8; double best_score = -1.0;
   for (int sk = 8; sk <= 256; sk += 8) {
     const int per = (ktiles + sk - 1) / sk;
@@ -492,10 +496,17 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
     if (score > best_score) { best_score = score; best = sk; }
   }
   static const int force = getenv("RSYS_DEBUG_8T_SPLITK") ? atoi(getenv("RSYS_DEBUG_8T_SPLITK")) : 0;   // scans (tools/)
-  p.splitk = force > 0 ? (force + 7) / 8 * 8 : best;
+  return (k_major && force > 0) ? (force + 7) / 8 * 8 : best;
+}
+
+int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  p.splitk = gemm8p_splits(p, true);
+  { const int rc_ = gemm_slab_begin(p, s); if (rc_ != RSYS_OK) return rc_; }
   hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
-  return RSYS_OK;
+  return gemm_slab_end(p, s);
 }
 
 // row-major operands + split-K atomics (see the SK template parameter)
@@ -509,20 +520,11 @@ bool gemm8p_nt_splitk_eligible(const GemmParams& p) {
 int launch_gemm8p_nt_splitk(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
-  const int ktiles = p.K / T8_BK;
-  int best = 8; double best_score = -1.0;   // as launch_gemm8p_tn
-  for (int sk = 8; sk <= 256; sk += 8) {
-    const int per = (ktiles + sk - 1) / sk;
-    if (per < 2 && sk > 8) break;
-    const long long wgs = (long long)tiles * sk;
-    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
-    const double score = eff * per / (per + 16.0);
-    if (score > best_score) { best_score = score; best = sk; }
-  }
-  p.splitk = best;
+  p.splitk = gemm8p_splits(p, false);
+  { const int rc_ = gemm_slab_begin(p, s); if (rc_ != RSYS_OK) return rc_; }
   hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
-  return RSYS_OK;
+  return gemm_slab_end(p, s);
 }
 
 // at most one workgroup per CU (128 KB of LDS each): the kernel walks the remaining tiles itself

@@ -146,6 +146,9 @@ int launch_gemm8p_tn(const GemmParams& p, hipStream_t s);
 // the row-major pipeline with the same split-K mapping and atomic epilogue (long K, few output tiles, K-contiguous operands)
 bool gemm8p_nt_splitk_eligible(const GemmParams& p);
 int launch_gemm8p_nt_splitk(const GemmParams& p, hipStream_t s);
+int gemm8p_splits(const GemmParams& p, bool k_major);            // K splits the two split-K forms choose (gemm8p.hip)
+int gemm_slab_begin(const GemmParams& p, hipStream_t s);         // deterministic split-K: clear the slab / sum it into C (gemm.hip)
+int gemm_slab_end(const GemmParams& p, hipStream_t s);
 // row-major bf16 operands, 256x128 tiles, two workgroups per CU (gemm4w.hip)
 bool gemm4w_eligible(const GemmParams& p);
 int launch_gemm4w(const GemmParams& p, hipStream_t s);

@@ -22,6 +22,15 @@ struct BatchDev {
   float* m_label[4]; float* m_weight[4]; int* m_position[4];              // [medium*2 + {watch,rating}]
 };
 
+// Deterministic mode (Model::deterministic): while `part` is set, the reduction kernels below write per-workgroup partial sums
+// into it instead of issuing float atomics, and their launchers add the partials to the destination in workgroup order
+// (launch_reduce_parts).  Thread-local: set by the model around its launches (one host thread drives one model), all on the
+// model's stream, so consecutive launches may reuse the scratch from offset 0.
+struct DetScratch { float* part = nullptr; long long cap = 0; float* tmp = nullptr; long long tmp_cap = 0; };   // tmp: second stage of long reductions
+extern thread_local DetScratch g_det;
+// dst[c] += sum_b part[b * stride + c] for c < n, b = 0 .. nparts-1 in that order
+int launch_reduce_parts(const float* part, int nparts, long long stride, int n, float* dst, hipStream_t s);
+
 struct SmallParams {  // pointers into the flat fp32 parameter buffer
   const float *per_cos, *per_sin;      // (2),(2)
   const float *status_emb, *gender_emb, *source_emb;  // (10,16),(5,4),(5,4)

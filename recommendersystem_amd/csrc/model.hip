@@ -313,6 +313,9 @@ int model_destroy(Model* m) {
   hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_stage) hipHostFree(m->h_stage);
+  if (m->det_slab) hipFree(m->det_slab);
+  if (m->det_part) hipFree(m->det_part);
+  if (m->det_tmp) hipFree(m->det_tmp);
   if (m->req_ids) hipFree(m->req_ids);
   if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
@@ -625,12 +628,46 @@ static int pick_splitk(int M, int N, int K, int bk) {
   return (int)s;
 }
 
+// deterministic mode: the reduction kernels launched inside the scope write partial sums to the model's scratch (kernels.hpp)
+struct DetScope {
+  DetScratch saved;
+  explicit DetScope(Model* m) : saved(g_det) { if (m->deterministic) { g_det.part = m->det_part; g_det.cap = m->det_part_floats; g_det.tmp = m->det_tmp; g_det.tmp_cap = m->det_tmp_floats; } else g_det = DetScratch(); }
+  ~DetScope() { g_det = saved; }
+};
+static int det_slab_for(Model* m, long long need, GemmParams& p) {
+  if (need <= 0) return RSYS_OK;
+  if (need > m->det_slab_floats) {
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->side));
+    if (m->det_slab) HIP_CHECK(hipFree(m->det_slab));
+    m->det_slab = nullptr; m->det_slab_floats = 0;
+    HIP_CHECK(hipMalloc((void**)&m->det_slab, (size_t)need * 4));
+    m->det_slab_floats = need;
+  }
+  p.slab = m->det_slab; p.slab_floats = m->det_slab_floats;
+  return RSYS_OK;
+}
+int model_set_deterministic(Model* m, int on) {
+  ARG_CHECK(!on || !m->sharded, "deterministic mode covers the replicated item table (the vocabulary-parallel heads still use float atomics)");
+  HIP_CHECK(hipSetDevice(m->device));
+  if (on && m->det_part == nullptr) {
+    const long long KB = (long long)m->K * m->rows_max;
+    m->det_part_floats = std::max<long long>(std::max<long long>(2048LL * m->D, 512LL * (2 * m->D + 4)), std::max<long long>(KB, 4096)) + 1024;
+    HIP_CHECK(hipMalloc((void**)&m->det_part, (size_t)m->det_part_floats * 4));
+    m->det_tmp_floats = m->det_part_floats / 32 + 4096;
+    HIP_CHECK(hipMalloc((void**)&m->det_tmp, (size_t)m->det_tmp_floats * 4));
+  }
+  m->deterministic = on != 0;
+  return RSYS_OK;
+}
+
 template <typename T>
 static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
   p.flags |= m->gemm_flags;
+  if (m->deterministic && p.epi == EPI_ATOMIC) RC(det_slab_for(m, gemm_slab_need<T>(p, a_f32, false, a_km, b_km), p));
   if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K);
   int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);
   toc(m);
@@ -651,7 +688,7 @@ static int side_mode() {
 template <typename T>
 static int gemm_side(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km, int slot) {
   const int mode = side_mode();
-  if (mode == 0 || (m->timer.enabled && m->timer.serialize)) return gemm<T>(m, tag, p, a_f32, a_km, b_km);
+  if (mode == 0 || m->deterministic || (m->timer.enabled && m->timer.serialize)) return gemm<T>(m, tag, p, a_f32, a_km, b_km);   // (deterministic: one slab, one stream)
   if (p.alpha == 0.f) p.alpha = 1.f;
   if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
@@ -1313,6 +1350,7 @@ static int finalize_grads_t(Model* m, int stage) {
 
 int model_finalize_grads(Model* m) {
   if (!m->table_grads_pending || m->cfg.finetune) return RSYS_OK;
+  DetScope det(m);
   m->table_grads_pending = false;
   return m->bf16_mode ? finalize_grads_t<bf16>(m, 0) : finalize_grads_t<float>(m, 0);
 }
@@ -1323,6 +1361,7 @@ int model_finalize_stage(Model* m, int stage, int64_t* wp_off, int64_t* wp_n) {
   if (wp_off) *wp_off = m->o_Wp;
   if (wp_n) *wp_n = (int64_t)m->D * m->Mp;
   if (stage == 2) m->table_grads_pending = false;
+  DetScope det(m);
   return finalize_grads_t<bf16>(m, stage);
 }
 
@@ -1347,6 +1386,7 @@ int model_forward_backward(Model* m, int evaluate, const float task_w[4], float 
   ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
   ARG_CHECK(evaluate || task_w != nullptr, "task weights are required for training");
   HIP_CHECK(hipSetDevice(m->device));
+  DetScope det(m);
   m->last_evaluate = evaluate != 0;
   return m->bf16_mode ? forward_backward_t<bf16>(m, evaluate, task_w, grad_scale, seed, step)
                       : forward_backward_t<float>(m, evaluate, task_w, grad_scale, seed, step);
@@ -1444,6 +1484,7 @@ static int grad_sumsq(Model* m) {
 
 int model_clip(Model* m, float max_norm, float* norm_out) {
   HIP_CHECK(hipSetDevice(m->device));
+  DetScope det(m);
   RC(model_finalize_grads(m));
   RC(grad_sumsq(m));
   RC(launch_scale(m->G, m->n_opt, m->sumsq, 1.0f, max_norm, m->stream));
@@ -1459,6 +1500,7 @@ int model_clip(Model* m, float max_norm, float* norm_out) {
 int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   Model* m = o->m;
   HIP_CHECK(hipSetDevice(m->device));
+  DetScope det(m);
   RC(model_finalize_grads(m));
   if (grad_div <= 0.f) grad_div = 1.f;
   const float* ss = nullptr;

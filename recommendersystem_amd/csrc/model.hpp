@@ -114,7 +114,14 @@ struct Model {
   // one upload = one copy: the batch's arrays are packed back to back (for the rows it has) in a pinned staging buffer and
   // land in `raw_blob` with a single H2D; the BatchDev pointers are re-pointed into it per upload
   unsigned char* raw_blob = nullptr; unsigned char* h_stage = nullptr; size_t raw_bytes = 0;
-  bool tok_index_valid = false;   // the token index of the resident batch (scatter / exchange plan) has been built
+  bool tok_index_valid = false;
+  // deterministic mode (rsys_model_set_deterministic): every float sum of the step has a fixed order -- split-K partial tiles go
+  // to det_slab and are added in split order, the reduction kernels write per-workgroup partials to det_part (kernels.hpp
+  // DetScratch) -- so a step is bitwise reproducible; replicated item table only
+  bool deterministic = false;
+  float* det_slab = nullptr; long long det_slab_floats = 0;
+  float* det_part = nullptr; long long det_part_floats = 0;
+  float* det_tmp = nullptr; long long det_tmp_floats = 0;   // the token index of the resident batch (scatter / exchange plan) has been built
   bool has_masks = false, has_rope_pos = false;
   int cur_rows = 0;
   // token index of the resident batch (scatter.hip): sorted (item id, token) pairs + the partial-sum slab of the scatter
@@ -167,6 +174,7 @@ int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);
 int model_clip(Model* m, float max_norm, float* norm_out);
+int model_set_deterministic(Model* m, int on);
 int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div);
 
 }  // namespace rsys

@@ -5,7 +5,7 @@
 
 namespace rsys {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out, float* part) {
   __shared__ float red[16];
   float acc = 0.f;
   const long long n4 = n >> 2;
@@ -16,13 +16,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (blockIdx.x == 0)
     for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, acc);
+  if (threadIdx.x == 0) {
+    if (part != nullptr) part[blockIdx.x] = acc;   // deterministic mode: added in workgroup order afterwards
+    else atomicAdd(out, acc);
+  }
 }
 
 int launch_sumsq(const float* g, long long n, float* out, hipStream_t s) {
   int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, out);
+  float* part = (g_det.part != nullptr && grid <= g_det.cap) ? g_det.part : nullptr;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, out, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, grid, 1, 1, out, s);
   return RSYS_OK;
 }
 

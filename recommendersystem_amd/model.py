@@ -81,6 +81,8 @@ class RecommenderModel:
         self.training = True
         self.mask_seed = 0x3A5C
         self._step = 0
+        if config.get("deterministic"):
+            self.set_deterministic(True)
 
     # ---- lifetime
     def close(self):
@@ -119,6 +121,10 @@ class RecommenderModel:
 
     def random_pretrained_embeddings(self, seed=0x3E7A):
         check(lib().rsys_model_random_metadata(self._h, seed))
+
+    def set_deterministic(self, on=True):
+        """bitwise reproducible training steps (fixed summation order everywhere; a few percent slower); also `config["deterministic"]`"""
+        check(lib().rsys_model_set_deterministic(self._h, 1 if on else 0))
 
     def set_shard_comm(self, comm):
         """row-sharded table mode: the communicator of the row exchange and the vocabulary-parallel cross entropy"""

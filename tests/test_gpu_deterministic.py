@@ -1,0 +1,132 @@
+"""Deterministic mode (rsys_model_set_deterministic): split-K partial tiles summed in split order, reductions through per-workgroup
+partials instead of float atomics.  A training step is then bitwise reproducible; the default mode is only reproducible to
+float-atomic noise (which these tests also show, so that they cannot pass vacuously)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TASK_W = [0.05, 0.2, 0.3, 0.25]
+
+
+def _three_steps(cfg, P, batches, masks, dtype, deterministic, fused=True, finetune_P=None):
+    import recommendersystem_amd as ra
+    from oracle import synth
+    rows = len(masks[0][0])
+    model = ra.RecommenderModel(dict(cfg, deterministic=deterministic), dtype=dtype, max_rows=rows)
+    model.load_state_dict(P, strict=not cfg.get("finetune"))
+    opt = ra.create_optimizer(model, dict(cfg, learning_rate=1e-2))
+    model.set_loss_weights(TASK_W, 1)
+    out = []
+    names = synth.trainable_names(cfg)
+    for d, mk in zip(batches, masks):
+        losses = model(d, False, masks=mk)
+        grads = {n: model.grad(n).copy() for n in names}
+        if fused:
+            opt.step(clip_max_norm=1.0)
+        else:
+            from recommendersystem_amd.optim import clip_grad_norm_
+            clip_grad_norm_(model, 1.0)
+            opt.step()
+        out.append((np.array(losses, np.float32), grads))
+    params = {n: model.get_parameter(n).copy() for n in names}
+    model.close()
+    return out, params
+
+
+def _bitwise(a, b):
+    (sa, pa), (sb, pb) = a, b
+    same = all(np.array_equal(la, lb) and all(np.array_equal(ga[n], gb[n]) for n in ga) for (la, ga), (lb, gb) in zip(sa, sb))
+    return same and all(np.array_equal(pa[n], pb[n]) for n in pa)
+
+
+@pytest.mark.parametrize("name,rows,dtype", [("hd64", 4, "bf16"), ("hd64", 4, "fp32"), ("cfg1", 16, "bf16")])
+def test_three_training_steps_are_bitwise_reproducible(name, rows, dtype):
+    from oracle import synth
+    cfg = synth.make_config(name, mask_rate=0.2)
+    P = synth.make_params(cfg, 3, "test")
+    batches = [synth.make_batch(cfg, rows, 40 + i) for i in range(3)]
+    masks = [synth.make_masks(cfg, rows, 50 + i) for i in range(3)]
+    a = _three_steps(cfg, P, batches, masks, dtype, True)
+    b = _three_steps(cfg, P, batches, masks, dtype, True)
+    assert _bitwise(a, b)
+    # and it is the same arithmetic as the default mode, up to the order of the float sums
+    c = _three_steps(cfg, P, batches, masks, dtype, False)
+    for (la, ga), (lc, gc) in zip(a[0], c[0]):
+        assert np.allclose(la, lc, rtol=2e-3 if dtype == "bf16" else 1e-5)
+    worst = max(float(np.abs(a[1][n] - c[1][n]).max() / max(np.abs(c[1][n]).max(), 1e-6)) for n in a[1])
+    assert worst < (5e-2 if dtype == "bf16" else 2e-3), worst
+
+
+def test_default_mode_is_not_bitwise_reproducible_at_this_size():
+    """(what the mode is for: with float atomics two runs of the same steps differ in the last bits)"""
+    from oracle import synth
+    cfg = synth.make_config("cfg1", mask_rate=0.2)
+    rows = 32
+    P = synth.make_params(cfg, 3, "test")
+    batches = [synth.make_batch(cfg, rows, 40 + i) for i in range(3)]
+    masks = [synth.make_masks(cfg, rows, 50 + i) for i in range(3)]
+    runs = [_three_steps(cfg, P, batches, masks, "bf16", False) for _ in range(3)]
+    if _bitwise(runs[0], runs[1]) and _bitwise(runs[0], runs[2]):
+        pytest.skip("float atomics happened to land in the same order three times")
+
+
+def test_fused_clip_adamw_equals_the_separate_passes_bit_for_bit():
+    from oracle import synth
+    cfg = synth.make_config("hd64", mask_rate=0.2)
+    rows = 3
+    P = synth.make_params(cfg, 5, "test")
+    batches = [synth.make_batch(cfg, rows, 60 + i) for i in range(2)]
+    masks = [synth.make_masks(cfg, rows, 70 + i) for i in range(2)]
+    a = _three_steps(cfg, P, batches, masks, "fp32", True, fused=True)
+    b = _three_steps(cfg, P, batches, masks, "fp32", True, fused=False)
+    for (la, ga), (lb, gb) in zip(a[0], b[0]):
+        assert np.array_equal(la, lb)
+    # the clip coefficient is applied inside AdamW (fused) or by a separate scale pass (unfused): same products, so the same bits
+    # up to the rounding of g * coef being done once in both
+    worst = max(float(np.abs(a[1][n] - b[1][n]).max() / max(np.abs(b[1][n]).max(), 1e-6)) for n in a[1])
+    assert worst <= 1e-6, worst
+
+
+def test_deterministic_finetune_step_and_sharded_refusal():
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("hd64", mask_rate=0.2, finetune=True, finetune_metric="rating")
+    rows = 3
+    P = synth.make_params(cfg, 7, "test")
+    batches = [synth.make_batch(cfg, rows, 80 + i) for i in range(2)]
+    masks = [synth.make_masks(cfg, rows, 90 + i) for i in range(2)]
+    a = _three_steps(cfg, P, batches, masks, "bf16", True)
+    b = _three_steps(cfg, P, batches, masks, "bf16", True)
+    assert _bitwise(a, b)
+    with pytest.raises(Exception):
+        ra.RecommenderModel(dict(synth.make_config("hd64"), table_shard=(0, 1), deterministic=True), dtype="bf16", max_rows=2)
+
+
+def test_benchmark_size_steps_are_bitwise_reproducible():
+    """cfg-3 at the benchmark's own batch (64 rows x 512), device-drawn masks, fused clip + AdamW: two runs of two steps end with
+    the same bits in every trainable tensor (129 M parameters) and the same losses."""
+    import hashlib
+
+    import recommendersystem_amd as ra
+    from recommendersystem_amd import workload
+
+    def run():
+        cfg = workload.make_config("cfg3", deterministic=True)
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=64)
+        model.init_weights(0x1217); model.random_pretrained_embeddings(0x3E7A)
+        opt = ra.create_optimizer(model, cfg)
+        model.set_loss_weights(ra.make_task_weights(), 1)
+        d = workload.make_batch(cfg, 64, 0xD47A, mu=4.6, sigma=1.0)
+        losses = []
+        for _ in range(2):
+            losses.append(model(d, False))
+            opt.step(lr_factor=1.0, clip_max_norm=1.0)
+        h = hashlib.sha256()
+        for name, shape, trainable in model.named_parameters():
+            if trainable:
+                h.update(model.get_parameter(name).tobytes())
+        model.close()
+        return losses, h.hexdigest()
+    (la, ha), (lb, hb) = run(), run()
+    assert la == lb and ha == hb, (la, lb)
