@@ -130,3 +130,58 @@ def test_benchmark_size_steps_are_bitwise_reproducible():
         return losses, h.hexdigest()
     (la, ha), (lb, hb) = run(), run()
     assert la == lb and ha == hb, (la, lb)
+
+
+def test_data_parallel_step_on_two_concurrent_ranks_is_bitwise_reproducible():
+    """Deterministic models behind the data-parallel all-reduce (early buckets armed, in-process rank group: ranks summed in rank
+    order, as a ring with a fixed topology does): the reduced gradients and the updated parameters repeat bit for bit."""
+    import threading
+
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.optim import AdamW
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=True)
+    rows, world = 2, 2
+    P = synth.make_params(cfg, 23, "test")
+    batches = [synth.make_batch(cfg, rows, 24 + 10 * r) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, 25 + 10 * r) for r in range(world)]
+    names = synth.trainable_names(cfg)
+
+    def once():
+        group = rdist.LocalGroup(world)
+        out = [None] * world; err = [None] * world
+
+        def rank_fn(r):
+            try:
+                comm = rdist.LocalComm(group, r)
+                model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+                model.load_state_dict(P)
+                model.set_loss_weights(TASK_W, 1)
+                comm.begin_grad_sync(model)
+                losses = model(batches[r], False, masks=masks[r])
+                comm.all_reduce_grads(model)
+                G = {n: model.grad(n).copy() for n in names}
+                AdamW(model, lr=1e-2).step(clip_max_norm=1.0, grad_div=float(world))
+                Pn = {n: model.get_parameter(n).copy() for n in names}
+                model.close(); comm.close()
+                out[r] = (losses, G, Pn)
+            except BaseException as e:   # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        group.close()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+    a, b = once(), once()
+    for r in range(world):
+        assert a[r][0] == b[r][0]
+        for n in names:
+            assert np.array_equal(a[r][1][n], b[r][1][n]), (r, n)
+            assert np.array_equal(a[r][2][n], b[r][2][n]), (r, n)
+            assert np.array_equal(a[r][2][n], a[0][2][n]), (r, n)      # and the ranks agree with each other
