@@ -63,12 +63,26 @@ def traffic_of_name(db, syms):
     return total or None
 
 
-def flops_per_interaction(cfg, B):
-    """fwd+bwd, dense-attention upper bound, metadata projection once per step."""
+def flops_per_interaction(cfg, B, attention_density=1.0):
+    """fwd+bwd, metadata projection once per step; attention dense (the upper bound the roofline fraction is
+    quoted on) or scaled by the share of (query, key) pairs the packed users' mask allows (the "useful" figure)."""
     L, D, I, S = cfg["num_layers"], cfg["embed_dim"], cfg["intermediate_dim"], cfg["max_sequence_length"]
     V = cfg["vocab_sizes"]["0_matchedid"] + cfg["vocab_sizes"]["1_matchedid"]
     M, K = cfg["metadata_emb_size"], cfg["mask_topk"]
-    return 36 * L * (D * D + D * I) + 56 * S * D * L + 6 * K * V * D / S + 4 * V * M * D / (B * S) + 6 * (D * D + D) * 2 * K / S
+    return (36 * L * (D * D + D * I) + 56 * S * D * L * attention_density + 6 * K * V * D / S + 4 * V * M * D / (B * S)
+            + 6 * (D * D + D) * 2 * K / S)
+
+
+def attention_density(userid, S):
+    """sum over the packed users of a row of (tokens of the user)^2 over (2S)^2, averaged over rows: the same-user predicate of
+    model.py:479-487 (the token-mask predicate removes a few percent more)"""
+    u = np.asarray(userid).reshape(-1, S)
+    dens = []
+    for row in u:
+        cuts = np.flatnonzero(np.diff(row)) + 1
+        runs = np.diff(np.r_[0, cuts, S])
+        dens.append(float((runs.astype(np.float64) ** 2).sum()) / (S * S))
+    return float(np.mean(dens))
 
 
 def cpu_baseline(cfg, seed, rows=0, budget_s=40.0):
@@ -288,6 +302,8 @@ def main():
         value = inter / elapsed
         ms = elapsed / args.steps * 1e3
         fpi = flops_per_interaction(cfg, rows)
+        dens = attention_density(d["userid"], S)
+        fpi_useful = flops_per_interaction(cfg, rows, dens)
         # dominant kernel: the MFMA GEMM family, per instantiation
         var = {}
         for tag, r in rep.items():
@@ -327,6 +343,9 @@ def main():
                                                                   (f", sampled soft-max {args.sampled_softmax}/rank/medium" if args.sampled_softmax else "") + ")" if sharded else "")},
             "model_flops_per_interaction": fpi,
             "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            # the same fraction on "useful" FLOPs, attention scaled by the share of same-user (query, key) pairs of this batch
+            "attention_density": round(dens, 4), "model_flops_per_interaction_useful": round(fpi_useful, 1),
+            "step_mfma_frac_useful": round(value / world * fpi_useful / (MFMA_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline,
             "losses": [round(float(x), 4) for x in losses],
         }
