@@ -153,8 +153,8 @@ def cpu_baseline(cfg, seed, rows=0, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # 20 warm-up + 100 timed steps, median and p10 / p90
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--rows", type=int, default=64)
     ap.add_argument("--dtype", default="bf16")
