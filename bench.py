@@ -283,6 +283,24 @@ def main():
         train_epoch(model, loader, opt, sched, tw, 1, comm)
         ra.synchronize(); hg.barrier()
         loop_ms = hg.all_reduce([(time.perf_counter() - t1) / len(loader) * 1e3], "max")[0]
+    # exposed (non-overlapped) all-reduce time: the same resident-batch step with the gradient all-reduce left
+    # out.  Measured LAST: from here on the ranks' parameters drift apart, and nothing that is reported runs afterwards.
+    nocomm_ms = None
+    if comm is not None and not sharded:
+        model.upload(d)
+
+        def step_nc():
+            model.forward_resident(False)
+            opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=1.0)
+        for _ in range(3):
+            step_nc()
+        ra.synchronize(); hg.barrier()
+        t2 = time.perf_counter()
+        k_nc = max(10, args.steps // 5)
+        for _ in range(k_nc):
+            step_nc()
+        ra.synchronize(); hg.barrier()
+        nocomm_ms = hg.all_reduce([(time.perf_counter() - t2) / k_nc * 1e3], "max")[0]
     if rep:
         # the head GEMMs stop at the positive-weight rows (device-side limit): count the flops they really did
         npos = model.head_rows()
@@ -353,6 +371,9 @@ def main():
             q = lambda f: round(float(np.quantile(plain, f)), 3)
             out["ms_per_step_stats"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": int(len(plain)),
                                         "note": "HIP-event time between step boundaries on the compute stream, steps without per-kernel events"}
+        if nocomm_ms is not None:
+            out["ms_per_step_without_allreduce"] = round(nocomm_ms, 3)
+            out["allreduce_exposed_ms_per_step"] = round(ms - nocomm_ms, 3)     # what the gradient all-reduce adds to a step after its overlap with the backward
         if loop_ms is not None:
             out["train_loop_ms_per_step"] = round(loop_ms, 3)     # train_epoch: batch upload + loss read-back every step
             out["train_loop_interactions_per_sec"] = round(world * rows * S / (loop_ms * 1e-3), 1)
