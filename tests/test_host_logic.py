@@ -240,3 +240,21 @@ def test_prefetch_keeps_order_propagates_errors_and_stops_early():
     for b in data.Prefetch(src, depth=4):
         time.sleep(0.002)
     assert time.time() - t0 < 0.075
+
+
+def test_bench_attention_density_counts_same_user_pairs():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    S = 8
+    one_user = np.full((2, S), 7)
+    assert bench.attention_density(one_user, S) == 1.0
+    halves = np.array([[1] * 4 + [2] * 4, [3] * 2 + [4] * 6])          # (16 + 16) / 64 and (4 + 36) / 64
+    assert abs(bench.attention_density(halves, S) - (0.5 + 0.625) / 2) < 1e-12
+    singles = np.arange(2 * S).reshape(2, S)
+    assert abs(bench.attention_density(singles, S) - 1.0 / S) < 1e-12
+    cfg = {"num_layers": 2, "embed_dim": 8, "intermediate_dim": 16, "max_sequence_length": S, "metadata_emb_size": 3, "mask_topk": 2,
+           "vocab_sizes": {"0_matchedid": 5, "1_matchedid": 6}}
+    dense, half = bench.flops_per_interaction(cfg, 4), bench.flops_per_interaction(cfg, 4, 0.5)
+    assert dense - half == 0.5 * 56 * S * 8 * 2
