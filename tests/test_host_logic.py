@@ -234,12 +234,21 @@ def test_prefetch_keeps_order_propagates_errors_and_stops_early():
             break
     time.sleep(0.3)
     assert src.made < 20 and threading.active_count() <= n_threads    # the producer stopped with the consumer
-    # the producer really runs ahead: consuming 20 slow items while each step also takes 2 ms costs ~max, not the sum
-    src = Slow(20)
-    t0 = time.time()
-    for b in data.Prefetch(src, depth=4):
-        time.sleep(0.002)
-    assert time.time() - t0 < 0.075
+    # the producer really runs ahead: with a consumer that also takes 5 ms per item the loop costs ~max(producer, consumer), not the sum
+    class Slower(Slow):
+        def __iter__(self):
+            for i in range(self.n):
+                time.sleep(0.005)
+                yield {"i": i}
+
+    def consume(it):
+        t0 = time.time()
+        for b in it:
+            time.sleep(0.005)
+        return time.time() - t0
+    serial = consume(Slower(30))
+    overlapped = consume(data.Prefetch(Slower(30), depth=4))
+    assert overlapped < 0.8 * serial, (overlapped, serial)
 
 
 def test_bench_attention_density_counts_same_user_pairs():
