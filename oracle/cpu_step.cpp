@@ -352,6 +352,34 @@ struct Arena {
   }
 };
 
+// operand_round = "bf16" (cpu_step_set_operand_round): every array the HIP path stores as a bf16 GEMM operand is rounded to
+// bfloat16 (nearest even) at the point the kernels store it, accumulation stays float -- the same rounding points as
+// oracle/model_np.py's OracleModel(operand_round="bf16"), so that the benchmarked arithmetic can be checked at its own size
+bool g_round = false;
+inline float bf16r(float x) {
+  uint32_t u; memcpy(&u, &x, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  memcpy(&x, &u, 4);
+  return x;
+}
+void round_arr(float* x, int64_t n) {
+  if (!g_round) return;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < (n + 4095) / 4096; ++c) {
+    const int64_t i1 = std::min(n, c * 4096 + 4096);
+    for (int64_t i = c * 4096; i < i1; ++i) x[i] = bf16r(x[i]);
+  }
+}
+// rows x cols block of `src` (row stride ld) as a rounded dense copy; `src` itself when rounding is off and ld == cols
+const float* rounded_copy(Arena& ar, const float* src, int64_t rows, int64_t cols, int64_t ld) {
+  if (!g_round && ld == cols) return src;
+  float* d = ar.get((size_t)(rows * cols));
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t j = 0; j < cols; ++j) d[r * cols + j] = g_round ? bf16r(src[r * ld + j]) : src[r * ld + j];
+  return d;
+}
+
 inline bool allowed(int uq, int tq, int uk, int tk) { return uq == uk && (tk == 0 || tq == tk); }   // model.py:479-487
 
 constexpr int QB = 48;   // queries (or keys) per attention task
@@ -368,6 +396,7 @@ void attention_fwd(const Cfg& c, const float* q, const float* k, const float* v,
 #pragma omp parallel
   {
     std::vector<float> sbuf((size_t)QB * T);
+    float invs[QB];
 #pragma omp for schedule(dynamic, 1) collapse(3)
     for (int b = 0; b < c.rows; ++b)
       for (int h = 0; h < H; ++h)
@@ -393,10 +422,13 @@ void attention_fwd(const Cfg& c, const float* q, const float* k, const float* v,
             }
             const float den = exp_inplace(si, nk, mx, 1.0f);
             const float inv = 1.0f / den;
-            for (int j = 0; j < nk; ++j) si[j] *= inv;
+            if (g_round) { for (int j = 0; j < nk; ++j) si[j] = bf16r(si[j]); invs[i] = inv; }   // (the flash kernels round exp(s - max), not the quotient)
+            else for (int j = 0; j < nk; ++j) si[j] *= inv;
             lse[((int64_t)b * H + h) * T + i0 + i] = mx + logf(den);
           }
           gemm_block(nq, hd, nk, s, nk, 1, vh, ldk, 1, o + (base + i0) * ldq + h * hd, ldq, false);
+          if (g_round)
+            for (int i = 0; i < nq; ++i) { float* oi = o + (base + i0 + i) * ldq + h * hd; for (int e = 0; e < hd; ++e) oi[e] = bf16r(oi[e] * invs[i]); }
         }
   }
 }
@@ -511,6 +543,7 @@ extern "C" {
 
 int cpu_step_threads(void) { return omp_get_max_threads(); }
 void cpu_step_set_threads(int n) { if (n >= 1) omp_set_num_threads(n); }
+void cpu_step_set_operand_round(int bf16) { g_round = bf16 != 0; }
 void cpu_step_release(void) { for (auto& e : g_pool) free(e.first); g_pool.clear(); }
 
 // One forward + backward of sum_i task_w[i] * loss_i (model.py:493-529 and its autograd).  params / grads: pointer tables in
@@ -523,6 +556,22 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
   Arena ar;
   Phase ph;
   auto LP = [&](int l, int w) { return P[P_LAYER0 + l * L_COUNT + w]; };
+  // weights as GEMM operands: the bf16 shadow copies in operand-rounding mode (the metadata table is expected to hold
+  // bfloat16-representable values already: 4.9 GB at cfg-3, not copied)
+  std::vector<const float*> PWv;
+  if (g_round) {
+    PWv.assign(P_LAYER0 + c.L * L_COUNT, nullptr);
+    PWv[P_WP] = rounded_copy(ar, P[P_WP], D, M, M); PWv[P_LINW] = rounded_copy(ar, P[P_LINW], D, 32, 32); PWv[P_R0W] = rounded_copy(ar, P[P_R0W], D, D, D);
+    for (int l = 0; l < c.L; ++l) {
+      const int b = P_LAYER0 + l * L_COUNT;
+      PWv[b + L_WQ] = rounded_copy(ar, P[b + L_WQ], D, D, D); PWv[b + L_WK] = rounded_copy(ar, P[b + L_WK], Dk, D, D);
+      PWv[b + L_WV] = rounded_copy(ar, P[b + L_WV], Dk, D, D); PWv[b + L_WO] = rounded_copy(ar, P[b + L_WO], D, D, D);
+      PWv[b + L_W1] = rounded_copy(ar, P[b + L_W1], I, D, D); PWv[b + L_W3] = rounded_copy(ar, P[b + L_W3], I, D, D);
+      PWv[b + L_W2] = rounded_copy(ar, P[b + L_W2], D, I, I);
+    }
+  }
+  auto PW = [&](int i) { return g_round ? PWv[i] : P[i]; };
+  auto LW = [&](int l, int w) { return PW(P_LAYER0 + l * L_COUNT + w); };
   auto LG = [&](int l, int w) { return G[P_LAYER0 + l * L_COUNT + w]; };
   for (int64_t i = 0; i < N; ++i) {
     if (bt->matchedid[i] < -1 || bt->matchedid[i] >= V) return -1;
@@ -550,17 +599,19 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
     for (int j = 0; j < 16; ++j) f[15 + j] = P[P_STATUS][sti * 16 + j];
     f[31] = bt->progress[i];
   }
+  round_arr(feat, N * 32);
   ph.mark("action features");
   // ---- fused item table F = E + Meta Wp^T + bp (model.py:120-133, 143-145)
   float* F = ar.get((size_t)(V + 1) * D);
-  gemm_nt(V + 1, D, M, P[P_META], M, P[P_WP], M, F, D);
+  gemm_nt(V + 1, D, M, P[P_META], M, PW(P_WP), M, F, D);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t)(V + 1); ++i)
     for (int j = 0; j < D; ++j) F[i * D + j] += P[P_E][i * D + j] + P[P_BP][j];
+  const float* Fq = rounded_copy(ar, F, V + 1, D, D);   // the tied watch-head operand
   ph.mark("fused table");
   // ---- x0: even tokens items, odd tokens actions (model.py:403-415)
   float* x = ar.get(NT * D);
-  gemm_nt((int)N, D, 32, feat, 32, P[P_LINW], 32, x + D, 2 * D);
+  gemm_nt((int)N, D, 32, feat, 32, PW(P_LINW), 32, x + D, 2 * D);
   std::vector<int> uid(NT), tm(NT), ids(N);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < N; ++i) {
@@ -606,27 +657,32 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
     a.lse = ar.get((size_t)c.rows * H * T); a.o = ar.get(NT * D); a.h = ar.get(NT * D); a.hn = ar.get(NT * D); a.r2 = ar.get(NT);
     a.a = ar.get(NT * (size_t)I); a.b = ar.get(NT * (size_t)I); a.g = ar.get(NT * (size_t)I);
     rmsnorm_fwd(a.x, LP(l, L_SA), a.xn, a.r1, NT, D);
-    gemm_nt((int)NT, D, D, a.xn, D, LP(l, L_WQ), D, a.q, D);
-    gemm_nt((int)NT, Dk, D, a.xn, D, LP(l, L_WK), D, a.k, Dk);
-    gemm_nt((int)NT, Dk, D, a.xn, D, LP(l, L_WV), D, a.v, Dk);
+    round_arr(a.xn, NT * D);
+    gemm_nt((int)NT, D, D, a.xn, D, LW(l, L_WQ), D, a.q, D);
+    gemm_nt((int)NT, Dk, D, a.xn, D, LW(l, L_WK), D, a.k, Dk);
+    gemm_nt((int)NT, Dk, D, a.xn, D, LW(l, L_WV), D, a.v, Dk);
     rope(a.q, NT, T, H, hd, cs.data(), sn.data(), 1.f);
     rope(a.k, NT, T, KV, hd, cs.data(), sn.data(), 1.f);
-    attention_fwd(c, a.q, a.k, a.v, uid.data(), tm.data(), R, a.o, a.lse);
+    round_arr(a.q, NT * D); round_arr(a.k, NT * Dk); round_arr(a.v, NT * Dk);
+    attention_fwd(c, a.q, a.k, a.v, uid.data(), tm.data(), R, a.o, a.lse);   // (rounds its output itself in operand-rounding mode)
     memcpy(a.h, a.x, (size_t)NT * D * 4);
-    gemm_nt((int)NT, D, D, a.o, D, LP(l, L_WO), D, a.h, D, true);
+    gemm_nt((int)NT, D, D, a.o, D, LW(l, L_WO), D, a.h, D, true);
     rmsnorm_fwd(a.h, LP(l, L_MLP), a.hn, a.r2, NT, D);
-    gemm_nt((int)NT, I, D, a.hn, D, LP(l, L_W1), D, a.a, I);
-    gemm_nt((int)NT, I, D, a.hn, D, LP(l, L_W3), D, a.b, I);
+    round_arr(a.hn, NT * D);
+    gemm_nt((int)NT, I, D, a.hn, D, LW(l, L_W1), D, a.a, I);
+    gemm_nt((int)NT, I, D, a.hn, D, LW(l, L_W3), D, a.b, I);
     swiglu_fwd(a.a, a.b, a.g, NT * (int64_t)I);
+    round_arr(a.g, NT * (int64_t)I); round_arr(a.a, NT * (int64_t)I); round_arr(a.b, NT * (int64_t)I);   // (the product used the accumulators; the backward reads the stored operands)
     float* out = ar.get(NT * D);
     memcpy(out, a.h, (size_t)NT * D * 4);
-    gemm_nt((int)NT, D, I, a.g, I, LP(l, L_W2), I, out, D, true);
+    gemm_nt((int)NT, D, I, a.g, I, LW(l, L_W2), I, out, D, true);
     x = out;
   }
   float* xL = x;
   float* y = ar.get(NT * D);
   float* rf = ar.get(NT);
   rmsnorm_fwd(xL, P[P_NORM], y, rf, NT, D);
+  round_arr(y, NT * D);
   ph.mark("trunk forward");
   // ---- heads (model.py:499-526)
   float* gy = ar.get(NT * D);
@@ -658,7 +714,8 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
     if (!rating) {
       const int s0 = medium == 0 ? 0 : c.V0, Vm = medium == 0 ? c.V0 : c.V1;
       for (int r = 0; r < KB; ++r) if (pos[bp[r]] < 0 || pos[bp[r]] >= Vm) return -1;
-      gemm_nt(KB, Vm, D, emb, D, F + (int64_t)s0 * D, D, logits, Vm);
+      gemm_nt(KB, Vm, D, emb, D, Fq + (int64_t)s0 * D, D, logits, Vm);
+      round_arr(logits, (int64_t)KB * Vm);
       double loss = 0;
 #pragma omp parallel for schedule(static) reduction(+ : loss)
       for (int r = 0; r < KB; ++r) {
@@ -671,15 +728,16 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
         const float coef = tw * lab[bp[r]] * w[bp[r]] / ws;
         exp_inplace(lr, Vm, lse, coef);
         lr[t] -= coef;
+        if (g_round) for (int j = 0; j < Vm; ++j) lr[j] = bf16r(lr[j]);
       }
       losses[ti] = (float)(loss / ws);
       if (tw != 0.f) {
-        gemm_nn(KB, D, Vm, logits, Vm, F + (int64_t)s0 * D, D, gemb, D);
+        gemm_nn(KB, D, Vm, logits, Vm, Fq + (int64_t)s0 * D, D, gemb, D);
         gemm_tn(Vm, D, KB, logits, Vm, emb, D, gF + (int64_t)s0 * D, D, true);
         for (int r = 0; r < KB; ++r) { float* d = gy + 2 * (int64_t)bp[r] * D; for (int j = 0; j < D; ++j) d[j] += gemb[(int64_t)r * D + j]; }
       }
     } else {
-      gemm_nt(KB, D, D, emb, D, P[P_R0W], D, z, D);
+      gemm_nt(KB, D, D, emb, D, PW(P_R0W), D, z, D);
       std::vector<float> gp(KB);
       double loss = 0;
 #pragma omp parallel for schedule(static) reduction(+ : loss)
@@ -687,8 +745,8 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
         float pr = P[P_R2B][0];
         for (int j = 0; j < D; ++j) {
           const float zz = z[(int64_t)r * D + j] + P[P_R0B][j];
-          z[(int64_t)r * D + j] = zz;
-          const float hh = gelu_f(zz);
+          z[(int64_t)r * D + j] = g_round ? bf16r(zz) : zz;
+          const float hh = g_round ? bf16r(gelu_f(zz)) : gelu_f(zz);
           hact[(int64_t)r * D + j] = hh;
           pr += hh * P[P_R2W][j];
         }
@@ -704,10 +762,10 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
         }
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < KB; ++r)
-          for (int j = 0; j < D; ++j) z[(int64_t)r * D + j] = gp[r] * P[P_R2W][j] * gelu_grad_f(z[(int64_t)r * D + j]);
+          for (int j = 0; j < D; ++j) { const float gz = gp[r] * P[P_R2W][j] * gelu_grad_f(z[(int64_t)r * D + j]); z[(int64_t)r * D + j] = g_round ? bf16r(gz) : gz; }
         gemm_tn(D, D, KB, z, D, emb, D, G[P_R0W], D, true);
         colsum_add(z, KB, D, D, G[P_R0B]);
-        gemm_nn(KB, D, D, z, D, P[P_R0W], D, gemb, D);
+        gemm_nn(KB, D, D, z, D, PW(P_R0W), D, gemb, D);
         for (int r = 0; r < KB; ++r) { float* d = gy + (2 * (int64_t)bp[r] + 1) * D; for (int j = 0; j < D; ++j) d[j] += gemb[(int64_t)r * D + j]; }
       }
     }
@@ -723,42 +781,57 @@ int cpu_step_forward_backward(const Cfg* cfg, const float* const* P, const Batch
   float* gq = ar.get(NT * D); float* gk = ar.get(NT * Dk); float* gv = ar.get(NT * Dk);
   float* delta = ar.get((size_t)c.rows * H * T);
   float *ga = ab, *gb = ab + NT * (size_t)I;
+  float* gxq = g_round ? ar.get(NT * D) : nullptr;   // the residual-stream gradient as a (rounded) GEMM operand
+  auto operand = [&](const float* g) -> const float* {
+    if (!g_round) return g;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < NT; ++i) for (int j = 0; j < D; ++j) gxq[i * D + j] = bf16r(g[i * D + j]);
+    return gxq;
+  };
   for (int l = c.L - 1; l >= 0; --l) {
     Layer& a = lay[l];
-    gemm_tn(D, I, (int)NT, gx, D, a.g, I, LG(l, L_W2), I);
-    gemm_nn((int)NT, I, D, gx, D, LP(l, L_W2), I, gg, I);
+    const float* gxo = operand(gx);
+    gemm_tn(D, I, (int)NT, gxo, D, a.g, I, LG(l, L_W2), I);
+    gemm_nn((int)NT, I, D, gxo, D, LW(l, L_W2), I, gg, I);
     swiglu_bwd(gg, a.a, a.b, ga, gb, NT * (int64_t)I);
+    round_arr(ga, NT * (int64_t)I); round_arr(gb, NT * (int64_t)I);
     gemm_tn(I, D, (int)NT, ga, I, a.hn, D, LG(l, L_W1), D);
     gemm_tn(I, D, (int)NT, gb, I, a.hn, D, LG(l, L_W3), D);
-    gemm_nn((int)NT, D, I, ga, I, LP(l, L_W1), D, ghn, D);
-    gemm_nn((int)NT, D, I, gb, I, LP(l, L_W3), D, ghn, D, true);
+    gemm_nn((int)NT, D, I, ga, I, LW(l, L_W1), D, ghn, D);
+    gemm_nn((int)NT, D, I, gb, I, LW(l, L_W3), D, ghn, D, true);
+    round_arr(ghn, NT * D);
     memset(LG(l, L_MLP), 0, (size_t)D * 4);
     rmsnorm_bwd(ghn, a.h, LP(l, L_MLP), a.r2, gx, true, LG(l, L_MLP), NT, D);       // gx = gh now
-    gemm_tn(D, D, (int)NT, gx, D, a.o, D, LG(l, L_WO), D);
-    gemm_nn((int)NT, D, D, gx, D, LP(l, L_WO), D, go, D);
+    const float* gho = operand(gx);
+    gemm_tn(D, D, (int)NT, gho, D, a.o, D, LG(l, L_WO), D);
+    gemm_nn((int)NT, D, D, gho, D, LW(l, L_WO), D, go, D);
+    round_arr(go, NT * D);
     attention_bwd(c, a.q, a.k, a.v, a.o, go, a.lse, uid.data(), tm.data(), R, gq, gk, gv, delta);
     rope(gq, NT, T, H, hd, cs.data(), sn.data(), -1.f);
     rope(gk, NT, T, KV, hd, cs.data(), sn.data(), -1.f);
+    round_arr(gq, NT * D); round_arr(gk, NT * Dk); round_arr(gv, NT * Dk);
     gemm_tn(D, D, (int)NT, gq, D, a.xn, D, LG(l, L_WQ), D);
     gemm_tn(Dk, D, (int)NT, gk, Dk, a.xn, D, LG(l, L_WK), D);
     gemm_tn(Dk, D, (int)NT, gv, Dk, a.xn, D, LG(l, L_WV), D);
-    gemm_nn((int)NT, D, D, gq, D, LP(l, L_WQ), D, ghn, D);
-    gemm_nn((int)NT, D, Dk, gk, Dk, LP(l, L_WK), D, ghn, D, true);
-    gemm_nn((int)NT, D, Dk, gv, Dk, LP(l, L_WV), D, ghn, D, true);
+    gemm_nn((int)NT, D, D, gq, D, LW(l, L_WQ), D, ghn, D);
+    gemm_nn((int)NT, D, Dk, gk, Dk, LW(l, L_WK), D, ghn, D, true);
+    gemm_nn((int)NT, D, Dk, gv, Dk, LW(l, L_WV), D, ghn, D, true);
+    round_arr(ghn, NT * D);
     memset(LG(l, L_SA), 0, (size_t)D * 4);
     rmsnorm_bwd(ghn, a.x, LP(l, L_SA), a.r1, gx, true, LG(l, L_SA), NT, D);
   }
   ph.mark("trunk backward");
   // ---- embeddings backward: gx even rows -> item table rows, odd rows -> action embedding
   for (int64_t i = 0; i < N; ++i) { float* d = gF + (int64_t)ids[i] * D; const float* s = gx + 2 * i * D; for (int j = 0; j < D; ++j) d[j] += s[j]; }
-  gemm_tn(D, M, V + 1, gF, D, P[P_META], M, G[P_WP], M);
+  gemm_tn(D, M, V + 1, rounded_copy(ar, gF, V + 1, D, D), D, P[P_META], M, G[P_WP], M);
   memset(G[P_BP], 0, (size_t)D * 4);
   colsum_add(gF, V + 1, D, D, G[P_BP]);
   gemm_tn(D, 32, (int)N, gx + D, 2 * D, feat, 32, G[P_LINW], 32);
   memset(G[P_LINB], 0, (size_t)D * 4);
   colsum_add(gx + D, N, D, 2 * D, G[P_LINB]);
   float* gf = ar.get(N * 32);
-  gemm_nn((int)N, 32, D, gx + D, 2 * D, P[P_LINW], 32, gf, 32);
+  if (g_round) gemm_nn((int)N, 32, D, rounded_copy(ar, gx + D, N, D, 2 * D), D, PW(P_LINW), 32, gf, 32);
+  else gemm_nn((int)N, 32, D, gx + D, 2 * D, P[P_LINW], 32, gf, 32);
   memset(G[P_PCOS], 0, 8); memset(G[P_PSIN], 0, 8);
   memset(G[P_STATUS], 0, (size_t)(c.vs_status + 1) * 16 * 4); memset(G[P_GENDER], 0, (size_t)(c.vs_gender + 1) * 4 * 4);
   memset(G[P_SOURCE], 0, (size_t)(c.vs_source + 1) * 4 * 4);

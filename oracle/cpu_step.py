@@ -45,6 +45,7 @@ def lib():
         L.cpu_step_sgemm_nt.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
         L.cpu_step_isa.restype = ctypes.c_int
         L.cpu_step_set_threads.argtypes = [ctypes.c_int]
+        L.cpu_step_set_operand_round.argtypes = [ctypes.c_int]
         # one thread per CPU this process is GRANTED: OpenMP's default is one per visible core, and 256 spinning threads on a
         # 16-CPU cgroup quota run the step ~10x slower (measured on the GPU box)
         L.cpu_step_set_threads(host_cpus())
@@ -103,8 +104,13 @@ def release():
 class CpuStep:
     """One model instance: fp32 parameters (copied), gradients, AdamW moments; `step` = forward + backward + clip + AdamW."""
 
-    def __init__(self, cfg, P, lr=1e-4):
+    def __init__(self, cfg, P, lr=1e-4, operand_round=None):
+        """operand_round="bf16": the rounding points of model_np.OracleModel(operand_round="bf16") (every array the HIP path stores
+        as a bf16 GEMM operand is rounded where the kernels store it; float accumulation).  The metadata table must then hold
+        bfloat16-representable values (it is not copied)."""
         assert not cfg.get("finetune")
+        assert operand_round in (None, "bf16")
+        self.operand_round = operand_round
         self.cfg = cfg
         self.names = param_order(cfg)
         assert set(self.names) == set(synth.param_shapes(cfg)), "parameter table does not cover the state dict"
@@ -141,7 +147,15 @@ class CpuStep:
         gt = _table([self.G.get(k, dummy) for k in self.names])
         tw = np.ascontiguousarray(task_w, np.float32)
         losses = np.zeros(4, np.float32)
-        rc = lib().cpu_step_forward_backward(ctypes.byref(self.c), pt, ctypes.byref(b), tw.ctypes.data, losses.ctypes.data, gt)
+        lib().cpu_step_set_operand_round(1 if self.operand_round == "bf16" else 0)
+        if self.operand_round == "bf16":
+            meta = self.P["item_embedding.metadata_embedding.embedding.weight"]
+            probe = meta[:: max(1, meta.shape[0] // 64)]
+            assert np.array_equal(model_np.bf16_round(probe), probe), "operand_round: the metadata table must be bfloat16-representable"
+        try:
+            rc = lib().cpu_step_forward_backward(ctypes.byref(self.c), pt, ctypes.byref(b), tw.ctypes.data, losses.ctypes.data, gt)
+        finally:
+            lib().cpu_step_set_operand_round(0)
         if rc != 0:
             raise ValueError("cpu_step: index out of range in the batch")
         return [float(x) for x in losses], self.G

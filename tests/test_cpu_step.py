@@ -54,6 +54,32 @@ def test_losses_and_gradients_match_the_numpy_oracle(name, rows, style):
         assert np.abs(G[k] - ref_G[k]).max() <= 2e-4 * scale + 1e-9, (k, np.abs(G[k] - ref_G[k]).max(), scale)
 
 
+@pytest.mark.parametrize("name,rows,tol,check_gap", [("tiny", 3, 3e-2, False), ("hd64", 2, 1.5e-2, True)])
+def test_bf16_operand_rounding_matches_the_numpy_oracle(name, rows, tol, check_gap):
+    """operand_round="bf16": the C++ step rounds at the numpy oracle's rounding points (what the bench-shape GPU parity test
+    compares the benchmarked arithmetic with).  Roundings amplify last-bit differences of the float sums (a value on a rounding
+    boundary flips a whole bf16 ulp: the numpy oracle run in float32 differs from itself in float64 by as much), hence looser bounds
+    than the unrounded comparison; the forward's rounding points show in the watch losses (equal to 1e-6), the backward's in the
+    gradients at hd64, where the two restatements are several times closer to each other than the rounded model is to the exact one."""
+    cfg, P, dm = _case(name, rows, 11, "test")
+    meta = "item_embedding.metadata_embedding.embedding.weight"
+    P[meta] = model_np.bf16_round(P[meta])
+    tw = train_np.make_task_weights()
+    ref_losses, ref_G = model_np.OracleModel(cfg, P, np.float64, operand_round="bf16").forward(dm, False, True, tw)
+    exact_losses, exact_G = model_np.OracleModel(cfg, P, np.float64).forward(dm, False, True, tw)
+    losses, G = cpu_step.CpuStep(cfg, P, operand_round="bf16").forward_backward(dm, tw)
+    assert np.allclose(losses, ref_losses, rtol=1e-3, atol=1e-6), (losses, ref_losses)     # (a rating loss over a few rows: one flipped ulp is 6e-4)
+    assert not np.allclose(losses, exact_losses, rtol=1e-4, atol=1e-6)
+    worst, gap = 0.0, 0.0
+    for k in synth.trainable_names(cfg):
+        scale = max(np.abs(ref_G[k]).max(), 1e-12)
+        worst = max(worst, np.abs(G[k] - ref_G[k]).max() / scale)
+        gap = max(gap, np.abs(exact_G[k] - ref_G[k]).max() / scale)
+    assert worst <= tol, worst
+    if check_gap:
+        assert gap > 3 * worst, (gap, worst)      # the rounding mode moves the gradients more than the two restatements differ
+
+
 def test_repeated_userid_in_one_row_takes_the_whole_row_path():
     """a userid that comes back later in the same row (never produced by the packer, allowed by the mask rule)"""
     cfg, P, dm = _case("tiny", 2, 5, "test")

@@ -1,0 +1,248 @@
+"""Parity AT THE BENCHMARKED SIZES (BASELINE.json configs[2..4]), through the C ABI on the GPU:
+
+ (a) cfg-3, 64 rows, bf16 -- the exact step bench.py times (every trunk GEMM on the persistent 256x256 LDS-DMA kernel, the grouped
+     weight-gradient launch, the 200 K-class tied head with its fused cross entropy, the sorted segmented scatter, fused clip +
+     AdamW) -- against the oracle's C++ step (oracle/cpu_step.cpp, pinned to the numpy oracle, which is pinned to the
+     reference's own outputs) run with the SAME storage roundings (operand_round="bf16"): the four losses, the global
+     gradient norm, every named gradient and the parameters after one optimizer step
+     (transformer.model.py:493-529 + autograd, transformer.py:259-276);
+ (b) cfg-4 at its own size (D = 1024, 200 K items): two concurrent ranks with a row-sharded table against the same two ranks'
+     batches through the replicated path (extension beyond the reference: parity unpinned, acceptance = the pinned replicated path);
+ (c) cfg-5: the LoRA finetune step at cfg-3's size (one user per row, target on the held-out event,
+     transformer.model.py:235-271,361-371,418-435) against the numpy oracle, fp32 and bf16, plus a short loop that must learn.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+E_NAME = "item_embedding.matchedid_embedding.embedding.weight"
+M_NAME = "item_embedding.metadata_embedding.embedding.weight"
+
+
+def _perturb_scales(model, seed):
+    """init leaves the norm scales at 1 and the phases at 0 (model.py:5-12): move them so that their gradients are exercised"""
+    rng = np.random.default_rng(seed)
+    for n, shape, tr in model.named_parameters():
+        if n.endswith(".scale") or "periodic_time" in n:
+            model.set_parameter(n, (1.0 if n.endswith(".scale") else 0.0) + 0.1 * rng.standard_normal(shape).astype(np.float32))
+
+
+def test_bench_shape_step_vs_cpp_oracle():
+    import recommendersystem_amd as ra
+    from oracle import cpu_step, model_np, synth, train_np
+    cfg = synth.make_config("cfg3")
+    rows, lr = 64, 1e-4
+    d = synth.make_batch(cfg, rows, 0xD47A, mu=4.6, sigma=1.0)
+    wm, rm = synth.make_masks(cfg, rows, 0x3A5C)
+    tw = train_np.make_task_weights()
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.init_weights(0x1217)
+    model.random_pretrained_embeddings(0x3E7A)
+    _perturb_scales(model, 3)
+    P = {k: v for k, v in model.state_dict(include_frozen=True).items() if not k.startswith("watch_head.")}
+    names = synth.trainable_names(cfg)
+    model.set_loss_weights(tw, 1)
+    losses = model(d, False, masks=(wm, rm))
+    G = {n: model.grad(n) for n in names}
+    opt = ra.optim.AdamW(model, lr=lr)
+    opt.step(clip_max_norm=1.0)
+    Pn = {n: model.get_parameter(n) for n in names}
+    model.close()
+
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    cs = cpu_step.CpuStep(cfg, P, lr=lr, operand_round="bf16")
+    ref_losses, ref_G = cs.forward_backward(dm, tw)
+    norm_gpu = float(np.sqrt(sum(float((G[n].astype(np.float64) ** 2).sum()) for n in names)))
+    ref_G = {n: ref_G[n].copy() for n in names}
+    ref_norm = cs.clip_adamw()
+    cpu_step.release()
+
+    e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(losses, ref_losses)]
+    rows_g = sorted(((float(np.abs(G[n] - ref_G[n]).max() / max(np.abs(ref_G[n]).max(), 1e-30)), n) for n in names), reverse=True)
+    print("bench-shape parity: losses", losses, "oracle", ref_losses, "rel", e_l)
+    print("  grad norm", norm_gpu, "oracle", ref_norm, " worst gradients (of tensor max):", rows_g[:4])
+    assert max(e_l) <= 5e-3, (losses, ref_losses)
+    assert abs(norm_gpu - ref_norm) <= 1e-2 * ref_norm, (norm_gpu, ref_norm)
+    assert rows_g[0][0] <= 5e-2, rows_g[:6]
+    # one fused clip + AdamW step.  The first Adam step moves every element by lr * g / (|g| + eps) ~ +-lr: elements whose two
+    # gradients disagree in sign (|g| within the bf16 noise of zero) differ by 2 lr, all the others by ~lr * eps / |g|
+    flips, total, worst = 0, 0, 0.0
+    for n in names:
+        diff = np.abs(Pn[n] - cs.P[n])
+        worst = max(worst, float(diff.max()))
+        flips += int((diff > 0.5 * lr).sum()); total += diff.size
+    print(f"  parameters after clip + AdamW: max |diff| {worst:.3e} (lr {lr}), {flips} of {total} elements moved the other way")
+    assert worst <= 2.0 * lr * 1.02 + 1e-7, worst
+    assert flips <= 0.02 * total, (flips, total)
+
+
+def test_cfg4_own_size_sharded_step_equals_replicated():
+    """D = 1024, H = 16, 200 K x 1024 item table row-sharded over two concurrent ranks of this GPU (in-process rank group), 8 rows
+    per rank, bf16, one optimizer step: sparse row exchange, vocabulary-parallel cross entropy, dense all-reduce, global-norm clip
+    over the shards, AdamW -- against the ranks' batches as micro-steps of ONE replicated model."""
+    import threading
+
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.optim import AdamW
+    cfg = synth.make_config("cfg4")
+    world, rows, lr = 2, 8, 1e-4
+    tw = [0.05, 0.2, 0.3, 0.25]
+    batches = [synth.make_batch(cfg, rows, 0xD47A ^ r, mu=4.6, sigma=1.0) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, 900 + r) for r in range(world)]
+    names = synth.trainable_names(cfg)
+
+    def build(c):
+        m = ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+        m.init_weights(0x1217); m.random_pretrained_embeddings(0x3E7A)    # generated by GLOBAL row: shards = slices of the replicated tables
+        _perturb_scales(m, 5)
+        m.set_loss_weights(tw, 1)
+        return m
+
+    ref = build(cfg)
+    l_ref = [ref(b, False, masks=mk) for b, mk in zip(batches, masks)]
+    G_ref = {n: ref.grad(n) for n in names}
+    AdamW(ref, lr=lr).step(clip_max_norm=1.0, grad_div=float(world))
+    P_ref = {n: ref.get_parameter(n) for n in names}
+    ref.close()
+
+    group = rdist.LocalGroup(world)
+    out = [None] * world; err = [None] * world
+
+    def rank(r):
+        try:
+            comm = rdist.LocalComm(group, r)
+            c = dict(cfg); c["table_shard"] = (r, world)
+            m = build(c)
+            m.set_shard_comm(comm)
+            lo, hi = m.table_rows()
+            losses = m(batches[r], False, masks=masks[r])
+            comm.all_reduce_grads(m)
+            G = {n: m.grad(n) for n in names}
+            AdamW(m, lr=lr).step(clip_max_norm=1.0, grad_div=float(world))
+            Pn = {n: m.get_parameter(n) for n in names}
+            m.close(); comm.close()
+            out[r] = (losses, G, Pn, lo, hi)
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    group.close()
+    for e in err:
+        if e is not None:
+            raise e
+    worst_l, worst_g, worst_p = 0.0, ("", 0.0), 0.0
+    for r, (losses, G, Pn, lo, hi) in enumerate(out):
+        for a, b in zip(losses, l_ref[r]):
+            worst_l = max(worst_l, abs(a - b) / max(abs(b), 1.0))
+        for n in names:
+            g_ref, p_ref = (G_ref[n][lo:hi], P_ref[n][lo:hi]) if n == E_NAME else (G_ref[n], P_ref[n])
+            e = float(np.abs(G[n] - g_ref).max() / max(np.abs(G_ref[n]).max(), 1e-30))
+            if e > worst_g[1]:
+                worst_g = (n, e)
+            worst_p = max(worst_p, float(np.abs(Pn[n] - p_ref).max()))
+    print(f"cfg-4 own size, world {world}: losses {worst_l:.2e}, worst gradient {worst_g}, parameters max |diff| {worst_p:.2e} (lr {lr})")
+    assert worst_l <= 2e-3, worst_l                  # measured by tools/rehearse_sharded.py: 3e-5
+    assert worst_g[1] <= 5e-2, worst_g
+    assert worst_p <= 2.0 * lr * 1.02 + 1e-7, worst_p
+
+
+def _finetune_batch(cfg, rows, seed, medium, metric):
+    """one user per row, the only target is the row's last event with a `metric` target in `medium` (Finetune/transformer.jl:52-133)"""
+    from oracle import synth
+    S = cfg["max_sequence_length"]
+    d = {k: np.array(v).reshape(rows, S) for k, v in synth.make_batch(cfg, rows, seed, mu=6.5, sigma=0.3).items()}
+    first = d["userid"][:, :1]
+    d["userid"] = np.where(d["userid"] == first, first, 0).astype(np.int32)   # one user per row, the rest is the pad user
+    key = f"{medium}.{metric}.weight"
+    keep = np.zeros((rows, S), bool)
+    for b in range(rows):
+        nz = np.nonzero((d[key][b] > 0) & (d["userid"][b] == first[b, 0]))[0]
+        assert len(nz), "no target in this row"
+        keep[b, nz[-1]] = True
+    for k in list(d):
+        if k.endswith((".weight", ".label", ".position")):
+            d[k] = (d[k] * keep.astype(d[k].dtype)) if k.startswith(f"{medium}.{metric}.") else np.zeros_like(d[k])
+    return {k: v.reshape(-1) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("medium,metric", [(1, "watch"), (0, "rating")])
+def test_cfg5_lora_finetune_step_at_cfg3_size_vs_numpy_oracle(medium, metric):
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg = synth.make_config("cfg3", finetune=True, finetune_metric=metric, finetune_medium=medium)
+    cfg["lora_dropout"] = 0.0
+    V = cfg["vocab_sizes"]["0_matchedid"] + cfg["vocab_sizes"]["1_matchedid"]
+    D = cfg["embed_dim"]
+    ti = medium * 2 + (0 if metric == "watch" else 1)
+    tw = [0.0] * 4; tw[ti] = 1.0
+    d = _finetune_batch(cfg, 1, 77, medium, metric)
+    for dtype, tol_loss, tol_grad in (("fp32", 1e-4, 1e-3), ("bf16", 5e-3, 5e-2)):
+        model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=1)
+        model.init_weights(0x1217)
+        model.random_pretrained_embeddings(0x3E7A)
+        _perturb_scales(model, 3)
+        lora = [n for n, _, tr in model.named_parameters() if tr]
+        assert lora and all("lora_" in n for n in lora)
+        rng = np.random.default_rng(8)
+        for n in lora:                                   # lora_B starts at zero (model.py:252-254): its A gradients would vanish
+            if "lora_B" in n:
+                model.set_parameter(n, 0.02 * rng.standard_normal(model._shape(n)[1]).astype(np.float32))
+        model.set_loss_weights(tw, 1)
+        losses = model(d, False)
+        G = {n: model.grad(n) for n in lora}
+        # the fused item table on the host in float64 (8192 rows at a time), with the projection weight rounded like the kernels' operand
+        P = {k: v for k, v in model.state_dict(include_frozen=True).items() if not k.startswith("watch_head.")}
+        model.close()
+        meta = P.pop(M_NAME)
+        Wp = P["item_embedding.projection_layer.weight"]
+        Wp = (model_np.bf16_round(Wp) if dtype == "bf16" else Wp).astype(np.float64)
+        F = np.zeros((V + 1, D), np.float64)
+        for r0 in range(0, V, 8192):
+            F[r0:r0 + 8192] = meta[r0:r0 + 8192].astype(np.float64) @ Wp.T
+        F += P[E_NAME].astype(np.float64) + P["item_embedding.projection_layer.bias"].astype(np.float64)
+        del meta
+        P64 = {k: v.astype(np.float64) for k, v in P.items()}
+        P64["item_embedding.fused_embedding"] = F
+        ref = model_np.OracleModel(cfg, P64, np.float64, operand_round="bf16" if dtype == "bf16" else None)
+        dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d))
+        l_ref, G_ref = ref.forward(dm, False, True, tw)
+        e_l = abs(losses[ti] - l_ref[ti]) / max(abs(l_ref[ti]), 1e-6)
+        worst = max(((float(np.abs(G[n] - G_ref[n]).max() / max(np.abs(G_ref[n]).max(), 1e-30)), n) for n in lora))
+        print(f"cfg-5 LoRA step at cfg-3 size [{medium}.{metric}, {dtype}]: loss {losses[ti]:.6f} oracle {l_ref[ti]:.6f} rel {e_l:.2e}; worst LoRA gradient {worst}")
+        assert e_l <= tol_loss, (losses, l_ref)
+        assert worst[0] <= tol_grad, worst
+        assert max(np.abs(G_ref[n]).max() for n in lora) > 0
+
+
+def test_cfg5_lora_finetune_loop_learns_at_cfg3_size():
+    """the reference's finetune step sizes (train.py:591-597: 16 rows x 2 accumulation steps, lr 2e-4, dropout 0.1) on a fixed
+    set of users: the chosen task's training loss must fall and only the LoRA tensors move"""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    medium, metric = 1, "watch"
+    cfg = synth.make_config("cfg3", finetune=True, finetune_metric=metric, finetune_medium=medium, learning_rate=2e-4)
+    cfg["lora_dropout"] = 0.1
+    ti = medium * 2
+    tw = [0.0] * 4; tw[ti] = 1.0
+    micro = [_finetune_batch(cfg, 16, 500 + i, medium, metric) for i in range(2)]
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=16)
+    model.init_weights(0x1217); model.random_pretrained_embeddings(0x3E7A)
+    opt = ra.create_optimizer(model, cfg)
+    model.set_loss_weights(tw, 2)
+    w1 = model.get_parameter("transformers.layers.3.mlp.w1.weight")
+    curve = []
+    for step in range(60):
+        ls = [model(b, False)[ti] for b in micro]
+        opt.step(clip_max_norm=1.0)
+        curve.append(float(np.mean(ls)))
+    assert np.isfinite(curve).all()
+    print("cfg-5 loop at cfg-3 size: loss", [round(c, 4) for c in curve[::10]], "->", round(curve[-1], 4))
+    assert curve[-1] < curve[0] - 0.05, (curve[0], curve[-1])
+    np.testing.assert_array_equal(model.get_parameter("transformers.layers.3.mlp.w1.weight"), w1)
+    model.close()
