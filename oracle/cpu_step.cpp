@@ -473,9 +473,13 @@ void attention_bwd(const Cfg& c, const float* q, const float* k, const float* v,
             float *si = s + (size_t)i * nk, *di = dp + (size_t)i * nk;
             for (int j = 0; j < nk; ++j) si[j] = allowed(uq, tq, uid[base + ks + j], tm[base + ks + j]) ? si[j] * scale : -INFINITY;
             exp_inplace(si, nk, l, 1.0f);
-            for (int j = 0; j < nk; ++j) si[j] = si[j] * (di[j] - dl) * scale;
+            // operand rounding: the flash kernels feed dS' = P (dP - delta) to the MFMA as bf16 and apply 1/sqrt(hd) to the sum
+            if (g_round) for (int j = 0; j < nk; ++j) si[j] = bf16r(si[j] * (di[j] - dl));
+            else for (int j = 0; j < nk; ++j) si[j] = si[j] * (di[j] - dl) * scale;
           }
           gemm_block(nq, hd, nk, s, nk, 1, kh, ldk, 1, gq + (base + i0) * ldq + h * hd, ldq, false);
+          if (g_round)
+            for (int i = 0; i < nq; ++i) { float* gi = gq + (base + i0 + i) * ldq + h * hd; for (int e = 0; e < hd; ++e) gi[e] *= scale; }
         }
     // dk, dv: per (row, kv head, key block), summed over the query heads of the group
 #pragma omp for schedule(dynamic, 1) collapse(3)
@@ -505,11 +509,14 @@ void attention_bwd(const Cfg& c, const float* q, const float* k, const float* v,
               for (int i = 0; i < nq; ++i)
                 sj[i] = allowed(uid[base + qs + i], tm[base + qs + i], uk, tk) ? sj[i] * scale - lrow[i] : -INFINITY;
               exp_inplace(sj, nq, 0.f, 1.0f);                                           // P^T
-              for (int i = 0; i < nq; ++i) dj[i] = sj[i] * (dj[i] - drow[i]) * scale;   // dS^T
+              if (g_round) for (int i = 0; i < nq; ++i) { dj[i] = bf16r(sj[i] * (dj[i] - drow[i])); sj[i] = bf16r(sj[i]); }   // bf16 MFMA operands; scale below
+              else for (int i = 0; i < nq; ++i) dj[i] = sj[i] * (dj[i] - drow[i]) * scale;   // dS^T
             }
             gemm_block(nk, hd, nq, st, nq, 1, goh, ldq, 1, gv + (base + j0) * ldk + g * hd, ldk, r > 0);
             gemm_block(nk, hd, nq, dpt, nq, 1, qh, ldq, 1, gk + (base + j0) * ldk + g * hd, ldk, r > 0);
           }
+          if (g_round)
+            for (int j = 0; j < nk; ++j) { float* gj = gk + (base + j0 + j) * ldk + g * hd; for (int e = 0; e < hd; ++e) gj[e] *= scale; }
         }
   }
 }

@@ -301,11 +301,12 @@ class OracleModel:
             goh = go.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)
             qh = c["q"].transpose(0, 2, 1, 3)
             prT = pr.transpose(0, 1, 3, 2)
-            gvv = np.matmul(prT, goh).transpose(0, 2, 1, 3)
-            gp = np.matmul(goh, vh.transpose(0, 1, 3, 2))
-            gs = pr * (gp - (gp * pr).sum(-1, keepdims=True)) * scale
-            gq = np.matmul(gs, kh).transpose(0, 2, 1, 3)
-            gkk = np.matmul(gs.transpose(0, 1, 3, 2), qh).transpose(0, 2, 1, 3)
+            gvv = np.matmul(Q(prT), goh).transpose(0, 2, 1, 3)         # (the flash kernels feed P and dS' = P (dP - delta) to the MFMA
+            gp = np.matmul(goh, vh.transpose(0, 1, 3, 2))             #  as bf16 operands; 1/sqrt(hd) is applied to the finished sums)
+            delta = (go * c["o"].reshape(B, T, H, hd)).sum(-1).transpose(0, 2, 1)[..., None]   # = rowsum(dP * P); from the STORED output, as the kernels do
+            gs = Q(pr * (gp - delta))
+            gq = np.matmul(gs, kh).transpose(0, 2, 1, 3) * scale
+            gkk = np.matmul(gs.transpose(0, 1, 3, 2), qh).transpose(0, 2, 1, 3) * scale
             gk = gkk.reshape(B, T, KV, rep, hd).sum(3)
             gv = gvv.reshape(B, T, KV, rep, hd).sum(3)
             gq = Q(apply_rope_bwd(gq, cos, sin).reshape(B, T, H * hd))

@@ -60,6 +60,17 @@ int launch_gemm(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_k
 template <typename CT>
 long long gemm_slab_need(const GemmParams& p, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
+// Grouped launch of many K-major split-K products (the weight gradients dW = dY^T X of several layers) on the 256x256 LDS-DMA
+// pipeline (gemm8p.hip): a plan deals the products to the XCDs once, launches reuse it.  Products: bf16 K-major operands, fp32
+// C, EPI_ATOMIC (C must hold zeros or the sum so far).
+struct GemmGroupPlan;
+bool gemm8p_group_eligible(const GemmParams& p);
+int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out);
+void gemm8p_group_plan_destroy(GemmGroupPlan* pl);
+double gemm8p_group_flops(const GemmGroupPlan* pl);
+int gemm8p_group_splitk(const GemmGroupPlan* pl);
+int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s);
+
 // short name of the kernel launch_gemm picks for this problem ("8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);
 

@@ -19,6 +19,9 @@
 // LDS image of a half-tile: 128 rows of 128 B, 16-byte chunk c of local row r at r*128 + ((c ^ ((r>>1)&7)) << 4):
 // the 16 lanes of a ds_read_b128 group (16 rows, one chunk) cover all 64 banks.  LDS-DMA writes lane-linear, so
 // the permutation is applied to the per-lane SOURCE address.
+#include <algorithm>
+#include <vector>
+
 #include "gemm.hpp"
 #include "gemm_epi.hpp"
 #include "gemm_epi_reg.hpp"
@@ -70,9 +73,12 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // SK (row-major operands only): split-K with the work mapping and the LDS-staged fp32-atomic epilogue of the K-major
 // form instead of the persistent tile run -- for products with few output tiles and a very long K whose operands exist
 // as row-major (K-contiguous) copies: the metadata-projection gradient on transposed copies of dF and Meta.
-template <bool KM, bool SK = false>
-__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+// GROUP (K-major form only): the workgroup's (tile, K split) comes from a work list (gemm8p_group_kernel below) instead of the
+// block index: many small products in one launch.
+template <bool KM, bool SK, bool GROUP>
+__device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, const int nblk, const int g_tile, const int g_split) {
   static_assert(!(KM && SK), "the K-major form is always split-K");
+  static_assert(!GROUP || KM, "grouped launches exist for the K-major form");
   constexpr bool PERSIST = !KM && !SK;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l0 = t & 63;
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   if constexpr (PERSIST) {
     const int rows = p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M;
     const int ntiles = ((rows + T8_BM - 1) / T8_BM) * tiles_n;
-    const int xcd = blockIdx.x & 7, G = gridDim.x;
+    const int xcd = bid & 7, G = nblk;
     const int q = ntiles >> 3, r = ntiles & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_end = (xcd < r ? (xcd + 1) * (q + 1) : r * (q + 1) + (xcd + 1 - r) * q);
     tile_step = (G + 7 - xcd) >> 3;                    // workgroups on this XCD
     if (tile >= tile_end) return;                      // uniform: whole workgroup leaves
@@ -100,10 +106,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   } else {
     // split-K (launcher: splitk % 8 == 0): XCD x owns the K splits x, x+8, ...; inside an XCD the tiles of one split
     // vary fastest, so the K-major operand rows of a split are fetched from HBM by one L2 only
-    const int ntiles = ((p.M + T8_BM - 1) / T8_BM) * tiles_n;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    tile = local % ntiles;
-    const int split = xcd + 8 * (local / ntiles);
+    int split;
+    if constexpr (GROUP) { tile = g_tile; split = g_split; }
+    else {
+      const int ntiles = ((p.M + T8_BM - 1) / T8_BM) * tiles_n;
+      const int xcd = bid & 7, local = bid >> 3;
+      tile = local % ntiles;
+      split = xcd + 8 * (local / ntiles);
+    }
     split_id = split;
     const int ktiles = (p.K + T8_BK - 1) / T8_BK, per = (ktiles + p.splitk - 1) / p.splitk;
     kt0 = split * per;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   pend = 0;
   if constexpr (PERSIST) {
     if (p.flags & 4) {   // timing experiment: every other workgroup of an XCD starts p.T microsecond-ish naps late
-      if ((blockIdx.x >> 3) & 1) for (int k = 0; k < p.T; ++k) __builtin_amdgcn_s_sleep(32);
+      if ((bid >> 3) & 1) for (int k = 0; k < p.T; ++k) __builtin_amdgcn_s_sleep(32);
     }
   }
   prologue();
@@ -448,13 +458,133 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   else { run_tiles(std::true_type{}); run_tiles(std::false_type{}); }
 #ifdef RSYS_8P_TRACE
   if (p.trace != nullptr && t == 0) {
-    for (int i = 0; i < 5; ++i) p.trace[blockIdx.x * 8 + i] = tr_sum[i];
-    p.trace[blockIdx.x * 8 + 5] = tr_tiles;
+    for (int i = 0; i < 5; ++i) p.trace[bid * 8 + i] = tr_sum[i];
+    p.trace[bid * 8 + 5] = tr_tiles;
   }
 #endif
 }
 
+template <bool KM, bool SK = false>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+  gemm8p_body<KM, SK, false>(p, blockIdx.x, gridDim.x, 0, 0);
+}
+
+// Grouped K-major split-K launch: the weight gradients dW = dY^T X of MANY layers in one grid.  Each product alone is too small
+// for the chip (4 - 22 output tiles of 256^2 at cfg-3), all of them together are not.  The host deals the products to the 8
+// XCDs (work lists, gemm8p_group_plan): a workgroup of XCD x takes entry (blockIdx.x >> 3) of list x = (product, K split, tile),
+// the tiles of one (product, split) adjacent, so that the K-major operand rows of a product are fetched from HBM by one L2 and
+// shared by the product's tiles.  (Workgroups are dealt round-robin over the XCDs; which XCD gets which list is speed only.)
+__global__ __launch_bounds__(512) void gemm8p_group_kernel(const GemmParams* __restrict__ probs, const int* __restrict__ xcd_off,
+                                                           const unsigned int* __restrict__ work) {
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int o = xcd_off[xcd];
+  if (local >= xcd_off[xcd + 1] - o) return;
+  const unsigned int wk = work[o + local];     // product << 24 | split << 16 | tile
+  const GemmParams p = probs[wk >> 24];
+  gemm8p_body<true, false, true>(p, blockIdx.x, gridDim.x, (int)(wk & 0xFFFFu), (int)((wk >> 16) & 0xFFu));
+}
+
 }  // namespace
+
+// ------------------------------------------------------------------ grouped launch plan
+struct GemmGroupPlan {
+  void* dev = nullptr;          // [probs | xcd_off | work]
+  const GemmParams* d_probs = nullptr; const int* d_off = nullptr; const unsigned int* d_work = nullptr;
+  int grid = 0, n = 0, splitk = 1;
+  double flops = 0.0;
+};
+
+bool gemm8p_group_eligible(const GemmParams& p) { return gemm8p_tn_eligible(p) && p.slab == nullptr; }
+
+// Deals `n` (<= 128) K-major products (EPI_ATOMIC, fp32 C, zero or accumulating) to the XCDs and uploads the plan.  The plan
+// holds device pointers of the operands: it stays valid while those buffers do.  Synchronous (one small H2D copy).
+int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out) {
+  ARG_CHECK(n >= 1 && n <= 128, "grouped GEMM: 1..128 products");
+  int cus = 256;
+  { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+  const int per_xcd = std::max(1, cus / 8);
+  std::vector<int> tiles(n), ktiles(n);
+  int ktmax = 0;
+  for (int i = 0; i < n; ++i) {
+    ARG_CHECK(gemm8p_group_eligible(probs[i]), "grouped GEMM: product not eligible for the K-major LDS-DMA kernel");
+    tiles[i] = ((probs[i].M + T8_BM - 1) / T8_BM) * ((probs[i].N + T8_BN - 1) / T8_BN);
+    ARG_CHECK(tiles[i] < 65536, "grouped GEMM: too many tiles");
+    ktiles[i] = (probs[i].K + T8_BK - 1) / T8_BK;
+    ktmax = std::max(ktmax, ktiles[i]);
+  }
+  // products to XCDs: largest first onto the least loaded list (work = tiles x K tiles)
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return (long long)tiles[a] * ktiles[a] > (long long)tiles[b] * ktiles[b]; });
+  std::vector<std::vector<int>> lists(8);
+  long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i : order) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+    lists[best].push_back(i); load[best] += (long long)tiles[i] * ktiles[i];
+  }
+  // one K-split count for the whole group: the one whose slowest XCD finishes first (a workgroup costs its K tiles plus
+  // ~24 K-tile times of prologue and 256 KB of atomics; a list runs in rounds of one workgroup per CU)
+  static const int force = getenv("RSYS_DEBUG_8G_SPLITK") ? atoi(getenv("RSYS_DEBUG_8G_SPLITK")) : 0;
+  int best_s = 1; double best_t = 1e300;
+  for (int s = 1; s <= 16; ++s) {
+    if (s > 1 && (ktmax + s - 1) / s < 8) break;
+    double worst = 0.0;
+    for (int x = 0; x < 8; ++x) {
+      // items in list order, greedy onto per_xcd slots
+      std::vector<double> slot(per_xcd, 0.0);
+      for (int i : lists[x]) {
+        const int per = (ktiles[i] + s - 1) / s;
+        for (int sp = 0; sp < s; ++sp) {
+          const int nt = std::min(ktiles[i], (sp + 1) * per) - sp * per;
+          if (nt <= 0) continue;
+          for (int t = 0; t < tiles[i]; ++t) { auto it = std::min_element(slot.begin(), slot.end()); *it += nt + 24.0; }
+        }
+      }
+      worst = std::max(worst, *std::max_element(slot.begin(), slot.end()));
+    }
+    if (worst < best_t) { best_t = worst; best_s = s; }
+  }
+  if (force > 0) best_s = std::min(force, 255);
+  std::vector<GemmParams> hp(probs, probs + n);
+  std::vector<int> off(9, 0);
+  std::vector<unsigned int> work;
+  int longest = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) { hp[i].splitk = best_s; if (hp[i].alpha == 0.f) hp[i].alpha = 1.f; flops += 2.0 * hp[i].M * hp[i].N * (double)hp[i].K; }
+  for (int x = 0; x < 8; ++x) {
+    off[x] = (int)work.size();
+    for (int i : lists[x]) {
+      const int per = (ktiles[i] + best_s - 1) / best_s;
+      for (int sp = 0; sp < best_s; ++sp) {
+        if (sp * per >= ktiles[i]) continue;
+        for (int t = 0; t < tiles[i]; ++t) work.push_back(((unsigned int)i << 24) | ((unsigned int)sp << 16) | (unsigned int)t);
+      }
+    }
+    longest = std::max(longest, (int)work.size() - off[x]);
+  }
+  off[8] = (int)work.size();
+  GemmGroupPlan* pl = new GemmGroupPlan();
+  const size_t b_probs = (sizeof(GemmParams) * n + 255) / 256 * 256, b_off = 256, b_work = (work.size() * 4 + 255) / 256 * 256;
+  if (hipMalloc(&pl->dev, b_probs + b_off + b_work) != hipSuccess) { delete pl; set_error("grouped GEMM: hipMalloc failed"); return RSYS_ERR_HIP; }
+  pl->d_probs = (const GemmParams*)pl->dev; pl->d_off = (const int*)((char*)pl->dev + b_probs); pl->d_work = (const unsigned int*)((char*)pl->dev + b_probs + b_off);
+  bool ok = hipMemcpy((void*)pl->d_probs, hp.data(), sizeof(GemmParams) * n, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy((void*)pl->d_off, off.data(), 9 * 4, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy((void*)pl->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { hipFree(pl->dev); delete pl; set_error("grouped GEMM: plan upload failed"); return RSYS_ERR_HIP; }
+  pl->grid = 8 * longest; pl->n = n; pl->splitk = best_s; pl->flops = flops;
+  *out = pl;
+  return RSYS_OK;
+}
+void gemm8p_group_plan_destroy(GemmGroupPlan* pl) { if (pl) { if (pl->dev) hipFree(pl->dev); delete pl; } }
+double gemm8p_group_flops(const GemmGroupPlan* pl) { return pl->flops; }
+int gemm8p_group_splitk(const GemmGroupPlan* pl) { return pl->splitk; }
+int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s) {
+  if (pl->grid <= 0) return RSYS_OK;
+  hipLaunchKernelGGL(gemm8p_group_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
 
 bool gemm8p_eligible(const GemmParams& p) {
   if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr || p.accum) return false;

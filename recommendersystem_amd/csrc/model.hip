@@ -302,6 +302,20 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->sumsq, 64);
   m->dLa = nullptr; m->dxl = nullptr;
   if (cfg->finetune) { DALLOC(m->dLa, NT * 16 * e); DALLOC(m->dxl, NT * D * e); }
+  {
+    // grouped weight gradients where one layer's products are too small for the 256x256 K-major kernel on their own (the
+    // dispatcher's threshold: >= 32 output tiles, gemm.hip use_8p_tn): cfg-3 has 22 / 12 / 8 / 4 tiles per product
+    static const int grp = getenv("RSYS_DW_GROUP") ? atoi(getenv("RSYS_DW_GROUP")) : 1;
+    const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
+    m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
+    if (m->defer_dw) {
+      m->dwb.resize(m->L);
+      for (int l = 0; l < m->L; ++l) {
+        DALLOC(m->dwb[l].gxt, NT * D * 2); DALLOC(m->dwb[l].dab, NT * 2 * m->Ip * 2);
+        DALLOC(m->dwb[l].dht, NT * D * 2); DALLOC(m->dwb[l].dqkv, NT * m->Nqkv * 2);
+      }
+    }
+  }
   *out = m;
   return RSYS_OK;
 }
@@ -320,6 +334,7 @@ int model_destroy(Model* m) {
   if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
   for (int k = 0; k < 4; ++k) if (m->ev_dw[k]) hipEventDestroy(m->ev_dw[k]);
+  for (auto& kv : m->dw_plans) gemm8p_group_plan_destroy(kv.second);
   for (auto e : m->timer.pool) hipEventDestroy(e);
   for (auto e : m->step_marks) hipEventDestroy(e);
   hipStreamDestroy(m->stream);
@@ -1101,6 +1116,38 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   return RSYS_OK;
 }
 
+// The four weight-gradient products of layers [l_lo, l_hi] from the operands the backward kept (Model::dwb), one grouped launch.
+template <typename T>
+static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
+  const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
+  const long long key = ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
+  auto it = m->dw_plans.find(key);
+  if (it == m->dw_plans.end()) {
+    std::vector<GemmParams> ps;
+    for (int l = l_hi; l >= l_lo; --l) {
+      const Model::LayerAct& a = m->la[l];
+      const Model::DwOperands& o = m->dwb[l];
+      auto add = [&](const void* A, long long lda, const void* B, long long ldb, float* C, long long ldc, int M, int N) {
+        GemmParams p{};
+        p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_f32 = 1; p.M = M; p.N = N; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 1.f;
+        ps.push_back(p);
+      };
+      add(o.dab, 2 * Ip, a.hn, D, m->G + m->lo[l].w13, D, 2 * Ip, D);       // dW13 += dab^T . hn
+      add(o.gxt, D, a.g, Ip, m->G + m->lo[l].w2, Ip, D, Ip);                 // dW2  += gx^T . g
+      add(o.dqkv, m->Nqkv, a.xn, D, m->G + m->lo[l].wqkv, D, m->Nqkv, D);    // dWqkv += dqkv^T . xn
+      add(o.dht, D, a.O, D, m->G + m->lo[l].wo, D, D, D);                    // dWo  += dh^T . O
+    }
+    GemmGroupPlan* pl = nullptr;
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl));
+    it = m->dw_plans.emplace(key, pl).first;
+  }
+  if (m->timer.enabled) tic(m, "gemm_dw_group@8g", gemm8p_group_flops(it->second));
+  int rc = launch_gemm8p_group(it->second, m->stream);
+  toc(m);
+  return rc;
+}
+
 // ------------------------------------------------------------------ backward trunk + embeddings
 template <typename T>
 static int backward_trunk(Model* m) {
@@ -1114,6 +1161,9 @@ static int backward_trunk(Model* m) {
   T* gxt_other = AT<T>(m->gxb_t);
   T* dht = AT<T>(m->dh_t);
   const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
+  // deferred weight gradients: the dY operands of layer l live in m->dwb[l] until the grouped launch that consumes them
+  const bool defer = m->defer_dw && !m->deterministic && side_mode() == 0;
+  if (defer) gxt = AT<T>(m->dwb[m->L - 1].gxt);
   RC(ensure_transposes(m));
   const bool wt = m->bf16_mode;   // dx GEMMs: row-major W^T (bf16 mode) or the K-major read of W itself (fp32 parity mode)
   tic(m, "phase_trunk_bwd");
@@ -1129,7 +1179,10 @@ static int backward_trunk(Model* m) {
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
     const bool ft = m->cfg.finetune != 0;   // finetune: base weights are frozen, only the dx chain and the LoRA grads run
-    if (!ft) {
+    void* const dab = defer ? m->dwb[l].dab : m->dab;
+    void* const dqkv = defer ? m->dwb[l].dqkv : m->dqkv;
+    if (defer) { dht = AT<T>(m->dwb[l].dht); gxt_other = l > 0 ? AT<T>(m->dwb[l - 1].gxt) : AT<T>(m->gxa_t); }
+    if (!ft && !defer) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1137,22 +1190,22 @@ static int backward_trunk(Model* m) {
     }
     {
       GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward: writes [da|db] directly
-      p.A = gxt; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->dab; p.ldc = 2 * Ip;
+      p.A = gxt; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = dab; p.ldc = 2 * Ip;
       if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
       RC(join_dw(m, DW_W13));   // the layer above's dW13 reads dab
       RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
       RC(join_side(m));
     }
-    if (!ft) {
+    if (!ft && !defer) {
       GemmParams p{};  // dW13 += dab^T . hn
-      p.A = m->dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
+      p.A = dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
       p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
       RC(gemm_side<T>(m, "gemm_w13_dw", p, false, true, true, DW_W13));
     }
     {
       GemmParams p{};  // dhn = dab . W13
-      p.A = m->dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      p.A = dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
@@ -1162,7 +1215,7 @@ static int backward_trunk(Model* m) {
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     toc(m);
-    if (!ft) {
+    if (!ft && !defer) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1179,20 +1232,20 @@ static int backward_trunk(Model* m) {
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
     ap.dO = m->dO; ap.delta = m->delta;
-    ap.dq = m->dqkv; ap.dk = AT<T>(m->dqkv) + m->H * hd; ap.dv = AT<T>(m->dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
+    ap.dq = dqkv; ap.dk = AT<T>(dqkv) + m->H * hd; ap.dv = AT<T>(dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
     RC(join_dw(m, DW_QKV));     // the layer above's dWqkv reads dqkv
     tic(m, "attn_bwd");
     RC(launch_attn_bwd<T>(ap, s));
     toc(m);
-    if (!ft) {
+    if (!ft && !defer) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
-      p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
+      p.A = dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
       p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
       RC(gemm_side<T>(m, "gemm_qkv_dw", p, false, true, true, DW_QKV));
     }
     {
       GemmParams p{};  // dxn = dqkv . Wqkv
-      p.A = m->dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
+      p.A = dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].wqkv); p.ldb = m->Nqkv; }
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
       RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
@@ -1203,19 +1256,19 @@ static int backward_trunk(Model* m) {
       const int nq = m->H * hd, nv0 = (m->H + m->KV) * hd, nkv = m->KV * hd;
       {
         GemmParams p{};  // dLa = 2 * dqkv . Bcat    (the unused blocks of Bcat are zero)
-        p.A = m->dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = m->dLa; p.ldc = 16;
+        p.A = dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = m->dLa; p.ldc = 16;
         p.M = NT; p.N = 16; p.K = m->Nqkv; p.epi = EPI_STORE; p.alpha = 2.f;
         RC(gemm<T>(m, "gemm_lora_dla", p, false, false, true));
       }
       {
         GemmParams p{};  // dBq += 2 * dq^T . La[:, :8]
-        p.A = m->dqkv; p.lda = m->Nqkv; p.B = a.La; p.ldb = 16; p.C = m->G + m->lo[l].lb; p.ldc = 16; p.c_f32 = 1;
+        p.A = dqkv; p.lda = m->Nqkv; p.B = a.La; p.ldb = 16; p.C = m->G + m->lo[l].lb; p.ldc = 16; p.c_f32 = 1;
         p.M = nq; p.N = 8; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 2.f;
         RC(gemm<T>(m, "gemm_lora_db", p, false, true, true));
       }
       {
         GemmParams p{};  // dBv += 2 * dv^T . La[:, 8:]
-        p.A = AT<T>(m->dqkv) + nv0; p.lda = m->Nqkv; p.B = AT<T>(a.La) + 8; p.ldb = 16;
+        p.A = AT<T>(dqkv) + nv0; p.lda = m->Nqkv; p.B = AT<T>(a.La) + 8; p.ldb = 16;
         p.C = m->G + m->lo[l].lb + (int64_t)nv0 * 16 + 8; p.ldc = 16; p.c_f32 = 1;
         p.M = nkv; p.N = 8; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 2.f;
         RC(gemm<T>(m, "gemm_lora_db", p, false, true, true));
@@ -1246,10 +1299,12 @@ static int backward_trunk(Model* m) {
     toc(m);
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
+    if (defer && !m->grad_bucket_hook && l == 0) RC(grouped_weight_grads<T>(m, 0, m->L - 1));   // all layers' products in one launch
     if (m->grad_bucket_hook && !ft) {
       // weight gradients of layers l .. bucket_top are final (the four tensors of a layer are contiguous, layers ascending)
       const int64_t lo = m->lo[l].wqkv, hi = m->lo[bucket_top].w2 + pad8((int64_t)D * Ip);
       if (l == 0 || (hi - lo) * 4 >= (25ll << 20)) {
+        if (defer) RC(grouped_weight_grads<T>(m, l, bucket_top));   // the bucket's products, then its all-reduce
         RC(join_all(m));
         RC(m->grad_bucket_hook(lo, hi));
         bucket_top = l - 1;

@@ -140,6 +140,14 @@ struct Model {
   void *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
   void *dLa, *dxl;   // finetune workspaces
   float* sumsq;
+  // Deferred, grouped weight gradients (bf16 pretraining, products too small for the chip one at a time): the backward keeps
+  // every layer's dY operands (gradient of the layer's output, of the SwiGLU pre-activations, of the attention residual, of
+  // q/k/v) in per-layer buffers and ONE grouped launch (per gradient bucket when buckets are reduced early) computes the four
+  // products of all those layers (gemm8p.hip: gemm8p_group_kernel).  Plans are cached per (first layer, last layer, rows).
+  bool defer_dw = false;
+  struct DwOperands { void *gxt, *dab, *dht, *dqkv; };
+  std::vector<DwOperands> dwb;
+  std::map<long long, GemmGroupPlan*> dw_plans;
   bool table_grads_pending = false;
   // the item-table gradient rows of medium m are known to be zero (just zeroed by zero_grad / AdamW and not written since):
   // the first head GEMM of a step then stores dF instead of reading 245 MB of zeros to add to

@@ -54,7 +54,7 @@ def test_losses_and_gradients_match_the_numpy_oracle(name, rows, style):
         assert np.abs(G[k] - ref_G[k]).max() <= 2e-4 * scale + 1e-9, (k, np.abs(G[k] - ref_G[k]).max(), scale)
 
 
-@pytest.mark.parametrize("name,rows,tol,check_gap", [("tiny", 3, 3e-2, False), ("hd64", 2, 1.5e-2, True)])
+@pytest.mark.parametrize("name,rows,tol,check_gap", [("tiny", 3, 3e-2, False), ("hd64", 2, 1e-2, True)])
 def test_bf16_operand_rounding_matches_the_numpy_oracle(name, rows, tol, check_gap):
     """operand_round="bf16": the C++ step rounds at the numpy oracle's rounding points (what the bench-shape GPU parity test
     compares the benchmarked arithmetic with).  Roundings amplify last-bit differences of the float sums (a value on a rounding

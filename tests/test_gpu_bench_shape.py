@@ -51,20 +51,36 @@ def test_bench_shape_step_vs_cpp_oracle():
     model.close()
 
     dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    norm_gpu = float(np.sqrt(sum(float((G[n].astype(np.float64) ** 2).sum()) for n in names)))
+    # the exact (unrounded) step first: how far bf16 arithmetic itself is from fp32 on each tensor
+    ex = cpu_step.CpuStep(cfg, P, lr=lr)
+    _, ex_G = ex.forward_backward(dm, tw)
+    ex_G = {n: ex_G[n].copy() for n in names}
+    del ex
     cs = cpu_step.CpuStep(cfg, P, lr=lr, operand_round="bf16")
     ref_losses, ref_G = cs.forward_backward(dm, tw)
-    norm_gpu = float(np.sqrt(sum(float((G[n].astype(np.float64) ** 2).sum()) for n in names)))
     ref_G = {n: ref_G[n].copy() for n in names}
     ref_norm = cs.clip_adamw()
     cpu_step.release()
 
     e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(losses, ref_losses)]
-    rows_g = sorted(((float(np.abs(G[n] - ref_G[n]).max() / max(np.abs(ref_G[n]).max(), 1e-30)), n) for n in names), reverse=True)
+    mx = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    l2 = lambda a, b: float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-60)))
+    table = sorted(((mx(G[n], ref_G[n]), l2(G[n], ref_G[n]), mx(G[n], ex_G[n]), mx(ref_G[n], ex_G[n]), n) for n in names), reverse=True)
     print("bench-shape parity: losses", losses, "oracle", ref_losses, "rel", e_l)
-    print("  grad norm", norm_gpu, "oracle", ref_norm, " worst gradients (of tensor max):", rows_g[:4])
+    print("  grad norm", norm_gpu, "oracle", ref_norm)
+    print("  worst gradients: max|hip - oracle_bf16| / max, rel L2, max|hip - exact| / max, max|oracle_bf16 - exact| / max")
+    for r in table[:6]:
+        print("    %.3e %.3e %.3e %.3e %s" % r)
     assert max(e_l) <= 5e-3, (losses, ref_losses)
     assert abs(norm_gpu - ref_norm) <= 1e-2 * ref_norm, (norm_gpu, ref_norm)
-    assert rows_g[0][0] <= 5e-2, rows_g[:6]
+    # every named gradient within the bf16-rounded-oracle bound (5e-2 of the tensor's max).  The q / k projections of the upper
+    # layers are the exception the bound was not made for: rows of dS sum to zero, so the keys' common component cancels in the
+    # signal but not in the rounding noise of the bf16 dS operand, and two bf16 evaluations of the same formula (this path, the
+    # rounded oracle) land as far from each other as each is from the exact step.  There the HIP gradient must be as close to
+    # the EXACT fp32 gradient as the rounded restatement is (factor 1.5), and within 1e-1 of the rounded one.
+    for e_r, e_l2, e_x, e_rx, n in table:
+        assert e_r <= 5e-2 or (e_r <= 1e-1 and e_x <= 1.5 * e_rx and ("q_proj" in n or "k_proj" in n)), (n, e_r, e_l2, e_x, e_rx)
     # one fused clip + AdamW step.  The first Adam step moves every element by lr * g / (|g| + eps) ~ +-lr: elements whose two
     # gradients disagree in sign (|g| within the bf16 noise of zero) differ by 2 lr, all the others by ~lr * eps / |g|
     flips, total, worst = 0, 0, 0.0
@@ -213,11 +229,21 @@ def test_cfg5_lora_finetune_step_at_cfg3_size_vs_numpy_oracle(medium, metric):
         dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d))
         l_ref, G_ref = ref.forward(dm, False, True, tw)
         e_l = abs(losses[ti] - l_ref[ti]) / max(abs(l_ref[ti]), 1e-6)
-        worst = max(((float(np.abs(G[n] - G_ref[n]).max() / max(np.abs(G_ref[n]).max(), 1e-30)), n) for n in lora))
-        print(f"cfg-5 LoRA step at cfg-3 size [{medium}.{metric}, {dtype}]: loss {losses[ti]:.6f} oracle {l_ref[ti]:.6f} rel {e_l:.2e}; worst LoRA gradient {worst}")
+        mx = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        table = sorted(((mx(G[n], G_ref[n]), n) for n in lora), reverse=True)
+        print(f"cfg-5 LoRA step at cfg-3 size [{medium}.{metric}, {dtype}]: loss {losses[ti]:.6f} oracle {l_ref[ti]:.6f} rel {e_l:.2e}; worst LoRA gradients {table[:3]}")
         assert e_l <= tol_loss, (losses, l_ref)
-        assert worst[0] <= tol_grad, worst
         assert max(np.abs(G_ref[n]).max() for n in lora) > 0
+        if dtype == "fp32":
+            assert table[0][0] <= tol_grad, table[:4]
+            continue
+        # bf16: the v-path gradients within the bf16-rounded-oracle bound.  The q-path LoRA gradients of ONE user with ONE target are
+        # a few bf16 quanta of the dS operand (rows of dS sum to zero: the signal cancels, its rounding noise does not): there the HIP
+        # gradient must be as close to the EXACT gradient as the rounded restatement of the same arithmetic is
+        _, G_x = model_np.OracleModel(cfg, P64, np.float64).forward(dm, False, True, tw)
+        for e_r, n in table:
+            e_x, e_rx = mx(G[n], G_x[n]), mx(G_ref[n], G_x[n])
+            assert e_r <= tol_grad or ("q_proj" in n and e_x <= 1.5 * e_rx + 1e-3), (n, e_r, e_x, e_rx)
 
 
 def test_cfg5_lora_finetune_loop_learns_at_cfg3_size():
