@@ -122,6 +122,7 @@ int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {
   const int64_t cnt = (int64_t)2 * m->cur_rows * m->S * m->D;
   ARG_CHECK(n == cnt, "trunk output has rows*2S*D floats");
   HIP_CHECK(hipSetDevice(m->device));
+  { const int rc_ = model_materialise_trunk_output(m); if (rc_ != RSYS_OK) return rc_; }   // (a training pass computed it at the selected tokens only)
   HIP_CHECK(hipStreamSynchronize(m->stream));
   if (!m->bf16_mode) { HIP_CHECK(hipMemcpy(out, m->out, cnt * 4, hipMemcpyDeviceToHost)); return RSYS_OK; }
   std::vector<unsigned short> host(cnt);

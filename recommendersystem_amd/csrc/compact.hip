@@ -1,0 +1,171 @@
+// Selected-token (compact) row sets for the top of the trunk.
+//
+// A training pass reads the trunk's output only at the positions the four heads select (transformer.model.py:501-513: at most
+// mask_topk * rows positions per (medium, metric), the positive-weight ones of them carry loss), and everything downstream of
+// the LAST layer's attention is token-local (output projection, residual, RMSNorm, SwiGLU, final RMSNorm, transformer.model.py:
+// 297-309,335-343).  So the last layer's tail and its backward run on the compact set of selected tokens: forward rows that no
+// head reads are never computed, backward rows whose gradient is identically zero are never multiplied.  This file holds the
+// index kernels: the union of the heads' live positions as a sorted token list + its inverse map, and row gathers / scatters
+// through them.  Compact buffers are valid for rows [0, n) and ZERO for rows [n, n rounded up to 256): the GEMMs that consume
+// them stop at a device-side row / reduction limit rounded up to a tile (gemm.hpp m_dev / k_dev).
+#include "kernels.hpp"
+
+namespace rsys {
+
+namespace {
+
+struct UnionLists { const int* idx[4]; const int* npos[4]; };
+
+// One workgroup: bitmap of the selected tokens in LDS, two-level scan, then slot[tok] = rank among the selected (or -1) and
+// sel[rank] = tok.  Token of position i of task ti: 2 i + (ti & 1) (even tokens: item -> watch heads, odd: action -> rating heads).
+__global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT, int* __restrict__ slot, int* __restrict__ sel, int* nsel) {
+  extern __shared__ unsigned int bits[];   // ceil(NT / 32) words
+  __shared__ int wave_tot[16];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int nw = (NT + 31) >> 5;
+  for (int i = t; i < nw; i += 1024) bits[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    if (ul.idx[ti] == nullptr) continue;
+    const int n = *ul.npos[ti];
+    for (int r = t; r < n; r += 1024) {
+      const int tok = 2 * ul.idx[ti][r] + (ti & 1);
+      atomicOr(&bits[tok >> 5], 1u << (tok & 31));
+    }
+  }
+  __syncthreads();
+  const int per = (nw + 1023) / 1024;
+  const int w0 = t * per, w1 = min(nw, w0 + per);
+  int cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popc(bits[w]);
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+  if (l == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int k = 0; k < 16; ++k) { int v = wave_tot[k]; if (k < wv) base += v; total += v; }
+  int rank = base + inc - cnt;
+  for (int w = w0; w < w1; ++w) {
+    const unsigned int b = bits[w];
+    for (int j = 0; j < 32; ++j) {
+      const int tok = w * 32 + j;
+      if (tok >= NT) break;
+      if ((b >> j) & 1u) { slot[tok] = rank; sel[rank] = tok; ++rank; } else slot[tok] = -1;
+    }
+  }
+  if (t == 0) *nsel = total;
+}
+
+// rows [0, n) <- src rows sel[r]; rows [n, pad256(n)) <- 0.  One wave per row.
+template <typename T>
+__global__ void gather_rows_sel_kernel(const T* __restrict__ src, long long ld, const int* __restrict__ sel, const int* __restrict__ n_dev, int cap,
+                                       T* dst, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  const int n = *n_dev, npad = min(cap, (n + 255) & ~255);
+  if (row >= npad) return;
+  constexpr int E = 16 / sizeof(T);
+  uint4* d4 = (uint4*)(dst + (long long)row * D);
+  if (row < n) {
+    const uint4* s4 = (const uint4*)(src + (long long)sel[row] * ld);
+    for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+  } else {
+    for (int c = l; c < D / E; c += 64) d4[c] = make_uint4(0, 0, 0, 0);
+  }
+}
+
+// dst rows sel[r] <- src rows r, r < n
+template <typename T>
+__global__ void scatter_rows_sel_kernel(const T* __restrict__ src, const int* __restrict__ sel, const int* __restrict__ n_dev, T* dst, long long ld, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= *n_dev) return;
+  constexpr int E = 16 / sizeof(T);
+  const uint4* s4 = (const uint4*)(src + (long long)row * D);
+  uint4* d4 = (uint4*)(dst + (long long)sel[row] * ld);
+  for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+}
+
+// heads: dst[r] = compact[slot[2 idx[r] + parity]] (zeros where that token is not in the set: zero-weight padding positions)
+template <typename T>
+__global__ void gather_rows_slot_kernel(const T* __restrict__ compact, const int* __restrict__ slot, const int* __restrict__ idx, int parity, T* dst,
+                                        int n, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n) return;
+  constexpr int E = 16 / sizeof(T);
+  const int s = slot[2 * idx[row] + parity];
+  uint4* d4 = (uint4*)(dst + (long long)row * D);
+  if (s >= 0) {
+    const uint4* s4 = (const uint4*)(compact + (long long)s * D);
+    for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+  } else {
+    for (int c = l; c < D / E; c += 64) d4[c] = make_uint4(0, 0, 0, 0);
+  }
+}
+
+// heads backward: compact[slot[2 idx[r] + parity]] += src[r] for the live rows r < *npos (one task at a time: no two rows of a
+// task share a token)
+__global__ void scatter_rows_add_slot_kernel(const float* __restrict__ src, const int* __restrict__ slot, const int* __restrict__ idx, int parity,
+                                             const int* __restrict__ npos, float* compact, int n, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n || row >= *npos) return;
+  const int s = slot[2 * idx[row] + parity];
+  if (s < 0) return;
+  const float4* s4 = (const float4*)(src + (long long)row * D);
+  float4* d4 = (float4*)(compact + (long long)s * D);
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 a = d4[c], b = s4[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[c] = a;
+  }
+}
+
+}  // namespace
+
+int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, int* slot, int* sel, int* nsel, hipStream_t s) {
+  ARG_CHECK(ntask >= 1 && ntask <= 4 && NT >= 1 && NT <= (1 << 19), "token union: 1..4 tasks, at most 2^19 tokens (64 KB bitmap in LDS)");
+  UnionLists ul{};
+  for (int i = 0; i < ntask; ++i) { ul.idx[i] = idx[i]; ul.npos[i] = npos[i]; }
+  hipLaunchKernelGGL(token_union_kernel, dim3(1), dim3(1024), (size_t)((NT + 31) / 32) * 4, s, ul, NT, slot, sel, nsel);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+template <typename T>
+int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "gather_rows_sel: rows must be 16-byte multiples");
+  hipLaunchKernelGGL((gather_rows_sel_kernel<T>), dim3((cap + 3) / 4), dim3(256), 0, s, src, ld, sel, n_dev, cap, dst, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_gather_rows_sel<bf16>(const bf16*, long long, const int*, const int*, int, bf16*, int, hipStream_t);
+template int launch_gather_rows_sel<float>(const float*, long long, const int*, const int*, int, float*, int, hipStream_t);
+
+template <typename T>
+int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int cap, T* dst, long long ld, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "scatter_rows_sel: rows must be 16-byte multiples");
+  hipLaunchKernelGGL((scatter_rows_sel_kernel<T>), dim3((cap + 3) / 4), dim3(256), 0, s, src, sel, n_dev, dst, ld, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_scatter_rows_sel<bf16>(const bf16*, const int*, const int*, int, bf16*, long long, int, hipStream_t);
+template int launch_scatter_rows_sel<float>(const float*, const int*, const int*, int, float*, long long, int, hipStream_t);
+
+template <typename T>
+int launch_gather_rows_slot(const T* compact, const int* slot, const int* idx, int parity, T* dst, int n, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0, "gather_rows_slot: rows must be 16-byte multiples");
+  hipLaunchKernelGGL((gather_rows_slot_kernel<T>), dim3((n + 3) / 4), dim3(256), 0, s, compact, slot, idx, parity, dst, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_gather_rows_slot<bf16>(const bf16*, const int*, const int*, int, bf16*, int, int, hipStream_t);
+template int launch_gather_rows_slot<float>(const float*, const int*, const int*, int, float*, int, int, hipStream_t);
+
+int launch_scatter_rows_add_slot(const float* src, const int* slot, const int* idx, int parity, const int* npos, float* compact, int n, int D,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(scatter_rows_add_slot_kernel, dim3((n + 3) / 4), dim3(256), 0, s, src, slot, idx, parity, npos, compact, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
+}  // namespace rsys

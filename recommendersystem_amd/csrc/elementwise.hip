@@ -189,9 +189,19 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* src) {
 
 template <typename T, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
-                                                          long long rows, int D) {
+                                                          long long rows, int D, const int* __restrict__ rows_dev) {
   const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int l = threadIdx.x & 63;
+  if (rows_dev != nullptr) {   // compact row set (compact.hip): rows [0, n) are live, rows [n, n rounded up to 256) are written as zeros
+    const long long n = *rows_dev;
+    if (row >= min(rows, (n + 255) & ~255LL)) return;
+    if (row >= n) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { const int c = (j * 64 + l) * 4; if (EXACT || c < D) store4<T>(y + row * D + c, 0.f, 0.f, 0.f, 0.f); }
+      if (l == 0 && rstd) rstd[row] = 0.f;
+      return;
+    }
+  }
   if (row >= rows) return;
   float4 v[NJ];
   float ss = 0.f;
@@ -215,10 +225,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 }
 
 template <typename T>
-int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s) {
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
   const dim3 grid(div_up(rows, 4)), block(256);
-#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D)
+#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev)
   if (D == 256) RSYS_NORM_FWD(1, true);
   else if (D == 512) RSYS_NORM_FWD(2, true);
   else if (D == 1024) RSYS_NORM_FWD(4, true);
@@ -231,15 +241,16 @@ int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, lo
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t);
-template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t, const int*);
+template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*);
 
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
 template <typename TG, typename TO, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
-                                                          float* part, long long rows, int D) {
+                                                          float* part, long long rows, int D, const int* __restrict__ rows_dev,
+                                                          const int* __restrict__ resid_slot) {
   extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (4 * D in deterministic mode: `part` set)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
@@ -252,8 +263,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   }
   for (int c = threadIdx.x; c < D; c += 256) sds[c] = 0.f;
   __syncthreads();
+  // compact row set (compact.hip): rows [0, n) live, rows [n, n rounded up to 256) get zero outputs
+  const long long n_live = rows_dev != nullptr ? (long long)*rows_dev : rows;
+  if (rows_dev != nullptr) rows = min(rows, (n_live + 255) & ~255LL);
   for (long long row = wave0; row < rows; row += nwaves) {
+    if (row >= n_live) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = (j * 64 + l) * 4;
+        if (EXACT || c < D) { *(float4*)(dx_out + row * D + c) = make_float4(0, 0, 0, 0); if (dx_out_t) store4<TO>(dx_out_t + row * D + c, 0.f, 0.f, 0.f, 0.f); }
+      }
+      continue;
+    }
     const float r = rstd[row];
+    // residual gradient: dense rows, or (resid_slot) the compact row resid_slot[row] of `resid`, zero where that is -1
+    const long long rrow = resid_slot != nullptr ? (long long)resid_slot[row] : row;
     float4 gv[NJ], xv[NJ], rv[NJ];
     float dot = 0.f;
 #pragma unroll
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
       const bool ok = EXACT || c < D;
       const float4 g4 = ok ? load4<TG>(g + row * D + c) : make_float4(0, 0, 0, 0);
       xv[j] = ok ? *(const float4*)(x + row * D + c) : make_float4(0, 0, 0, 0);
-      rv[j] = (ok && resid) ? *(const float4*)(resid + row * D + c) : make_float4(0, 0, 0, 0);
+      rv[j] = (ok && resid && rrow >= 0) ? *(const float4*)(resid + rrow * D + c) : make_float4(0, 0, 0, 0);
       gv[j] = make_float4(g4.x * sc[j].x, g4.y * sc[j].y, g4.z * sc[j].z, g4.w * sc[j].w);
       dot += gv[j].x * xv[j].x + gv[j].y * xv[j].y + gv[j].z * xv[j].z + gv[j].w * xv[j].w;
       // dscale uses the un-scaled g
@@ -309,12 +333,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
 
 template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
-                           float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
+                           float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev,
+                           const int* resid_slot) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
   float* part = det_part((long long)grid.x * D);
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
-                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D)
+                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot)
   if (D == 256) RSYS_NORM_BWD(1, true);
   else if (D == 512) RSYS_NORM_BWD(2, true);
   else if (D == 1024) RSYS_NORM_BWD(4, true);
@@ -330,18 +355,18 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
 }
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
-  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s);
+                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev, const int* resid_slot) {
+  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, resid_slot);
 }
-template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t);
-template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*);
+template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, const int*);
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s) {
-  return rmsnorm_bwd_any<float, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev) {
+  return rmsnorm_bwd_any<float, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, nullptr);
 }
-template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t);
-template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t);
+template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*);
+template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*);
 
 // --------------------------------------------------------------------- dropout (LoRA input, finetune)
 template <typename T>

@@ -48,18 +48,21 @@ int launch_action_features(const BatchDev& b, const SmallParams& sp, T* feat /*[
 // x0[2n] = F32[id'] ; also token-level uid/tm arrays (interleaved, model.py:468-469)
 int launch_gather_items(const BatchDev& b, const float* F32, int V, int D, float* x0, int* uid_t, int* tm_t, hipStream_t s);
 
+// rows_dev (optional, device): compact row set -- rows [0, *rows_dev) are computed, rows up to the next multiple of 256 are
+// written as zeros, the rest is left alone (compact.hip)
 template <typename T>
-int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s);
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr);
 
 // dx_out = resid_grad + d/dx rmsnorm ; dscale += column sums (atomic)
 // dx_out_t (optional): T-typed copy of dx_out, the A operand of the GEMMs that consume it
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s);
+                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
+                       const int* resid_slot = nullptr /* resid_grad is compact: row resid_slot[row] of it, zero where -1 */);
 // same with an f32 incoming gradient (final norm: gy is f32)
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr);
 
 // dst = (accumulate ? dst : 0) + src * mask / (1 - p), mask ~ Bernoulli(1-p) from Philox(seed, stream)(element index):
 // nn.Dropout of the LoRA input (model.py:238,265,269); the backward pass regenerates the same mask
@@ -103,6 +106,16 @@ size_t seg_scatter_slab_floats(int N, int D);
 // gE[id'] += sum over the tokens n (ascending) with masked id' of gx0[n * ldx .. + D); one writer per table row, no atomics
 int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const int* m_matchedid, const int* skey, const int* sidx,
                                        int N, int V, int D, float* gE, float* slab, hipStream_t s);
+
+// ---- selected-token (compact) row sets for the top of the trunk (compact.hip)
+// union of the tasks' live positions (token 2 idx + (task & 1), rows r < *npos[task]): sel[0 .. *nsel) ascending, slot[token] = rank or -1
+int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, int* slot, int* sel, int* nsel, hipStream_t s);
+// dst rows [0, n) <- src rows sel[r]; dst rows [n, n rounded up to 256) <- 0   (n = *n_dev <= cap)
+template <typename T> int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s);
+template <typename T> int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int cap, T* dst, long long ld, int D, hipStream_t s);
+// heads: dst[r] = compact[slot[2 idx[r] + parity]] (zeros where -1), r < n; and compact[slot[..]] += src[r] for r < min(n, *npos)
+template <typename T> int launch_gather_rows_slot(const T* compact, const int* slot, const int* idx, int parity, T* dst, int n, int D, hipStream_t s);
+int launch_scatter_rows_add_slot(const float* src, const int* slot, const int* idx, int parity, const int* npos, float* compact, int n, int D, hipStream_t s);
 
 // ---- row-sharded item table (shard.hip): exchange plan, rows by id, vocabulary-parallel cross entropy
 int launch_plan_unique(const int* skey, const int* sidx, int N, int V, int* slot, int* uniq, int* tok2u, int* plan /*{U, uV}*/, hipStream_t s);

@@ -308,12 +308,26 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     static const int grp = getenv("RSYS_DW_GROUP") ? atoi(getenv("RSYS_DW_GROUP")) : 1;
     const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
     m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
+    static const int sp = getenv("RSYS_SPARSE_TOP") ? atoi(getenv("RSYS_SPARSE_TOP")) : 1;
+    m->sparse_top = sp != 0 && !cfg->finetune && !m->sharded && NT <= (1 << 19);
     if (m->defer_dw) {
       m->dwb.resize(m->L);
       for (int l = 0; l < m->L; ++l) {
-        DALLOC(m->dwb[l].gxt, NT * D * 2); DALLOC(m->dwb[l].dab, NT * 2 * m->Ip * 2);
-        DALLOC(m->dwb[l].dht, NT * D * 2); DALLOC(m->dwb[l].dqkv, NT * m->Nqkv * 2);
+        m->dwb[l] = Model::DwOperands{nullptr, nullptr, nullptr, nullptr};
+        DALLOC(m->dwb[l].dqkv, NT * m->Nqkv * 2);
+        if (l == m->L - 1 && m->sparse_top) continue;   // (the top layer's other products run on the compact rows)
+        DALLOC(m->dwb[l].gxt, NT * D * 2); DALLOC(m->dwb[l].dab, NT * 2 * m->Ip * 2); DALLOC(m->dwb[l].dht, NT * D * 2);
       }
+    }
+    if (m->sparse_top) {
+      const int64_t cap = (std::min<int64_t>(NT, 4 * KB) + 255) / 256 * 256;
+      m->ctop_cap = (int)cap;
+      DALLOC(m->c_sel, cap * 4); DALLOC(m->c_slot, NT * 4); DALLOC(m->c_n, 64);
+      DALLOC(m->c_x, cap * D * 4); DALLOC(m->c_h, cap * D * 4); DALLOC(m->c_xL, cap * D * 4); DALLOC(m->c_rstd2, cap * 4); DALLOC(m->c_rstdf, cap * 4);
+      DALLOC(m->c_O, cap * D * e); DALLOC(m->c_hn, cap * D * e); DALLOC(m->c_ab, cap * 2 * m->Ip * e); DALLOC(m->c_g, cap * m->Ip * e); DALLOC(m->c_out, cap * D * e);
+      DALLOC(m->c_gy, cap * D * 4); DALLOC(m->c_gx, cap * D * 4); DALLOC(m->c_dh, cap * D * 4);
+      DALLOC(m->c_dab, cap * 2 * m->Ip * e); DALLOC(m->c_dhn, cap * D * e); DALLOC(m->c_dO, cap * D * e);
+      if (m->bf16_mode) { DALLOC(m->c_gx_t, cap * D * 2); DALLOC(m->c_dh_t, cap * D * 2); } else { m->c_gx_t = m->c_gx; m->c_dh_t = m->c_dh; }
     }
   }
   *out = m;
@@ -785,6 +799,72 @@ static SmallParams small_params(Model* m) {
   return sp;
 }
 
+// token-local tail of layer l (model.py:300-309): h = x + O Wo^T ; out = h + W2 (silu(W1 hn) * W3 hn), hn = RMSNorm(h)
+template <typename T>
+static int layer_tail_dense(Model* m, int l) {
+  const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
+  hipStream_t s = m->stream;
+  Model::LayerAct& a = m->la[l];
+  float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
+  {
+    GemmParams p{};
+    p.A = a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
+    p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
+    RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
+  }
+  tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
+  RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
+  toc(m);
+  {
+    GemmParams p{};
+    p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
+    p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
+    RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
+  }
+  {
+    GemmParams p{};
+    p.A = a.g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = xnext; p.ldc = D; p.c_f32 = 1;
+    p.M = NT; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = a.h; p.ldr = D;
+    RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
+  }
+  return RSYS_OK;
+}
+
+// The same tail of the LAST layer plus the final norm on the compact set of selected tokens (Model::sparse_top, compact.hip):
+// every buffer has ctop_cap rows, the GEMMs stop at the device-side row count.
+template <typename T>
+static int top_tail_compact(Model* m) {
+  const int D = m->D, Ip = m->Ip, l = m->L - 1, cap = m->ctop_cap;
+  hipStream_t s = m->stream;
+  Model::LayerAct& a = m->la[l];
+  const int* n = m->c_n;
+  tic(m, "phase_top_compact_fwd");
+  RC(launch_gather_rows_sel<T>(AT<T>(a.O), D, m->c_sel, n, cap, AT<T>(m->c_O), D, s));
+  RC(launch_gather_rows_sel<float>(a.x, D, m->c_sel, n, cap, m->c_x, D, s));
+  {
+    GemmParams p{};
+    p.A = m->c_O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->c_h; p.ldc = D; p.c_f32 = 1;
+    p.M = cap; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = m->c_x; p.ldr = D; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_o_fwd", p, false, false, false));
+  }
+  RC(launch_rmsnorm_fwd<T>(m->c_h, m->P + m->lo[l].mlp, AT<T>(m->c_hn), m->c_rstd2, cap, D, s, n));
+  {
+    GemmParams p{};
+    p.A = m->c_hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->c_ab; p.ldc = 2 * Ip;
+    p.M = cap; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = m->c_g; p.ldc2 = Ip; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_w13_fwd", p, false, false, false));
+  }
+  {
+    GemmParams p{};
+    p.A = m->c_g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->c_xL; p.ldc = D; p.c_f32 = 1;
+    p.M = cap; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = m->c_h; p.ldr = D; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_w2_fwd", p, false, false, false));
+  }
+  RC(launch_rmsnorm_fwd<T>(m->c_xL, m->P + m->o_norm, AT<T>(m->c_out), m->c_rstdf, cap, D, s, n));
+  toc(m);
+  return RSYS_OK;
+}
+
 // ------------------------------------------------------------------ forward trunk (model.py:464-491, 335-343)
 template <typename T>
 static int forward_trunk(Model* m) {
@@ -868,33 +948,34 @@ static int forward_trunk(Model* m) {
     tic(m, "attn_fwd");
     RC(launch_attn_fwd<T>(ap, s));
     toc(m);
-    {
-      GemmParams p{};
-      p.A = a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
-      p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
-      RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
-    }
-    tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
-    RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
-    toc(m);
-    {
-      GemmParams p{};
-      p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
-      p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
-      RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
-    }
-    {
-      GemmParams p{};
-      p.A = a.g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = xnext; p.ldc = D; p.c_f32 = 1;
-      p.M = NT; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = a.h; p.ldr = D;
-      RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
-    }
+    if (l == m->L - 1 && m->top_is_sparse) break;   // the tail of the last layer and the final norm run on the selected tokens
+    RC(layer_tail_dense<T>(m, l));
   }
+  if (m->top_is_sparse) { toc(m); return top_tail_compact<T>(m); }
   tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
   RC(launch_rmsnorm_fwd<T>(m->xL, m->P + m->o_norm, AT<T>(m->out), m->rstdf, NT, D, s));
   toc(m);
   toc(m);
   return RSYS_OK;
+}
+
+// The dense trunk output of the resident forward (tests, rsys_trunk_output_get): a training pass with the compact top has not
+// computed it; the dense tail of the last layer and the final norm run now, from the saved attention output.
+template <typename T>
+static int materialise_output_t(Model* m) {
+  const int D = m->D, NT = 2 * m->cur_rows * m->S;
+  RC(layer_tail_dense<T>(m, m->L - 1));
+  RC(launch_rmsnorm_fwd<T>(m->xL, m->P + m->o_norm, AT<T>(m->out), m->rstdf, NT, D, m->stream));
+  return RSYS_OK;
+}
+int model_materialise_trunk_output(Model* m) {
+  if (!m->top_is_sparse) return RSYS_OK;
+  ARG_CHECK(m->cur_rows > 0, "no batch uploaded");
+  HIP_CHECK(hipSetDevice(m->device));
+  const bool tim = m->timer.enabled; m->timer.enabled = false;
+  const int rc = m->bf16_mode ? materialise_output_t<bf16>(m) : materialise_output_t<float>(m);
+  m->timer.enabled = tim;
+  return rc;
 }
 
 // ------------------------------------------------------------------ sampled soft-max watch head (cfg-4 option)
@@ -1039,18 +1120,20 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   hipStream_t s = m->stream;
   const bool train = !evaluate;
   tic(m, "phase_heads");
+  const bool ctop = m->top_is_sparse;   // trunk output and its gradient live in the compact buffers (rows = selected tokens)
   HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
-  if (train) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
-  {   // position selection of the four (medium, metric) tasks in one launch
-    const float* ws[4]; int* is[4]; float* sts[4]; int* nps[4];
-    for (int ti = 0; ti < 4; ++ti) { ws[ti] = m->bd.m_weight[ti]; is[ti] = m->idx[ti]; sts[ti] = m->stats + 2 * ti; nps[ti] = m->npos + ti; }
-    RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
-  }
+  if (train && !ctop) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
+  if (train && ctop) HIP_CHECK(hipMemsetAsync(m->c_gy, 0, (size_t)m->ctop_cap * D * 4, s));
+  auto add_rows = [&](const float* src, int ti, int parity) -> int {   // d(trunk output) += the head's row gradients
+    if (ctop) return launch_scatter_rows_add_slot(src, m->c_slot, m->idx[ti], parity, m->npos + ti, m->c_gy, KB, D, s);
+    return launch_scatter_rows_add(src, m->idx[ti], parity, m->gy, D, KB, D, s);
+  };
   for (int ti = 0; ti < 4; ++ti) {
     const int medium = ti >> 1, metric = ti & 1;
     float* st = m->stats + 2 * ti;
     int* np = m->npos + ti;   // positive-weight rows come first: the head GEMMs and the CE kernel stop there
-    RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
+    if (ctop) RC(launch_gather_rows_slot<T>(AT<T>(m->c_out), m->c_slot, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
+    else RC(launch_gather_rows<T>(AT<T>(m->out), D, m->idx[ti], metric, AT<T>(m->Ew), KB, D, s));
     const bool bwd = train && tw[ti] != 0.f;
     if (metric == 0 && m->sharded) {
       RC(watch_head_sharded<T>(m, ti, medium, train, bwd, tw[ti]));
@@ -1075,7 +1158,7 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
           p.M = KB; p.N = D; p.K = Vm; p.epi = EPI_ATOMIC; p.m_dev = np;
           RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
         }
-        RC(launch_scatter_rows_add(m->dE, m->idx[ti], 0, m->gy, D, KB, D, s));
+        RC(add_rows(m->dE, ti, 0));
         if (!m->cfg.finetune) {
           GemmParams p{};  // dF[s:e] += dlogits^T . Ew
           p.A = m->logits; p.lda = m->ldl; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_E + (int64_t)vs * D; p.ldc = D; p.c_f32 = 1;
@@ -1108,10 +1191,78 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
           p.M = KB; p.N = D; p.K = D; p.epi = EPI_STORE;
           RC(gemm<T>(m, "gemm_rating_dx", p, false, false, true));
         }
-        RC(launch_scatter_rows_add(m->dE, m->idx[ti], 1, m->gy, D, KB, D, s));
+        RC(add_rows(m->dE, ti, 1));
       }
     }
   }
+  toc(m);
+  return RSYS_OK;
+}
+
+// position selection of the four (medium, metric) tasks in one launch (model.py:501,509): depends on the masked batch only, so it
+// runs before the trunk; with the compact top also the union of the live positions
+static int select_positions_all(Model* m) {
+  const int N = m->cur_rows * m->S, KB = m->K * m->cur_rows;
+  const float* ws[4]; int* is[4]; float* sts[4]; int* nps[4];
+  for (int ti = 0; ti < 4; ++ti) { ws[ti] = m->bd.m_weight[ti]; is[ti] = m->idx[ti]; sts[ti] = m->stats + 2 * ti; nps[ti] = m->npos + ti; }
+  RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, m->stream));
+  if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_slot, m->c_sel, m->c_n, m->stream));
+  return RSYS_OK;
+}
+
+// Backward of top_tail_compact for the last layer: W2 / SwiGLU / W13 / RMSNorm / Wo on the compact rows (gradients of all other
+// tokens are identically zero there), then d(attention output) scattered into the zeroed dense buffer the attention backward reads.
+// The weight gradients reduce over the compact rows (k_dev); each has one operand whose rows [n, n rounded up to 256) are zero.
+template <typename T>
+static int top_tail_compact_bwd(Model* m, bool wt) {
+  const int D = m->D, Ip = m->Ip, l = m->L - 1, cap = m->ctop_cap, NT = 2 * m->cur_rows * m->S;
+  hipStream_t s = m->stream;
+  const int* n = m->c_n;
+  const bool cp = m->bf16_mode;
+  tic(m, "phase_top_compact_bwd");
+  {
+    GemmParams p{};  // dW2 += gx^T . g
+    p.A = m->c_gx_t; p.lda = D; p.B = m->c_g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
+    p.M = D; p.N = Ip; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    RC(gemm<T>(m, "gemm_top_w2_dw", p, false, true, true));
+  }
+  {
+    GemmParams p{};  // dg = gx . W2, fused with the SwiGLU backward
+    p.A = m->c_gx_t; p.lda = D; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = m->c_dab; p.ldc = 2 * Ip;
+    if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
+    p.M = cap; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = m->c_ab; p.ldc2 = 2 * Ip; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_w2_dx", p, false, false, !wt));
+  }
+  {
+    GemmParams p{};  // dW13 += dab^T . hn
+    p.A = m->c_dab; p.lda = 2 * Ip; p.B = m->c_hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
+    p.M = 2 * Ip; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    RC(gemm<T>(m, "gemm_top_w13_dw", p, false, true, true));
+  }
+  {
+    GemmParams p{};  // dhn = dab . W13
+    p.A = m->c_dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->c_dhn; p.ldc = D;
+    if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
+    p.M = cap; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_w13_dx", p, false, false, !wt));
+  }
+  RC(launch_rmsnorm_bwd<T>(AT<T>(m->c_dhn), m->c_h, m->P + m->lo[l].mlp, m->c_rstd2, m->c_gx, m->c_dh, cp ? AT<T>(m->c_dh_t) : nullptr,
+                           m->G + m->lo[l].mlp, cap, D, s, n));
+  {
+    GemmParams p{};  // dWo += dh^T . O
+    p.A = m->c_dh_t; p.lda = D; p.B = m->c_O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
+    p.M = D; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    RC(gemm<T>(m, "gemm_top_o_dw", p, false, true, true));
+  }
+  {
+    GemmParams p{};  // dO = dh . Wo
+    p.A = m->c_dh_t; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->c_dO; p.ldc = D;
+    if (wt) p.B = WT<T>(m, m->lo[l].wo);
+    p.M = cap; p.N = D; p.K = D; p.epi = EPI_STORE; p.m_dev = n;
+    RC(gemm<T>(m, "gemm_top_o_dx", p, false, false, !wt));
+  }
+  HIP_CHECK(hipMemsetAsync(m->dO, 0, (size_t)NT * D * sizeof(T), s));
+  RC(launch_scatter_rows_sel<T>(AT<T>(m->c_dO), m->c_sel, n, cap, AT<T>(m->dO), D, D, s));
   toc(m);
   return RSYS_OK;
 }
@@ -1120,7 +1271,8 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
 template <typename T>
 static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
   const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
-  const long long key = ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
+  const bool top_compact = m->top_is_sparse;   // the last layer's W2 / W13 / Wo products ran on the compact rows already
+  const long long key = ((long long)top_compact << 56) | ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
   auto it = m->dw_plans.find(key);
   if (it == m->dw_plans.end()) {
     std::vector<GemmParams> ps;
@@ -1132,10 +1284,11 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
         p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_f32 = 1; p.M = M; p.N = N; p.K = NT; p.epi = EPI_ATOMIC; p.alpha = 1.f;
         ps.push_back(p);
       };
-      add(o.dab, 2 * Ip, a.hn, D, m->G + m->lo[l].w13, D, 2 * Ip, D);       // dW13 += dab^T . hn
-      add(o.gxt, D, a.g, Ip, m->G + m->lo[l].w2, Ip, D, Ip);                 // dW2  += gx^T . g
-      add(o.dqkv, m->Nqkv, a.xn, D, m->G + m->lo[l].wqkv, D, m->Nqkv, D);    // dWqkv += dqkv^T . xn
-      add(o.dht, D, a.O, D, m->G + m->lo[l].wo, D, D, D);                    // dWo  += dh^T . O
+      const bool full = !(top_compact && l == m->L - 1);
+      if (full) add(o.dab, 2 * Ip, a.hn, D, m->G + m->lo[l].w13, D, 2 * Ip, D);       // dW13 += dab^T . hn
+      if (full) add(o.gxt, D, a.g, Ip, m->G + m->lo[l].w2, Ip, D, Ip);                 // dW2  += gx^T . g
+      add(o.dqkv, m->Nqkv, a.xn, D, m->G + m->lo[l].wqkv, D, m->Nqkv, D);              // dWqkv += dqkv^T . xn
+      if (full) add(o.dht, D, a.O, D, m->G + m->lo[l].wo, D, D, D);                    // dWo  += dh^T . O
     }
     GemmGroupPlan* pl = nullptr;
     HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -1163,14 +1316,20 @@ static int backward_trunk(Model* m) {
   const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
   // deferred weight gradients: the dY operands of layer l live in m->dwb[l] until the grouped launch that consumes them
   const bool defer = m->defer_dw && !m->deterministic && side_mode() == 0;
-  if (defer) gxt = AT<T>(m->dwb[m->L - 1].gxt);
+  const bool ctop = m->top_is_sparse;
+  if (defer && !ctop) gxt = AT<T>(m->dwb[m->L - 1].gxt);
   RC(ensure_transposes(m));
   const bool wt = m->bf16_mode;   // dx GEMMs: row-major W^T (bf16 mode) or the K-major read of W itself (fp32 parity mode)
   tic(m, "phase_trunk_bwd");
   const double nb_bytes = (sizeof(T) + 4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT;   // g, x, residual gradient in; dx (+ its bf16 operand copy) out
-  tic(m, "hbm_rmsnorm_bwd", (4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT);
-  RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
-  toc(m);
+  if (ctop) {   // final norm on the compact rows: c_gx = d(last layer's output) at the selected tokens, zero everywhere else
+    RC(launch_rmsnorm_bwd_f32<T>(m->c_gy, m->c_xL, m->P + m->o_norm, m->c_rstdf, nullptr, m->c_gx, cp ? AT<T>(m->c_gx_t) : nullptr,
+                                 m->G + m->o_norm, m->ctop_cap, D, s, m->c_n));
+  } else {
+    tic(m, "hbm_rmsnorm_bwd", (4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT);
+    RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
+    toc(m);
+  }
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
@@ -1179,9 +1338,12 @@ static int backward_trunk(Model* m) {
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
     const bool ft = m->cfg.finetune != 0;   // finetune: base weights are frozen, only the dx chain and the LoRA grads run
-    void* const dab = defer ? m->dwb[l].dab : m->dab;
+    const bool top = ctop && l == m->L - 1;   // this layer's token-local part runs on the compact rows
+    void* const dab = (defer && !top) ? m->dwb[l].dab : m->dab;
     void* const dqkv = defer ? m->dwb[l].dqkv : m->dqkv;
-    if (defer) { dht = AT<T>(m->dwb[l].dht); gxt_other = l > 0 ? AT<T>(m->dwb[l - 1].gxt) : AT<T>(m->gxa_t); }
+    if (defer) { if (!top) dht = AT<T>(m->dwb[l].dht); gxt_other = l > 0 ? AT<T>(m->dwb[l - 1].gxt) : AT<T>(m->gxa_t); }
+    if (top) RC(top_tail_compact_bwd<T>(m, wt));
+    if (!top) {
     if (!ft && !defer) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
@@ -1229,6 +1391,7 @@ static int backward_trunk(Model* m) {
       RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
       RC(join_side(m));
     }
+    }   // !top
     ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
     ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
     ap.dO = m->dO; ap.delta = m->delta;
@@ -1295,7 +1458,11 @@ static int backward_trunk(Model* m) {
       }
     }
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
-    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
+    if (top)   // the residual gradient dh exists at the selected tokens only (compact rows, through the token -> row map)
+      RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->c_dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s,
+                               nullptr, m->c_slot));
+    else
+      RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
     toc(m);
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
@@ -1429,6 +1596,8 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   RC(launch_mask_tokens(b, m->cfg.finetune, m->cfg.finetune_metric, m->cfg.mask_rate, seed, step, m->stream));
   m->drop_active = m->cfg.finetune && !evaluate && m->cfg.lora_dropout > 0.f;   // nn.Dropout is active in train() mode only
   m->drop_seed = seed ^ 0xD409ull; m->drop_step = step;
+  m->top_is_sparse = m->sparse_top && !evaluate;
+  RC(select_positions_all(m));
   RC(forward_trunk<T>(m));
   float tw[4];
   for (int i = 0; i < 4; ++i) tw[i] = task_w ? task_w[i] * grad_scale : 0.f;
@@ -1468,6 +1637,7 @@ static int infer_t(Model* m, int task, const int32_t* sel, int64_t n_sel, float*
   HIP_CHECK(hipMemcpyAsync(b.m_rating, b.rating, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_progress, b.progress, N * 4, hipMemcpyDeviceToDevice, s));
   m->drop_active = false;
+  m->top_is_sparse = false;
   RC(forward_trunk<T>(m));
   // the rows to report: all of m->out, or the selected ones gathered into the (free) dx buffer of the backward
   const T* src = AT<T>(m->out);

@@ -148,6 +148,18 @@ struct Model {
   struct DwOperands { void *gxt, *dab, *dht, *dqkv; };
   std::vector<DwOperands> dwb;
   std::map<long long, GemmGroupPlan*> dw_plans;
+  // Compact top of the trunk (compact.hip).  A training pass reads the trunk's output only at the positions the heads select, and
+  // everything after the last layer's attention is token-local: the last layer's output projection, MLP and the final norm run --
+  // forward and backward -- on the sorted set of selected tokens c_sel[0 .. *c_n) (c_slot: token -> row of the compact buffers
+  // or -1).  Rows no head reads are not computed; backward rows whose gradient is identically zero are not multiplied.
+  bool sparse_top = false;        // this model uses it for its training passes (pretraining, replicated table)
+  bool top_is_sparse = false;     // the resident forward ran the compact tail: la[L-1].{h,hn,ab,g}, xL and out are NOT materialised
+  int ctop_cap = 0;               // rows of the compact buffers: min(tokens, 4 * mask_topk * rows) rounded up to 256
+  int *c_sel = nullptr, *c_slot = nullptr, *c_n = nullptr;
+  float *c_x = nullptr, *c_h = nullptr, *c_xL = nullptr, *c_rstd2 = nullptr, *c_rstdf = nullptr;
+  void *c_O = nullptr, *c_hn = nullptr, *c_ab = nullptr, *c_g = nullptr, *c_out = nullptr;
+  float *c_gy = nullptr, *c_gx = nullptr, *c_dh = nullptr;
+  void *c_gx_t = nullptr, *c_dab = nullptr, *c_dhn = nullptr, *c_dh_t = nullptr, *c_dO = nullptr;
   bool table_grads_pending = false;
   // the item-table gradient rows of medium m are known to be zero (just zeroed by zero_grad / AdamW and not written since):
   // the first head GEMM of a step then stores dF instead of reading 245 MB of zeros to add to
@@ -178,6 +190,7 @@ int model_batch_upload(Model* m, const rsys_batch* b);
 int model_forward_backward(Model* m, int evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step);
 int model_infer(Model* m, int task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n);   // token_index == nullptr: every token
 int model_item_table(Model* m, float* out, int64_t n);
+int model_materialise_trunk_output(Model* m);   // dense trunk output of the resident forward in m->out (a training pass computes it at the selected tokens only)
 int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);
