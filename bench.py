@@ -27,13 +27,15 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8p": "gemm8p_kernel<false, false>",                  # 256x256 LDS-DMA, persistent, row-major operands (gemm8p.hip)
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
     "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
+    "8g": "gemm8p_group_kernel",                          # the K-major pipeline, all layers' weight gradients in one grouped launch
     "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
-                "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+                "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
+                "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 TRAFFIC_FILE = "r2c_pmc_traffic.json"
 
@@ -71,6 +73,36 @@ def flops_per_interaction(cfg, B, attention_density=1.0):
     M, K = cfg["metadata_emb_size"], cfg["mask_topk"]
     return (36 * L * (D * D + D * I) + 56 * S * D * L * attention_density + 6 * K * V * D / S + 4 * V * M * D / (B * S)
             + 6 * (D * D + D) * 2 * K / S)
+
+
+def git_blob_id(path):
+    """the id `git hash-object` gives the file (the GPU box has no .git): which committed PMC summary a line quotes"""
+    import hashlib
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def attention_tile_density(userid, S, tile=64):
+    """share of the (tile x tile) blocks of a row's (2S)^2 score matrix that hold an allowed (query, key) pair under the same-user
+    predicate (model.py:479-480) -- the blocks the block-sparse attention kernels visit (the token-mask predicate of :481-487
+    empties almost none of them; per-wave skipping inside a visited block is not counted: an upper bound on executed work)"""
+    u = np.repeat(np.asarray(userid).reshape(-1, S), 2, axis=1)
+    T = 2 * S
+    nt = (T + tile - 1) // tile
+    vis = 0
+    for row in u:
+        lo = np.array([row[i * tile:(i + 1) * tile].min() for i in range(nt)])
+        hi = np.array([row[i * tile:(i + 1) * tile].max() for i in range(nt)])
+        # users are contiguous runs inside a row (the packer, train.py:91-98): two tiles share a user iff their id sets intersect
+        sets = [set(row[i * tile:(i + 1) * tile].tolist()) for i in range(nt)]
+        for i in range(nt):
+            for j in range(nt):
+                if lo[i] <= hi[j] and lo[j] <= hi[i] and not sets[i].isdisjoint(sets[j]):
+                    vis += 1
+    return vis / float(len(u) * nt * nt)
 
 
 def attention_density(userid, S):
@@ -252,7 +284,8 @@ def main():
     hg.barrier()
     # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first tenth of the timed steps: ~300 event
     # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
-    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else max(1, args.steps // 10))
+    # (at least five instrumented steps once 20 are timed: two samples left the per-kernel entries swinging by 30 %)
+    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else (max(5, args.steps // 10) if args.steps >= 20 else max(1, args.steps // 10)))
     if n_instr:
         model.timing(True, serialize=True)
     ra.synchronize()
@@ -312,6 +345,16 @@ def main():
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
                 rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith("@8p")) else fl   # 256-row tiles
+        # compact top of the trunk: those GEMMs stop at the selected tokens (device-side limit), their tags carry the capacity
+        try:
+            top_cap = int(model.debug_get("top.cap", rows)[0])
+            top_n = int(model.debug_get("top.n", rows)[0]) if top_cap else 0
+        except Exception:
+            top_cap, top_n = 0, 0
+        if top_cap:
+            for full in [k for k in rep if k.startswith("gemm_top_")]:
+                q = 256 if full.endswith("@8p") else (64 if full.split("@")[0].endswith("_dw") else 128)
+                rep[full]["flops"] *= min(top_cap, up(top_n, q)) / float(top_cap)
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses
 
@@ -322,6 +365,16 @@ def main():
         fpi = flops_per_interaction(cfg, rows)
         dens = attention_density(d["userid"], S)
         fpi_useful = flops_per_interaction(cfg, rows, dens)
+        # FLOPs the kernels really execute per step: every GEMM call site at its device-side limits (head GEMMs at the live rows,
+        # the compact top at the selected tokens) + the attention kernels at the 64 x 64 blocks they visit (2 products forward,
+        # 7 backward: the dK/dV and the dQ kernel each recompute S and dP)
+        executed = None
+        if rep:
+            hd = cfg["embed_dim"] // cfg["num_heads"]
+            tdens = attention_tile_density(d["userid"], S)
+            attn_fl = cfg["num_layers"] * cfg["num_heads"] * rows * (2 * S) ** 2 * tdens * (2 + 7) * 2.0 * hd
+            gemm_fl = sum(r["flops"] for tag, r in rep.items() if tag.startswith("gemm_")) / n_instr
+            executed = {"gemm_flops_per_step": gemm_fl, "attention_flops_per_step": attn_fl, "attention_tile_density": round(tdens, 4)}
         # dominant kernel: the MFMA GEMM family, per instantiation
         var = {}
         for tag, r in rep.items():
@@ -345,7 +398,10 @@ def main():
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": KERNEL_LABEL.get(dom, dom), "achieved": round(ach, 1),
                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                        "traffic": traffic_of(traffic_db, dom), "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                        "traffic": traffic_of(traffic_db, dom),
+                        "traffic_source": (None if not traffic_db else {"file": "profiles/" + TRAFFIC_FILE, "git_blob": git_blob_id(os.path.join(ROOT, "profiles", TRAFFIC_FILE)),
+                                                                        "note": "separate rocprofv3 --pmc passes of this workload (tools/prof_round.sh), read from the committed summary, not measured in this run"}),
+                        "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],
                         "share_of_step": round(a["ms"] / n_instr / ms, 3), "instrumented_steps": n_instr}
         out = {
@@ -364,6 +420,10 @@ def main():
             # the same fraction on "useful" FLOPs, attention scaled by the share of same-user (query, key) pairs of this batch
             "attention_density": round(dens, 4), "model_flops_per_interaction_useful": round(fpi_useful, 1),
             "step_mfma_frac_useful": round(value / world * fpi_useful / (MFMA_PEAK_TFLOPS * 1e12), 4),
+            # ... and on the FLOPs that were EXECUTED (zero-weight head rows, unselected tokens of the last layer's tail and masked
+            # attention blocks are skipped, not computed): the utilisation figure; the two above price the model's nominal work
+            "step_mfma_frac_executed": (None if executed is None else round((executed["gemm_flops_per_step"] + executed["attention_flops_per_step"]) / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4)),
+            "executed": executed,
             "roofline": roofline,
             "losses": [round(float(x), 4) for x in losses],
         }
@@ -373,7 +433,10 @@ def main():
                                         "note": "HIP-event time between step boundaries on the compute stream, steps without per-kernel events"}
         if nocomm_ms is not None:
             out["ms_per_step_without_allreduce"] = round(nocomm_ms, 3)
-            out["allreduce_exposed_ms_per_step"] = round(ms - nocomm_ms, 3)     # what the gradient all-reduce adds to a step after its overlap with the backward
+            # what the gradient all-reduce adds to a step after its overlap with the backward: both arms without per-kernel events
+            # (the median of the un-instrumented timed steps against the un-instrumented no-all-reduce loop)
+            with_ar = float(np.median(plain)) if len(plain) else ms
+            out["allreduce_exposed_ms_per_step"] = round(with_ar - nocomm_ms, 3)
         if loop_ms is not None:
             out["train_loop_ms_per_step"] = round(loop_ms, 3)     # train_epoch: batch upload + loss read-back every step
             out["train_loop_interactions_per_sec"] = round(world * rows * S / (loop_ms * 1e-3), 1)

@@ -332,6 +332,12 @@ class RecommenderModel:
         V = self.config["vocab_sizes"]["0_matchedid"] + self.config["vocab_sizes"]["1_matchedid"]
         if key == "npos":
             out = np.empty(4, np.int32)
+        elif key in ("top.n", "top.cap"):
+            out = np.empty(1, np.int32)
+        elif key == "top.sel":
+            out = np.empty(int(self.debug_get("top.cap", rows)[0]), np.int32)
+        elif key == "top.slot":
+            out = np.empty(2 * n, np.int32)
         elif key.startswith("idx."):
             out = np.empty(self.config["mask_topk"] * rows, np.int32)
         elif key.startswith("tokens."):

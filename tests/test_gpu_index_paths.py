@@ -48,6 +48,18 @@ def _check_selection_and_gather(model, cfg, rows, masked, what):
         got = model.debug_get(f"idx.{ti}", rows)
         assert np.array_equal(got, want), (what, ti, got[:8], want[:8])
         assert int(npos[ti]) == min(int((w > 0).sum()), KB), (what, ti)
+    # compact top of the trunk (training passes): the sorted union of the tasks' live tokens (2 i + metric) and its inverse map
+    if int(model.debug_get("top.cap", rows)[0]) > 0:
+        toks = []
+        for ti, (m, metric) in enumerate(TASKS):
+            got = model.debug_get(f"idx.{ti}", rows)[:int(npos[ti])]
+            toks.append(2 * got.astype(np.int64) + (ti & 1))
+        want = np.unique(np.concatenate(toks)).astype(np.int32)
+        n_sel = int(model.debug_get("top.n", rows)[0])
+        assert n_sel == want.size, (what, n_sel, want.size)
+        assert np.array_equal(model.debug_get("top.sel", rows)[:n_sel], want), what
+        slot = np.full(2 * rows * S, -1, np.int32); slot[want] = np.arange(want.size, dtype=np.int32)
+        assert np.array_equal(model.debug_get("top.slot", rows), slot), what
     # interleave (model.py:403-415, 468-469): per-token userid / token_mask_ids, every event twice
     uid = np.asarray(masked["userid"]).reshape(-1).astype(np.int32)
     tm = np.asarray(masked["token_mask_ids"]).reshape(-1).astype(np.int32)
