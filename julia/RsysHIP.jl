@@ -1,4 +1,7 @@
-# Julia binding of librsys_hip.so (C ABI: include/rsys.h) -- thin `ccall` wrappers, 1:1 with the header.
+# Julia binding of librsys_hip.so (C ABI: include/rsys.h) -- thin `ccall` wrappers, 1:1 with the header: every entry point of
+# the header is bound here except the per-kernel unit-test access (rsys_dev_*, rsys_op_gemm*, rsys_op_attention,
+# rsys_op_embedding_scatter).  tests/test_julia_binding.py parses the `ccall` tuples and the two struct mirrors below and checks
+# names, arity and C types against include/rsys.h (Julia itself cannot run in the build image).
 #
 # NOT EXECUTED in the build container (Julia is absent from the image, SURVEY.md 8(c)); it is the stub a
 # maintainer adds so that notebooks/Training/run.jl:70 (`julia rungpu.jl`, which remote-launches torchrun
@@ -113,6 +116,112 @@ set_shard_comm!(m::Model, c::Comm) = check(ccall((:rsys_model_set_shard_comm, LI
 function table_rows(m::Model)
     lo = Ref{Int64}(0); hi = Ref{Int64}(0)
     check(ccall((:rsys_table_rows, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), m.h, lo, hi)); (lo[], hi[])
+end
+
+
+# ---- lifetime, library
+version() = unsafe_string(ccall((:rsys_version, LIB), Cstring, ()))
+function device_count()
+    n = Ref{Int32}(0); check(ccall((:rsys_device_count, LIB), Int32, (Ref{Int32},), n)); Int(n[])
+end
+synchronize() = check(ccall((:rsys_device_synchronize, LIB), Int32, ()))
+destroy!(m::Model) = (m.h == C_NULL || check(ccall((:rsys_model_destroy, LIB), Int32, (Ptr{Cvoid},), m.h)); m.h = C_NULL; nothing)
+destroy!(o::Optimizer) = (o.h == C_NULL || check(ccall((:rsys_adamw_destroy, LIB), Int32, (Ptr{Cvoid},), o.h)); o.h = C_NULL; nothing)
+destroy!(c::Comm) = (c.h == C_NULL || check(ccall((:rsys_comm_destroy, LIB), Int32, (Ptr{Cvoid},), c.h)); c.h = C_NULL; nothing)
+
+# ---- parameters (state-dict names of transformer.model.py:346-359)
+random_pretrained_embeddings!(m::Model, seed::Integer) = check(ccall((:rsys_model_random_metadata, LIB), Int32, (Ptr{Cvoid}, UInt64), m.h, seed))
+function set_rope!(m::Model, c::Matrix{Float32}, s::Matrix{Float32})   # (head_dim / 2, n_pos) column-major = (n_pos, head_dim / 2) row-major
+    GC.@preserve c s check(ccall((:rsys_model_set_rope, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64), m.h, c, s, size(c, 2)))
+end
+function param_count(m::Model)
+    n = Ref{Int32}(0); check(ccall((:rsys_param_count, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}), m.h, n)); Int(n[])
+end
+function param_info(m::Model, i::Integer)            # i is 0-based like the C ABI
+    name = Vector{UInt8}(undef, 256); shape = Vector{Int64}(undef, 2); nd = Ref{Int32}(0); tr = Ref{Int32}(0)
+    GC.@preserve name shape check(ccall((:rsys_param_info, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{UInt8}, Csize_t, Ptr{Int64}, Ref{Int32}, Ref{Int32}),
+                                        m.h, i, name, length(name), shape, nd, tr))
+    (unsafe_string(pointer(name)), nd[] == 1 ? (shape[1],) : (shape[1], shape[2]), tr[] != 0)
+end
+function grad!(m::Model, name::String, out::Array{Float32})
+    GC.@preserve out check(ccall((:rsys_grad_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float32}, Int64), m.h, name, out, length(out)))
+    out
+end
+zero_grad!(m::Model) = check(ccall((:rsys_zero_grad, LIB), Int32, (Ptr{Cvoid},), m.h))
+refresh_shadow!(m::Model) = check(ccall((:rsys_refresh_shadow, LIB), Int32, (Ptr{Cvoid},), m.h))
+function grad_buffer(m::Model)
+    p = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int64}(0)
+    check(ccall((:rsys_grad_buffer, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}), m.h, p, n)); (p[], n[])
+end
+function param_buffer(m::Model)
+    p = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int64}(0)
+    check(ccall((:rsys_param_buffer, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}), m.h, p, n)); (p[], n[])
+end
+
+# ---- clip, heads, serving
+function clip_grad_norm!(m::Model, max_norm::Real)    # transformer.py:273
+    out = Ref{Float32}(0f0)
+    check(ccall((:rsys_clip_grad_norm, LIB), Int32, (Ptr{Cvoid}, Float32, Ref{Float32}), m.h, max_norm, out)); out[]
+end
+function head_rows(m::Model)
+    out = Vector{Int32}(undef, 4)
+    GC.@preserve out check(ccall((:rsys_head_rows_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), m.h, out)); out
+end
+function item_table(m::Model, V::Integer, D::Integer)  # register.py:27-33: (D, V) column-major = (V, D) row-major
+    out = Matrix{Float32}(undef, D, V)
+    GC.@preserve out check(ccall((:rsys_item_table, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int64), m.h, out, length(out))); out
+end
+function infer(m::Model, task::Integer, rows::Integer, S::Integer, D::Integer)   # model.py:531-538 over every token of the resident batch
+    out = task == 0 ? Array{Float32}(undef, D, 2S, rows) : Array{Float32}(undef, 2S, rows)
+    GC.@preserve out check(ccall((:rsys_infer, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float32}, Int64), m.h, task, out, length(out))); out
+end
+function trunk_output(m::Model, rows::Integer, S::Integer, D::Integer)
+    out = Array{Float32}(undef, D, 2S, rows)
+    GC.@preserve out check(ccall((:rsys_trunk_output_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int64), m.h, out, length(out))); out
+end
+function debug_get!(m::Model, key::String, out::Array)
+    GC.@preserve out check(ccall((:rsys_debug_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Cvoid}, Int64), m.h, key, out, sizeof(out))); out
+end
+
+# ---- optimizer state (checkpoint / resume, transformer.py:456-466,690-695)
+function adamw_state(o::Optimizer, name::String, n::Integer)
+    m = Vector{Float32}(undef, n); v = Vector{Float32}(undef, n); st = Ref{Int32}(0)
+    GC.@preserve m v check(ccall((:rsys_adamw_state_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float32}, Ptr{Float32}, Int64, Ref{Int32}),
+                                 o.h, name, m, v, n, st))
+    (m, v, Int(st[]))
+end
+function adamw_state!(o::Optimizer, name::String, m::Vector{Float32}, v::Vector{Float32}, step::Integer)
+    GC.@preserve m v check(ccall((:rsys_adamw_state_set, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float32}, Ptr{Float32}, Int64, Int32),
+                                 o.h, name, m, v, length(m), step))
+end
+
+# ---- collectives beyond the gradient all-reduce
+function allreduce_f64!(c::Comm, x::Vector{Float64})   # reduce_mean, transformer.py:199-204
+    GC.@preserve x check(ccall((:rsys_allreduce_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), c.h, x, length(x))); x
+end
+function grad_sync_early(m::Model)
+    n = Ref{Int64}(0); check(ccall((:rsys_grad_sync_early, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), m.h, n)); n[]
+end
+# in-process rank group (tests on a one-GPU box): `world` ranks as host threads of this process
+function local_group(world::Integer, device::Integer)
+    g = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:rsys_local_group_create, LIB), Int32, (Int32, Int32, Ref{Ptr{Cvoid}}), world, device, g)); g[]
+end
+local_group_destroy(g::Ptr{Cvoid}) = check(ccall((:rsys_local_group_destroy, LIB), Int32, (Ptr{Cvoid},), g))
+function local_comm(g::Ptr{Cvoid}, rank::Integer, world::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:rsys_comm_init_local, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), g, rank, h)); Comm(h[], world)
+end
+
+# ---- instrumentation
+step_mark!(m::Model) = check(ccall((:rsys_step_mark, LIB), Int32, (Ptr{Cvoid},), m.h))
+function step_marks(m::Model, cap::Integer = 65536)
+    ms = Vector{Float32}(undef, cap); n = Ref{Int32}(0)
+    GC.@preserve ms check(ccall((:rsys_step_marks_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int32, Ref{Int32}), m.h, ms, cap, n)); ms[1:n[]]
+end
+op_timing!(m::Model, mode::Integer) = check(ccall((:rsys_op_timing, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, mode))
+function timing_report(m::Model)
+    buf = Vector{UInt8}(undef, 1 << 16)
+    GC.@preserve buf check(ccall((:rsys_timing_get, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), m.h, buf, length(buf)))
+    unsafe_string(pointer(buf))
 end
 
 # One optimizer step of train_epoch (transformer.py:256-276) with grad_accum = 1
