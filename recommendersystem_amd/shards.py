@@ -80,48 +80,76 @@ def save_media_embeddings(datadir, media, num_items, max_ts, **dims):
     h5.write_h5(os.path.join(datadir, "media_embeddings.h5"), {"metadata": media_embedding_matrix(media, num_items, max_ts, **dims)}, blosc=3)
 
 
-def get_data(data, userid, num_items_0):
-    """transformer.jl:79-146.  `data` = {"user": {...}, "items": [events]}; returns the 27 arrays of this user's tokens.
-    Targets: watch = first time the item leaves the planned states (or an inferred watch), rating / status = the value
-    changed; `token_mask_ids` marks tokens that carry a rating target (they can be masked, model.py:479-487)."""
-    items = project(tokenize(data["items"]))
-    u = data["user"]
-    N = len(items)
-    d = {k: np.zeros(N, np.int32) for k in _INT_KEYS}
-    d["time"] = np.zeros(N, np.float64)
-    d["rating"] = np.zeros(N, np.float32)
-    d["progress"] = np.zeros(N, np.float32)
+def _empty_record(n):
+    """the 27 arrays of the batch record, all zero, for n tokens"""
+    d = {k: np.zeros(n, np.int32) for k in _INT_KEYS}
+    d["time"] = np.zeros(n, np.float64)
+    d["rating"] = np.zeros(n, np.float32)
+    d["progress"] = np.zeros(n, np.float32)
     for m in MEDIUMS:
         for metric in METRICS:
-            d[f"{m}.{metric}.label"] = np.zeros(N, np.float32)
-            d[f"{m}.{metric}.weight"] = np.zeros(N, np.float32)
-            d[f"{m}.{metric}.position"] = np.zeros(N, np.int32)
-    for i, x in enumerate(items):
-        m = x["medium"]
-        d["userid"][i] = userid
-        d["time"][i] = x["history_max_ts"]
-        d["gender"][i] = 0 if u["gender"] is None else u["gender"] + 1
-        d["source"][i] = u["source"]
-        d["matchedid"][i] = x["matchedid"] + (num_items_0 if m == 1 else 0)
-        d["status"][i] = x["status"]
-        d["rating"][i] = x["rating"]
-        d["progress"][i] = x["progress"]
-        hs, hr = x["history_status"], x["history_rating"]
-        inferred_watch = x["status"] == 0 and hs is None
-        new_watch = x["status"] > PLANNED_STATUS and (hs is None or 0 < hs <= PLANNED_STATUS)
-        if inferred_watch or new_watch:
-            d[f"{m}.watch.label"][i] = 1
-            d[f"{m}.watch.weight"][i] = 1
-            d[f"{m}.watch.position"][i] = x["matchedid"]
-        if x["rating"] > 0 and x["rating"] != hr:
-            d["token_mask_ids"][i] = 1
-            d[f"{m}.rating.label"][i] = x["rating"]
-            d[f"{m}.rating.weight"][i] = 1
-            d[f"{m}.rating.position"][i] = x["matchedid"]
-        if x["status"] > 0 and x["status"] != hs:
-            d[f"{m}.status.label"][i] = x["status"]
-            d[f"{m}.status.weight"][i] = 1
-            d[f"{m}.status.position"][i] = x["matchedid"]
+            d[f"{m}.{metric}.label"] = np.zeros(n, np.float32)
+            d[f"{m}.{metric}.weight"] = np.zeros(n, np.float32)
+            d[f"{m}.{metric}.position"] = np.zeros(n, np.int32)
+    return d
+
+
+def _event_columns(events):
+    """The events of one user as columns.  `prev_status` / `prev_rating`: the state of the same item before the event
+    (`history_status` / `history_rating` of the importer, import_list.jl:624-635), NaN where the item is new to the user."""
+    col = lambda key, dt: np.array([x[key] for x in events], dt) if events else np.zeros(0, dt)
+    prev = lambda key: np.array([np.nan if x[key] is None else x[key] for x in events], np.float64) if events else np.zeros(0, np.float64)
+    return {"medium": col("medium", np.int64), "matchedid": col("matchedid", np.int64), "status": col("status", np.int64),
+            "rating": col("rating", np.float32), "progress": col("progress", np.float32), "time": col("history_max_ts", np.float64),
+            "prev_status": prev("history_status"), "prev_rating": prev("history_rating")}
+
+
+def _target_masks(c):
+    """The three target rules of the writer (transformer.jl:120-139) as boolean columns over the events:
+      watch   the event is an implied watch (status 0 on an item the user has no state for), or the item's status rises above
+              the planned states from no state / a planned state;
+      rating  the event carries a rating that differs from the item's previous one;
+      status  the event carries a status that differs from the item's previous one."""
+    new_item = np.isnan(c["prev_status"])
+    was_planned = (c["prev_status"] > 0) & (c["prev_status"] <= PLANNED_STATUS)      # (NaN compares false)
+    watch = ((c["status"] == 0) & new_item) | ((c["status"] > PLANNED_STATUS) & (new_item | was_planned))
+    rating = (c["rating"] > 0) & ~(c["rating"].astype(np.float64) == c["prev_rating"])
+    status = (c["status"] > 0) & ~(c["status"].astype(np.float64) == c["prev_status"])
+    return {"watch": watch, "rating": rating, "status": status}
+
+
+def _write_events(d, at, c, user, userid, num_items_0, with_targets):
+    """events `c` into tokens at .. at + n of record `d`; targets (label, weight 1, per-medium position) where asked"""
+    n = len(c["medium"])
+    sl = slice(at, at + n)
+    d["userid"][sl] = userid
+    d["time"][sl] = c["time"]
+    d["gender"][sl] = 0 if user["gender"] is None else user["gender"] + 1      # 0 = unknown (transformer.jl:111)
+    d["source"][sl] = user["source"]
+    d["matchedid"][sl] = c["matchedid"] + num_items_0 * (c["medium"] == 1)     # global id: anime behind manga (:114)
+    d["status"][sl] = c["status"]
+    d["rating"][sl] = c["rating"]
+    d["progress"][sl] = c["progress"]
+    if not with_targets:
+        return
+    masks = _target_masks(c)
+    labels = {"watch": np.ones(n, np.float32), "rating": c["rating"], "status": c["status"].astype(np.float32)}
+    d["token_mask_ids"][sl] = masks["rating"]                                  # tokens whose rating may be hidden (model.py:479-487)
+    for m in MEDIUMS:
+        in_m = c["medium"] == m
+        for metric in METRICS:
+            hit = masks[metric] & in_m
+            d[f"{m}.{metric}.label"][sl] = np.where(hit, labels[metric], 0)
+            d[f"{m}.{metric}.weight"][sl] = hit
+            d[f"{m}.{metric}.position"][sl] = np.where(hit, c["matchedid"], 0)
+
+
+def get_data(data, userid, num_items_0):
+    """transformer.jl:79-146.  `data` = {"user": {...}, "items": [events]}; returns the 27 arrays of this user's tokens: the
+    projected events as columns, every event a candidate target (rules: _target_masks)."""
+    c = _event_columns(project(tokenize(data["items"])))
+    d = _empty_record(len(c["medium"]))
+    _write_events(d, 0, c, data["user"], userid, num_items_0, with_targets=True)
     return d
 
 
@@ -207,58 +235,18 @@ NUM_TEST_ITEMS = 1                      # :55
 
 def get_finetune_data(data, userid, num_items_0, max_seq_len=FINETUNE_SEQ_LEN):
     """Finetune/transformer.jl:52-133.  `data` = {"user", "items": history events, "test_items": [<= 1 held-out event]}.
-    One row of `max_seq_len` tokens: the newest max_seq_len - 1 projected history tokens, then the test event; only the
-    test event gets targets (same rules as the pretraining writer), and every task's weights are normalised to sum 1."""
+    One row of `max_seq_len` tokens: the newest max_seq_len - 1 projected history tokens (context: no targets), then the test
+    event, which alone is a target (same rules as the pretraining writer); every task's weights are normalised to sum 1."""
     assert len(data["test_items"]) <= NUM_TEST_ITEMS
-    items = project(tokenize(data["items"]))
-    if len(items) > max_seq_len - NUM_TEST_ITEMS:
-        items = items[len(items) - (max_seq_len - NUM_TEST_ITEMS):]
-    u = data["user"]
-    N = max_seq_len
-    d = {k: np.zeros(N, np.int32) for k in _INT_KEYS}
-    d["time"] = np.zeros(N, np.float64)
-    d["rating"] = np.zeros(N, np.float32)
-    d["progress"] = np.zeros(N, np.float32)
+    history = project(tokenize(data["items"]))[-(max_seq_len - NUM_TEST_ITEMS):]
+    d = _empty_record(max_seq_len)
+    _write_events(d, 0, _event_columns(history), data["user"], userid, num_items_0, with_targets=False)
+    _write_events(d, len(history), _event_columns(data["test_items"]), data["user"], userid, num_items_0, with_targets=True)
     for m in MEDIUMS:
         for metric in METRICS:
-            d[f"{m}.{metric}.label"] = np.zeros(N, np.float32)
-            d[f"{m}.{metric}.weight"] = np.zeros(N, np.float32)
-            d[f"{m}.{metric}.position"] = np.zeros(N, np.int32)
-    i = 0
-    for source, istest in ((items, False), (data["test_items"], True)):
-        for x in source:
-            m = x["medium"]
-            d["userid"][i] = userid
-            d["time"][i] = x["history_max_ts"]
-            d["gender"][i] = 0 if u["gender"] is None else u["gender"] + 1
-            d["source"][i] = u["source"]
-            d["matchedid"][i] = x["matchedid"] + (num_items_0 if m == 1 else 0)
-            d["status"][i] = x["status"]
-            d["rating"][i] = x["rating"]
-            d["progress"][i] = x["progress"]
-            if istest:
-                hs, hr = x["history_status"], x["history_rating"]
-                inferred_watch = x["status"] == 0 and hs is None
-                new_watch = x["status"] > PLANNED_STATUS and (hs is None or 0 < hs <= PLANNED_STATUS)
-                if inferred_watch or new_watch:
-                    d[f"{m}.watch.label"][i] = 1
-                    d[f"{m}.watch.weight"][i] = 1
-                    d[f"{m}.watch.position"][i] = x["matchedid"]
-                if x["rating"] > 0 and x["rating"] != hr:
-                    d["token_mask_ids"][i] = 1
-                    d[f"{m}.rating.label"][i] = x["rating"]
-                    d[f"{m}.rating.weight"][i] = 1
-                    d[f"{m}.rating.position"][i] = x["matchedid"]
-                if x["status"] > 0 and x["status"] != hs:
-                    d[f"{m}.status.label"][i] = x["status"]
-                    d[f"{m}.status.weight"][i] = 1
-                    d[f"{m}.status.position"][i] = x["matchedid"]
-            i += 1
-    for m in MEDIUMS:
-        for metric in METRICS:
-            wsum = d[f"{m}.{metric}.weight"].sum()
-            if wsum > 0:
-                d[f"{m}.{metric}.weight"] /= wsum
+            w = d[f"{m}.{metric}.weight"]
+            if w.sum() > 0:
+                w /= w.sum()
     return d
 
 
