@@ -268,7 +268,13 @@ int32_t rsys_local_group_create(int32_t world, int32_t device, void** out) {
   *out = g;
   return RSYS_OK;
 }
-int32_t rsys_local_group_destroy(void* group) { delete (LocalGroup*)group; return RSYS_OK; }
+int32_t rsys_local_group_destroy(void* group) {
+  if (!group) return RSYS_OK;
+  LocalGroup* g = (LocalGroup*)group;
+  { std::lock_guard<std::mutex> lk(g->mu); if (g->refs > 0) { set_error("in-process group: close its communicators first (rsys_comm_destroy)"); return RSYS_ERR_STATE; } }
+  delete g;
+  return RSYS_OK;
+}
 int32_t rsys_comm_init_local(void* group, int32_t rank, rsys_comm** out) {
   ARG_CHECK(group && out, "null");
   return comm_init_local((LocalGroup*)group, rank, out);

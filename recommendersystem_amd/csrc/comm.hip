@@ -81,9 +81,16 @@ int comm_init_rccl(const unsigned char id_buf[128], int rank, int world, int dev
   c->rank = rank; c->world = world; c->device = device;
   ncclUniqueId_t id;
   memcpy(id.internal, id_buf, 128);
-  NCCL_CHECK(g_rccl.CommInitRank(&c->comm, world, id, rank));
+  {
+    const int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) {
+      set_error(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+      delete c;
+      return RSYS_ERR_COMM;
+    }
+  }
   rc = comm_common_init(c);
-  if (rc) return rc;
+  if (rc) { comm_destroy(c); return rc; }   // (frees whatever the failed step had created: communicator, stream, events)
   { const char* f = getenv("RSYS_FORCE_RCCL"); c->force = f && f[0] == '1'; }
   *out = c;
   return RSYS_OK;
@@ -109,14 +116,18 @@ static int local_fail(LocalGroup* g, int rc) {
 int comm_init_local(LocalGroup* g, int rank, rsys_comm** out) {
   ARG_CHECK(g != nullptr && rank >= 0 && rank < g->world, "in-process group: rank");
   HIP_CHECK(hipSetDevice(g->device));
+  ARG_CHECK(g->world <= 16, "in-process group: at most 16 ranks (reduce_ptrs_kernel's pointer list)");
   rsys_comm* c = new rsys_comm();
   c->rank = rank; c->world = g->world; c->device = g->device; c->lg = g;
+  { std::lock_guard<std::mutex> lk(g->mu); ++g->refs; }    // (comm_destroy drops it, also on the failure paths below)
   int rc = comm_common_init(c);
-  if (rc) return rc;
+  if (rc) { comm_destroy(c); return rc; }
   LocalRankSlot& sl = g->slot[rank];
-  HIP_CHECK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-  { std::lock_guard<std::mutex> lk(g->mu); ++g->refs; }
+  if (hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+    set_error("in-process group: hipEventCreate failed");
+    comm_destroy(c);
+    return RSYS_ERR_HIP;
+  }
   *out = c;
   return RSYS_OK;
 }
@@ -132,10 +143,12 @@ int comm_destroy(rsys_comm* c) {
     if (sl.done) hipEventDestroy(sl.done);
     if (sl.tmp) hipFree(sl.tmp);
     sl = LocalRankSlot();
+    { std::lock_guard<std::mutex> lk(c->lg->mu); --c->lg->refs; }   // (rsys_local_group_destroy refuses while communicators are open)
   }
-  hipFree(c->scratch);
-  hipEventDestroy(c->ev_ready); hipEventDestroy(c->ev_done);
-  hipStreamDestroy(c->stream);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->ev_ready) hipEventDestroy(c->ev_ready);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
+  if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return RSYS_OK;
 }
@@ -188,6 +201,7 @@ static int local_all_reduce(rsys_comm* c, T* buf, size_t n, int op, hipStream_t 
   }
   int rc = local_begin(c, buf, nullptr, nullptr, s);
   if (rc) return rc;
+  if (g->world > 16) { set_error("in-process group: more than 16 ranks"); return RSYS_ERR_ARG; }
   PtrList pl; pl.n = g->world;
   for (int q = 0; q < g->world; ++q) pl.p[q] = g->slot[q].send;
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
@@ -259,13 +273,18 @@ int comm_exchange(rsys_comm* c, const void* send, const long long* send_off, voi
     rc = local_end(c, s);
     return rc ? local_fail(g, rc) : RSYS_OK;
   }
+  // one grouped send / receive per peer, issued in rank order on every rank.  An error inside the group must not leave it
+  // open (every later RCCL call of this thread would join it): close it first, then report the first failure.
   NCCL_CHECK(g_rccl.GroupStart());
-  for (int q = 0; q < W; ++q) {
+  int bad = 0; const char* what = "";
+  for (int q = 0; q < W && !bad; ++q) {
     const long long ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
-    if (ns) NCCL_CHECK(g_rccl.Send((const char*)send + send_off[q] * eb, (size_t)ns * eb, NCCL_INT8, q, c->comm, s));
-    if (nr) NCCL_CHECK(g_rccl.Recv((char*)recv + recv_off[q] * eb, (size_t)nr * eb, NCCL_INT8, q, c->comm, s));
+    if (ns && (bad = g_rccl.Send((const char*)send + send_off[q] * eb, (size_t)ns * eb, NCCL_INT8, q, c->comm, s)) != 0) { what = "ncclSend"; break; }
+    if (nr && (bad = g_rccl.Recv((char*)recv + recv_off[q] * eb, (size_t)nr * eb, NCCL_INT8, q, c->comm, s)) != 0) { what = "ncclRecv"; break; }
   }
-  NCCL_CHECK(g_rccl.GroupEnd());
+  const int end = g_rccl.GroupEnd();
+  if (bad) { set_error(std::string(what) + " inside the row exchange: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(bad) : "rccl error")); return RSYS_ERR_COMM; }
+  NCCL_CHECK(end);
   return RSYS_OK;
 }
 

@@ -30,9 +30,16 @@ class RendezvousError(RuntimeError):
     pass
 
 
+MAX_HEADER = 1 << 20          # a frame's JSON header (a list of floats at most)
+HANDSHAKE_HEADER = 4096       # the first frame of a connection: {"token", "rank"}, nothing else and no payload
+
+
 def _send_frame(sock, header, raw=b""):
+    """frame = !IQ (header bytes, payload bytes: 64-bit, a gathered table shard may exceed 4 GiB) + JSON header + payload"""
     head = json.dumps(dict(header, raw=len(raw))).encode()
-    sock.sendall(struct.pack("!II", len(head), len(raw)) + head + raw)
+    sock.sendall(struct.pack("!IQ", len(head), len(raw)) + head)
+    if raw:
+        sock.sendall(raw)
 
 
 def _recv_exact(sock, n):
@@ -45,8 +52,11 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv_frame(sock):
-    nh, nr = struct.unpack("!II", _recv_exact(sock, 8))
+def _recv_frame(sock, max_header=MAX_HEADER, max_raw=None):
+    """the lengths are checked BEFORE anything is allocated (`max_raw` None: trusted peer that passed the handshake)"""
+    nh, nr = struct.unpack("!IQ", _recv_exact(sock, 12))
+    if nh > max_header or (max_raw is not None and nr > max_raw):
+        raise RendezvousError(f"frame of {nh} + {nr} bytes exceeds the limit of this stage of the protocol")
     header = json.loads(_recv_exact(sock, nh).decode())
     return header, (_recv_exact(sock, nr) if nr else b"")
 
@@ -88,7 +98,14 @@ class HostGroup:
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                ls.bind(("", port))
+                # rank 0 listens on the rendezvous address only (127.0.0.1 under launch_local / torchrun --standalone), not on
+                # every interface; a MASTER_ADDR that is not an address of this host falls back to all interfaces
+                try:
+                    ls.bind((addr, port))
+                except (OSError, socket.gaierror) as e:
+                    if getattr(e, "errno", None) in (98, 48):      # EADDRINUSE: try the next port
+                        raise
+                    ls.bind(("", port))
             except OSError as e:
                 err = e
                 ls.close()
@@ -106,9 +123,9 @@ class HostGroup:
                 conn, _ = self.listener.accept()
             except socket.timeout:
                 raise RendezvousError(f"rendezvous timed out: {len(peers) + 1} of {self.world} ranks arrived") from None
-            conn.settimeout(10.0)
+            conn.settimeout(2.0)          # (a stranger on the port costs the rendezvous two seconds, not ten)
             try:
-                hello, _ = _recv_frame(conn)
+                hello, _ = _recv_frame(conn, max_header=HANDSHAKE_HEADER, max_raw=0)
                 ok = hello.get("token") == token and 0 < int(hello.get("rank", -1)) < self.world and hello["rank"] not in peers
                 _send_frame(conn, {"ok": bool(ok)})
             except (OSError, ValueError, RendezvousError, struct.error):
@@ -132,7 +149,7 @@ class HostGroup:
                 try:
                     s.settimeout(10.0)
                     _send_frame(s, {"token": token, "rank": self.rank})
-                    reply, _ = _recv_frame(s)
+                    reply, _ = _recv_frame(s, max_header=HANDSHAKE_HEADER, max_raw=0)
                     if reply.get("ok"):
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         s.settimeout(self.timeout)

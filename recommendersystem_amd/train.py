@@ -163,6 +163,26 @@ def reduce_mean(comm, x, w):
 _RATING_SCALES = [1, 0, -1]   # prediction scales of the three evaluation moments (model.py:395-401)
 
 
+def lockstep_batches(model, dataloader, comm):
+    """The batches of `dataloader`, in step with the other ranks when the item table is row-sharded (config["table_shard"]).
+    There every upload / forward contains collectives (exchange plan, row exchange, vocabulary-parallel heads), so a rank that
+    had one batch more or fewer than its peers would leave them waiting inside a collective; the reference's forward has none,
+    and its per-rank loaders may well differ in length (train.py:46-51: shards by file).  Before every batch the ranks add up
+    who still has one (one scalar all-reduce over the communicator) and ALL stop at the first iteration in which somebody has
+    run out; the longer loaders' tails are dropped.  Replicated table: the loader as it is."""
+    sharded = comm is not None and comm.world > 1 and bool(getattr(model, "config", {}).get("table_shard"))
+    if not sharded:
+        yield from dataloader
+        return
+    it = iter(dataloader)
+    while True:
+        batch = next(it, None)
+        ready = comm.all_reduce_sum([0.0 if batch is None else 1.0])[0]
+        if ready < comm.world - 0.5:
+            return
+        yield batch
+
+
 def evaluate_metrics(model, dataloader, comm=None):
     """train.py:207-235: eval forward (fresh random masks, model(d, True)), weight-averaged per task,
     rating -> quadratic-minimum MSE over prediction scales {1, 0, -1}."""
@@ -170,7 +190,7 @@ def evaluate_metrics(model, dataloader, comm=None):
     moments = np.zeros((len(tasks), len(_RATING_SCALES)))   # watch tasks use column 0 only
     mass = np.zeros(len(tasks))
     model.eval()
-    for batch in dataloader:
+    for batch in lockstep_batches(model, dataloader, comm):
         out = model(batch, True)
         w = np.asarray(model.last_weight_sums, np.float64)
         for i, (_, metric) in enumerate(tasks):
@@ -194,7 +214,7 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     model.set_loss_weights(task_weights, grad_accum_steps)
     optimizer.zero_grad(set_to_none=True)
     world = 1 if comm is None else comm.world
-    for step, data in enumerate(dataloader):
+    for step, data in enumerate(lockstep_batches(model, dataloader, comm)):
         if comm is not None and (step + 1) % grad_accum_steps == 0:
             comm.begin_grad_sync(model)        # last micro-step: finished buckets are reduced during the backward
         tloss = model(data, False)

@@ -6,6 +6,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -119,3 +120,57 @@ def test_bench_gpus2_without_gpus_fails_cleanly_on_every_rank():
     assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
     assert p.stdout.strip() == ""
     assert p.stderr.count("ranks need one each") == 2
+
+
+def test_rendezvous_rejects_oversized_and_foreign_handshakes_without_allocating(monkeypatch):
+    """rank 0 honoured two 32-bit length prefixes (up to 4 GiB each) before the token check, on every interface.  Now the
+    first frame of a connection is capped (4 KB header, no payload) before anything is read, the listener binds the rendezvous
+    address, and payload lengths are 64-bit.  A stranger that announces a 3 GiB frame, one that sends garbage and one with the
+    wrong token are dropped; the real rank 1 still joins, and a > 4 GiB-capable length field round-trips."""
+    import struct
+    import threading
+
+    from recommendersystem_amd import dist
+
+    port = _free_port()
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RSYS_RDZV_PORT=str(port), TORCHELASTIC_RUN_ID="hs").items():
+        monkeypatch.setenv(k, v)
+    groups = [None, None]; err = []
+
+    def rank(r):
+        try:
+            groups[r] = dist.HostGroup(r, 2, timeout=30)
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+    t0 = threading.Thread(target=rank, args=(0,)); t0.start()
+    deadline = time.time() + 10
+    while True:                                       # wait for the listener, then three strangers before the real rank
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1.0); break
+        except OSError:
+            assert time.time() < deadline; time.sleep(0.05)
+    s.sendall(struct.pack("!IQ", 3 << 30, 3 << 30)); time.sleep(0.1)
+    try:
+        assert s.recv(16) == b""                     # closed without a reply: nothing of the announced 6 GiB was awaited
+    except OSError:
+        pass
+    s.close()
+    s = socket.create_connection(("127.0.0.1", port), timeout=1.0); s.sendall(b"GET / HTTP/1.0\r\n\r\n"); s.close()
+    s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+    dist._send_frame(s, {"token": "someone-else", "rank": 1})
+    assert dist._recv_frame(s)[0] == {"ok": False, "raw": 0}
+    s.close()
+    t1 = threading.Thread(target=rank, args=(1,)); t1.start()
+    t0.join(40); t1.join(40)
+    assert not err, err
+    assert groups[0].listener.getsockname()[0] == "127.0.0.1"          # not 0.0.0.0
+    out = [None, None]
+    th = [threading.Thread(target=lambda r=r: out.__setitem__(r, groups[r].all_reduce([r + 1.0], "sum"))) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(20)
+    assert out == [[3.0], [3.0]]
+    assert struct.calcsize("!IQ") == 12 and struct.unpack("!IQ", struct.pack("!IQ", 7, 5 << 32))[1] == 5 << 32
+    for g in groups:
+        g.close()

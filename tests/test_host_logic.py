@@ -267,3 +267,67 @@ def test_bench_attention_density_counts_same_user_pairs():
            "vocab_sizes": {"0_matchedid": 5, "1_matchedid": 6}}
     dense, half = bench.flops_per_interaction(cfg, 4), bench.flops_per_interaction(cfg, 4, 0.5)
     assert dense - half == 0.5 * 56 * S * 8 * 2
+
+
+def test_sharded_table_ranks_stop_together_when_loaders_differ_in_length():
+    """Row-sharded table: every forward holds collectives, so a rank with one batch more than its peers would leave them inside a
+    collective for good.  train_epoch / evaluate_metrics draw their batches through `lockstep_batches`: three ranks as
+    threads with 2, 4 and 3 batches and a communicator stand-in whose all-reduce needs all three to arrive -- everybody takes
+    exactly two steps and nobody waits for a peer that has left."""
+    import threading
+
+    from recommendersystem_amd.train import evaluate_metrics, lockstep_batches
+
+    world = 3
+    barrier = threading.Barrier(world, timeout=20)
+    slots = [0.0] * world
+
+    class FakeComm:
+        def __init__(self, rank):
+            self.rank, self.world = rank, world
+
+        def all_reduce_sum(self, values):
+            assert len(values) in (1, 8)
+            slots[self.rank] = list(values)
+            barrier.wait()
+            tot = [sum(s[i] for s in slots) for i in range(len(values))]
+            barrier.wait()
+            return tot
+
+    class FakeModel:
+        def __init__(self, sharded):
+            self.config = {"table_shard": (0, world)} if sharded else {}
+            self.calls = 0
+            self.last_weight_sums = [1.0] * 4
+
+        def eval(self): pass
+        def train(self): pass
+
+        def __call__(self, batch, evaluate):
+            self.calls += 1
+            return [1.0, [1.0, 0.5, 1.0], 1.0, [1.0, 0.5, 1.0]]
+
+    lengths = [2, 4, 3]
+    taken = [None] * world; err = [None] * world
+
+    def rank(r):
+        try:
+            m = FakeModel(True)
+            taken[r] = [b for b in lockstep_batches(m, [f"b{r}.{i}" for i in range(lengths[r])], FakeComm(r))]
+            evaluate_metrics(m, list(range(lengths[r])), FakeComm(r))
+            taken[r] = (taken[r], m.calls)
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(30)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting inside a collective"
+    assert err == [None] * world, err
+    for r in range(world):
+        assert taken[r] == ([f"b{r}.0", f"b{r}.1"], 2), taken[r]
+    # replicated table: the loader is passed through untouched and no collective is issued
+    m = FakeModel(False)
+    assert list(lockstep_batches(m, [1, 2, 3], FakeComm(0))) == [1, 2, 3]
+    assert list(lockstep_batches(FakeModel(True), [1, 2, 3], None)) == [1, 2, 3]
