@@ -140,6 +140,7 @@ int32_t rsys_trunk_output_get(rsys_model* h, float* out, int64_t n) {
 //   "tokens.userid" | "tokens.token_mask_ids"   int32 [rows*2S]  interleaved per-token arrays (model.py:468-469)
 //   "embed.x0"     f32 [rows*2S*D]         interleaved input embeddings (even rows: gathered item rows)
 //   "table.fused"  f32 [(V+1)*D]           the fused item table the gather reads (row V = mask row)
+//   "host_syncs" int32 [2]: blocking host waits inside the last rsys_forward_backward {stream drains, event waits}
 //   "top.n" int32 [1] | "top.sel" int32 [top.cap] | "top.slot" int32 [rows*2S] | "top.cap" int32 [1]: compact top of the last training
 //                  pass (model.hpp sparse_top): number of selected tokens, the sorted tokens, token -> compact row (-1: not selected)
 int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes) {
@@ -162,6 +163,8 @@ int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes)
   else if (k == "tokens.token_mask_ids") { src = m->tm_t; n = 2 * N * 4; }
   else if (k == "embed.x0") { src = m->x0; n = 2 * N * m->D * 4; }
   else if (k == "table.fused") { src = m->F32; n = (int64_t)m->TR * m->D * 4; }
+  else if (k == "host_syncs") {   // blocking host waits inside the last rsys_forward_backward: {stream drains, waits on the early-counts event}
+    ARG_CHECK(bytes == 8, "host_syncs: two int32"); ((int32_t*)out)[0] = m->host_stream_syncs; ((int32_t*)out)[1] = m->host_event_waits; return RSYS_OK; }
   else if (k == "top.cap") { ARG_CHECK(bytes == 4, "top.cap: one int32"); *(int32_t*)out = m->top_is_sparse ? m->ctop_cap : 0; return RSYS_OK; }
   else if (k == "top.n" && m->top_is_sparse) { src = m->c_n; n = 4; }
   else if (k == "top.sel" && m->top_is_sparse) { src = m->c_sel; n = (int64_t)m->ctop_cap * 4; }

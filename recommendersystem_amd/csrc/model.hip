@@ -274,6 +274,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     DALLOC(m->logits, cap * m->ldl_loc * e); DALLOC(m->dEwC, cap * D * 4); m->dE = m->dEwC;
     DALLOC(m->EwAll, cap * D * e); DALLOC(m->EwC, cap * D * e);
     DALLOC(m->metaOwn, (KB * 4 + 4) * 4); DALLOC(m->metaAll, (int64_t)W * (KB * 4 + 4) * 4); DALLOC(m->metaC, cap * 4 * 4 + 4096);
+    DALLOC(m->metaAllT[0], (int64_t)W * (KB * 4 + 4) * 4); DALLOC(m->metaAllT[1], (int64_t)W * (KB * 4 + 4) * 4);
+    HIP_CHECK(hipHostMalloc((void**)&m->h_counts, 2 * 64 * sizeof(int), hipHostMallocDefault));
+    HIP_CHECK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
     DALLOC(m->vp_max, cap * 4); DALLOC(m->vp_lmax, cap * 4); DALLOC(m->vp_sums, 2 * cap * 4); DALLOC(m->vp_nlive, 64); DALLOC(m->vp_pre, 64 * 4);
     // exchange plan of the resident batch
     DALLOC(m->u_slot, N * 4); DALLOC(m->u_ids, (N + 1) * 4); DALLOC(m->u_tok, N * 4); DALLOC(m->u_plan, 64);
@@ -341,6 +344,8 @@ int model_destroy(Model* m) {
   hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_stage) hipHostFree(m->h_stage);
+  if (m->h_counts) hipHostFree(m->h_counts);
+  if (m->ev_counts) hipEventDestroy(m->ev_counts);
   if (m->det_slab) hipFree(m->det_slab);
   if (m->det_part) hipFree(m->det_part);
   if (m->det_tmp) hipFree(m->det_tmp);
@@ -666,6 +671,7 @@ struct DetScope {
 static int det_slab_for(Model* m, long long need, GemmParams& p) {
   if (need <= 0) return RSYS_OK;
   if (need > m->det_slab_floats) {
+    ++m->host_stream_syncs;
     HIP_CHECK(hipStreamSynchronize(m->stream));
     HIP_CHECK(hipStreamSynchronize(m->side));
     if (m->det_slab) HIP_CHECK(hipFree(m->det_slab));
@@ -677,11 +683,12 @@ static int det_slab_for(Model* m, long long need, GemmParams& p) {
   return RSYS_OK;
 }
 int model_set_deterministic(Model* m, int on) {
-  ARG_CHECK(!on || !m->sharded, "deterministic mode covers the replicated item table (the vocabulary-parallel heads still use float atomics)");
+  ARG_CHECK(!on || !m->sharded || m->cfg.sampled_negatives == 0,
+            "deterministic mode covers the full soft-max (replicated or row-sharded table); the sampled soft-max's target-class gradients use float atomics");
   HIP_CHECK(hipSetDevice(m->device));
   if (on && m->det_part == nullptr) {
     const long long KB = (long long)m->K * m->rows_max;
-    m->det_part_floats = std::max<long long>(std::max<long long>(2048LL * m->D, 512LL * (2 * m->D + 4)), std::max<long long>(KB, 4096)) + 1024;
+    m->det_part_floats = std::max<long long>(std::max<long long>(2048LL * m->D, 512LL * (2 * m->D + 4)), std::max<long long>(KB * m->sh_world, 4096)) + 1024;   // (sharded: one loss term per gathered row)
     HIP_CHECK(hipMalloc((void**)&m->det_part, (size_t)m->det_part_floats * 4));
     m->det_tmp_floats = m->det_part_floats / 32 + 4096;
     HIP_CHECK(hipMalloc((void**)&m->det_tmp, (size_t)m->det_tmp_floats * 4));
@@ -1040,6 +1047,41 @@ static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive,
   return RSYS_OK;
 }
 
+// ------------------------------------------------------------------ sizes of the sharded heads' collectives, ahead of the trunk
+// Row meta (target, label * weight, loss coefficient) of the selected positions depends on the masked batch only: per watch task
+// it is gathered over the ranks now, the live-row prefix (and the sampled soft-max's number of in-batch targets among this
+// rank's classes) is computed with the kernels the heads use later, and copied to pinned host memory behind one event.  Every
+// rank calls this at the same point (it contains collectives).
+template <typename T>
+static int sharded_counts_early(Model* m, bool train, const float tw[4]) {
+  const int D = m->D, rows = m->cur_rows, KB = m->K * rows, W = m->sh_world, KBmax = m->K * m->rows_max;
+  hipStream_t s = m->stream;
+  ARG_CHECK(W + 1 <= 48, "row-sharded table: at most 47 ranks");
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const int ti = 2 * t2, medium = t2;
+    int len, col0, lrow;
+    shard_medium_range(m, medium, &len, &col0, &lrow);
+    RC(launch_vp_meta(m->idx[ti], m->bd.m_label[ti], m->bd.m_weight[ti], m->bd.m_position[ti], m->stats + 2 * ti, m->npos + ti,
+                      train ? tw[ti] : 0.f, KB, KBmax, m->metaOwn, s));
+    RC(comm_all_gather(m->shard_comm, m->metaOwn, m->metaAllT[t2], ((size_t)KBmax * 4 + 4) * 4, s));
+    // (the row payload EwAll is not there yet: this pass is for the counts and the packed meta only)
+    RC(launch_vp_compact<T>(AT<T>(m->EwAll), m->metaAllT[t2], W, KBmax, D, AT<T>(m->EwC), m->metaC, m->vp_nlive, m->vp_pre, s));
+    const bool sampled = m->cfg.sampled_negatives > 0 && train;
+    const int ss_ns = sampled ? std::min(len, m->cfg.sampled_negatives) : 0;
+    const bool ss_targets = sampled && ss_ns > 0 && ss_ns < len;
+    int* h = m->h_counts + 64 * t2;
+    h[48] = 0;
+    if (ss_targets) {
+      RC(launch_ss_targets(m->metaC, m->vp_nlive, W * KBmax, len, col0, m->ss_bitmap, m->ss_cols + ss_ns, m->ss_tcount, s));
+      HIP_CHECK(hipMemcpyAsync(h + 48, m->ss_tcount, 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_CHECK(hipMemcpyAsync(h, m->vp_pre, (W + 1) * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_CHECK(hipEventRecord(m->ev_counts, s));
+  m->counts_pending = true;
+  return RSYS_OK;
+}
+
 // ------------------------------------------------------------------ watch head over a row-sharded table (cfg-4)
 // Vocabulary-parallel form of model.py:153-170 + 514-519: the selected rows of ALL ranks against this rank's rows of the
 // medium.  all-gather (rows, row meta) -> pack the live rows -> local logits -> all-reduce(max) -> all-reduce(sum-exp,
@@ -1055,22 +1097,23 @@ static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd
   T* Fm = AT<T>(m->FT) + (int64_t)lrow * D;
   float* st = m->stats + 2 * ti;
   int* np = m->npos + ti;
-  // every rank contributes a block of KBmax rows (ranks may hold batches of different row counts: the tail is dead rows)
-  RC(launch_vp_meta(m->idx[ti], m->bd.m_label[ti], m->bd.m_weight[ti], m->bd.m_position[ti], st, np, train ? tw : 0.f, KB, KBmax, m->metaOwn, s));
+  // every rank contributes a block of KBmax rows (ranks may hold batches of different row counts: the tail is dead rows); the
+  // rows' meta was gathered ahead of the trunk (sharded_counts_early)
+  (void)st; (void)np; (void)KB;
   RC(comm_all_gather(c, m->Ew, m->EwAll, (size_t)KBmax * D * m->esz, s));
-  RC(comm_all_gather(c, m->metaOwn, m->metaAll, ((size_t)KBmax * 4 + 4) * 4, s));
-  RC(launch_vp_compact<T>(AT<T>(m->EwAll), m->metaAll, W, KBmax, D, AT<T>(m->EwC), m->metaC, m->vp_nlive, m->vp_pre, s));
+  RC(launch_vp_compact<T>(AT<T>(m->EwAll), m->metaAllT[medium], W, KBmax, D, AT<T>(m->EwC), m->metaC, m->vp_nlive, m->vp_pre, s));
   // sampled soft-max (training passes only; an evaluation reports the exact loss): list the in-batch targets among this rank's
   // classes behind the slots of the sampled ones -- unless every class is sampled anyway
   const bool sampled = m->cfg.sampled_negatives > 0 && train;
   const int ss_ns = sampled ? std::min(len, m->cfg.sampled_negatives) : 0;
   const bool ss_targets = sampled && ss_ns > 0 && ss_ns < len;
   if (ss_targets) RC(launch_ss_targets(m->metaC, m->vp_nlive, W * KBmax, len, col0, m->ss_bitmap, m->ss_cols + ss_ns, m->ss_tcount, s));
-  std::vector<int> pre(W + 1);
-  int n_t = 0;
-  HIP_CHECK(hipMemcpyAsync(pre.data(), m->vp_pre, (W + 1) * 4, hipMemcpyDeviceToHost, s));
-  if (ss_targets) HIP_CHECK(hipMemcpyAsync(&n_t, m->ss_tcount, 4, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));   // (the one host sync of the step: the sizes of the collectives below)
+  // the sizes of the collectives below were copied to the host before the trunk forward: the event is long past by now, so this
+  // wait does not drain the stream (one wait per step, the second task finds it done)
+  if (m->counts_pending) { HIP_CHECK(hipEventSynchronize(m->ev_counts)); m->counts_pending = false; ++m->host_event_waits; }
+  const int* hc = m->h_counts + 64 * medium;
+  std::vector<int> pre(hc, hc + W + 1);
+  const int n_t = ss_targets ? hc[48] : 0;
   const int nlive = pre[W], cap = W * KBmax, own0 = pre[m->sh_rank], nown = pre[m->sh_rank + 1] - own0;
   if (nlive == 0) return RSYS_OK;
   const int npad = std::min(cap, (nlive + 255) & ~255);
@@ -1291,6 +1334,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
       if (full) add(o.dht, D, a.O, D, m->G + m->lo[l].wo, D, D, D);                    // dWo  += dh^T . O
     }
     GemmGroupPlan* pl = nullptr;
+    ++m->host_stream_syncs;   // (first use of this layer range / batch size only)
     HIP_CHECK(hipStreamSynchronize(m->stream));
     RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl));
     it = m->dw_plans.emplace(key, pl).first;
@@ -1597,10 +1641,12 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   m->drop_active = m->cfg.finetune && !evaluate && m->cfg.lora_dropout > 0.f;   // nn.Dropout is active in train() mode only
   m->drop_seed = seed ^ 0xD409ull; m->drop_step = step;
   m->top_is_sparse = m->sparse_top && !evaluate;
-  RC(select_positions_all(m));
-  RC(forward_trunk<T>(m));
+  m->host_stream_syncs = 0; m->host_event_waits = 0;
   float tw[4];
   for (int i = 0; i < 4; ++i) tw[i] = task_w ? task_w[i] * grad_scale : 0.f;
+  RC(select_positions_all(m));
+  if (m->sharded) RC(sharded_counts_early<T>(m, !evaluate, tw));
+  RC(forward_trunk<T>(m));
   RC(heads<T>(m, evaluate, tw));
   if (!evaluate) RC(backward_trunk<T>(m));
   return RSYS_OK;

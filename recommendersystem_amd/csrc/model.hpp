@@ -100,6 +100,13 @@ struct Model {
   // vocabulary-parallel head workspaces: gathered selected rows of all ranks, packed live rows, row statistics
   void *EwAll = nullptr, *EwC = nullptr; float *metaOwn = nullptr, *metaAll = nullptr, *metaC = nullptr, *vp_max = nullptr, *vp_lmax = nullptr, *vp_sums = nullptr;
   int *vp_nlive = nullptr, *vp_pre = nullptr; float* dEwC = nullptr;
+  // The sizes of the vocabulary-parallel heads' collectives (live rows per rank, in-batch targets of the sampled soft-max) depend on the
+  // masked batch only, so they are computed and copied to pinned host memory BEFORE the trunk forward (sharded_counts_early); the
+  // heads wait for an event that is a whole trunk forward old instead of draining the stream once per task.
+  float* metaAllT[2] = {nullptr, nullptr};   // the gathered row meta of the two watch tasks (kept from the early pass)
+  int* h_counts = nullptr;                   // pinned: [2][64] = per watch task pre[0 .. W] and, at [48], the number of in-batch targets
+  hipEvent_t ev_counts = nullptr; bool counts_pending = false;
+  int host_stream_syncs = 0, host_event_waits = 0;   // blocking host waits inside the last rsys_forward_backward (tests)
   int64_t ldl_loc = 0; float* sumsq_E = nullptr;
   // sampled softmax: sampled local classes, their rows of F, the rows' gradients, target logits and their gradients
   int* ss_cols = nullptr; void* ss_F = nullptr; float *ss_dF = nullptr, *ss_tl = nullptr, *ss_dt = nullptr;

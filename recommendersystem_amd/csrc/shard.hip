@@ -237,7 +237,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void vp_finish_kernel(T* logits, long long ldl, int Vloc, int col0, const float* __restrict__ metaC,
                                                         const float* __restrict__ gmax, const float* __restrict__ sums, int cap,
                                                         const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
-                                                        float* loss_out) {
+                                                        float* loss_out, float* part) {
   constexpr int E = 16 / sizeof(T);
   const int row = blockIdx.x, t = threadIdx.x;
   if (row >= ((*nlive + 255) & ~255)) return;
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256) void vp_finish_kernel(T* logits, long long ldl
   const float lse = gmax[row] + logf(sums[row]);
   const float lw = metaC[4LL * row + 1], coef = metaC[4LL * row + 2];
   const int tgt = __float_as_int(metaC[4LL * row]) - col0;
-  if (t == 0 && row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) atomicAdd(loss_out, (lse - sums[cap + row]) * lw);
+  if (t == 0 && row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) {
+    if (part != nullptr) part[row] = (lse - sums[cap + row]) * lw;   // deterministic mode: the rows' terms are added in row order afterwards
+    else atomicAdd(loss_out, (lse - sums[cap + row]) * lw);
+  }
   for (int c = t; c < nchunks; c += 256) {
     uint4 raw = ((const uint4*)lr)[c];
     T* e = (T*)&raw;
@@ -276,8 +279,12 @@ int launch_vp_rebase(const float* lmax, const float* gmax, float* sums, int n, h
 template <typename T>
 int launch_vp_finish(T* logits, long long ldl, int Vloc, int col0, const float* metaC, const float* gmax, const float* sums, int cap,
                      const int* nlive, const int* pre, int rank, float* loss_out, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((vp_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, gmax, sums, cap, nlive, pre, rank, loss_out);
+  float* part = g_det.part != nullptr && (long long)grid_rows <= g_det.cap ? g_det.part : nullptr;   // deterministic mode (kernels.hpp DetScratch)
+  if (g_det.part != nullptr && part == nullptr) { set_error("vocabulary-parallel CE: deterministic scratch too small"); return RSYS_ERR_STATE; }
+  if (part != nullptr) HIP_CHECK(hipMemsetAsync(part, 0, (size_t)grid_rows * 4, s));   // (rows without a term write nothing)
+  hipLaunchKernelGGL((vp_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, Vloc, col0, metaC, gmax, sums, cap, nlive, pre, rank, loss_out, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, grid_rows, 1, 1, loss_out, s);
   return RSYS_OK;
 }
 // ------------------------------------------------------------------ sampled softmax (cfg-4 option; no reference counterpart)

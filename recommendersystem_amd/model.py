@@ -334,6 +334,8 @@ class RecommenderModel:
             out = np.empty(4, np.int32)
         elif key in ("top.n", "top.cap"):
             out = np.empty(1, np.int32)
+        elif key == "host_syncs":
+            out = np.empty(2, np.int32)
         elif key == "top.sel":
             out = np.empty(int(self.debug_get("top.cap", rows)[0]), np.int32)
         elif key == "top.slot":

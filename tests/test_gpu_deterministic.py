@@ -185,3 +185,64 @@ def test_data_parallel_step_on_two_concurrent_ranks_is_bitwise_reproducible():
             assert np.array_equal(a[r][1][n], b[r][1][n]), (r, n)
             assert np.array_equal(a[r][2][n], b[r][2][n]), (r, n)
             assert np.array_equal(a[r][2][n], a[0][2][n]), (r, n)      # and the ranks agree with each other
+
+
+def test_row_sharded_table_is_bitwise_reproducible_too():
+    """Deterministic mode on the row-sharded table (full soft-max): the vocabulary-parallel heads sum their loss terms in row order,
+    their split-K gradient goes through ordered slabs, the row exchange adds requester by requester and the in-process group
+    reduces in rank order -- two runs of two optimizer steps on two concurrent ranks end with the same bits on every rank.  The
+    sampled soft-max (float atomics on shared target rows) is still refused."""
+    import threading
+
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+    world, rows = 2, 3
+    P = synth.make_params(cfg, 3, "test")
+    E, M = "item_embedding.matchedid_embedding.embedding.weight", "item_embedding.metadata_embedding.embedding.weight"
+    batches = [[synth.make_batch(cfg, rows, 40 + 10 * r + i) for i in range(2)] for r in range(world)]
+    masks = [[synth.make_masks(cfg, rows, 50 + 10 * r + i) for i in range(2)] for r in range(world)]
+    names = synth.trainable_names(cfg)
+
+    def run():
+        group = rdist.LocalGroup(world)
+        out = [None] * world; err = [None] * world
+
+        def rank(r):
+            try:
+                comm = rdist.LocalComm(group, r)
+                c = dict(cfg, deterministic=True); c["table_shard"] = (r, world)
+                m = ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+                m.set_shard_comm(comm)
+                lo, hi = m.table_rows()
+                sd = dict(P); sd[E] = P[E][lo:hi]; sd[M] = P[M][lo:hi]
+                m.load_state_dict(sd)
+                opt = ra.create_optimizer(m, dict(cfg, learning_rate=1e-2))
+                m.set_loss_weights(TASK_W, 1)
+                res = []
+                for d, mk in zip(batches[r], masks[r]):
+                    losses = m(d, False, masks=mk)
+                    comm.all_reduce_grads(m)
+                    res.append((np.array(losses, np.float32), {n: m.grad(n).copy() for n in names}))
+                    opt.step(clip_max_norm=1.0, grad_div=float(world))
+                out[r] = (res, {n: m.get_parameter(n).copy() for n in names})
+                m.close(); comm.close()
+            except BaseException as e:   # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        group.close()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+    a, b = run(), run()
+    for r in range(world):
+        assert _bitwise(a[r], b[r]), r
+    with pytest.raises(ra.RsysError):
+        c = dict(cfg, deterministic=True); c["table_shard"] = (0, 1); c["sampled_softmax"] = 8
+        ra.RecommenderModel(c, dtype="bf16", max_rows=rows)

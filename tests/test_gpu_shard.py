@@ -430,3 +430,40 @@ def test_sharded_checkpoint_is_the_reference_layout_and_reshards(tmp_path):
         assert epoch == 0 and np.array_equal(m.get_parameter(E_NAME), z["model/" + E_NAME][lo:hi])
         assert np.array_equal(opt.state_dict()["state"][E_NAME]["exp_avg_sq"], z["optimizer/exp_avg_sq/" + E_NAME][lo:hi])
         m.close()
+
+
+def test_sharded_step_enqueues_without_draining_the_stream():
+    """the vocabulary-parallel heads used to drain the stream once per watch task to learn the sizes of their
+    collectives.  Those sizes depend on the masked batch only: they are gathered and copied to the host BEFORE the trunk forward,
+    and the heads wait for that (by then long signalled) event once.  Counted inside the C ABI: from the second step on a
+    training pass of a sharded model takes 0 stream drains and 1 event wait, also with the sampled soft-max."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+    world, rows = 2, 3
+    P = synth.make_params(cfg, 23, "test")
+    batches = [synth.make_batch(cfg, rows, 24 + 10 * r) for r in range(world)]
+    for sampled in (0, 16):
+        group = rdist.LocalGroup(world)
+
+        def rank_fn(r):
+            comm = rdist.LocalComm(group, r)
+            c = dict(cfg); c["table_shard"] = (r, world)
+            if sampled:
+                c["sampled_softmax"] = sampled
+            model = ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+            model.set_shard_comm(comm)
+            _load(model, P)
+            model.set_loss_weights(TASK_W, 1)
+            counts = []
+            for step in range(3):
+                losses = model(batches[r], False)
+                counts.append(model.debug_get("host_syncs", rows).tolist())
+                assert np.isfinite(losses).all()
+            model.close(); comm.close()
+            return counts
+        res = _run_ranks(world, rank_fn)
+        group.close()
+        for counts in res:
+            assert counts[1] == [0, 1] and counts[2] == [0, 1], (sampled, counts)
