@@ -37,7 +37,7 @@ KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent,
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
                 "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r2c_pmc_traffic.json"
+TRAFFIC_FILE = "r3a_pmc_traffic.json"
 
 
 def traffic_of(db, variant):

@@ -1514,7 +1514,10 @@ static int backward_trunk(Model* m) {
     if (m->grad_bucket_hook && !ft) {
       // weight gradients of layers l .. bucket_top are final (the four tensors of a layer are contiguous, layers ascending)
       const int64_t lo = m->lo[l].wqkv, hi = m->lo[bucket_top].w2 + pad8((int64_t)D * Ip);
-      if (l == 0 || (hi - lo) * 4 >= (25ll << 20)) {
+      // DDP's 25 MB buckets; with the grouped weight gradients a bucket is also a launch, and a grouped launch wants several
+      // layers' products to fill the chip: two buckets (upper and lower half of the trunk) as long as each has its 25 MB
+      const bool boundary = defer ? (l == m->L / 2 && (hi - lo) * 4 >= (25ll << 20)) : (hi - lo) * 4 >= (25ll << 20);
+      if (l == 0 || boundary) {
         if (defer) RC(grouped_weight_grads<T>(m, l, bucket_top));   // the bucket's products, then its all-reduce
         RC(join_all(m));
         RC(m->grad_bucket_hook(lo, hi));
@@ -1522,7 +1525,8 @@ static int backward_trunk(Model* m) {
         // From here on all-reduce kernels share the CUs with the backward.  A persistent grid (one workgroup pinned per
         // CU, a fixed share of the tiles each) would stall on every CU a communication kernel holds, so the 256x256
         // GEMMs go back to one workgroup per tile until the reduction is over: the tiles flow to whatever CUs are free.
-        m->gemm_flags |= 2;
+        static const bool keep_persistent = getenv("RSYS_DEBUG_KEEP_PERSISTENT") != nullptr;   // (measurement of what the switch costs)
+        if (!keep_persistent) m->gemm_flags |= 2;
       }
     }
   }
