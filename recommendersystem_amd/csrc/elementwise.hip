@@ -761,6 +761,64 @@ int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float
   return RSYS_OK;
 }
 
+// dstT[c][r] (bf16, row stride ldt) = src[r][c] (f32) and colsum[c] += sum_r src[r][c], one pass over src: the K-contiguous operand
+// copy dF^T of the metadata-projection gradient dWp = dF^T Meta (model.hip finalize) straight from the fp32 table gradient -- it used
+// to be a row-major bf16 copy (cast_colsum) plus a 2 x 205 MB transpose of that copy.  A workgroup owns `rows_per_block` rows
+// (a multiple of 64) and walks them in 64 x 64 tiles through LDS; rows in [rows, rows rounded up to 64) are written as zeros
+// (the GEMM's K padding).  Column sums: registers -> LDS -> one partial per column and workgroup.
+__global__ __launch_bounds__(256) void cast_transpose_colsum_kernel(const float* __restrict__ src, bf16* __restrict__ dstT, long long rows, int D,
+                                                                    long long ldt, float* colsum, int rows_per_block, float* part) {
+  __shared__ unsigned short tile[64][72];          // [column][row] of the current 64 x 64 tile (row pitch 144 B: 16-byte aligned reads)
+  __shared__ float red[16][64];
+  const int t = threadIdx.x;
+  const int lr = t >> 4, c4 = (t & 15) * 4;         // loads: row lr + 16 i, columns c4 .. c4 + 3 of the tile
+  const int oc = t >> 2, or8 = (t & 3) * 16;        // stores: tile column oc, rows or8 .. or8 + 15
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long rend = min((rows + 63) & ~63LL, r0 + rows_per_block);
+  for (int ct = 0; ct < D / 64; ++ct) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (long long rb = r0; rb < rend; rb += 64) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long r = rb + lr + 16 * i;
+        const float4 v = r < rows ? *(const float4*)(src + r * D + ct * 64 + c4) : make_float4(0, 0, 0, 0);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const bf16 b0 = (bf16)v.x, b1 = (bf16)v.y, b2 = (bf16)v.z, b3 = (bf16)v.w;
+        tile[c4 + 0][lr + 16 * i] = *(const unsigned short*)&b0; tile[c4 + 1][lr + 16 * i] = *(const unsigned short*)&b1;
+        tile[c4 + 2][lr + 16 * i] = *(const unsigned short*)&b2; tile[c4 + 3][lr + 16 * i] = *(const unsigned short*)&b3;
+      }
+      __syncthreads();
+      {
+        const uint4 q0 = *(const uint4*)&tile[oc][or8], q1 = *(const uint4*)&tile[oc][or8 + 8];
+        uint4* d = (uint4*)(dstT + (long long)(ct * 64 + oc) * ldt + rb + or8);
+        d[0] = q0; d[1] = q1;
+      }
+      __syncthreads();
+    }
+    *(float4*)&red[lr][c4] = acc;
+    __syncthreads();
+    if (t < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += red[k][t];
+      if (part != nullptr) part[(long long)blockIdx.x * D + ct * 64 + t] = v;
+      else if (v != 0.f) atomicAdd(&colsum[ct * 64 + t], v);
+    }
+    __syncthreads();
+  }
+}
+int launch_cast_transpose_colsum(const float* src, bf16* dstT, long long rows, int D, long long ldt, float* colsum, hipStream_t s) {
+  ARG_CHECK(D % 64 == 0 && ldt % 8 == 0 && ldt >= ((rows + 63) & ~63LL), "cast_transpose_colsum: D % 64, ldt % 8, ldt >= rows rounded up to 64");
+  const long long chunks = (rows + 63) / 64;
+  const int cpb = (int)std::max<long long>(1, (chunks + 2047) / 2048);
+  const int grid = (int)((chunks + cpb - 1) / cpb);
+  float* part = det_part((long long)grid * D);
+  hipLaunchKernelGGL(cast_transpose_colsum_kernel, dim3(grid), dim3(256), 0, s, src, dstT, rows, D, ldt, colsum, cpb * 64, part);
+  HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, grid, D, D, colsum, s);
+  return RSYS_OK;
+}
+
 // --------------------------------------------------------------------- embedding scatter-add (K16)
 // gE[id'] += gx0[2n]; one wave per interaction, 256 contiguous bytes per atomic wave-instruction
 // (MI355X_MICROARCH.md "Global float atomics": full rate for this shape).

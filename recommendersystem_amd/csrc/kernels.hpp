@@ -95,6 +95,8 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
 // dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 1024)
 int launch_cast_colsum(const float* src, bf16* dst, long long rows, int D, float* colsum, hipStream_t s);
+// dstT[c][r] = bf16(src[r][c]) (row stride ldt, rows up to the next multiple of 64 zero-filled) and colsum += column sums, one pass (D % 64 == 0)
+int launch_cast_transpose_colsum(const float* src, bf16* dstT, long long rows, int D, long long ldt, float* colsum, hipStream_t s);
 
 int launch_embedding_scatter_add(const float* gx0, const BatchDev& b, int V, int D, float* gE, hipStream_t s);   // float atomics (A/B reference only)
 

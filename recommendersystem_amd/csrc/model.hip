@@ -1587,7 +1587,10 @@ static int backward_trunk(Model* m) {
 template <typename T>
 static int finalize_grads_t(Model* m, int stage) {
   tic(m, stage == 2 ? "phase_table_bwd_gemm" : "phase_table_bwd");
-  if (stage != 2) {
+  const bool direct = m->bf16_mode && m->D % 64 == 0;   // fp32 dF -> bf16 dF^T + bias gradient in one pass
+  if (stage != 2 && direct) {
+    RC(launch_cast_transpose_colsum(m->G + m->o_E, (bf16*)m->dFT, m->TR, m->D, m->Vp, m->G + m->o_bp, m->stream));
+  } else if (stage != 2) {
     m->table_dirty = true;   // (FT is borrowed below)
     const bool fused = m->bf16_mode && m->D <= 1024 && 1024 % (m->D >> 2) == 0;
     if (fused) {   // operand copy of dF in the fused-table buffer (dead until the next forward rebuilds it) + bias gradient, one pass
