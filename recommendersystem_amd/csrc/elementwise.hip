@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
     }
   }
   __syncthreads();
+  if (wave0 - w >= n_live) return;   // (a compact row set: workgroups without a live row have nothing to add -- uniform: wave0 - w = first row of the workgroup)
   for (int c = threadIdx.x; c < D; c += 256) atomicAdd(&dscale[c], sds[c]);
 }
 
