@@ -193,6 +193,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   for (int k = 0; k < 4; ++k) HIP_CHECK(hipEventCreateWithFlags(&m->ev_dw[k], hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&m->ev_sel, hipEventDisableTiming));
   build_layout(m);
   const int64_t D = m->D, N = (int64_t)m->rows_max * m->S, NT = 2 * N, KB = (int64_t)m->K * m->rows_max;
   const size_t e = m->esz;
@@ -351,7 +352,7 @@ int model_destroy(Model* m) {
   if (m->det_tmp) hipFree(m->det_tmp);
   if (m->req_ids) hipFree(m->req_ids);
   if (m->rows_xchg) hipFree(m->rows_xchg);
-  hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); hipStreamDestroy(m->side);
+  hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); if (m->ev_sel) hipEventDestroy(m->ev_sel); hipStreamDestroy(m->side);
   for (int k = 0; k < 4; ++k) if (m->ev_dw[k]) hipEventDestroy(m->ev_dw[k]);
   for (auto& kv : m->dw_plans) gemm8p_group_plan_destroy(kv.second);
   for (auto e : m->timer.pool) hipEventDestroy(e);
@@ -806,6 +807,8 @@ static SmallParams small_params(Model* m) {
   return sp;
 }
 
+static int select_join(Model* m);   // (position selection runs on the side stream: defined with select_positions_all below)
+
 // token-local tail of layer l (model.py:300-309): h = x + O Wo^T ; out = h + W2 (silu(W1 hn) * W3 hn), hn = RMSNorm(h)
 template <typename T>
 static int layer_tail_dense(Model* m, int l) {
@@ -845,6 +848,7 @@ static int top_tail_compact(Model* m) {
   hipStream_t s = m->stream;
   Model::LayerAct& a = m->la[l];
   const int* n = m->c_n;
+  RC(select_join(m));
   tic(m, "phase_top_compact_fwd");
   RC(launch_gather_rows_sel<T>(AT<T>(a.O), D, m->c_sel, n, cap, AT<T>(m->c_O), D, s));
   RC(launch_gather_rows_sel<float>(a.x, D, m->c_sel, n, cap, m->c_x, D, s));
@@ -1164,6 +1168,7 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   const bool train = !evaluate;
   tic(m, "phase_heads");
   const bool ctop = m->top_is_sparse;   // trunk output and its gradient live in the compact buffers (rows = selected tokens)
+  RC(select_join(m));
   HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
   if (train && !ctop) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
   if (train && ctop) HIP_CHECK(hipMemsetAsync(m->c_gy, 0, (size_t)m->ctop_cap * D * 4, s));
@@ -1244,12 +1249,25 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
 
 // position selection of the four (medium, metric) tasks in one launch (model.py:501,509): depends on the masked batch only, so it
 // runs before the trunk; with the compact top also the union of the live positions
+// Both are one-workgroup kernels (~40 us each) that nothing needs before the last layer's tail; running them on the side stream
+// beside the fused-table GEMM was measured and is NOT the default (see below; select_join is the matching wait).
 static int select_positions_all(Model* m) {
   const int N = m->cur_rows * m->S, KB = m->K * m->cur_rows;
   const float* ws[4]; int* is[4]; float* sts[4]; int* nps[4];
   for (int ti = 0; ti < 4; ++ti) { ws[ti] = m->bd.m_weight[ti]; is[ti] = m->idx[ti]; sts[ti] = m->stats + 2 * ti; nps[ti] = m->npos + ti; }
-  RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, m->stream));
-  if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_slot, m->c_sel, m->c_n, m->stream));
+  // (RSYS_SELECT_ASIDE=1: measured on one box, alternating, 30 steps each: 24.27 / 24.41 / 24.36 ms in line against 24.44 / 24.61 / 24.38 ms
+  // aside -- a 1024-thread workgroup landing on a CU stalls that CU's share of the persistent GEMM's tiles: off by default)
+  static const bool aside_on = getenv("RSYS_SELECT_ASIDE") && atoi(getenv("RSYS_SELECT_ASIDE")) == 1;
+  const bool aside = aside_on && !m->sharded && !(m->timer.enabled && m->timer.serialize);   // (sharded: the early counts need them at once)
+  hipStream_t s = aside ? m->side : m->stream;
+  if (aside) { HIP_CHECK(hipEventRecord(m->ev_fork, m->stream)); HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
+  RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
+  if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_slot, m->c_sel, m->c_n, s));
+  if (aside) { HIP_CHECK(hipEventRecord(m->ev_sel, m->side)); m->sel_pending = true; }
+  return RSYS_OK;
+}
+static int select_join(Model* m) {
+  if (m->sel_pending) { HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_sel, 0)); m->sel_pending = false; }
   return RSYS_OK;
 }
 

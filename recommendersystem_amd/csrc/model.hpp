@@ -48,6 +48,7 @@ struct Model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  hipEvent_t ev_sel = nullptr; bool sel_pending = false;   // position selection + token union of the pass, running on the side stream
   // deferred joins (RSYS_SIDE_STREAM=2): one event per weight-gradient product of a layer (W2, W13, Wo, Wqkv), recorded on the
   // side stream behind it; the main stream waits for a product only where the buffer it reads is overwritten next
   hipEvent_t ev_dw[4] = {nullptr, nullptr, nullptr, nullptr};
