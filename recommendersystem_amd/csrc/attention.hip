@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
   const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
+  if (p.q_active != nullptr && qt >= p.q_active[b]) return;   // nobody reads this query tile's output (uniform: whole workgroup)
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
   const float c2 = rsqrtf((float)HD) * LOG2E;        // scores are handled in log2 units
@@ -517,7 +518,9 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Qs + i * C::TILE, t); zero_pad_cols<T, HD>(dOs + i * C::TILE, t); }
-  const unsigned int bits = p.kmap[b * nt + kvt], fullbits = p.kmap_full[b * nt + kvt];
+  const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
+  const unsigned int act = qa >= 32 ? ~0u : ((1u << qa) - 1u);   // query tiles whose dO can be non-zero
+  const unsigned int bits = p.kmap[b * nt + kvt] & act, fullbits = p.kmap_full[b * nt + kvt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.kmap16[(b * nt + kvt) * 4 + w]);   // q tiles that may see this wave's 16 keys
 
   TileRegs<T, HD> rq, rdo;
@@ -611,6 +614,14 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
+  if (p.q_active != nullptr && qt >= p.q_active[b]) {   // dO of these queries is identically zero: so is dQ (uniform: whole workgroup)
+    constexpr int CPRZ = HD / C::E;
+    for (int c = t; c < 64 * CPRZ; c += 256) {
+      const int row = c / CPRZ, ch = c % CPRZ;
+      if (qt * 64 + row < p.T) *(uint4*)((T*)p.dq + (tok0 + qt * 64 + row) * p.ldg + h * HD + ch * C::E) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
   const int q = qt * 64 + w * 16 + fr;
   const bool qv = q < p.T;

@@ -58,6 +58,43 @@ __global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT
   if (t == 0) *nsel = total;
 }
 
+// Token order of the last layer under the compact top: inside every batch row the selected tokens come first (in their original
+// order), then the others.  Attention does not care about the order of the tokens it is given (positions enter through RoPE,
+// applied per token from pos_p; the mask compares per-token keys), so the last layer runs on this order and its attention
+// kernels only visit the leading query tiles (q_active).  One workgroup per batch row; T <= 2048 tokens.
+//   perm[b T + p]  = original (global) token at permuted place p        uid_p / tm_p / pos_p: that token's ids and position
+//   slot_p[b T + p] = compact row of that token or -1                    sel_p[r] = permuted place (global) of compact row r
+__global__ __launch_bounds__(1024) void selected_first_kernel(const int* __restrict__ slot, const int* __restrict__ uid, const int* __restrict__ tm,
+                                                              const int* __restrict__ rope_pos, int T, int* __restrict__ perm, int* __restrict__ uid_p,
+                                                              int* __restrict__ tm_p, int* __restrict__ pos_p, int* __restrict__ slot_p,
+                                                              int* __restrict__ sel_p, int* __restrict__ q_active) {
+  __shared__ int wave_tot[16];
+  const int b = blockIdx.x, t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const long long base = (long long)b * T;
+  const int per = (T + 1023) / 1024;               // 1 or 2 consecutive tokens per thread
+  const int j0 = t * per, j1 = min(T, j0 + per);
+  int sl[2] = {-1, -1}, cnt = 0;
+  for (int j = j0; j < j1; ++j) { sl[j - j0] = slot[base + j]; cnt += sl[j - j0] >= 0; }
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+  if (l == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int before = 0, n_sel = 0;
+  for (int k = 0; k < 16; ++k) { int v = wave_tot[k]; if (k < wv) before += v; n_sel += v; }
+  int rank = before + inc - cnt;                   // selected tokens of this row before j0
+  for (int j = j0; j < j1; ++j) {
+    const int s = sl[j - j0];
+    const int p = s >= 0 ? rank : n_sel + (j - rank);
+    perm[base + p] = (int)(base + j);
+    uid_p[base + p] = uid[base + j]; tm_p[base + p] = tm[base + j];
+    pos_p[base + p] = rope_pos != nullptr ? rope_pos[base + j] : j;
+    slot_p[base + p] = s;
+    if (s >= 0) { sel_p[s] = (int)(base + p); ++rank; }
+  }
+  if (t == 0) q_active[b] = (n_sel + 63) >> 6;
+}
+
 // rows [0, n) <- src rows sel[r]; rows [n, pad256(n)) <- 0.  One wave per row.
 template <typename T>
 __global__ void gather_rows_sel_kernel(const T* __restrict__ src, long long ld, const int* __restrict__ sel, const int* __restrict__ n_dev, int cap,
@@ -83,6 +120,17 @@ __global__ void scatter_rows_sel_kernel(const T* __restrict__ src, const int* __
   constexpr int E = 16 / sizeof(T);
   const uint4* s4 = (const uint4*)(src + (long long)row * D);
   uint4* d4 = (uint4*)(dst + (long long)sel[row] * ld);
+  for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+}
+
+// dst rows map[r] <- src rows r, r < n (host count)
+template <typename T>
+__global__ void scatter_rows_map_kernel(const T* __restrict__ src, const int* __restrict__ map, int n, T* dst, long long ld, int D) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (row >= n) return;
+  constexpr int E = 16 / sizeof(T);
+  const uint4* s4 = (const uint4*)(src + (long long)row * D);
+  uint4* d4 = (uint4*)(dst + (long long)map[row] * ld);
   for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
 }
 
@@ -131,6 +179,14 @@ int launch_token_union(const int* const* idx, const int* const* npos, int ntask,
   return RSYS_OK;
 }
 
+int launch_selected_first(const int* slot, const int* uid, const int* tm, const int* rope_pos, int B, int T, int* perm, int* uid_p, int* tm_p,
+                          int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s) {
+  ARG_CHECK(T >= 1 && T <= 2048, "selected-first order: at most 2048 tokens per row");
+  hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, slot, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 template <typename T>
 int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s) {
   ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "gather_rows_sel: rows must be 16-byte multiples");
@@ -150,6 +206,16 @@ int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int 
 }
 template int launch_scatter_rows_sel<bf16>(const bf16*, const int*, const int*, int, bf16*, long long, int, hipStream_t);
 template int launch_scatter_rows_sel<float>(const float*, const int*, const int*, int, float*, long long, int, hipStream_t);
+
+template <typename T>
+int launch_scatter_rows_map(const T* src, const int* map, int n, T* dst, long long ld, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "scatter_rows_map: rows must be 16-byte multiples");
+  hipLaunchKernelGGL((scatter_rows_map_kernel<T>), dim3((n + 3) / 4), dim3(256), 0, s, src, map, n, dst, ld, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_scatter_rows_map<bf16>(const bf16*, const int*, int, bf16*, long long, int, hipStream_t);
+template int launch_scatter_rows_map<float>(const float*, const int*, int, float*, long long, int, hipStream_t);
 
 template <typename T>
 int launch_gather_rows_slot(const T* compact, const int* slot, const int* idx, int parity, T* dst, int n, int D, hipStream_t s) {

@@ -189,7 +189,7 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* src) {
 
 template <typename T, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
-                                                          long long rows, int D, const int* __restrict__ rows_dev) {
+                                                          long long rows, int D, const int* __restrict__ rows_dev, const int* __restrict__ in_rows) {
   const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int l = threadIdx.x & 63;
   if (rows_dev != nullptr) {   // compact row set (compact.hip): rows [0, n) are live, rows [n, n rounded up to 256) are written as zeros
@@ -203,12 +203,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
   }
   if (row >= rows) return;
+  const long long xrow = in_rows != nullptr ? (long long)in_rows[row] : row;
   float4 v[NJ];
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + l) * 4;
-    v[j] = (EXACT || c < D) ? *(const float4*)(x + row * D + c) : make_float4(0, 0, 0, 0);
+    v[j] = (EXACT || c < D) ? *(const float4*)(x + xrow * D + c) : make_float4(0, 0, 0, 0);
     ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
   }
   ss = wave_sum(ss);
@@ -225,10 +226,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 }
 
 template <typename T>
-int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev) {
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev, const int* in_rows) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
   const dim3 grid(div_up(rows, 4)), block(256);
-#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev)
+#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev, in_rows)
   if (D == 256) RSYS_NORM_FWD(1, true);
   else if (D == 512) RSYS_NORM_FWD(2, true);
   else if (D == 1024) RSYS_NORM_FWD(4, true);
@@ -241,8 +242,8 @@ int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, lo
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t, const int*);
-template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*);
+template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*);
+template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*, const int*);
 
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
 template <typename TG, typename TO, int NJ, bool EXACT>
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
                                                           float* part, long long rows, int D, const int* __restrict__ rows_dev,
-                                                          const int* __restrict__ resid_slot) {
+                                                          const int* __restrict__ resid_slot, const int* __restrict__ io_rows) {
   extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (4 * D in deterministic mode: `part` set)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
     const float r = rstd[row];
     // residual gradient: dense rows, or (resid_slot) the compact row resid_slot[row] of `resid`, zero where that is -1
     const long long rrow = resid_slot != nullptr ? (long long)resid_slot[row] : row;
+    const long long xrow = io_rows != nullptr ? (long long)io_rows[row] : row;   // x is read at, dx written to, this row
     float4 gv[NJ], xv[NJ], rv[NJ];
     float dot = 0.f;
 #pragma unroll
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
       const int c = (j * 64 + l) * 4;
       const bool ok = EXACT || c < D;
       const float4 g4 = ok ? load4<TG>(g + row * D + c) : make_float4(0, 0, 0, 0);
-      xv[j] = ok ? *(const float4*)(x + row * D + c) : make_float4(0, 0, 0, 0);
+      xv[j] = ok ? *(const float4*)(x + xrow * D + c) : make_float4(0, 0, 0, 0);
       rv[j] = (ok && resid && rrow >= 0) ? *(const float4*)(resid + rrow * D + c) : make_float4(0, 0, 0, 0);
       gv[j] = make_float4(g4.x * sc[j].x, g4.y * sc[j].y, g4.z * sc[j].z, g4.w * sc[j].w);
       dot += gv[j].x * xv[j].x + gv[j].y * xv[j].y + gv[j].z * xv[j].z + gv[j].w * xv[j].w;
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
         float4 o;
         o.x = r * gv[j].x - xv[j].x * k + rv[j].x; o.y = r * gv[j].y - xv[j].y * k + rv[j].y;
         o.z = r * gv[j].z - xv[j].z * k + rv[j].z; o.w = r * gv[j].w - xv[j].w * k + rv[j].w;
-        *(float4*)(dx_out + row * D + c) = o;
-        if (dx_out_t) store4<TO>(dx_out_t + row * D + c, o.x, o.y, o.z, o.w);   // operand copy for the next GEMMs (bf16 mode)
+        *(float4*)(dx_out + xrow * D + c) = o;
+        if (dx_out_t) store4<TO>(dx_out_t + xrow * D + c, o.x, o.y, o.z, o.w);   // operand copy for the next GEMMs (bf16 mode)
       }
     }
   }
@@ -335,12 +337,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
 template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
                            float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev,
-                           const int* resid_slot) {
+                           const int* resid_slot, const int* io_rows = nullptr) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
   float* part = det_part((long long)grid.x * D);
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
-                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot)
+                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot, io_rows)
   if (D == 256) RSYS_NORM_BWD(1, true);
   else if (D == 512) RSYS_NORM_BWD(2, true);
   else if (D == 1024) RSYS_NORM_BWD(4, true);
@@ -356,11 +358,12 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
 }
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev, const int* resid_slot) {
-  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, resid_slot);
+                       float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev, const int* resid_slot,
+                       const int* io_rows) {
+  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, resid_slot, io_rows);
 }
-template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*);
-template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, const int*);
+template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*, const int*);
+template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, const int*, const int*);
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
                            float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev) {

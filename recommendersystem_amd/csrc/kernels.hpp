@@ -51,14 +51,16 @@ int launch_gather_items(const BatchDev& b, const float* F32, int V, int D, float
 // rows_dev (optional, device): compact row set -- rows [0, *rows_dev) are computed, rows up to the next multiple of 256 are
 // written as zeros, the rest is left alone (compact.hip)
 template <typename T>
-int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr);
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
+                       const int* in_rows = nullptr /* output row r is computed from input row in_rows[r] */);
 
 // dx_out = resid_grad + d/dx rmsnorm ; dscale += column sums (atomic)
 // dx_out_t (optional): T-typed copy of dx_out, the A operand of the GEMMs that consume it
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
                        float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
-                       const int* resid_slot = nullptr /* resid_grad is compact: row resid_slot[row] of it, zero where -1 */);
+                       const int* resid_slot = nullptr /* resid_grad is compact: row resid_slot[row] of it, zero where -1 */,
+                       const int* io_rows = nullptr /* x is read at, and dx_out / dx_out_t written to, row io_rows[row] (g, rstd, resid_slot: row) */);
 // same with an f32 incoming gradient (final norm: gy is f32)
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
@@ -112,9 +114,13 @@ int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const in
 // ---- selected-token (compact) row sets for the top of the trunk (compact.hip)
 // union of the tasks' live positions (token 2 idx + (task & 1), rows r < *npos[task]): sel[0 .. *nsel) ascending, slot[token] = rank or -1
 int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, int* slot, int* sel, int* nsel, hipStream_t s);
+// selected-first token order of every batch row (slot from launch_token_union): see compact.hip
+int launch_selected_first(const int* slot, const int* uid, const int* tm, const int* rope_pos, int B, int T, int* perm, int* uid_p, int* tm_p,
+                          int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s);
 // dst rows [0, n) <- src rows sel[r]; dst rows [n, n rounded up to 256) <- 0   (n = *n_dev <= cap)
 template <typename T> int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s);
 template <typename T> int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int cap, T* dst, long long ld, int D, hipStream_t s);
+template <typename T> int launch_scatter_rows_map(const T* src, const int* map, int n, T* dst, long long ld, int D, hipStream_t s);   // dst[map[r]] = src[r]
 // heads: dst[r] = compact[slot[2 idx[r] + parity]] (zeros where -1), r < n; and compact[slot[..]] += src[r] for r < min(n, *npos)
 template <typename T> int launch_gather_rows_slot(const T* compact, const int* slot, const int* idx, int parity, T* dst, int n, int D, hipStream_t s);
 int launch_scatter_rows_add_slot(const float* src, const int* slot, const int* idx, int parity, const int* npos, float* compact, int n, int D, hipStream_t s);
@@ -178,6 +184,10 @@ struct AttnParams {
   // [B][ceil(T/64)][4]: the same "some allowed pair" bits per group of 16 queries (qmap16: bit j = kv tile j) and per
   // group of 16 keys (kmap16: bit j = q tile j): a wave owns one such group and skips the tiles it has nothing in
   unsigned int *qmap16, *kmap16;
+  // optional [B]: only the first q_active[b] query tiles of row b matter (the compact top, model.hpp: the tokens of the last layer are
+  // ordered selected-first).  Forward and dQ skip the other query tiles (their outputs are never read; dQ writes zeros), dK/dV
+  // leaves them out of its sums (their dO is identically zero).
+  const int* q_active;
   // backward
   const void* dO; float* delta;   // delta [B][H][T] = rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv

@@ -332,6 +332,10 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       DALLOC(m->c_gy, cap * D * 4); DALLOC(m->c_gx, cap * D * 4); DALLOC(m->c_dh, cap * D * 4);
       DALLOC(m->c_dab, cap * 2 * m->Ip * e); DALLOC(m->c_dhn, cap * D * e); DALLOC(m->c_dO, cap * D * e);
       if (m->bf16_mode) { DALLOC(m->c_gx_t, cap * D * 2); DALLOC(m->c_dh_t, cap * D * 2); } else { m->c_gx_t = m->c_gx; m->c_dh_t = m->c_dh; }
+      DALLOC(m->c_perm, NT * 4); DALLOC(m->uid_p, NT * 4); DALLOC(m->tm_p, NT * 4); DALLOC(m->pos_p, NT * 4); DALLOC(m->c_slot_p, NT * 4);
+      DALLOC(m->c_sel_p, cap * 4); DALLOC(m->c_qact, (int64_t)m->rows_max * 4 + 64);
+      const int64_t mb = (int64_t)m->rows_max * ((m->T + 63) / 64) * 4;
+      DALLOC(m->qmap_p, mb); DALLOC(m->kmap_p, mb); DALLOC(m->qmap_full_p, mb); DALLOC(m->kmap_full_p, mb); DALLOC(m->qmap16_p, mb * 4); DALLOC(m->kmap16_p, mb * 4);
     }
   }
   *out = m;
@@ -811,14 +815,14 @@ static int select_join(Model* m);   // (position selection runs on the side stre
 
 // token-local tail of layer l (model.py:300-309): h = x + O Wo^T ; out = h + W2 (silu(W1 hn) * W3 hn), hn = RMSNorm(h)
 template <typename T>
-static int layer_tail_dense(Model* m, int l) {
+static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* attention output in token order (default: the layer's own) */) {
   const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
   hipStream_t s = m->stream;
   Model::LayerAct& a = m->la[l];
   float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
   {
     GemmParams p{};
-    p.A = a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
+    p.A = O_in ? O_in : a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
     p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
     RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
   }
@@ -850,7 +854,7 @@ static int top_tail_compact(Model* m) {
   const int* n = m->c_n;
   RC(select_join(m));
   tic(m, "phase_top_compact_fwd");
-  RC(launch_gather_rows_sel<T>(AT<T>(a.O), D, m->c_sel, n, cap, AT<T>(m->c_O), D, s));
+  RC(launch_gather_rows_sel<T>(AT<T>(a.O), D, m->c_sel_p, n, cap, AT<T>(m->c_O), D, s));   // (the layer's attention ran in selected-first order)
   RC(launch_gather_rows_sel<float>(a.x, D, m->c_sel, n, cap, m->c_x, D, s));
   {
     GemmParams p{};
@@ -916,12 +920,23 @@ static int forward_trunk(Model* m) {
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
+  AttnParams ap_top = ap;   // the last layer under the compact top: selected-first token order, its own tile maps, leading query tiles only
+  if (m->top_is_sparse) {
+    RC(select_join(m));
+    RC(launch_selected_first(m->c_slot, m->uid_t, m->tm_t, rpos, rows, m->T, m->c_perm, m->uid_p, m->tm_p, m->pos_p, m->c_slot_p, m->c_sel_p, m->c_qact, s));
+    ap_top.uid = m->uid_p; ap_top.tm = m->tm_p;
+    ap_top.qmap = m->qmap_p; ap_top.kmap = m->kmap_p; ap_top.qmap_full = m->qmap_full_p; ap_top.kmap_full = m->kmap_full_p;
+    ap_top.qmap16 = m->qmap16_p; ap_top.kmap16 = m->kmap16_p;
+    RC(launch_attn_tilemap(ap_top, s));
+    ap_top.q_active = m->c_qact;
+  }
   tic(m, "phase_trunk_fwd");
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
-    float* xnext = (l + 1 < m->L) ? m->la[l + 1].x : m->xL;
+    const bool top = m->top_is_sparse && l == m->L - 1;   // this layer runs in selected-first token order
+    const int* rpos_l = top ? m->pos_p : rpos;
     tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
-    RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s));
+    RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s, nullptr, top ? m->c_perm : nullptr));
     toc(m);
     const bool ft = m->cfg.finetune != 0;
     T* xnd = AT<T>(a.xn);   // LoRA input: dropout(x) in a training pass (model.py:265,269), else x itself
@@ -940,7 +955,7 @@ static int forward_trunk(Model* m) {
       GemmParams p{};
       p.A = a.xn; p.lda = D; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = a.qkv; p.ldc = m->Nqkv;
       p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
-      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
     }
@@ -954,10 +969,11 @@ static int forward_trunk(Model* m) {
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_lora_b_fwd", p, false, false, false));
     }
-    ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
-    ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+    AttnParams& apl = top ? ap_top : ap;
+    apl.q = a.qkv; apl.k = AT<T>(a.qkv) + m->H * hd; apl.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; apl.ld = m->Nqkv;
+    apl.o = a.O; apl.ldo = D; apl.lse = a.lse;
     tic(m, "attn_fwd");
-    RC(launch_attn_fwd<T>(ap, s));
+    RC(launch_attn_fwd<T>(apl, s));
     toc(m);
     if (l == m->L - 1 && m->top_is_sparse) break;   // the tail of the last layer and the final norm run on the selected tokens
     RC(layer_tail_dense<T>(m, l));
@@ -974,8 +990,19 @@ static int forward_trunk(Model* m) {
 // computed it; the dense tail of the last layer and the final norm run now, from the saved attention output.
 template <typename T>
 static int materialise_output_t(Model* m) {
-  const int D = m->D, NT = 2 * m->cur_rows * m->S;
-  RC(layer_tail_dense<T>(m, m->L - 1));
+  const int D = m->D, NT = 2 * m->cur_rows * m->S, l = m->L - 1, hd = m->hd;
+  // the last layer's attention ran in selected-first order over the leading query tiles only: run all of them, then bring the
+  // attention output back to token order (into the free dO buffer of the backward) for the dense tail
+  Model::LayerAct& a = m->la[l];
+  AttnParams ap{};
+  ap.B = m->cur_rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.uid = m->uid_p; ap.tm = m->tm_p; ap.qmap = m->qmap_p; ap.kmap = m->kmap_p; ap.qmap_full = m->qmap_full_p; ap.kmap_full = m->kmap_full_p;
+  ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p;
+  ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
+  ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
+  RC(launch_attn_fwd<T>(ap, m->stream));
+  RC(launch_scatter_rows_map<T>(AT<T>(a.O), m->c_perm, NT, AT<T>(m->dO), D, D, m->stream));
+  RC(layer_tail_dense<T>(m, l, m->dO));
   RC(launch_rmsnorm_fwd<T>(m->xL, m->P + m->o_norm, AT<T>(m->out), m->rstdf, NT, D, m->stream));
   return RSYS_OK;
 }
@@ -1323,7 +1350,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     RC(gemm<T>(m, "gemm_top_o_dx", p, false, false, !wt));
   }
   HIP_CHECK(hipMemsetAsync(m->dO, 0, (size_t)NT * D * sizeof(T), s));
-  RC(launch_scatter_rows_sel<T>(AT<T>(m->c_dO), m->c_sel, n, cap, AT<T>(m->dO), D, D, s));
+  RC(launch_scatter_rows_sel<T>(AT<T>(m->c_dO), m->c_sel_p, n, cap, AT<T>(m->dO), D, D, s));   // (selected-first order, as the attention backward reads it)
   toc(m);
   return RSYS_OK;
 }
@@ -1460,7 +1487,14 @@ static int backward_trunk(Model* m) {
     ap.dq = dqkv; ap.dk = AT<T>(dqkv) + m->H * hd; ap.dv = AT<T>(dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
     RC(join_dw(m, DW_QKV));     // the layer above's dWqkv reads dqkv
     tic(m, "attn_bwd");
-    RC(launch_attn_bwd<T>(ap, s));
+    if (top) {   // selected-first token order of the last layer: its ids, tile maps, RoPE positions; dO is non-zero in the leading query tiles only
+      AttnParams at = ap;
+      at.uid = m->uid_p; at.tm = m->tm_p; at.rope_pos = m->pos_p; at.q_active = m->c_qact;
+      at.qmap = m->qmap_p; at.kmap = m->kmap_p; at.qmap_full = m->qmap_full_p; at.kmap_full = m->kmap_full_p; at.qmap16 = m->qmap16_p; at.kmap16 = m->kmap16_p;
+      RC(launch_attn_bwd<T>(at, s));
+    } else {
+      RC(launch_attn_bwd<T>(ap, s));
+    }
     toc(m);
     if (!ft && !defer) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
@@ -1521,8 +1555,9 @@ static int backward_trunk(Model* m) {
     }
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
     if (top)   // the residual gradient dh exists at the selected tokens only (compact rows, through the token -> row map)
+      // ... and this layer's rows are in selected-first order: x is read at, and dx written to, the original token of each place
       RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->c_dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s,
-                               nullptr, m->c_slot));
+                               nullptr, m->c_slot_p, m->c_perm));
     else
       RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
     toc(m);

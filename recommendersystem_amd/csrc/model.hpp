@@ -168,6 +168,12 @@ struct Model {
   void *c_O = nullptr, *c_hn = nullptr, *c_ab = nullptr, *c_g = nullptr, *c_out = nullptr;
   float *c_gy = nullptr, *c_gx = nullptr, *c_dh = nullptr;
   void *c_gx_t = nullptr, *c_dab = nullptr, *c_dhn = nullptr, *c_dh_t = nullptr, *c_dO = nullptr;
+  // ... and the last layer runs on a SELECTED-FIRST token order (inside every batch row the selected tokens, then the others; attention
+  // is indifferent to token order): its attention kernels then visit only the leading query tiles c_qact[b] of a row.  c_perm: original
+  // token of a permuted place; uid_p / tm_p / pos_p: ids and RoPE position per permuted place; c_slot_p / c_sel_p: the compact maps in
+  // permuted places; *_p maps: the attention tile maps of that order.  la[L-1].{xn, rstd1, qkv, O, lse} are stored in permuted order.
+  int *c_perm = nullptr, *uid_p = nullptr, *tm_p = nullptr, *pos_p = nullptr, *c_slot_p = nullptr, *c_sel_p = nullptr, *c_qact = nullptr;
+  unsigned int *qmap_p = nullptr, *kmap_p = nullptr, *qmap_full_p = nullptr, *kmap_full_p = nullptr, *qmap16_p = nullptr, *kmap16_p = nullptr;
   bool table_grads_pending = false;
   // the item-table gradient rows of medium m are known to be zero (just zeroed by zero_grad / AdamW and not written since):
   // the first head GEMM of a step then stores dF instead of reading 245 MB of zeros to add to
