@@ -8,6 +8,8 @@
 // index kernels: the union of the heads' live positions as a sorted token list + its inverse map, and row gathers / scatters
 // through them.  Compact buffers are valid for rows [0, n) and ZERO for rows [n, n rounded up to 256): the GEMMs that consume
 // them stop at a device-side row / reduction limit rounded up to a tile (gemm.hpp m_dev / k_dev).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace rsys {
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT
 __global__ __launch_bounds__(1024) void selected_first_kernel(const int* __restrict__ slot, const int* __restrict__ uid, const int* __restrict__ tm,
                                                               const int* __restrict__ rope_pos, int T, int* __restrict__ perm, int* __restrict__ uid_p,
                                                               int* __restrict__ tm_p, int* __restrict__ pos_p, int* __restrict__ slot_p,
-                                                              int* __restrict__ sel_p, int* __restrict__ q_active) {
+                                                              int* __restrict__ sel_p, int* __restrict__ q_active, int identity) {
   __shared__ int wave_tot[16];
   const int b = blockIdx.x, t = threadIdx.x, l = t & 63, wv = t >> 6;
   const long long base = (long long)b * T;
@@ -85,14 +87,14 @@ __global__ __launch_bounds__(1024) void selected_first_kernel(const int* __restr
   int rank = before + inc - cnt;                   // selected tokens of this row before j0
   for (int j = j0; j < j1; ++j) {
     const int s = sl[j - j0];
-    const int p = s >= 0 ? rank : n_sel + (j - rank);
+    const int p = identity ? j : (s >= 0 ? rank : n_sel + (j - rank));   // (identity: A/B measurement of what the order buys)
     perm[base + p] = (int)(base + j);
     uid_p[base + p] = uid[base + j]; tm_p[base + p] = tm[base + j];
     pos_p[base + p] = rope_pos != nullptr ? rope_pos[base + j] : j;
     slot_p[base + p] = s;
     if (s >= 0) { sel_p[s] = (int)(base + p); ++rank; }
   }
-  if (t == 0) q_active[b] = (n_sel + 63) >> 6;
+  if (t == 0) q_active[b] = identity ? (T + 63) >> 6 : (n_sel + 63) >> 6;
 }
 
 // rows [0, n) <- src rows sel[r]; rows [n, pad256(n)) <- 0.  One wave per row.
@@ -182,7 +184,8 @@ int launch_token_union(const int* const* idx, const int* const* npos, int ntask,
 int launch_selected_first(const int* slot, const int* uid, const int* tm, const int* rope_pos, int B, int T, int* perm, int* uid_p, int* tm_p,
                           int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s) {
   ARG_CHECK(T >= 1 && T <= 2048, "selected-first order: at most 2048 tokens per row");
-  hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, slot, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active);
+  static const int identity = getenv("RSYS_TOP_ORDER") && atoi(getenv("RSYS_TOP_ORDER")) == 0 ? 1 : 0;   // RSYS_TOP_ORDER=0: keep the token order
+  hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, slot, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active, identity);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
