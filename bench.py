@@ -37,7 +37,14 @@ KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent,
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
                 "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
-TRAFFIC_FILE = "r3a_pmc_traffic.json"
+def _latest_traffic_file():
+    """the newest committed PMC summary (profiles/r<round><letter>_pmc_traffic.json, written by tools/prof_round.sh)"""
+    import glob
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return names[-1] if names else "none"
+
+
+TRAFFIC_FILE = _latest_traffic_file()
 
 
 def traffic_of(db, variant):

@@ -775,21 +775,26 @@ __global__ __launch_bounds__(256) void cast_transpose_colsum_kernel(const float*
   __shared__ unsigned short tile[64][72];          // [column][row] of the current 64 x 64 tile (row pitch 144 B: 16-byte aligned reads)
   __shared__ float red[16][64];
   const int t = threadIdx.x;
-  const int lr = t >> 4, c4 = (t & 15) * 4;         // loads: row lr + 16 i, columns c4 .. c4 + 3 of the tile
+  const int lr = t >> 4, c4 = (t & 15) * 4;         // loads: rows 4 lr .. 4 lr + 3, columns c4 .. c4 + 3 of the tile (a 4 x 4 block per thread)
   const int oc = t >> 2, or8 = (t & 3) * 16;        // stores: tile column oc, rows or8 .. or8 + 15
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long rend = min((rows + 63) & ~63LL, r0 + rows_per_block);
   for (int ct = 0; ct < D / 64; ++ct) {
     float4 acc = make_float4(0, 0, 0, 0);
     for (long long rb = r0; rb < rend; rb += 64) {
+      float4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long long r = rb + lr + 16 * i;
-        const float4 v = r < rows ? *(const float4*)(src + r * D + ct * 64 + c4) : make_float4(0, 0, 0, 0);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        const bf16 b0 = (bf16)v.x, b1 = (bf16)v.y, b2 = (bf16)v.z, b3 = (bf16)v.w;
-        tile[c4 + 0][lr + 16 * i] = *(const unsigned short*)&b0; tile[c4 + 1][lr + 16 * i] = *(const unsigned short*)&b1;
-        tile[c4 + 2][lr + 16 * i] = *(const unsigned short*)&b2; tile[c4 + 3][lr + 16 * i] = *(const unsigned short*)&b3;
+        const long long r = rb + 4 * lr + i;
+        v[i] = r < rows ? *(const float4*)(src + r * D + ct * 64 + c4) : make_float4(0, 0, 0, 0);
+        acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
+      }
+      {   // the block transposed in registers: one 8-byte LDS store (4 consecutive rows) per column
+        bf16x4 o;
+        o[0] = (bf16)v[0].x; o[1] = (bf16)v[1].x; o[2] = (bf16)v[2].x; o[3] = (bf16)v[3].x; *(bf16x4*)&tile[c4 + 0][4 * lr] = o;
+        o[0] = (bf16)v[0].y; o[1] = (bf16)v[1].y; o[2] = (bf16)v[2].y; o[3] = (bf16)v[3].y; *(bf16x4*)&tile[c4 + 1][4 * lr] = o;
+        o[0] = (bf16)v[0].z; o[1] = (bf16)v[1].z; o[2] = (bf16)v[2].z; o[3] = (bf16)v[3].z; *(bf16x4*)&tile[c4 + 2][4 * lr] = o;
+        o[0] = (bf16)v[0].w; o[1] = (bf16)v[1].w; o[2] = (bf16)v[2].w; o[3] = (bf16)v[3].w; *(bf16x4*)&tile[c4 + 3][4 * lr] = o;
       }
       __syncthreads();
       {

@@ -183,6 +183,16 @@ def test_committed_bench_line_follows_the_contract():
         assert set(("gather", "scatter", "adamw", "rmsnorm_fwd", "rmsnorm_bwd")) <= set(d["hbm_kernels"])
         assert all(0 < k["GBps"] < 8000 for k in d["hbm_kernels"].values())
         assert "no extrapolation" in c["sample"]
+    if path.split(os.sep)[-1] >= "r3":               # round 3 on: utilisation on executed FLOPs, >= 5 instrumented steps,
+        assert 0 < d["step_mfma_frac_executed"] < d["step_mfma_frac"]                # the PMC summary the traffic figure was read from
+        ex = d["executed"]
+        assert ex["gemm_flops_per_step"] > 0 and ex["attention_flops_per_step"] > 0 and 0 < ex["attention_tile_density"] <= 1
+        total = ex["gemm_flops_per_step"] + ex["attention_flops_per_step"]
+        assert abs(d["step_mfma_frac_executed"] - total / (d["ms_per_step"] * 1e-3) / 2.5e15) < 2e-4
+        assert r["instrumented_steps"] >= 5
+        src = r["traffic_source"]
+        blob = __import__("bench").git_blob_id(os.path.join(root, src["file"]))
+        assert src["git_blob"] == blob, (src, blob)                                  # the committed file IS the one the line quotes
 
 
 def test_cli_training_config(tmp_path):
