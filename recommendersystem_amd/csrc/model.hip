@@ -313,7 +313,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
     m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
     static const int sp = getenv("RSYS_SPARSE_TOP") ? atoi(getenv("RSYS_SPARSE_TOP")) : 1;
-    m->sparse_top = sp != 0 && !cfg->finetune && !m->sharded && NT <= (1 << 19);
+    m->sparse_top = sp != 0 && !cfg->finetune && NT <= (1 << 19);
     if (m->defer_dw) {
       m->dwb.resize(m->L);
       for (int l = 0; l < m->L; ++l) {
@@ -1016,6 +1016,13 @@ int model_materialise_trunk_output(Model* m) {
   return rc;
 }
 
+// d(trunk output) += the row gradients of head `ti` (rows r < n of `src` belong to positions idx[ti][r]; item tokens parity 0,
+// action tokens parity 1): into the dense buffer, or -- compact top -- into the selected tokens' rows through the slot map
+static int head_add_rows(Model* m, const float* src, int ti, int parity, int n) {
+  if (m->top_is_sparse) return launch_scatter_rows_add_slot(src, m->c_slot, m->idx[ti], parity, m->npos + ti, m->c_gy, n, m->D, m->stream);
+  return launch_scatter_rows_add(src, m->idx[ti], parity, m->gy, m->D, n, m->D, m->stream);
+}
+
 // ------------------------------------------------------------------ sampled soft-max watch head (cfg-4 option)
 // Called by watch_head_sharded after the selected rows of all ranks have been gathered and packed.  Per rank: n_s sampled
 // local classes (one per stratum, fresh per step and medium, weighted by the stratum's size) instead of all `len`; see shard.hip.
@@ -1073,7 +1080,7 @@ static int watch_head_sampled(Model* m, int ti, int medium, bool bwd, int nlive,
   }
   m->gE_clean[medium] = false;
   RC(comm_all_reduce_f32(c, m->dEwC, (size_t)nlive * D, COMM_SUM, s));
-  if (nown > 0) RC(launch_scatter_rows_add(m->dEwC + (size_t)own0 * D, m->idx[ti], 0, m->gy, D, nown, D, s));
+  if (nown > 0) RC(head_add_rows(m, m->dEwC + (size_t)own0 * D, ti, 0, nown));
   m->table_grads_pending = true;
   return RSYS_OK;
 }
@@ -1175,7 +1182,7 @@ static int watch_head_sharded(Model* m, int ti, int medium, bool train, bool bwd
     RC(gemm<T>(m, "gemm_head_dx", p, false, false, true));
   }
   RC(comm_all_reduce_f32(c, m->dEwC, (size_t)nlive * D, COMM_SUM, s));
-  if (nown > 0) RC(launch_scatter_rows_add(m->dEwC + (size_t)own0 * D, m->idx[ti], 0, m->gy, D, nown, D, s));
+  if (nown > 0) RC(head_add_rows(m, m->dEwC + (size_t)own0 * D, ti, 0, nown));
   if (len > 0) {
     GemmParams p{};  // dF[local rows of the medium] (+)= dlogits^T . (selected rows of all ranks): complete, no all-reduce
     p.A = m->logits; p.lda = m->ldl_loc; p.B = m->EwC; p.ldb = D; p.C = m->G + m->o_E + (int64_t)lrow * D; p.ldc = D; p.c_f32 = 1;
@@ -1199,10 +1206,7 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
   HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
   if (train && !ctop) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
   if (train && ctop) HIP_CHECK(hipMemsetAsync(m->c_gy, 0, (size_t)m->ctop_cap * D * 4, s));
-  auto add_rows = [&](const float* src, int ti, int parity) -> int {   // d(trunk output) += the head's row gradients
-    if (ctop) return launch_scatter_rows_add_slot(src, m->c_slot, m->idx[ti], parity, m->npos + ti, m->c_gy, KB, D, s);
-    return launch_scatter_rows_add(src, m->idx[ti], parity, m->gy, D, KB, D, s);
-  };
+  auto add_rows = [&](const float* src, int ti, int parity) -> int { return head_add_rows(m, src, ti, parity, KB); };
   for (int ti = 0; ti < 4; ++ti) {
     const int medium = ti >> 1, metric = ti & 1;
     float* st = m->stats + 2 * ti;
