@@ -313,7 +313,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
     m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
     static const int sp = getenv("RSYS_SPARSE_TOP") ? atoi(getenv("RSYS_SPARSE_TOP")) : 1;
-    m->sparse_top = sp != 0 && !cfg->finetune && NT <= (1 << 19);
+    m->sparse_top = sp != 0 && NT <= (1 << 19);   // (also the LoRA finetune: one target per row -- the last layer's tail shrinks to `rows` tokens)
     if (m->defer_dw) {
       m->dwb.resize(m->L);
       for (int l = 0; l < m->L; ++l) {
@@ -965,7 +965,7 @@ static int forward_trunk(Model* m) {
       GemmParams p{};
       p.A = a.La; p.lda = 16; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = a.qkv; p.ldc = m->Nqkv;
       p.M = NT; p.N = m->Nqkv; p.K = 16; p.epi = EPI_QKV_ROPE; p.alpha = 2.f; p.accum = 1;
-      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos; p.T = m->T; p.hd = hd;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_lora_b_fwd", p, false, false, false));
     }
@@ -1311,8 +1311,9 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
   hipStream_t s = m->stream;
   const int* n = m->c_n;
   const bool cp = m->bf16_mode;
+  const bool ft = m->cfg.finetune != 0;   // finetune: the base weights are frozen, only the dx chain runs here (the LoRA tensors sit before the attention)
   tic(m, "phase_top_compact_bwd");
-  {
+  if (!ft) {
     GemmParams p{};  // dW2 += gx^T . g
     p.A = m->c_gx_t; p.lda = D; p.B = m->c_g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
     p.M = D; p.N = Ip; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
@@ -1325,7 +1326,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     p.M = cap; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = m->c_ab; p.ldc2 = 2 * Ip; p.m_dev = n;
     RC(gemm<T>(m, "gemm_top_w2_dx", p, false, false, !wt));
   }
-  {
+  if (!ft) {
     GemmParams p{};  // dW13 += dab^T . hn
     p.A = m->c_dab; p.lda = 2 * Ip; p.B = m->c_hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
     p.M = 2 * Ip; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
@@ -1340,7 +1341,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
   }
   RC(launch_rmsnorm_bwd<T>(AT<T>(m->c_dhn), m->c_h, m->P + m->lo[l].mlp, m->c_rstd2, m->c_gx, m->c_dh, cp ? AT<T>(m->c_dh_t) : nullptr,
                            m->G + m->lo[l].mlp, cap, D, s, n));
-  {
+  if (!ft) {
     GemmParams p{};  // dWo += dh^T . O
     p.A = m->c_dh_t; p.lda = D; p.B = m->c_O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
     p.M = D; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
