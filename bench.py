@@ -352,6 +352,11 @@ def main():
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
                 rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith("@8p")) else fl   # 256-row tiles
+        # the rating heads stop at their live rows too (tasks 1 and 3; one tag covers both launches)
+        KBr = cfg["mask_topk"] * rows
+        for tag, q in (("gemm_rating_fwd", 128), ("gemm_rating_dx", 128), ("gemm_rating_dw", 64)):
+            for full in [k for k in rep if k.split("@")[0] == tag]:
+                rep[full]["flops"] *= (min(KBr, up(npos[1], q)) + min(KBr, up(npos[3], q))) / (2.0 * KBr)
         # compact top of the trunk: those GEMMs stop at the selected tokens (device-side limit), their tags carry the capacity
         try:
             top_cap = int(model.debug_get("top.cap", rows)[0])

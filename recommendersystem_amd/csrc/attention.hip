@@ -252,10 +252,14 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
   const size_t bytes = sizeof(unsigned int) * p.B * ((p.T + 63) / 64);
-  HIP_CHECK(hipMemsetAsync(p.kmap, 0, bytes, s));
-  HIP_CHECK(hipMemsetAsync(p.kmap_full, 0, bytes, s));
-  HIP_CHECK(hipMemsetAsync(p.qmap_full, 0, bytes, s));
-  HIP_CHECK(hipMemsetAsync(p.kmap16, 0, bytes * 4, s));
+  if (p.maps_zero_base != nullptr) {
+    HIP_CHECK(hipMemsetAsync(p.maps_zero_base, 0, p.maps_zero_bytes, s));
+  } else {
+    HIP_CHECK(hipMemsetAsync(p.kmap, 0, bytes, s));
+    HIP_CHECK(hipMemsetAsync(p.kmap_full, 0, bytes, s));
+    HIP_CHECK(hipMemsetAsync(p.qmap_full, 0, bytes, s));
+    HIP_CHECK(hipMemsetAsync(p.kmap16, 0, bytes * 4, s));
+  }
   hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;

@@ -471,9 +471,10 @@ int launch_gather_rows(const T* src, long long ld, const int* idx, int parity, T
 template int launch_gather_rows<bf16>(const bf16*, long long, const int*, int, bf16*, int, int, hipStream_t);
 template int launch_gather_rows<float>(const float*, long long, const int*, int, float*, int, int, hipStream_t);
 
-__global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int* __restrict__ idx, int parity, float* dst, long long ld, int n, int D) {
+__global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int* __restrict__ idx, int parity, float* dst, long long ld, int n, int D,
+                                        const int* __restrict__ npos) {
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
-  if (row >= n) return;
+  if (row >= n || (npos != nullptr && row >= *npos)) return;   // (rows from *npos on are zero-weight padding: their gradient is zero)
   const float4* s4 = (const float4*)(src + (long long)row * D);
   float4* d4 = (float4*)(dst + (2LL * idx[row] + parity) * ld);
   for (int c = l; c < (D >> 2); c += 64) {
@@ -482,8 +483,8 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ src, const int
     d4[c] = a;
   }
 }
-int launch_scatter_rows_add(const float* src, const int* idx, int parity, float* dst, long long ld, int n, int D, hipStream_t s) {
-  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, idx, parity, dst, ld, n, D);
+int launch_scatter_rows_add(const float* src, const int* idx, int parity, float* dst, long long ld, int n, int D, hipStream_t s, const int* npos) {
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(div_up(n, 4)), dim3(256), 0, s, src, idx, parity, dst, ld, n, D, npos);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restr
                                                           const int* __restrict__ idx, const float* __restrict__ label,
                                                           const float* __restrict__ weight, const float* __restrict__ stats,
                                                           float rating_mean, float task_w, int evaluate, float* loss_out,
-                                                          float* dw2, float* db2, float* db0, float* part) {
+                                                          float* dw2, float* db2, float* db0, float* part, const int* __restrict__ npos) {
   extern __shared__ __attribute__((aligned(16))) float sds[];  // 2*D floats: dw2 | db0  (deterministic mode: one such pair per wave + 4 scalars per wave)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nacc = part != nullptr ? 4 * 2 * D + 16 : 2 * D;
@@ -578,6 +579,9 @@ __global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restr
   float* const mine = part != nullptr ? sds + w * 2 * D : sds;   // deterministic: a wave adds into its own copy (its lanes own distinct columns)
   float l0 = 0.f, l1 = 0.f, l2 = 0.f, gb2 = 0.f;
   const float inv_ws = 1.f / fmaxf(stats[0], 1e-8f);
+  // the positive-weight rows come first (select_positions): rows from *npos on are zero-weight padding, of which only those up to
+  // the next multiple of 128 are touched (their dz = 0 is what the row- / K-limited GEMMs around this kernel read)
+  if (npos != nullptr) n = min(n, (*npos + 127) & ~127);
   for (int row = blockIdx.x * 4 + w; row < n; row += gridDim.x * 4) {
     const int i = idx[row];
     const float wt = weight[i], tgt = label[i] - rating_mean;
@@ -629,12 +633,12 @@ __global__ __launch_bounds__(256) void rating_tail_kernel(T* z, const T* __restr
 template <typename T>
 int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const float* b2, const int* idx,
                        const float* label, const float* weight, const float* stats, float rating_mean, float task_w,
-                       int evaluate, float* loss_out, float* dw2, float* db2, float* db0, hipStream_t s) {
+                       int evaluate, float* loss_out, float* dw2, float* db2, float* db0, hipStream_t s, const int* npos) {
   int grid = std::min(div_up(n, 4), 512);
   const long long prow = 2LL * D + 4;
   float* part = det_part(grid * prow);
   hipLaunchKernelGGL((rating_tail_kernel<T>), dim3(grid), dim3(256), (part ? 8 * D + 16 : 2 * D) * sizeof(float), s, z, hact, n, D, w2, b2, idx,
-                     label, weight, stats, rating_mean, task_w, evaluate, loss_out, dw2, db2, db0, part);
+                     label, weight, stats, rating_mean, task_w, evaluate, loss_out, dw2, db2, db0, part, npos);
   HIP_CHECK(hipGetLastError());
   if (part != nullptr) {
     int rc = RSYS_OK;
@@ -647,8 +651,8 @@ int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const
   }
   return RSYS_OK;
 }
-template int launch_rating_tail<bf16>(bf16*, const bf16*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
-template int launch_rating_tail<float>(float*, const float*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t);
+template int launch_rating_tail<bf16>(bf16*, const bf16*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t, const int*);
+template int launch_rating_tail<float>(float*, const float*, int, int, const float*, const float*, const int*, const float*, const float*, const float*, float, float, int, float*, float*, float*, float*, hipStream_t, const int*);
 
 // --------------------------------------------------------------------- inference outputs (model.py:531-538)
 // dst[i] = (float)src[i]: the trunk output leaves the device as float32 in one copy

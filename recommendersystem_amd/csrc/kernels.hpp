@@ -80,7 +80,8 @@ int launch_select_positions_batch(int ntask, const float* const* w, int N, int t
 template <typename T>
 int launch_gather_rows(const T* src, long long ld, const int* idx, int parity, T* dst, int n, int D, hipStream_t s);
 
-int launch_scatter_rows_add(const float* src, const int* idx, int parity, float* dst, long long ld, int n, int D, hipStream_t s);
+int launch_scatter_rows_add(const float* src, const int* idx, int parity, float* dst, long long ld, int n, int D, hipStream_t s,
+                            const int* npos = nullptr /* device: only rows r < *npos are added */);
 
 // cross entropy over logits[n][ldl] (valid cols < V): accumulates loss_out[0] += sum ce*label*w ;
 // overwrites logits with dlogits = coef*(softmax - onehot), coef = tw*label*w/max(wsum,1e-8); pad cols zeroed
@@ -92,7 +93,8 @@ int launch_ce_fwd_bwd(T* logits, long long ldl, int n, int V, const int* idx, co
 template <typename T>
 int launch_rating_tail(T* z, const T* hact, int n, int D, const float* w2, const float* b2, const int* idx,
                        const float* label, const float* weight, const float* stats, float rating_mean, float task_w,
-                       int evaluate, float* loss_out /*[3]*/, float* dw2, float* db2, float* db0, hipStream_t s);
+                       int evaluate, float* loss_out /*[3]*/, float* dw2, float* db2, float* db0, hipStream_t s,
+                       const int* npos = nullptr /* device: number of positive-weight rows (they come first); rows beyond the next multiple of 128 are skipped */);
 
 int launch_colsum_add(const float* src, long long ld, long long rows, int cols, float* dst, hipStream_t s);
 // dst = bf16(src) and colsum += column sums of src, one pass (D/4 must divide 1024)
@@ -188,6 +190,9 @@ struct AttnParams {
   // ordered selected-first).  Forward and dQ skip the other query tiles (their outputs are never read; dQ writes zeros), dK/dV
   // leaves them out of its sums (their dO is identically zero).
   const int* q_active;
+  // optional: kmap, kmap_full, qmap_full and kmap16 (the maps the tile-map kernel ORs into) live back to back in one allocation
+  // starting here: one zero-fill instead of four
+  void* maps_zero_base; size_t maps_zero_bytes;
   // backward
   const void* dO; float* delta;   // delta [B][H][T] = rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv

@@ -244,9 +244,14 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   }
   DALLOC(m->feat, N * 32 * e); DALLOC(m->x0, NT * D * 4);
   DALLOC(m->uid_t, NT * 4); DALLOC(m->tm_t, NT * 4);
-  DALLOC(m->qmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
-  DALLOC(m->qmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4); DALLOC(m->kmap_full, (int64_t)m->rows_max * ((m->T + 63) / 64) * 4);
-  DALLOC(m->qmap16, (int64_t)m->rows_max * ((m->T + 63) / 64) * 16); DALLOC(m->kmap16, (int64_t)m->rows_max * ((m->T + 63) / 64) * 16);
+  {   // attention tile maps: the four the tile-map kernel ORs into sit back to back (one zero-fill per step), then the two it stores
+    const int64_t mb = ((int64_t)m->rows_max * ((m->T + 63) / 64) * 4 + 255) / 256 * 256;
+    unsigned char* base = nullptr;
+    DALLOC(base, mb * 7 + mb * 5);
+    m->kmap = (unsigned int*)base; m->kmap_full = (unsigned int*)(base + mb); m->qmap_full = (unsigned int*)(base + 2 * mb); m->kmap16 = (unsigned int*)(base + 3 * mb);
+    m->qmap = (unsigned int*)(base + 7 * mb); m->qmap16 = (unsigned int*)(base + 8 * mb);
+    m->maps_zero_bytes = (size_t)(7 * mb);
+  }
   m->la.resize(m->L);
   for (int l = 0; l < m->L; ++l) {
     Model::LayerAct& a = m->la[l];
@@ -334,8 +339,11 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       if (m->bf16_mode) { DALLOC(m->c_gx_t, cap * D * 2); DALLOC(m->c_dh_t, cap * D * 2); } else { m->c_gx_t = m->c_gx; m->c_dh_t = m->c_dh; }
       DALLOC(m->c_perm, NT * 4); DALLOC(m->uid_p, NT * 4); DALLOC(m->tm_p, NT * 4); DALLOC(m->pos_p, NT * 4); DALLOC(m->c_slot_p, NT * 4);
       DALLOC(m->c_sel_p, cap * 4); DALLOC(m->c_qact, (int64_t)m->rows_max * 4 + 64);
-      const int64_t mb = (int64_t)m->rows_max * ((m->T + 63) / 64) * 4;
-      DALLOC(m->qmap_p, mb); DALLOC(m->kmap_p, mb); DALLOC(m->qmap_full_p, mb); DALLOC(m->kmap_full_p, mb); DALLOC(m->qmap16_p, mb * 4); DALLOC(m->kmap16_p, mb * 4);
+      const int64_t mb = ((int64_t)m->rows_max * ((m->T + 63) / 64) * 4 + 255) / 256 * 256;
+      unsigned char* base = nullptr;
+      DALLOC(base, mb * 12);
+      m->kmap_p = (unsigned int*)base; m->kmap_full_p = (unsigned int*)(base + mb); m->qmap_full_p = (unsigned int*)(base + 2 * mb); m->kmap16_p = (unsigned int*)(base + 3 * mb);
+      m->qmap_p = (unsigned int*)(base + 7 * mb); m->qmap16_p = (unsigned int*)(base + 8 * mb);
     }
   }
   *out = m;
@@ -918,6 +926,7 @@ static int forward_trunk(Model* m) {
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
+  ap.maps_zero_base = m->kmap; ap.maps_zero_bytes = m->maps_zero_bytes;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
   AttnParams ap_top = ap;   // the last layer under the compact top: selected-first token order, its own tile maps, leading query tiles only
@@ -927,6 +936,7 @@ static int forward_trunk(Model* m) {
     ap_top.uid = m->uid_p; ap_top.tm = m->tm_p;
     ap_top.qmap = m->qmap_p; ap_top.kmap = m->kmap_p; ap_top.qmap_full = m->qmap_full_p; ap_top.kmap_full = m->kmap_full_p;
     ap_top.qmap16 = m->qmap16_p; ap_top.kmap16 = m->kmap16_p;
+    ap_top.maps_zero_base = m->kmap_p;
     RC(launch_attn_tilemap(ap_top, s));
     ap_top.q_active = m->c_qact;
   }
@@ -1020,7 +1030,7 @@ int model_materialise_trunk_output(Model* m) {
 // action tokens parity 1): into the dense buffer, or -- compact top -- into the selected tokens' rows through the slot map
 static int head_add_rows(Model* m, const float* src, int ti, int parity, int n) {
   if (m->top_is_sparse) return launch_scatter_rows_add_slot(src, m->c_slot, m->idx[ti], parity, m->npos + ti, m->c_gy, n, m->D, m->stream);
-  return launch_scatter_rows_add(src, m->idx[ti], parity, m->gy, m->D, n, m->D, m->stream);
+  return launch_scatter_rows_add(src, m->idx[ti], parity, m->gy, m->D, n, m->D, m->stream, m->npos + ti);
 }
 
 // ------------------------------------------------------------------ sampled soft-max watch head (cfg-4 option)
@@ -1252,22 +1262,23 @@ static int heads(Model* m, int evaluate, const float tw[4]) {
         GemmParams p{};
         p.A = m->Ew; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->z; p.ldc = D;
         p.M = KB; p.N = D; p.K = D; p.epi = EPI_GELU; p.bias = m->P + m->o_r0b; p.C2 = m->hact; p.ldc2 = D;
+        p.m_dev = np;   // (the rating head too stops at the positive-weight rows: zero-weight padding adds nothing to loss or gradients)
         RC(gemm<T>(m, "gemm_rating_fwd", p, false, false, false));
       }
       RC(launch_rating_tail<T>(AT<T>(m->z), AT<T>(m->hact), KB, D, m->P + m->o_r2w, m->P + m->o_r2b, m->idx[ti],
                                m->bd.m_label[ti], m->bd.m_weight[ti], st, m->cfg.rating_mean, bwd ? tw[ti] : 0.f,
-                               bwd ? 0 : 1, m->loss_acc + 3 * ti, m->G + m->o_r2w, m->G + m->o_r2b, m->G + m->o_r0b, s));
+                               bwd ? 0 : 1, m->loss_acc + 3 * ti, m->G + m->o_r2w, m->G + m->o_r2b, m->G + m->o_r0b, s, np));
       if (bwd) {
         if (!m->cfg.finetune) {
           GemmParams p{};  // dW0 += dz^T . Er
           p.A = m->z; p.lda = D; p.B = m->Ew; p.ldb = D; p.C = m->G + m->o_r0w; p.ldc = D; p.c_f32 = 1;
-          p.M = D; p.N = D; p.K = KB; p.epi = EPI_ATOMIC;
+          p.M = D; p.N = D; p.K = KB; p.epi = EPI_ATOMIC; p.k_dev = np;   // (dz of the padding rows up to the next tile is zero: rating_tail)
           RC(gemm<T>(m, "gemm_rating_dw", p, false, true, true));
         }
         {
           GemmParams p{};  // dEr = dz . W0
           p.A = m->z; p.lda = D; p.B = W<T>(m, m->o_r0w); p.ldb = D; p.C = m->dE; p.ldc = D; p.c_f32 = 1;
-          p.M = KB; p.N = D; p.K = D; p.epi = EPI_STORE;
+          p.M = KB; p.N = D; p.K = D; p.epi = EPI_STORE; p.m_dev = np;
           RC(gemm<T>(m, "gemm_rating_dx", p, false, false, true));
         }
         RC(add_rows(m->dE, ti, 1));

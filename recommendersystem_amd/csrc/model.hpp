@@ -137,6 +137,7 @@ struct Model {
   unsigned char *d_wm = nullptr, *d_rm = nullptr;
   int* d_rope_pos = nullptr;
   // activations (void* = T-typed)
+  size_t maps_zero_bytes = 0;   // kmap | kmap_full | qmap_full | kmap16 are one allocation: bytes of the region the tile-map kernel needs zeroed
   void* feat; float* x0; int *uid_t, *tm_t; unsigned int *qmap, *kmap, *qmap_full, *kmap_full, *qmap16, *kmap16;
   struct LayerAct { float* x; void* xn; void* xnd; void* La; void* qkv; void* O; float* lse; float* rstd1; float* h; void* hn; float* rstd2; void* ab; void* g; };
   std::vector<LayerAct> la;
