@@ -125,7 +125,8 @@ int32_t rsys_infer(rsys_model* m, int32_t task, float* out, int64_t n);
  * retrieval and the candidates' action tokens for ranking): token_index[n_tokens] = flat token indices in [0, rows*2S);
  * out = n_tokens*D floats (retrieval: the trunk output rows) or n_tokens floats (ranking: the rating head on those rows only) */
 int32_t rsys_infer_select(rsys_model* m, int32_t task, const int32_t* token_index, int64_t n_tokens, float* out, int64_t n);
-/* debug/parity: trunk output of the last forward (rows*2S*D floats) */
+/* debug/parity: trunk output of the last forward (rows*2S*D floats).  A training pass computes it only at the positions the heads
+ * select; this call then runs the dense tail of the last layer first (results as model.py:335-343 over every token). */
 int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);
 
 /* debug/parity: integer and index paths of the last forward, read back bit-exactly (tests compare them with the
@@ -133,7 +134,10 @@ int32_t rsys_trunk_output_get(rsys_model* m, float* out, int64_t n);
  * "masked.matchedid", "masked.status" (int32 [rows*S]); "masked.rating", "masked.progress" (f32); "masked.<medium>.
  * <watch|rating>.<label|weight|position>"; "idx.<task>" (int32 [mask_topk*rows], task = medium*2 + metric); "npos"
  * (int32 [4]); "tokens.userid", "tokens.token_mask_ids" (int32 [rows*2S], model.py:468-469); "embed.x0" (f32
- * [rows*2S*D]); "table.fused" (f32 [(V+1)*D]).  `bytes` must be the exact size of the array. */
+ * [rows*2S*D]); "table.fused" (f32 [(V+1)*D]); after a training pass also the compact top of the trunk: "top.cap",
+ * "top.n" (int32 [1]: capacity / number of selected tokens), "top.sel" (int32 [top.cap], the sorted selected tokens), "top.slot"
+ * (int32 [rows*2S], token -> compact row or -1); "host_syncs" (int32 [2]: stream drains and event waits inside the last
+ * rsys_forward_backward).  `bytes` must be the exact size of the array. */
 int32_t rsys_debug_get(rsys_model* m, const char* key, void* out, int64_t bytes);
 
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) -- train.py:273; norm_out may be NULL */
