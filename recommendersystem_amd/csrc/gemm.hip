@@ -480,7 +480,8 @@ static int pick_rowmajor_kernel(const GemmParams& p) {
   const bool e8 = gemm8p_eligible(p), e4 = gemm4w_eligible(p);
   if (hint == 2) return e8 ? 2 : 0;
   if (hint == 3) return e4 ? 3 : 0;
-  const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int Me = (p.m_dev != nullptr && p.m_expect > 0) ? std::min(p.M, p.m_expect) : p.M;   // rows the launch is expected to compute
+  const long long t256 = (long long)((Me + 255) / 256) * ((p.N + 255) / 256);
   if (e8 && t256 >= 128) return 2;   // at least half the CUs get a 256x256 tile
   return 0;
 }

@@ -32,6 +32,9 @@ struct GemmParams {
   // optional device-side problem limits (no host sync): tiles whose first row is >= *m_dev are not computed, and the
   // reduction stops at *k_dev rounded up to a tile (rows / k beyond the limit must hold data that contributes zero)
   const int* m_dev; const int* k_dev;
+  // host-side estimates of *m_dev / *k_dev (0: none): only the kernel choice and the K-split count look at them -- a product whose
+  // capacity is 16 K rows but which will stop at ~3 K should be tiled for 3 K
+  int m_expect, k_expect;
   float alpha;
   int accum;        // EPI_STORE / EPI_QKV_ROPE with a T output: C = C + result (LoRA updates)
   const float* bias;

@@ -713,7 +713,8 @@ int model_set_deterministic(Model* m, int on) {
 template <typename T>
 static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, bool b_km) {
   if (p.alpha == 0.f) p.alpha = 1.f;
-  if (p.epi == EPI_ATOMIC && p.splitk == 0) p.splitk = pick_splitk(p.M, p.N, p.K, is_bf16<T>::value ? 64 : 32);
+  if (p.epi == EPI_ATOMIC && p.splitk == 0)
+    p.splitk = pick_splitk(p.M, p.N, (p.k_dev != nullptr && p.k_expect > 0) ? std::min(p.K, p.k_expect) : p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
   p.flags |= m->gemm_flags;
   if (m->deterministic && p.epi == EPI_ATOMIC) RC(det_slab_for(m, gemm_slab_need<T>(p, a_f32, false, a_km, b_km), p));
@@ -850,6 +851,15 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
   }
   return RSYS_OK;
+}
+
+// how many selected tokens to expect (K splits of the compact weight gradients only; the device-side count decides what is computed.
+// The same hint for the row-limited GEMMs' kernel choice -- 128 x 128 tiles for ~3 K rows instead of 12 row tiles of 256 -- was
+// measured and is not used: w2_dx 37 -> 72 us, w13_dx 57 -> 62 us): pretraining masks 2 * mask_rate of the interactions and a part of them carries a target; finetuning has one target per row
+static int expected_selected(const Model* m) {
+  const long long N = (long long)m->cur_rows * m->S;
+  const long long e = m->cfg.finetune ? 2LL * m->cur_rows : (long long)(2.0 * m->cfg.mask_rate * (double)N * 0.6);
+  return (int)std::max<long long>(256, std::min<long long>(m->ctop_cap, e));
 }
 
 // The same tail of the LAST layer plus the final norm on the compact set of selected tokens (Model::sparse_top, compact.hip):
@@ -1328,6 +1338,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     GemmParams p{};  // dW2 += gx^T . g
     p.A = m->c_gx_t; p.lda = D; p.B = m->c_g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
     p.M = D; p.N = Ip; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    p.k_expect = expected_selected(m);
     RC(gemm<T>(m, "gemm_top_w2_dw", p, false, true, true));
   }
   {
@@ -1341,6 +1352,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     GemmParams p{};  // dW13 += dab^T . hn
     p.A = m->c_dab; p.lda = 2 * Ip; p.B = m->c_hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
     p.M = 2 * Ip; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    p.k_expect = expected_selected(m);
     RC(gemm<T>(m, "gemm_top_w13_dw", p, false, true, true));
   }
   {
@@ -1356,6 +1368,7 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     GemmParams p{};  // dWo += dh^T . O
     p.A = m->c_dh_t; p.lda = D; p.B = m->c_O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
     p.M = D; p.N = D; p.K = cap; p.epi = EPI_ATOMIC; p.k_dev = n;
+    p.k_expect = expected_selected(m);
     RC(gemm<T>(m, "gemm_top_o_dw", p, false, true, true));
   }
   {
