@@ -962,3 +962,55 @@ def test_inference_select_equals_the_full_forward_and_sees_parameter_changes(dty
     with pytest.raises(Exception):
         model.inference_select(d, "retrieval", [rows * 2 * S])
     model.close()
+
+
+@pytest.mark.parametrize("dtype,tol_loss,tol_grad", [("fp32", 1e-4, 5e-4), ("bf16", 4e-2, 1.5e-1)])
+def test_partial_batch_and_rows_without_targets(dtype, tol_loss, tol_grad):
+    """Ragged inputs through the compact top: a model built for 5 rows fed 3 (the compact buffers, the selected-first order and
+    the tile maps are sized for max_rows), one of them with no target at all (its leading query tiles count is zero: the last
+    layer's attention skips the row) and one whose masks select a single position.  Losses, dense trunk output and every
+    gradient against the oracle."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg, P, d = _setup("hd64", dict(mask_rate=0.2, mask_topk=16), 3, 61)
+    S = cfg["max_sequence_length"]
+    wm, rm = synth.make_masks(cfg, 3, 63)
+    wm[1] = False; rm[1] = False                      # row 1: nothing masked, so nothing selected
+    wm[2] = False; rm[2] = False; wm[2, S // 2] = True   # row 2: one watch position
+    y_ref, l_ref, G_ref, _ = _oracle(cfg, P, d, wm, rm)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=5)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    assert relerr(model.trunk_output(3), y_ref) < (1e-4 if dtype == "fp32" else 6e-2)
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= tol_loss * max(abs(b), 1.0), (losses, l_ref)
+    for n in synth.trainable_names(cfg):
+        assert np.abs(model.grad(n) - G_ref[n]).max() <= tol_grad * max(np.abs(G_ref[n]).max(), 1e-9), n
+    if int(model.debug_get("top.cap", 3)[0]) > 0:
+        slot = model.debug_get("top.slot", 3).reshape(3, 2 * S)
+        assert (slot[1] == -1).all() and (slot[2] >= 0).sum() <= 1
+    model.close()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batch_without_any_target_gives_zero_losses_and_gradients(dtype):
+    """Every target weight zero (a shard tail of padding): nothing is selected, the compact row set is empty, the step must
+    produce zero losses and all-zero finite gradients -- not NaNs from empty reductions."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg, P, d = _setup("hd64", dict(mask_rate=0.2, mask_topk=16), 2, 71)
+    d = {k: (np.zeros_like(v) if k.endswith(".weight") else v) for k, v in d.items()}
+    wm, rm = synth.make_masks(cfg, 2, 73)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=2)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    assert all(abs(x) == 0.0 for x in losses), losses
+    if int(model.debug_get("top.cap", 2)[0]) > 0:
+        assert int(model.debug_get("top.n", 2)[0]) == 0
+    for n in synth.trainable_names(cfg):
+        g = model.grad(n)
+        assert np.isfinite(g).all() and np.abs(g).max() == 0.0, n
+    assert np.isfinite(model.trunk_output(2)).all()
+    model.close()
