@@ -18,9 +18,11 @@ namespace {
 
 struct UnionLists { const int* idx[4]; const int* npos[4]; };
 
-// One workgroup: bitmap of the selected tokens in LDS, two-level scan, then slot[tok] = rank among the selected (or -1) and
-// sel[rank] = tok.  Token of position i of task ti: 2 i + (ti & 1) (even tokens: item -> watch heads, odd: action -> rating heads).
-__global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT, int* __restrict__ slot, int* __restrict__ sel, int* nsel) {
+// One workgroup: bitmap of the selected tokens in LDS and a two-level scan over its words; out: the bitmap (bits_out[w]), the number
+// of selected tokens before word w (pre_out[w]) and their total.  slot[tok] = rank among the selected (or -1) and sel[rank] = tok are
+// written by the many workgroups of selected_first_kernel from these two arrays (one workgroup writing 64 K slots took 42 us).
+// Token of position i of task ti: 2 i + (ti & 1) (even tokens: item -> watch heads, odd: action -> rating heads).
+__global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT, unsigned int* __restrict__ bits_out, int* __restrict__ pre_out, int* nsel) {
   extern __shared__ unsigned int bits[];   // ceil(NT / 32) words
   __shared__ int wave_tot[16];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -51,11 +53,8 @@ __global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT
   int rank = base + inc - cnt;
   for (int w = w0; w < w1; ++w) {
     const unsigned int b = bits[w];
-    for (int j = 0; j < 32; ++j) {
-      const int tok = w * 32 + j;
-      if (tok >= NT) break;
-      if ((b >> j) & 1u) { slot[tok] = rank; sel[rank] = tok; ++rank; } else slot[tok] = -1;
-    }
+    bits_out[w] = b; pre_out[w] = rank;
+    rank += __popc(b);
   }
   if (t == 0) *nsel = total;
 }
@@ -66,7 +65,8 @@ __global__ __launch_bounds__(1024) void token_union_kernel(UnionLists ul, int NT
 // kernels only visit the leading query tiles (q_active).  One workgroup per batch row; T <= 2048 tokens.
 //   perm[b T + p]  = original (global) token at permuted place p        uid_p / tm_p / pos_p: that token's ids and position
 //   slot_p[b T + p] = compact row of that token or -1                    sel_p[r] = permuted place (global) of compact row r
-__global__ __launch_bounds__(1024) void selected_first_kernel(const int* __restrict__ slot, const int* __restrict__ uid, const int* __restrict__ tm,
+__global__ __launch_bounds__(1024) void selected_first_kernel(const unsigned int* __restrict__ bits, const int* __restrict__ pre, int* __restrict__ slot,
+                                                              int* __restrict__ sel, const int* __restrict__ uid, const int* __restrict__ tm,
                                                               const int* __restrict__ rope_pos, int T, int* __restrict__ perm, int* __restrict__ uid_p,
                                                               int* __restrict__ tm_p, int* __restrict__ pos_p, int* __restrict__ slot_p,
                                                               int* __restrict__ sel_p, int* __restrict__ q_active, int identity) {
@@ -76,7 +76,15 @@ __global__ __launch_bounds__(1024) void selected_first_kernel(const int* __restr
   const int per = (T + 1023) / 1024;               // 1 or 2 consecutive tokens per thread
   const int j0 = t * per, j1 = min(T, j0 + per);
   int sl[2] = {-1, -1}, cnt = 0;
-  for (int j = j0; j < j1; ++j) { sl[j - j0] = slot[base + j]; cnt += sl[j - j0] >= 0; }
+  for (int j = j0; j < j1; ++j) {   // compact row of token base + j: selected tokens before it in its bitmap word + before that word
+    const long long tok = base + j;
+    const unsigned int b = bits[tok >> 5];
+    const int bit = (int)(tok & 31);
+    const int s = ((b >> bit) & 1u) ? pre[tok >> 5] + __popc(b & ((1u << bit) - 1u)) : -1;
+    sl[j - j0] = s; cnt += s >= 0;
+    slot[tok] = s;
+    if (s >= 0) sel[s] = (int)tok;
+  }
   int inc = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
@@ -172,20 +180,20 @@ __global__ void scatter_rows_add_slot_kernel(const float* __restrict__ src, cons
 
 }  // namespace
 
-int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, int* slot, int* sel, int* nsel, hipStream_t s) {
+int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, unsigned int* bits, int* pre, int* nsel, hipStream_t s) {
   ARG_CHECK(ntask >= 1 && ntask <= 4 && NT >= 1 && NT <= (1 << 19), "token union: 1..4 tasks, at most 2^19 tokens (64 KB bitmap in LDS)");
   UnionLists ul{};
   for (int i = 0; i < ntask; ++i) { ul.idx[i] = idx[i]; ul.npos[i] = npos[i]; }
-  hipLaunchKernelGGL(token_union_kernel, dim3(1), dim3(1024), (size_t)((NT + 31) / 32) * 4, s, ul, NT, slot, sel, nsel);
+  hipLaunchKernelGGL(token_union_kernel, dim3(1), dim3(1024), (size_t)((NT + 31) / 32) * 4, s, ul, NT, bits, pre, nsel);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
-int launch_selected_first(const int* slot, const int* uid, const int* tm, const int* rope_pos, int B, int T, int* perm, int* uid_p, int* tm_p,
-                          int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s) {
+int launch_selected_first(const unsigned int* bits, const int* pre, int* slot, int* sel, const int* uid, const int* tm, const int* rope_pos, int B, int T,
+                          int* perm, int* uid_p, int* tm_p, int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s) {
   ARG_CHECK(T >= 1 && T <= 2048, "selected-first order: at most 2048 tokens per row");
   static const int identity = getenv("RSYS_TOP_ORDER") && atoi(getenv("RSYS_TOP_ORDER")) == 0 ? 1 : 0;   // RSYS_TOP_ORDER=0: keep the token order
-  hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, slot, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active, identity);
+  hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, bits, pre, slot, sel, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active, identity);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

@@ -114,11 +114,12 @@ int launch_embedding_scatter_segmented(const float* gx0, long long ldx, const in
                                        int N, int V, int D, float* gE, float* slab, hipStream_t s);
 
 // ---- selected-token (compact) row sets for the top of the trunk (compact.hip)
-// union of the tasks' live positions (token 2 idx + (task & 1), rows r < *npos[task]): sel[0 .. *nsel) ascending, slot[token] = rank or -1
-int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, int* slot, int* sel, int* nsel, hipStream_t s);
-// selected-first token order of every batch row (slot from launch_token_union): see compact.hip
-int launch_selected_first(const int* slot, const int* uid, const int* tm, const int* rope_pos, int B, int T, int* perm, int* uid_p, int* tm_p,
-                          int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s);
+// union of the tasks' live positions (token 2 idx + (task & 1), rows r < *npos[task]) as a bitmap over the tokens + the number of
+// selected tokens before each bitmap word + their total; launch_selected_first turns it into sel[0 .. *nsel) ascending, slot[token] = rank or -1
+int launch_token_union(const int* const* idx, const int* const* npos, int ntask, int NT, unsigned int* bits, int* pre, int* nsel, hipStream_t s);
+// slot / sel from the bitmap of launch_token_union, and the selected-first token order of every batch row: see compact.hip
+int launch_selected_first(const unsigned int* bits, const int* pre, int* slot, int* sel, const int* uid, const int* tm, const int* rope_pos, int B, int T,
+                          int* perm, int* uid_p, int* tm_p, int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s);
 // dst rows [0, n) <- src rows sel[r]; dst rows [n, n rounded up to 256) <- 0   (n = *n_dev <= cap)
 template <typename T> int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s);
 template <typename T> int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int cap, T* dst, long long ld, int D, hipStream_t s);
@@ -207,7 +208,7 @@ int launch_sumsq(const float* g, long long n, float* out /*device scalar, accumu
 template <typename T>
 int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_decay, long long n_total,
                  float lr, float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div,
-                 float max_norm, int zero_grad, hipStream_t s);
+                 float max_norm, int zero_grad, hipStream_t s, long long sh_skip_lo = 0, long long sh_skip_hi = 0 /* elements [lo, hi) get no shadow copy */);
 template <typename T> int launch_cast(const float* src, T* dst, long long n, hipStream_t s);
 template <typename T> int launch_widen(const T* src, float* dst, long long n, hipStream_t s);
 template <typename T> int launch_rowdot(const T* h, const float* w, const float* b, float* out, int n, int D, hipStream_t s);

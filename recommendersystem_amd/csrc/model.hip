@@ -332,6 +332,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       const int64_t cap = (std::min<int64_t>(NT, 4 * KB) + 255) / 256 * 256;
       m->ctop_cap = (int)cap;
       DALLOC(m->c_sel, cap * 4); DALLOC(m->c_slot, NT * 4); DALLOC(m->c_n, 64);
+      DALLOC(m->c_bits, (NT / 32 + 2) * 4); DALLOC(m->c_pre, (NT / 32 + 2) * 4);
       DALLOC(m->c_x, cap * D * 4); DALLOC(m->c_h, cap * D * 4); DALLOC(m->c_xL, cap * D * 4); DALLOC(m->c_rstd2, cap * 4); DALLOC(m->c_rstdf, cap * 4);
       DALLOC(m->c_O, cap * D * e); DALLOC(m->c_hn, cap * D * e); DALLOC(m->c_ab, cap * 2 * m->Ip * e); DALLOC(m->c_g, cap * m->Ip * e); DALLOC(m->c_out, cap * D * e);
       DALLOC(m->c_gy, cap * D * 4); DALLOC(m->c_gx, cap * D * 4); DALLOC(m->c_dh, cap * D * 4);
@@ -942,7 +943,8 @@ static int forward_trunk(Model* m) {
   AttnParams ap_top = ap;   // the last layer under the compact top: selected-first token order, its own tile maps, leading query tiles only
   if (m->top_is_sparse) {
     RC(select_join(m));
-    RC(launch_selected_first(m->c_slot, m->uid_t, m->tm_t, rpos, rows, m->T, m->c_perm, m->uid_p, m->tm_p, m->pos_p, m->c_slot_p, m->c_sel_p, m->c_qact, s));
+    RC(launch_selected_first(m->c_bits, m->c_pre, m->c_slot, m->c_sel, m->uid_t, m->tm_t, rpos, rows, m->T, m->c_perm, m->uid_p, m->tm_p, m->pos_p, m->c_slot_p,
+                             m->c_sel_p, m->c_qact, s));
     ap_top.uid = m->uid_p; ap_top.tm = m->tm_p;
     ap_top.qmap = m->qmap_p; ap_top.kmap = m->kmap_p; ap_top.qmap_full = m->qmap_full_p; ap_top.kmap_full = m->kmap_full_p;
     ap_top.qmap16 = m->qmap16_p; ap_top.kmap16 = m->kmap16_p;
@@ -1314,7 +1316,7 @@ static int select_positions_all(Model* m) {
   hipStream_t s = aside ? m->side : m->stream;
   if (aside) { HIP_CHECK(hipEventRecord(m->ev_fork, m->stream)); HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
   RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
-  if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_slot, m->c_sel, m->c_n, s));
+  if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_bits, m->c_pre, m->c_n, s));
   if (aside) { HIP_CHECK(hipEventRecord(m->ev_sel, m->side)); m->sel_pending = true; }
   return RSYS_OK;
 }
@@ -1871,12 +1873,14 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
     ss = m->sumsq;
   }
   o->step += 1;
-  tic(m, "adamw", (m->bf16_mode ? 34.0 : 32.0) * m->n_opt);   // p, g, m, v read; p, m, v, zeroed g (+ bf16 shadow) written
+  // the bf16 shadow of the item table E is read by no kernel (the fused-table GEMM adds E in fp32): the pass does not write it
+  const long long e_lo = m->cfg.finetune ? 0 : m->o_E, e_hi = m->cfg.finetune ? 0 : m->o_E + pad8((int64_t)m->TR * m->D);
+  tic(m, "adamw", 32.0 * m->n_opt + (m->bf16_mode ? 2.0 * (m->n_opt - (e_hi - e_lo)) : 0.0));   // p, g, m, v read; p, m, v, zeroed g (+ bf16 shadow) written
   int rc;
   if (!m->cfg.finetune) { m->wt_dirty = true; m->table_dirty = true; }   // (finetune: only the LoRA segment moves; base weights, their transposes and the fused table stay)
   if (m->bf16_mode)
     rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
-                            o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);
+                            o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream, e_lo, e_hi);
   else
     rc = launch_adamw<float>(m->P, m->G, o->mom, o->var, nullptr, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                              o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream);

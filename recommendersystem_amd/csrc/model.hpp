@@ -165,6 +165,7 @@ struct Model {
   bool top_is_sparse = false;     // the resident forward ran the compact tail: la[L-1].{h,hn,ab,g}, xL and out are NOT materialised
   int ctop_cap = 0;               // rows of the compact buffers: min(tokens, 4 * mask_topk * rows) rounded up to 256
   int *c_sel = nullptr, *c_slot = nullptr, *c_n = nullptr;
+  unsigned int* c_bits = nullptr; int* c_pre = nullptr;   // bitmap of the selected tokens and the selected count before each of its words
   float *c_x = nullptr, *c_h = nullptr, *c_xL = nullptr, *c_rstd2 = nullptr, *c_rstdf = nullptr;
   void *c_O = nullptr, *c_hn = nullptr, *c_ab = nullptr, *c_g = nullptr, *c_out = nullptr;
   float *c_gy = nullptr, *c_gx = nullptr, *c_dh = nullptr;

@@ -45,7 +45,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m, float* v, T* shadow, long long n_decay,
                                                     long long n_total, float lr, float b1, float b2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, const float* sumsq, float grad_div,
-                                                    float max_norm, int zero_grad) {
+                                                    float max_norm, int zero_grad, long long sh_skip_lo, long long sh_skip_hi) {
   const float coef = grad_coef(sumsq, grad_div, max_norm);
   const long long n4 = n_total >> 2;  // n_decay and n_total are multiples of 4 (the flat layout pads every tensor)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m
     ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)v)[i] = vv;
     if (zero_grad) ((float4*)g)[i] = make_float4(0, 0, 0, 0);
     if constexpr (is_bf16<T>::value) {
-      if (shadow) {
+      if (shadow && !(i * 4 >= sh_skip_lo && i * 4 < sh_skip_hi)) {   // (no bf16 copy where no kernel reads one: the item table E)
         bf16x4 sv; sv[0] = (bf16)pp[0]; sv[1] = (bf16)pp[1]; sv[2] = (bf16)pp[2]; sv[3] = (bf16)pp[3];
         ((bf16x4*)shadow)[i] = sv;
       }
@@ -75,18 +75,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m
 template <typename T>
 int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_decay, long long n_total, float lr,
                  float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div, float max_norm,
-                 int zero_grad, hipStream_t s) {
-  ARG_CHECK(n_decay % 4 == 0 && n_total % 4 == 0, "adamw: flat sizes must be multiples of 4");
+                 int zero_grad, hipStream_t s, long long sh_skip_lo, long long sh_skip_hi) {
+  ARG_CHECK(n_decay % 4 == 0 && n_total % 4 == 0 && sh_skip_lo % 4 == 0 && sh_skip_hi % 4 == 0, "adamw: flat sizes must be multiples of 4");
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2s = sqrtf(1.f - powf(b2, (float)step));
   int grid = (int)std::min<long long>(((n_total >> 2) + 255) / 256, 4096);
   hipLaunchKernelGGL((adamw_kernel<T>), dim3(grid), dim3(256), 0, s, p, g, m, v, shadow, n_decay, n_total, lr, b1, b2, eps,
-                     wd, bc1, bc2s, sumsq, grad_div, max_norm, zero_grad);
+                     wd, bc1, bc2s, sumsq, grad_div, max_norm, zero_grad, sh_skip_lo, sh_skip_hi);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_adamw<bf16>(float*, float*, float*, float*, bf16*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t);
-template int launch_adamw<float>(float*, float*, float*, float*, float*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t);
+template int launch_adamw<bf16>(float*, float*, float*, float*, bf16*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t, long long, long long);
+template int launch_adamw<float>(float*, float*, float*, float*, float*, long long, long long, float, float, float, float, float, int, const float*, float, float, int, hipStream_t, long long, long long);
 
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* dst, long long n) {
