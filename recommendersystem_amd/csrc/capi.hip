@@ -457,6 +457,55 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
   return RSYS_OK;
 }
 
+int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32_t cols, int32_t fmt, int32_t layout, int32_t seg_cols,
+                            void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev, int32_t n_w,
+                            int32_t desc_mode) {
+  ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_quantize: null buffer");
+  F8Cast c{};
+  c.src = src; c.ld_src = ld_src; c.rows = rows; c.cols = cols; c.fmt = fmt; c.layout = layout; c.seg_cols = seg_cols;
+  c.amax = amax_dev; c.dst = (unsigned char*)dst; c.ld_dst = ld_dst; c.desc = desc_dev; c.wamax = wamax_dev; c.n_w = n_w; c.desc_mode = desc_mode;
+  HIP_CHECK(hipMemsetAsync(amax_dev, 0, 16, nullptr));
+  int rc = launch_f8_amax(c, nullptr);
+  if (!rc) rc = launch_f8_cast(c, nullptr);
+  if (rc) return rc;
+  HIP_CHECK(hipDeviceSynchronize());
+  return RSYS_OK;
+}
+
+int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, float* amax_dev,
+                           void* dst, void* dst_t, int64_t ld_t) {
+  ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_weights: null buffer");
+  ARG_CHECK(cols % 4 == 0 && rows % 16 == 0, "rsys_op_f8_weights: rows % 16, cols % 4");
+  F8WeightJob j{};
+  j.src = src; j.ld = ld; j.rows = rows; j.cols = cols; j.layout = layout; j.seg_rows = seg_rows; j.amax = amax_dev;
+  j.dst = (unsigned char*)dst; j.dst_t = (unsigned char*)dst_t; j.ld_t = ld_t;
+  const int ntiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+  std::vector<int> tj(ntiles, 0); int first = 0;
+  void* dev = nullptr;
+  HIP_CHECK(hipMalloc(&dev, sizeof(F8WeightJob) + 256 + (size_t)ntiles * 4 + 64));
+  F8WeightJob* dj = (F8WeightJob*)dev; int* dfirst = (int*)((char*)dev + ((sizeof(F8WeightJob) + 63) / 64) * 64); int* dtj = dfirst + 16;
+  bool ok = hipMemcpy(dj, &j, sizeof(j), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dfirst, &first, 4, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(dtj, tj.data(), (size_t)ntiles * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(amax_dev, 0, 16) == hipSuccess;
+  int rc = ok ? launch_f8_weights(dj, dtj, dfirst, ntiles, nullptr) : RSYS_ERR_HIP;
+  hipError_t e2 = hipDeviceSynchronize();
+  hipFree(dev);
+  if (rc) { if (!ok) set_error("rsys_op_f8_weights: job upload failed"); return rc; }
+  HIP_CHECK(e2);
+  return RSYS_OK;
+}
+
+int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                        int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kseg) {
+  GemmParams p{};
+  p.A = A8; p.B = B8; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.c_f32 = c_f32; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE;
+  p.f8 = a_fmt == F8_E5M2 ? 2 : 1; p.f8_desc = desc_dev; p.f8_seg_cols = seg_cols; p.f8_alt = alt; p.f8_kseg = kseg;
+  int rc = launch_gemm8p_f8(p, nullptr);
+  if (rc) return rc;
+  HIP_CHECK(hipDeviceSynchronize());
+  return RSYS_OK;
+}
+
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin) {

@@ -52,6 +52,16 @@ struct GemmParams {
   float* slab; long long slab_floats;
   int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
                     // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip)
+  // fp8 operands (launch_gemm8p_f8, the fp8 trunk of f8.hip): f8 = 1: A is e4m3, 2: A is e5m2; B is always e4m3.  lda / ldb / K
+  // count 1-byte elements.  The fp32 accumulators are multiplied by a descale 1 / (scale_A scale_B) before the epilogue:
+  int f8;
+  const float* f8_desc;   // device floats: [0..3] output descales, [4..5] accumulator ratios at K-segment boundaries
+  int f8_seg_cols;        // > 0: output column c takes f8_desc[c / f8_seg_cols] (q | k | v weights of different scale), else f8_desc[0]
+  int f8_alt;             // 1: 16-column blocks alternate between f8_desc[0] and f8_desc[1] (the [16 a | 16 b] SwiGLU interleave: W1 | W3)
+  int f8_kseg;            // > 0: K is a run of segments of f8_kseg K tiles (128 elements each) quantised with different scales; the
+                          // accumulators are multiplied by f8_desc[4 + j] when segment j ends, f8_desc[0] is the last segment's descale
+  int f8_rseg;            // split-K form: output ROW r takes f8_desc[r / f8_rseg] (rows of dY^T: segments of different scale); 0: f8_desc[0]
+  const int* f8_rowmap;   // split-K form: output row r is added to row f8_rowmap[r] of C (de-interleaved dab^T rows back to W13's order)
 };
 
 // CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).
@@ -73,6 +83,10 @@ void gemm8p_group_plan_destroy(GemmGroupPlan* pl);
 double gemm8p_group_flops(const GemmGroupPlan* pl);
 int gemm8p_group_splitk(const GemmGroupPlan* pl);
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s);
+
+// fp8 row-major operands on the persistent 256x256 pipeline (K tiles of 128 elements, v_mfma_f32_16x16x128_f8f6f4); p.f8 set
+bool gemm8p_f8_eligible(const GemmParams& p);
+int launch_gemm8p_f8(const GemmParams& p, hipStream_t s);
 
 // short name of the kernel launch_gemm picks for this problem ("8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);

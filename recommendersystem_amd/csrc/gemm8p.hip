@@ -75,11 +75,19 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // as row-major (K-contiguous) copies: the metadata-projection gradient on transposed copies of dF and Meta.
 // GROUP (K-major form only): the workgroup's (tile, K split) comes from a work list (gemm8p_group_kernel below) instead of the
 // block index: many small products in one launch.
-template <bool KM, bool SK, bool GROUP>
+// F8 (row-major operands only): 1-byte operands, A e4m3 (1) or e5m2 (2), B e4m3.  A K tile is still 128 bytes per row, i.e. 128
+// elements: the LDS image, the DMA pattern and the two 16-byte fragment reads per lane are byte for byte those of the bf16 form;
+// the two reads together are the lane's 32 k values of ONE v_mfma_f32_16x16x128_f8f6f4 (both operands use the same k order, so
+// which 32 of the 128 a lane group holds does not matter).  The accumulators are multiplied by the descale of the operands'
+// tensor-wise scales before the epilogue (GemmParams::f8_*).
+template <bool KM, bool SK, bool GROUP, int F8 = 0>
 __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, const int nblk, const int g_tile, const int g_split) {
   static_assert(!(KM && SK), "the K-major form is always split-K");
-  static_assert(!GROUP || KM, "grouped launches exist for the K-major form");
+  static_assert(!GROUP || KM || SK, "grouped launches exist for the split-K forms");
+  static_assert(!F8 || !KM, "fp8 operands are row-major");
   constexpr bool PERSIST = !KM && !SK;
+  constexpr int KE = F8 ? 128 : T8_BK;     // elements per K tile
+  constexpr int ES = F8 ? 1 : 2;           // bytes per element
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l0 = t & 63;
   int l = l0;   // refreshed per tile through an opaque move: nothing derived from it is carried across an epilogue
@@ -102,7 +110,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     tile_step = (G + 7 - xcd) >> 3;                    // workgroups on this XCD
     if (tile >= tile_end) return;                      // uniform: whole workgroup leaves
     tile_first = tile;
-    nt = p.K / T8_BK;                                  // launcher: K % 64 == 0, nt >= 2
+    nt = p.K / KE;                                     // launcher: K % 64 (128) == 0, nt >= 2
   } else {
     // split-K (launcher: splitk % 8 == 0): XCD x owns the K splits x, x+8, ...; inside an XCD the tiles of one split
     // vary fastest, so the K-major operand rows of a split are fetched from HBM by one L2 only
@@ -115,7 +123,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       split = xcd + 8 * (local / ntiles);
     }
     split_id = split;
-    const int ktiles = (p.K + T8_BK - 1) / T8_BK, per = (ktiles + p.splitk - 1) / p.splitk;
+    const int ktiles = (p.K + KE - 1) / KE, per = (ktiles + p.splitk - 1) / p.splitk;
     kt0 = split * per;
     nt = min(ktiles, kt0 + per) - kt0;
     if (nt <= 0) return;
@@ -134,8 +142,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       for (int h = 0; h < 2; ++h) {
         const int grow = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);   // clamped rows are never stored
         const int gcol = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), p.N - 1);
-        aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * 8) * 2);
-        boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * 8) * 2);
+        aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * (16 / ES)) * ES);
+        boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * (16 / ES)) * ES);
       }
     } else {
       // K-major: piece (w*2+j) = k rows (w*2+j)*4 + [0,4) of the half-tile, 256 B = eight 16-column blocks per row;
@@ -248,9 +256,19 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     if constexpr (T8_VARIANT & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (!(T8_VARIANT & 2)) __builtin_amdgcn_s_setprio(1);
     static_for<4>([&](auto i) { static_for<2>([&](auto j) {
+      if constexpr (F8 != 0) {
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        typedef __attribute__((ext_vector_type(4))) int i32x4v;
+        const i32x4v b0 = __builtin_bit_cast(i32x4v, bf[j][0]), b1 = __builtin_bit_cast(i32x4v, bf[j][1]);
+        const i32x4v a0 = __builtin_bit_cast(i32x4v, af[i][0]), a1 = __builtin_bit_cast(i32x4v, af[i][1]);
+        const i32x8 bb = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7), aa = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        // first operand (cbsz) = the B matrix (weights, e4m3), second (blgp) = the A matrix (e4m3 or e5m2); scales unused (0)
+        acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bb, aa, acc[ih * 4 + i][jh * 2 + j], 0, F8 == 2 ? 1 : 0, 0, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-        acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk)
+          acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+      }
     }); });
     if constexpr (!(T8_VARIANT & 2)) __builtin_amdgcn_s_setprio(0);
   };
@@ -280,8 +298,24 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   using W8 = std::integral_constant<int, 8>;
   using W10 = std::integral_constant<int, 10>;
   int pend = 0;
+  typedef const __attribute__((address_space(4))) float* cfloat_p;   // scalar loads: no vector memory counter involved
+  int kseg_left = 0, kseg_idx = 0;
   auto tile_body = [&](int kt) {
     const int bo = (kt & 1) << 16, bn = bo ^ 65536;
+    if constexpr (F8 != 0) {
+      if (p.f8_kseg > 0) {   // a K segment with another scale begins: bring the sums so far into its units
+        if (kseg_left == 0 && kt > 0) {
+          const float r = ((cfloat_p)p.f8_desc)[4 + kseg_idx];
+          ++kseg_idx;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= r;
+        }
+        if (kseg_left == 0) kseg_left = p.f8_kseg;
+        --kseg_left;
+      }
+    }
     // P1
     read_b(bf0, bo, 0);
     read_a(bo, 0);
@@ -358,6 +392,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  kseg_left = 0; kseg_idx = 0;
   // B0, A0, B1 of K tile 0 have landed
   if (nt > 1) wait_vm(W10{}, pend); else wait_vm(W2{}, pend);
   T8_BARRIER();
@@ -386,6 +421,13 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   TR_MARK(2);
   // ------------------------------------------------------------------ epilogue (gemm_epi_reg.hpp)
   if (p.epi == 99) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = acc[7][3][3] + acc[3][1][2]; if (!more) return; l = l0; asm volatile("" : "+v"(l)); fq = l >> 4; fr = l & 15; lane_offsets(); tile_offsets(); continue; }   // timing experiment: no epilogue
+  if constexpr (F8 != 0 && PERSIST) {
+    const cfloat_p d = (cfloat_p)p.f8_desc;
+    const int seg = p.f8_seg_cols > 0 ? (en0 + wc * 64) / p.f8_seg_cols : 0;   // (segments are multiples of 64 columns: uniform per wave)
+    const float ce = d[p.f8_alt ? 0 : seg], co = d[p.f8_alt ? 1 : seg];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[i][0] *= ce; acc[i][1] *= co; acc[i][2] *= ce; acc[i][3] *= co; }
+  }
   if constexpr (PERSIST) {
     epilogue_regs<WANT ? 1 : 0>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
     // A lower bound on the vector memory instructions of the epilogue that follow its last load: all stores where the
@@ -467,6 +509,11 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
 template <bool KM, bool SK = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   gemm8p_body<KM, SK, false>(p, blockIdx.x, gridDim.x, 0, 0);
+}
+
+template <int F8>
+__global__ __launch_bounds__(512) void gemm8p_f8_kernel(GemmParams p) {
+  gemm8p_body<false, false, false, F8>(p, blockIdx.x, gridDim.x, 0, 0);
 }
 
 // Grouped K-major split-K launch: the weight gradients dW = dY^T X of MANY layers in one grid.  Each product alone is too small
@@ -666,6 +713,40 @@ static int cu_count() {
     else n = 256;
   }
   return n;
+}
+
+// fp8 operands: the same eligibility in bytes (K tiles of 128 elements)
+bool gemm8p_f8_eligible(const GemmParams& p) {
+  if (p.f8 != 1 && p.f8 != 2) return false;
+  if (p.f8_desc == nullptr) return false;
+  if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr || p.accum) return false;
+  if (p.K % 128 != 0 || p.K < 256) return false;
+  if (p.lda % 16 != 0 || p.ldb % 16 != 0) return false;
+  if ((unsigned long long)p.M * p.lda >= (1ull << 32) || (unsigned long long)p.N * p.ldb >= (1ull << 32)) return false;
+  if (p.N % 8 != 0) return false;
+  if (p.f8_seg_cols > 0 && p.f8_seg_cols % 64 != 0) return false;
+  if (p.f8_alt && p.N % 32 != 0) return false;
+  if (p.f8_kseg > 0 && (p.K / 128) % p.f8_kseg != 0) return false;
+  const unsigned long long lim = 1ull << 32;
+  const bool cf = p.c_f32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
+  if ((unsigned long long)p.M * p.ldc * (cf ? 4 : 2) >= lim) return false;
+  if (p.C2 != nullptr && (unsigned long long)p.M * p.ldc2 * 2 >= lim) return false;
+  if (p.epi == EPI_RESIDUAL && (unsigned long long)p.M * p.ldr * 4 >= lim) return false;
+  if (p.epi == EPI_QKV_ROPE && p.alpha != 1.f) return false;
+  if (p.epi == EPI_SWIGLU && (p.N % 32 != 0 || p.ldc2 % 8 != 0)) return false;
+  return true;
+}
+
+int launch_gemm8p_f8(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  ARG_CHECK(gemm8p_f8_eligible(p), "fp8 GEMM: shape / operand layout not supported by the 256x256 fp8 pipeline (K % 128, K >= 256, strides % 16)");
+  if (p.alpha == 0.f) p.alpha = 1.f;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  const dim3 grid((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cu_count()));
+  if (p.f8 == 1) hipLaunchKernelGGL(gemm8p_f8_kernel<1>, grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL(gemm8p_f8_kernel<2>, grid, dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
 }
 
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {

@@ -223,4 +223,29 @@ int launch_fill_normal(float* dst, long long n, float std, unsigned long long se
 template <typename T>
 int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s, long long row0 = 0);
 
+// ---- fp8 trunk (f8.hip): torchao's tensor-wise dynamic scaling restated (transformer.py:671-676)
+enum { F8_E4M3 = 0, F8_E5M2 = 1 };
+enum { F8_LAYOUT_PLAIN = 0, F8_LAYOUT_SEGS = 1, F8_LAYOUT_SWIGLU = 2 };
+struct F8Cast {
+  const void* src; long long ld_src; int src_f32;   // bf16 (or f32) [rows][cols]
+  int rows, cols;
+  const int* rows_dev;                    // optional device-side row count (rows up to the next multiple of 256 are zero-filled)
+  int fmt, layout, seg_cols;              // SEGS: cols / seg_cols (<= 4) equal column segments with their own amax; SWIGLU: [16 a | 16 b] blocks, 2 amaxes
+  float* amax;                            // device, one slot per segment: zero before launch_f8_amax; read by launch_f8_cast
+  unsigned char* dst; long long ld_dst;   // [rows][cols] (SWIGLU: columns de-interleaved to [all a | all b])
+  // descales of the consumer GEMM (GemmParams::f8_desc), written by the cast: mode 1 = output-column segments (this tensor's scale x
+  // n_w weight scales), mode 2 = K segments (this tensor's segment j x weight j; desc[0] = last, desc[4 + j] = ratios)
+  float* desc; const float* wamax; int n_w; int desc_mode;
+};
+int launch_f8_amax(const F8Cast& c, hipStream_t s);
+int launch_f8_cast(const F8Cast& c, hipStream_t s);
+struct F8WeightJob {
+  const float* src; long long ld; int rows, cols;   // fp32 master [rows][cols]
+  int layout, seg_rows;                             // SEGS: rows / seg_rows (<= 3) row segments (q | k | v); SWIGLU: [16 w1 | 16 w3] row blocks
+  float* amax;                                      // one slot per segment
+  unsigned char* dst;                               // e4m3 [rows][cols]
+  unsigned char* dst_t; long long ld_t;             // e4m3 [cols][ld_t]: column = row (SWIGLU: de-interleaved to [all w1 | all w3])
+};
+int launch_f8_weights(const F8WeightJob* jobs_dev, const int* tile_job_dev, const int* tile_first_dev, int ntiles, hipStream_t s);
+
 }  // namespace rsys
