@@ -26,7 +26,11 @@ typedef struct rsys_model rsys_model;
 typedef struct rsys_optimizer rsys_optimizer;
 typedef struct rsys_comm rsys_comm;
 
-enum { RSYS_DTYPE_FP32 = 0, RSYS_DTYPE_BF16 = 1 };
+/* RSYS_DTYPE_FP8: bf16 arithmetic with the transformer blocks' linears (q k v o w1 w3 w2: forward and input-gradient products) on
+ * tensor-wise dynamically scaled fp8 operands -- the reference's pretraining arithmetic (transformer.py:671-676, torchao
+ * "tensorwise": e4m3 inputs and weights, e5m2 output gradients); pretraining only, needs embed_dim % 128 == 0 >= 256,
+ * intermediate_dim % 128 == 0, (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14 */
+enum { RSYS_DTYPE_FP32 = 0, RSYS_DTYPE_BF16 = 1, RSYS_DTYPE_FP8 = 2 };
 
 /* mirrors the config dict of train.py:535-560 (+ finetune keys of :520-524) */
 typedef struct rsys_config {
@@ -217,20 +221,23 @@ int32_t rsys_op_embedding_scatter(const float* gx0, int64_t ldx, const int32_t* 
                                   int32_t V, int32_t D, float* gE, int32_t atomic);
 /* fp8 trunk (RSYS_DTYPE_FP8: the reference's torchao "tensorwise" float8 linears, transformer.py:671-676), unit-test access on
  * caller-provided device buffers.  fmt: 0 = e4m3, 1 = e5m2.
- * rsys_op_f8_quantize: amax_dev[seg] = max |src| per column segment (layout 0: one; 1: cols / seg_cols equal segments; 2: the
- *   [16 a | 16 b] column blocks of the W13 output, two segments), then dst = sat_rne(src * FMAX / amax) as fp8 bytes (layout 2:
- *   columns de-interleaved to [all a | all b]); src bf16 [rows][cols].  desc_mode 1 / 2 also writes the descales a consumer GEMM
- *   takes (1: desc[i] = 1 / (s_src s_w[i]) for n_w weight amaxes; 2: K segments, desc[0] = last segment, desc[4 + j] = ratios).
+ * rsys_op_f8_quantize: amax_dev[seg] = max |src| per column segment (layout 0: one; 1: column units of seg_cols, the first seg_rep
+ *   units are segment 0 and every further unit its own segment -- q | k | v with grouped-query heads; 2: the [16 a | 16 b] column
+ *   blocks of the W13 output, two segments), then dst = sat_rne(src * FMAX / amax) as fp8 bytes (layout 2: columns de-interleaved
+ *   to [all a | all b]); src bf16 [rows][cols].  desc_mode 1 / 2 also writes the descales a consumer GEMM takes (1: desc[u] =
+ *   1 / (s_src s_w[weight of output unit u]) for n_w weight amaxes, the first w_rep units on weight 0; 2: K segments, desc[0] =
+ *   last segment, desc[16 + j] = ratios); desc_dev holds 32 floats.
  * rsys_op_f8_weights: the same for one fp32 weight matrix [rows][cols] (row segments), plus its transposed copy dst_t [cols][ld_t].
  * rsys_op_gemm_f8: C[M,N] = descale * sum_k A8[m][k] B8[n][k] on the 256x256 fp8 pipeline (K % 128 == 0, K >= 256); a_fmt as fmt,
- *   B is e4m3; desc_dev / seg_cols / alt / kseg as GemmParams::f8_* (csrc/gemm.hpp); C bf16 or f32. */
+ *   B is e4m3; desc_dev / seg_cols / alt / kb0..kb2 as GemmParams::f8_* (csrc/gemm.hpp); C bf16 or f32. */
 int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32_t cols, int32_t fmt, int32_t layout, int32_t seg_cols,
-                            void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev, int32_t n_w,
-                            int32_t desc_mode);
-int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, float* amax_dev,
-                           void* dst, void* dst_t, int64_t ld_t);
+                            int32_t seg_rep, void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev,
+                            int32_t n_w, int32_t w_rep, int32_t desc_mode);
+int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, int32_t seg_rep,
+                           float* amax_dev, void* dst, void* dst_t, int64_t ld_t);
 int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                        int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kseg);
+                        int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kb0, int32_t kb1,
+                        int32_t kb2);
 /* per-step time distribution (bench.py): rsys_step_mark records an event on the model's stream at an optimizer-step
  * boundary; rsys_step_marks_get writes the milliseconds between consecutive marks (at most cap) and clears the marks */
 int32_t rsys_step_mark(rsys_model* m);

@@ -162,13 +162,18 @@ class OracleModel:
         """operand_round="bf16": every array the HIP path stores as a bf16 GEMM operand (weights' shadow copies,
         normalised activations, q/k/v, attention probabilities and outputs, SwiGLU products, logits, and the matching
         gradient operands of the backward) is rounded to bfloat16 at that point; accumulation stays in `dtype`.  This
-        is the reference's autocast arithmetic as the benchmarked mode computes it, for the tight bf16 parity check."""
+        is the reference's autocast arithmetic as the benchmarked mode computes it, for the tight bf16 parity check.
+        operand_round="fp8": the same, and the transformer blocks' linears (q k v o w1 w3 w2: forward and input-gradient
+        products) take tensor-wise dynamically scaled fp8 operands -- torchao's "tensorwise" float8 recipe the reference applies
+        to `transformers.*` for pretraining (transformer.py:671-676), restated in oracle/fp8.py (parity unpinned against torchao
+        itself).  Weight gradients use the bf16 operands, as the HIP path's fp8 mode does."""
         self.cfg = cfg
         self.dt = dtype
+        self.fp8 = operand_round == "fp8"
         if operand_round is None:
             self.q = lambda a: a
         else:
-            assert operand_round == "bf16"
+            assert operand_round in ("bf16", "fp8")
             self.q = lambda a: bf16_round(a).astype(dtype)
         self.P = {k: np.asarray(v, dtype) for k, v in P.items()}
         D = cfg["embed_dim"]; H = cfg["num_heads"]
@@ -181,6 +186,24 @@ class OracleModel:
     def W(self, name):
         """a weight as a GEMM operand (rounded like the bf16 shadow when operand rounding is on)"""
         return self.q(self.P[name])
+
+    def lin(self, x, name):
+        """y = x W^T of a trunk linear (torchao Float8Linear forward in fp8 mode: e4m3 input and weight, one scale per tensor)"""
+        if not self.fp8:
+            return x @ self.W(name).T
+        from . import fp8
+        qx, sx = fp8.quantize(np.asarray(x, np.float32), fp8.E4M3)
+        qw, sw = fp8.quantize(np.asarray(self.P[name], np.float32), fp8.E4M3)
+        return (qx.astype(self.dt) @ qw.astype(self.dt).T) * self.dt(fp8.descale(sx, sw))
+
+    def lin_dx(self, g, name):
+        """dx = g W (fp8 mode: e5m2 output gradient, e4m3 weight)"""
+        if not self.fp8:
+            return g @ self.W(name)
+        from . import fp8
+        qg, sg = fp8.quantize(np.asarray(g, np.float32), fp8.E5M2)
+        qw, sw = fp8.quantize(np.asarray(self.P[name], np.float32), fp8.E4M3)
+        return (qg.astype(self.dt) @ qw.astype(self.dt)) * self.dt(fp8.descale(sg, sw))
 
     # ---- embeddings
     def action_features(self, d):
@@ -233,9 +256,9 @@ class OracleModel:
             Q = self.q
             xn, r1 = rmsnorm(x, P[p + "sa_norm.scale"])
             xn = Q(xn)
-            q = xn @ self.W(p + "attn.q_proj.weight").T
-            k = xn @ self.W(p + "attn.k_proj.weight").T
-            v = xn @ self.W(p + "attn.v_proj.weight").T
+            q = self.lin(xn, p + "attn.q_proj.weight")
+            k = self.lin(xn, p + "attn.k_proj.weight")
+            v = self.lin(xn, p + "attn.v_proj.weight")
             if self.lora:                                               # model.py:263-271 (dropout = identity)
                 c["qa"] = Q(xn @ self.W(p + "attn.q_proj_lora_A.weight").T)
                 c["va"] = Q(xn @ self.W(p + "attn.v_proj_lora_A.weight").T)
@@ -251,16 +274,16 @@ class OracleModel:
             pr = np.exp(s); den = pr.sum(-1, keepdims=True)
             o = Q((np.matmul(Q(pr), vh) / den).transpose(0, 2, 1, 3).reshape(B, T, H * hd))   # (flash kernels round exp(s - max), not the quotient)
             pr /= den
-            h = x + o @ self.W(p + "attn.output_proj.weight").T
+            h = x + self.lin(o, p + "attn.output_proj.weight")
             hn, r2 = rmsnorm(h, P[p + "mlp_norm.scale"])
             hn = Q(hn)
-            a = hn @ self.W(p + "mlp.w1.weight").T
-            b = hn @ self.W(p + "mlp.w3.weight").T
+            a = self.lin(hn, p + "mlp.w1.weight")
+            b = self.lin(hn, p + "mlp.w3.weight")
             sig = 1.0 / (1.0 + np.exp(-a))
             g = Q(a * sig * b)
             a = Q(a); b = Q(b)                                          # (what the backward reads back; the product above used the accumulators)
             sig = 1.0 / (1.0 + np.exp(-a))
-            out = h + g @ self.W(p + "mlp.w2.weight").T
+            out = h + self.lin(g, p + "mlp.w2.weight")
             c.update(x=x, xn=xn, r1=r1, q=q, k=k, v=v, pr=pr, o=o, h=h, hn=hn, r2=r2, a=a, b=b, sig=sig, g=g)
             cache.append(c)
             x = out
@@ -284,18 +307,18 @@ class OracleModel:
             Q = self.q
             gxq = Q(gx)                                                 # the gradient as a GEMM operand
             G[p + "mlp.w2.weight"] = fl(gxq).T @ fl(c["g"])
-            gg = gxq @ self.W(p + "mlp.w2.weight")
+            gg = self.lin_dx(gxq, p + "mlp.w2.weight")
             ga = Q(gg * c["b"] * (c["sig"] * (1.0 + c["a"] * (1.0 - c["sig"]))))
             gb = Q(gg * c["a"] * c["sig"])
             G[p + "mlp.w1.weight"] = fl(ga).T @ fl(c["hn"])
             G[p + "mlp.w3.weight"] = fl(gb).T @ fl(c["hn"])
-            ghn = Q(ga @ self.W(p + "mlp.w1.weight") + gb @ self.W(p + "mlp.w3.weight"))
+            ghn = Q(self.lin_dx(ga, p + "mlp.w1.weight") + self.lin_dx(gb, p + "mlp.w3.weight"))
             dh, G[p + "mlp_norm.scale"] = rmsnorm_bwd(ghn, c["h"], P[p + "mlp_norm.scale"], c["r2"])
             gh = gx + dh
             ghq = Q(gh)
             # h = x + o Wo^T
             G[p + "attn.output_proj.weight"] = fl(ghq).T @ fl(c["o"])
-            go = Q(ghq @ self.W(p + "attn.output_proj.weight")).reshape(B, T, H, hd)
+            go = Q(self.lin_dx(ghq, p + "attn.output_proj.weight")).reshape(B, T, H, hd)
             kk = np.repeat(c["k"], rep, axis=2); vv = np.repeat(c["v"], rep, axis=2)
             pr = c["pr"]
             goh = go.transpose(0, 2, 1, 3); kh = kk.transpose(0, 2, 1, 3); vh = vv.transpose(0, 2, 1, 3)
@@ -312,7 +335,7 @@ class OracleModel:
             gq = Q(apply_rope_bwd(gq, cos, sin).reshape(B, T, H * hd))
             gk = Q(apply_rope_bwd(gk, cos, sin).reshape(B, T, KV * hd))
             gv = Q(gv.reshape(B, T, KV * hd))
-            gxn = gq @ self.W(p + "attn.q_proj.weight") + gk @ self.W(p + "attn.k_proj.weight") + gv @ self.W(p + "attn.v_proj.weight")
+            gxn = self.lin_dx(gq, p + "attn.q_proj.weight") + self.lin_dx(gk, p + "attn.k_proj.weight") + self.lin_dx(gv, p + "attn.v_proj.weight")
             if self.lora:
                 G[p + "attn.q_proj_lora_B.weight"] = 2.0 * fl(gq).T @ fl(c["qa"])
                 G[p + "attn.v_proj_lora_B.weight"] = 2.0 * fl(gv).T @ fl(c["va"])

@@ -103,11 +103,11 @@ _SIGS = [
     ("rsys_dev_memset", C.c_int32, [_P, C.c_int, C.c_size_t]),
     ("rsys_op_gemm", C.c_int32, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    ("rsys_op_f8_quantize", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P,
-                                          C.c_int32, C.c_int32]),
-    ("rsys_op_f8_weights", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64]),
+    ("rsys_op_f8_quantize", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P,
+                                          C.c_int32, C.c_int32, C.c_int32]),
+    ("rsys_op_f8_weights", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64]),
     ("rsys_op_gemm_f8", C.c_int32, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P,
-                                      C.c_int32, C.c_int32, C.c_int32]),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("rsys_op_gemm_rows", C.c_int32, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int32, C.c_int32, _P]),
     ("rsys_op_attention", C.c_int32, [C.c_int32] + [C.c_int32] * 5 + [_P] * 9),

@@ -100,7 +100,7 @@ def main(argv=None):
     ap.add_argument("--prod", action="store_true")
     ap.add_argument("--model", default="prod", help="prod (transformer.py:536-558) or a workload.make_config name")
     ap.add_argument("--metadata_emb_size", type=int, default=3072 * 2 + 4)
-    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32"))
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "fp8"))
     ap.add_argument("--local_batch_size", type=int, default=None)
     ap.add_argument("--global_batch_size", type=int, default=None, help="rows per optimizer step (transformer.py:593, 600: 32 / 512)")
     ap.add_argument("--num_epochs", type=int, default=None)

@@ -165,6 +165,37 @@ int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes)
   else if (k == "table.fused") { src = m->F32; n = (int64_t)m->TR * m->D * 4; }
   else if (k == "host_syncs") {   // blocking host waits inside the last rsys_forward_backward: {stream drains, waits on the early-counts event}
     ARG_CHECK(bytes == 8, "host_syncs: two int32"); ((int32_t*)out)[0] = m->host_stream_syncs; ((int32_t*)out)[1] = m->host_event_waits; return RSYS_OK; }
+  else if (k.compare(0, 4, "act.") == 0 && k.size() > 6) {   // act.<layer>.<x|xn|qkv|O|h|hn|ab|g>: a saved activation of the last forward (T-typed ones as stored)
+    const size_t dot = k.find('.', 4);
+    const int l = atoi(k.substr(4, dot - 4).c_str());
+    const std::string f = dot == std::string::npos ? "" : k.substr(dot + 1);
+    ARG_CHECK(l >= 0 && l < m->L, "act: layer index");
+    const Model::LayerAct& a = m->la[l];
+    const int64_t NT = 2 * N, e = m->esz;
+    if (f == "x") { src = a.x; n = NT * m->D * 4; } else if (f == "h") { src = a.h; n = NT * m->D * 4; }
+    else if (f == "xn") { src = a.xn; n = NT * m->D * e; } else if (f == "hn") { src = a.hn; n = NT * m->D * e; }
+    else if (f == "qkv") { src = a.qkv; n = NT * m->Nqkv * e; } else if (f == "O") { src = a.O; n = NT * m->D * e; }
+    else if (f == "ab") { src = a.ab; n = NT * 2 * m->Ip * e; } else if (f == "g") { src = a.g; n = NT * m->Ip * e; }
+  }
+  else if (k.compare(0, 3, "dw.") == 0 && !m->dwb.empty()) {   // dw.<layer>.<gxt|dab|dht|dqkv>: the dY operands the deferred weight gradients kept
+    const size_t dot = k.find('.', 3);
+    const int l = atoi(k.substr(3, dot - 3).c_str());
+    const std::string f = dot == std::string::npos ? "" : k.substr(dot + 1);
+    ARG_CHECK(l >= 0 && l < m->L, "dw: layer index");
+    const Model::DwOperands& o = m->dwb[l];
+    const int64_t NT = 2 * N;
+    if (f == "gxt" && o.gxt) { src = o.gxt; n = NT * m->D * 2; } else if (f == "dab" && o.dab) { src = o.dab; n = NT * 2 * m->Ip * 2; }
+    else if (f == "dht" && o.dht) { src = o.dht; n = NT * m->D * 2; } else if (f == "dqkv" && o.dqkv) { src = o.dqkv; n = NT * m->Nqkv * 2; }
+  }
+  else if (k.compare(0, 7, "f8keep.") == 0 && !m->f8_keep.empty()) {   // f8keep.<layer>.<0|1|2>: outputs of w13_dx, o_dx, qkv_dx (RSYS_F8_DEBUG_KEEP=1)
+    const size_t dot = k.find('.', 7);
+    const int l = atoi(k.substr(7, dot - 7).c_str()), j = dot == std::string::npos ? -1 : atoi(k.substr(dot + 1).c_str());
+    ARG_CHECK(l >= 0 && l < m->L && j >= 0 && j < 3, "f8keep: layer / product index");
+    src = m->f8_keep[(size_t)l * 3 + j]; n = 2 * N * m->D * 2;
+  }
+  else if (k == "f8.aamax" && m->fp8) { src = m->f8_aamax; n = (int64_t)m->L * 16 * 4; }
+  else if (k == "f8.wamax" && m->fp8) { src = m->f8_wamax; n = (int64_t)m->L * 8 * 4; }
+  else if (k == "f8.desc" && m->fp8) { src = m->f8_desc; n = (int64_t)m->L * 8 * 32 * 4; }
   else if (k == "top.cap") { ARG_CHECK(bytes == 4, "top.cap: one int32"); *(int32_t*)out = m->top_is_sparse ? m->ctop_cap : 0; return RSYS_OK; }
   else if (k == "top.n" && m->top_is_sparse) { src = m->c_n; n = 4; }
   else if (k == "top.sel" && m->top_is_sparse) { src = m->c_sel; n = (int64_t)m->ctop_cap * 4; }
@@ -458,12 +489,13 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
 }
 
 int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32_t cols, int32_t fmt, int32_t layout, int32_t seg_cols,
-                            void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev, int32_t n_w,
-                            int32_t desc_mode) {
+                            int32_t seg_rep, void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev,
+                            int32_t n_w, int32_t w_rep, int32_t desc_mode) {
   ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_quantize: null buffer");
   F8Cast c{};
-  c.src = src; c.ld_src = ld_src; c.rows = rows; c.cols = cols; c.fmt = fmt; c.layout = layout; c.seg_cols = seg_cols;
-  c.amax = amax_dev; c.dst = (unsigned char*)dst; c.ld_dst = ld_dst; c.desc = desc_dev; c.wamax = wamax_dev; c.n_w = n_w; c.desc_mode = desc_mode;
+  c.src = src; c.ld_src = ld_src; c.rows = rows; c.cols = cols; c.fmt = fmt; c.layout = layout; c.seg_cols = seg_cols; c.seg_rep = seg_rep < 1 ? 1 : seg_rep;
+  c.amax = amax_dev; c.dst = (unsigned char*)dst; c.ld_dst = ld_dst; c.desc = desc_dev; c.wamax = wamax_dev; c.n_w = n_w; c.w_rep = w_rep < 1 ? 1 : w_rep;
+  c.desc_mode = desc_mode;
   HIP_CHECK(hipMemsetAsync(amax_dev, 0, 16, nullptr));
   int rc = launch_f8_amax(c, nullptr);
   if (!rc) rc = launch_f8_cast(c, nullptr);
@@ -472,12 +504,12 @@ int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32
   return RSYS_OK;
 }
 
-int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, float* amax_dev,
-                           void* dst, void* dst_t, int64_t ld_t) {
+int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, int32_t seg_rep,
+                           float* amax_dev, void* dst, void* dst_t, int64_t ld_t) {
   ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_weights: null buffer");
   ARG_CHECK(cols % 4 == 0 && rows % 16 == 0, "rsys_op_f8_weights: rows % 16, cols % 4");
   F8WeightJob j{};
-  j.src = src; j.ld = ld; j.rows = rows; j.cols = cols; j.layout = layout; j.seg_rows = seg_rows; j.amax = amax_dev;
+  j.src = src; j.ld = ld; j.rows = rows; j.cols = cols; j.layout = layout; j.seg_rows = seg_rows; j.seg_rep = seg_rep < 1 ? 1 : seg_rep; j.amax = amax_dev;
   j.dst = (unsigned char*)dst; j.dst_t = (unsigned char*)dst_t; j.ld_t = ld_t;
   const int ntiles = ((rows + 63) / 64) * ((cols + 63) / 64);
   std::vector<int> tj(ntiles, 0); int first = 0;
@@ -495,11 +527,12 @@ int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t c
 }
 
 int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                        int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kseg) {
+                        int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kb0, int32_t kb1,
+                        int32_t kb2) {
   GemmParams p{};
   p.A = A8; p.B = B8; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.c_f32 = c_f32; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE;
-  p.f8 = a_fmt == F8_E5M2 ? 2 : 1; p.f8_desc = desc_dev; p.f8_seg_cols = seg_cols; p.f8_alt = alt; p.f8_kseg = kseg;
+  p.f8 = a_fmt == F8_E5M2 ? 2 : 1; p.f8_desc = desc_dev; p.f8_seg_cols = seg_cols; p.f8_alt = alt; p.f8_kb[0] = kb0; p.f8_kb[1] = kb1; p.f8_kb[2] = kb2;
   int rc = launch_gemm8p_f8(p, nullptr);
   if (rc) return rc;
   HIP_CHECK(hipDeviceSynchronize());

@@ -45,10 +45,13 @@ __device__ __forceinline__ unsigned int f8_pack4(float a, float b, float c, floa
 }
 
 // column segment of a 16-column group starting at column c0
-__device__ __forceinline__ int f8_seg_of(int c0, int layout, int seg_cols) {
-  if (layout == F8_LAYOUT_SEGS) return c0 / seg_cols;
+__device__ __forceinline__ int f8_seg_of(int c0, int layout, int seg_cols, int seg_rep) {
+  if (layout == F8_LAYOUT_SEGS) { const int u = c0 / seg_cols; return u < seg_rep ? 0 : u - seg_rep + 1; }
   if (layout == F8_LAYOUT_SWIGLU) return (c0 >> 4) & 1;
   return 0;
+}
+__host__ __device__ __forceinline__ int f8_nseg(int n, int layout, int seg, int seg_rep) {
+  return layout == F8_LAYOUT_SEGS ? n / seg - seg_rep + 1 : (layout == F8_LAYOUT_SWIGLU ? 2 : 1);
 }
 
 __device__ __forceinline__ void atomic_max_pos(float* slot, float v) {   // v >= 0: the bit patterns of non-negative floats order like ints
@@ -58,7 +61,7 @@ __device__ __forceinline__ void atomic_max_pos(float* slot, float v) {   // v >=
 // ---- amax over column segments: thread = one group of 16 columns of one row per trip
 template <typename T>
 __global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ src, long long ld, int rows, int cols, const int* __restrict__ rows_dev,
-                                                      int layout, int seg_cols, float* __restrict__ amax) {
+                                                      int layout, int seg_cols, int seg_rep, float* __restrict__ amax) {
   __shared__ float red[16];
   const int R = rows_dev ? min(*rows_dev, rows) : rows;
   const int cg = cols >> 4;
@@ -76,13 +79,13 @@ __global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ src,
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const float4 a = *(const float4*)(p + 4 * q); m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)))); }
     }
-    const int sg = f8_seg_of(g * 16, layout, seg_cols);
+    const int sg = f8_seg_of(g * 16, layout, seg_cols, seg_rep);
     mx[0] = sg == 0 ? fmaxf(mx[0], m) : mx[0];
     mx[1] = sg == 1 ? fmaxf(mx[1], m) : mx[1];
     mx[2] = sg == 2 ? fmaxf(mx[2], m) : mx[2];
     mx[3] = sg == 3 ? fmaxf(mx[3], m) : mx[3];
   }
-  const int nseg = layout == F8_LAYOUT_SEGS ? cols / seg_cols : (layout == F8_LAYOUT_SWIGLU ? 2 : 1);
+  const int nseg = f8_nseg(cols, layout, seg_cols, seg_rep);
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const float v = block_max(mx[sgi], red);
     if (threadIdx.x == 0 && v > 0.f) atomic_max_pos(amax + sgi, v);
@@ -94,19 +97,20 @@ __global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ src,
 template <typename T, int FMT>
 __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
   const int R = c.rows_dev ? min(*c.rows_dev, c.rows) : c.rows;
-  const int nseg = c.layout == F8_LAYOUT_SEGS ? c.cols / c.seg_cols : (c.layout == F8_LAYOUT_SWIGLU ? 2 : 1);
+  const int nseg = f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep);
   float sc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) sc[i] = i < nseg ? f8_scale_of(c.amax[i], FMT) : 0.f;
   if (blockIdx.x == 0 && threadIdx.x == 0 && c.desc != nullptr) {
-    if (c.desc_mode == 1) {          // output-column segments: one activation scale, n_w weight scales
+    if (c.desc_mode == 1) {          // output-column units: one activation scale, n_w weight scales
       const float ia = 1.0f / sc[0];
-      for (int i = 0; i < c.n_w; ++i) c.desc[i] = ia * (1.0f / f8_scale_of(c.wamax[i], F8_E4M3));
+      const int units = c.n_w - 1 + c.w_rep;
+      for (int u = 0; u < units; ++u) c.desc[u] = ia * (1.0f / f8_scale_of(c.wamax[u < c.w_rep ? 0 : u - c.w_rep + 1], F8_E4M3));
     } else if (c.desc_mode == 2) {   // K segments: segment j = (gradient scale j, weight scale j)
       float cj[4];
       for (int j = 0; j < nseg; ++j) cj[j] = (1.0f / sc[j]) * (1.0f / f8_scale_of(c.wamax[j], F8_E4M3));
       c.desc[0] = cj[nseg - 1];
-      for (int j = 0; j + 1 < nseg; ++j) c.desc[4 + j] = cj[j] / cj[j + 1];
+      for (int j = 0; j + 1 < nseg; ++j) c.desc[16 + j] = cj[j] / cj[j + 1];
     }
   }
   const int cg = c.cols >> 4;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
   const int half = c.cols >> 1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cg), g = (int)(i - (long long)r * cg);
-    const int sg = f8_seg_of(g * 16, c.layout, c.seg_cols);
+    const int sg = f8_seg_of(g * 16, c.layout, c.seg_cols, c.seg_rep);
     const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (sg ? half : 0) + (g >> 1) * 16 : g * 16;
     uint4 out = make_uint4(0u, 0u, 0u, 0u);
     if (r < R) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
 // ---- weights: fp32 master [rows][cols] -> e4m3 row-major copy + transposed copy, one 64 x 64 tile per workgroup, job table.
 // Row segments: qkv rows / seg_rows -> q | k | v; W13 rows in [16 w1 | 16 w3] blocks.
 __device__ __forceinline__ int f8w_seg(const F8WeightJob& j, int r) {
-  if (j.layout == F8_LAYOUT_SEGS) return r / j.seg_rows;
+  if (j.layout == F8_LAYOUT_SEGS) { const int u = r / j.seg_rows; return u < j.seg_rep ? 0 : u - j.seg_rep + 1; }
   if (j.layout == F8_LAYOUT_SWIGLU) return (r >> 4) & 1;
   return 0;
 }
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void f8_weight_amax_kernel(const F8WeightJob* 
     mx[1] = sg == 1 ? fmaxf(mx[1], m) : mx[1];
     mx[2] = sg == 2 ? fmaxf(mx[2], m) : mx[2];
   }
-  const int nseg = j.layout == F8_LAYOUT_SEGS ? j.rows / j.seg_rows : (j.layout == F8_LAYOUT_SWIGLU ? 2 : 1);
+  const int nseg = f8_nseg(j.rows, j.layout, j.seg_rows, j.seg_rep);
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const float v = block_max(mx[sgi], red);
     if (t == 0 && v > 0.f) atomic_max_pos(j.amax + sgi, v);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void f8_weight_cast_kernel(const F8WeightJob* 
   const int tcn = (j.cols + 63) >> 6;
   const int r0 = (tl / tcn) * 64, c0 = (tl % tcn) * 64;
   const int t = threadIdx.x, cl = (t & 15) * 4, cc = c0 + cl;
-  const int nseg = j.layout == F8_LAYOUT_SEGS ? j.rows / j.seg_rows : (j.layout == F8_LAYOUT_SWIGLU ? 2 : 1);
+  const int nseg = f8_nseg(j.rows, j.layout, j.seg_rows, j.seg_rep);
   float sc[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) sc[i] = i < nseg ? f8_scale_of(j.amax[i], F8_E4M3) : 0.f;
@@ -224,20 +228,21 @@ __global__ __launch_bounds__(256) void f8_weight_cast_kernel(const F8WeightJob* 
 
 int launch_f8_amax(const F8Cast& c, hipStream_t s) {
   ARG_CHECK(c.cols % 16 == 0 && c.rows > 0, "fp8 amax: columns in groups of 16");
-  ARG_CHECK(c.layout != F8_LAYOUT_SEGS || (c.seg_cols % 16 == 0 && c.cols % c.seg_cols == 0 && c.cols / c.seg_cols <= 4), "fp8 amax: at most 4 equal column segments");
+  ARG_CHECK(c.layout != F8_LAYOUT_SEGS || (c.seg_cols % 16 == 0 && c.cols % c.seg_cols == 0 && c.seg_rep >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) <= 4), "fp8 amax: at most 4 column segments");
   const long long total = (long long)c.rows * (c.cols >> 4);
   const int grid = (int)std::min<long long>((total + 255) / 256, 2048);
-  if (c.src_f32) hipLaunchKernelGGL(f8_amax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)c.src, c.ld_src, c.rows, c.cols, c.rows_dev, c.layout, c.seg_cols, c.amax);
-  else hipLaunchKernelGGL(f8_amax_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)c.src, c.ld_src, c.rows, c.cols, c.rows_dev, c.layout, c.seg_cols, c.amax);
+  if (c.src_f32) hipLaunchKernelGGL(f8_amax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)c.src, c.ld_src, c.rows, c.cols, c.rows_dev, c.layout, c.seg_cols, c.seg_rep, c.amax);
+  else hipLaunchKernelGGL(f8_amax_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)c.src, c.ld_src, c.rows, c.cols, c.rows_dev, c.layout, c.seg_cols, c.seg_rep, c.amax);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
 int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   ARG_CHECK(c.cols % 16 == 0 && c.rows > 0 && c.ld_dst % 16 == 0, "fp8 cast: columns in groups of 16");
-  ARG_CHECK(c.layout != F8_LAYOUT_SEGS || (c.seg_cols % 16 == 0 && c.cols % c.seg_cols == 0 && c.cols / c.seg_cols <= 4), "fp8 cast: at most 4 equal column segments");
+  ARG_CHECK(c.layout != F8_LAYOUT_SEGS || (c.seg_cols % 16 == 0 && c.cols % c.seg_cols == 0 && c.seg_rep >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) <= 4), "fp8 cast: at most 4 column segments");
   ARG_CHECK(c.layout != F8_LAYOUT_SWIGLU || c.cols % 32 == 0, "fp8 cast: [16 a | 16 b] column blocks");
   ARG_CHECK(c.desc_mode == 0 || (c.desc != nullptr && c.wamax != nullptr && c.n_w >= 1 && c.n_w <= 4), "fp8 cast: descale job");
+  ARG_CHECK(c.desc_mode != 1 || (c.w_rep >= 1 && c.n_w - 1 + c.w_rep <= 16), "fp8 cast: at most 16 output-column units");
   const long long total = (long long)c.rows * (c.cols >> 4);
   const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
   const bool e5 = c.fmt == F8_E5M2;

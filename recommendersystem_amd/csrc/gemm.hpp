@@ -55,11 +55,12 @@ struct GemmParams {
   // fp8 operands (launch_gemm8p_f8, the fp8 trunk of f8.hip): f8 = 1: A is e4m3, 2: A is e5m2; B is always e4m3.  lda / ldb / K
   // count 1-byte elements.  The fp32 accumulators are multiplied by a descale 1 / (scale_A scale_B) before the epilogue:
   int f8;
-  const float* f8_desc;   // device floats: [0..3] output descales, [4..5] accumulator ratios at K-segment boundaries
+  const float* f8_desc;   // device floats: [0..15] output descales, [16..18] accumulator ratios at K-segment boundaries
   int f8_seg_cols;        // > 0: output column c takes f8_desc[c / f8_seg_cols] (q | k | v weights of different scale), else f8_desc[0]
   int f8_alt;             // 1: 16-column blocks alternate between f8_desc[0] and f8_desc[1] (the [16 a | 16 b] SwiGLU interleave: W1 | W3)
-  int f8_kseg;            // > 0: K is a run of segments of f8_kseg K tiles (128 elements each) quantised with different scales; the
-                          // accumulators are multiplied by f8_desc[4 + j] when segment j ends, f8_desc[0] is the last segment's descale
+  int f8_kb[3];           // K is a run of segments quantised with different scales (dq | dk | dv, da | db): f8_kb[j] > 0 = the K tile
+                          // (128 elements each) at which segment j + 1 begins; there the accumulators are multiplied by
+                          // f8_desc[16 + j]; f8_desc[0] is the last segment's descale
   int f8_rseg;            // split-K form: output ROW r takes f8_desc[r / f8_rseg] (rows of dY^T: segments of different scale); 0: f8_desc[0]
   const int* f8_rowmap;   // split-K form: output row r is added to row f8_rowmap[r] of C (de-interleaved dab^T rows back to W13's order)
 };

@@ -299,21 +299,18 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   using W10 = std::integral_constant<int, 10>;
   int pend = 0;
   typedef const __attribute__((address_space(4))) float* cfloat_p;   // scalar loads: no vector memory counter involved
-  int kseg_left = 0, kseg_idx = 0;
+  int kseg_next = 0, kseg_idx = 0;
   auto tile_body = [&](int kt) {
     const int bo = (kt & 1) << 16, bn = bo ^ 65536;
     if constexpr (F8 != 0) {
-      if (p.f8_kseg > 0) {   // a K segment with another scale begins: bring the sums so far into its units
-        if (kseg_left == 0 && kt > 0) {
-          const float r = ((cfloat_p)p.f8_desc)[4 + kseg_idx];
-          ++kseg_idx;
+      if (kt == kseg_next) {   // (never at kt = 0) a K segment with another scale begins: bring the sums so far into its units
+        const float r = ((cfloat_p)p.f8_desc)[16 + kseg_idx];
+        ++kseg_idx;
+        kseg_next = kseg_idx < 3 ? p.f8_kb[kseg_idx] : 0;
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] *= r;
-        }
-        if (kseg_left == 0) kseg_left = p.f8_kseg;
-        --kseg_left;
+          for (int j = 0; j < 4; ++j) acc[i][j] *= r;
       }
     }
     // P1
@@ -392,7 +389,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  kseg_left = 0; kseg_idx = 0;
+  kseg_next = F8 != 0 ? p.f8_kb[0] : 0; kseg_idx = 0;
   // B0, A0, B1 of K tile 0 have landed
   if (nt > 1) wait_vm(W10{}, pend); else wait_vm(W2{}, pend);
   T8_BARRIER();
@@ -726,7 +723,8 @@ bool gemm8p_f8_eligible(const GemmParams& p) {
   if (p.N % 8 != 0) return false;
   if (p.f8_seg_cols > 0 && p.f8_seg_cols % 64 != 0) return false;
   if (p.f8_alt && p.N % 32 != 0) return false;
-  if (p.f8_kseg > 0 && (p.K / 128) % p.f8_kseg != 0) return false;
+  for (int j = 0; j < 3; ++j) if (p.f8_kb[j] < 0 || p.f8_kb[j] >= p.K / 128 || (j > 0 && p.f8_kb[j] > 0 && p.f8_kb[j] <= p.f8_kb[j - 1])) return false;
+  if (p.f8_seg_cols > 0 && (p.N + p.f8_seg_cols - 1) / p.f8_seg_cols > 16) return false;
   const unsigned long long lim = 1ull << 32;
   const bool cf = p.c_f32 || p.epi == EPI_ACCUM || p.epi == EPI_RESIDUAL || p.epi == EPI_TABLE;
   if ((unsigned long long)p.M * p.ldc * (cf ? 4 : 2) >= lim) return false;

@@ -230,18 +230,20 @@ struct F8Cast {
   const void* src; long long ld_src; int src_f32;   // bf16 (or f32) [rows][cols]
   int rows, cols;
   const int* rows_dev;                    // optional device-side row count (rows up to the next multiple of 256 are zero-filled)
-  int fmt, layout, seg_cols;              // SEGS: cols / seg_cols (<= 4) equal column segments with their own amax; SWIGLU: [16 a | 16 b] blocks, 2 amaxes
+  int fmt, layout, seg_cols, seg_rep;     // SEGS: column units of seg_cols; the first seg_rep units are segment 0, every further unit its own
+                                          // segment (q | k | v with grouped-query heads), <= 4 segments, each with its own amax; SWIGLU: [16 a | 16 b] blocks, 2 amaxes
   float* amax;                            // device, one slot per segment: zero before launch_f8_amax; read by launch_f8_cast
   unsigned char* dst; long long ld_dst;   // [rows][cols] (SWIGLU: columns de-interleaved to [all a | all b])
-  // descales of the consumer GEMM (GemmParams::f8_desc), written by the cast: mode 1 = output-column segments (this tensor's scale x
-  // n_w weight scales), mode 2 = K segments (this tensor's segment j x weight j; desc[0] = last, desc[4 + j] = ratios)
-  float* desc; const float* wamax; int n_w; int desc_mode;
+  // descales of the consumer GEMM (GemmParams::f8_desc), written by the cast: mode 1 = output-column units (this tensor's scale x
+  // the weight scale of unit u: the first w_rep units take weight 0, unit u >= w_rep weight u - w_rep + 1; n_w weights), mode 2 = K
+  // segments (this tensor's segment j x weight j; desc[0] = last, desc[16 + j] = ratios)
+  float* desc; const float* wamax; int n_w; int w_rep; int desc_mode;
 };
 int launch_f8_amax(const F8Cast& c, hipStream_t s);
 int launch_f8_cast(const F8Cast& c, hipStream_t s);
 struct F8WeightJob {
   const float* src; long long ld; int rows, cols;   // fp32 master [rows][cols]
-  int layout, seg_rows;                             // SEGS: rows / seg_rows (<= 3) row segments (q | k | v); SWIGLU: [16 w1 | 16 w3] row blocks
+  int layout, seg_rows, seg_rep;                    // SEGS: row units of seg_rows, the first seg_rep units are segment 0 (q | k | v); SWIGLU: [16 w1 | 16 w3] row blocks
   float* amax;                                      // one slot per segment
   unsigned char* dst;                               // e4m3 [rows][cols]
   unsigned char* dst_t; long long ld_t;             // e4m3 [cols][ld_t]: column = row (SWIGLU: de-interleaved to [all w1 | all w3])

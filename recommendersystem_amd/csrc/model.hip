@@ -161,10 +161,16 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
             "max_sequence_length must be a multiple of 4 and <= 1024");
   ARG_CHECK(cfg->max_rows >= 1, "max_rows");
   ARG_CHECK(cfg->mask_topk >= 1 && cfg->mask_topk <= cfg->max_sequence_length, "mask_topk");
-  ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16, "dtype");
+  ARG_CHECK(cfg->dtype == RSYS_DTYPE_FP32 || cfg->dtype == RSYS_DTYPE_BF16 || cfg->dtype == RSYS_DTYPE_FP8, "dtype");
   ARG_CHECK(cfg->lora_dropout >= 0.f && cfg->lora_dropout < 1.f, "lora_dropout must be in [0,1)");
   ARG_CHECK(cfg->sampled_negatives == 0 || (cfg->sampled_negatives > 0 && cfg->table_shard_world >= 1),
             "sampled_negatives needs the row-sharded table (table_shard_world >= 1)");
+  if (cfg->dtype == RSYS_DTYPE_FP8) {
+    ARG_CHECK(!cfg->finetune, "dtype fp8: the reference converts the trunk to float8 for pretraining only (transformer.py:671)");
+    ARG_CHECK(cfg->embed_dim % 128 == 0 && cfg->embed_dim >= 256 && cfg->intermediate_dim % 128 == 0 && cfg->num_heads > 0 && cfg->num_kv_heads > 0 &&
+              (cfg->num_kv_heads * (cfg->embed_dim / cfg->num_heads)) % 128 == 0 && cfg->num_heads / cfg->num_kv_heads <= 14,
+              "dtype fp8 needs embed_dim % 128 == 0 (>= 256), intermediate_dim % 128 == 0, (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14");
+  }
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { set_error("no HIP device visible: the HIP path has no CPU fallback"); return RSYS_ERR_HIP; }
@@ -172,7 +178,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   HIP_CHECK(hipSetDevice(device));
   Model* m = new Model();
   m->cfg = *cfg; m->device = device;
-  m->bf16_mode = cfg->dtype == RSYS_DTYPE_BF16;
+  m->bf16_mode = cfg->dtype == RSYS_DTYPE_BF16 || cfg->dtype == RSYS_DTYPE_FP8;
+  m->fp8 = cfg->dtype == RSYS_DTYPE_FP8;
   m->esz = m->bf16_mode ? 2 : 4;
   m->L = cfg->num_layers; m->H = cfg->num_heads; m->KV = cfg->num_kv_heads; m->D = cfg->embed_dim;
   m->I = cfg->intermediate_dim; m->Ip = (m->I + 15) / 16 * 16; m->S = cfg->max_sequence_length; m->T = 2 * m->S;
@@ -318,7 +325,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
     m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
     static const int sp = getenv("RSYS_SPARSE_TOP") ? atoi(getenv("RSYS_SPARSE_TOP")) : 1;
-    m->sparse_top = sp != 0 && NT <= (1 << 19);   // (also the LoRA finetune: one target per row -- the last layer's tail shrinks to `rows` tokens)
+    // (fp8 trunk: a tensor-wise scale is the amax over ALL tokens of the last layer's activations, so that layer stays dense)
+    m->sparse_top = sp != 0 && NT <= (1 << 19) && !m->fp8;   // (also the LoRA finetune: one target per row -- the last layer's tail shrinks to `rows` tokens)
     if (m->defer_dw) {
       m->dwb.resize(m->L);
       for (int l = 0; l < m->L; ++l) {
@@ -346,6 +354,42 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       m->kmap_p = (unsigned int*)base; m->kmap_full_p = (unsigned int*)(base + mb); m->qmap_full_p = (unsigned int*)(base + 2 * mb); m->kmap16_p = (unsigned int*)(base + 3 * mb);
       m->qmap_p = (unsigned int*)(base + 7 * mb); m->qmap16_p = (unsigned int*)(base + 8 * mb);
     }
+  }
+  if (m->fp8) {
+    const int L = m->L, Ip = m->Ip;
+    const int64_t base = m->lo[0].wqkv, end = m->lo[L - 1].w2 + (int64_t)D * Ip;
+    m->w8_base = base;
+    DALLOC(m->W8, end - base); DALLOC(m->W8T, end - base);
+    DALLOC(m->f8_wamax, L * 8 * 4); DALLOC(m->f8_aamax, L * 16 * 4); DALLOC(m->f8_desc, L * 8 * 32 * 4);
+    DALLOC(m->a8, NT * std::max<int64_t>(2 * Ip, m->Nqkv));
+    std::vector<F8WeightJob> jobs; std::vector<int> tile_job, tile_first;
+    bool aligned = true;
+    auto add = [&](int l, int64_t off, int rows, int cols, int layout, int seg_rows, int slot) {
+      F8WeightJob j{};
+      j.src = m->P + off; j.ld = cols; j.rows = rows; j.cols = cols; j.layout = layout; j.seg_rows = seg_rows; j.seg_rep = m->H / m->KV;
+      j.amax = m->f8_wamax + l * 8 + slot; j.dst = m->W8 + (off - base); j.dst_t = m->W8T + (off - base); j.ld_t = rows;
+      aligned = aligned && (off - base) % 16 == 0;
+      tile_first.push_back((int)tile_job.size());
+      const int nt = ((rows + 63) / 64) * ((cols + 63) / 64);
+      for (int t = 0; t < nt; ++t) tile_job.push_back((int)jobs.size());
+      jobs.push_back(j);
+    };
+    for (int l = 0; l < L; ++l) {
+      add(l, m->lo[l].wqkv, m->Nqkv, (int)D, F8_LAYOUT_SEGS, m->KV * hd, 0);   // q | k | v rows: three linears, three scales
+      add(l, m->lo[l].wo, (int)D, (int)D, F8_LAYOUT_PLAIN, 0, 3);
+      add(l, m->lo[l].w13, 2 * Ip, (int)D, F8_LAYOUT_SWIGLU, 0, 4);         // [16 w1 | 16 w3] row blocks
+      add(l, m->lo[l].w2, (int)D, Ip, F8_LAYOUT_PLAIN, 0, 6);
+    }
+    if (!aligned) { set_error("fp8 trunk: weight offsets are not 16-byte aligned in the fp8 copies"); return RSYS_ERR_ARG; }
+    if (getenv("RSYS_F8_DEBUG_KEEP") && atoi(getenv("RSYS_F8_DEBUG_KEEP")) != 0) {   // stage-wise parity tests of the backward products
+      m->f8_keep.assign((size_t)L * 3, nullptr);
+      for (size_t i = 0; i < m->f8_keep.size(); ++i) DALLOC(m->f8_keep[i], NT * D * 2);
+    }
+    m->f8_ntiles = (int)tile_job.size();
+    DALLOC(m->f8_jobs, jobs.size() * sizeof(F8WeightJob)); DALLOC(m->f8_tile_job, tile_job.size() * 4); DALLOC(m->f8_tile_first, tile_first.size() * 4);
+    HIP_CHECK(hipMemcpy(m->f8_jobs, jobs.data(), jobs.size() * sizeof(F8WeightJob), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->f8_tile_job, tile_job.data(), tile_job.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->f8_tile_first, tile_first.data(), tile_first.size() * 4, hipMemcpyHostToDevice));
   }
   *out = m;
   return RSYS_OK;
@@ -376,7 +420,7 @@ int model_destroy(Model* m) {
 }
 
 int model_refresh_shadow(Model* m) {
-  m->wt_dirty = true; m->table_dirty = true;
+  m->wt_dirty = true; m->table_dirty = true; m->w8_dirty = true;
   if (m->bf16_mode) RC(launch_cast<bf16>(m->P, (bf16*)m->Sh, m->n_total, m->stream));
   return RSYS_OK;
 }
@@ -541,7 +585,7 @@ int model_param_io(Model* m, const char* name, float* out, const float* in, int6
   }
   for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + internal_row(t, r) * t.ld, in + r * t.cols, t.cols * 4);
   HIP_CHECK(hipMemcpy(base, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-  if (which == 0) { m->wt_dirty = true; m->table_dirty = true; }
+  if (which == 0) { m->wt_dirty = true; m->table_dirty = true; m->w8_dirty = true; }
   if (which == 0 && m->bf16_mode)
     RC(launch_cast<bf16>(base, (bf16*)m->Sh + t.off, (int64_t)host.size(), m->stream));
   HIP_CHECK(hipStreamSynchronize(m->stream));
@@ -811,6 +855,65 @@ static int ensure_transposes(Model* m) {
   return RSYS_OK;
 }
 
+// ------------------------------------------------------------------ fp8 trunk (f8.hip)
+// this step's e4m3 weight copies: amax per linear, then the row-major and the transposed copy
+static int ensure_f8_weights(Model* m) {
+  if (!m->fp8 || !m->w8_dirty) return RSYS_OK;
+  tic(m, "f8_weights");
+  HIP_CHECK(hipMemsetAsync(m->f8_wamax, 0, (size_t)m->L * 8 * 4, m->stream));
+  RC(launch_f8_weights((const F8WeightJob*)m->f8_jobs, m->f8_tile_job, m->f8_tile_first, m->f8_ntiles, m->stream));
+  toc(m);
+  m->w8_dirty = false;
+  return RSYS_OK;
+}
+
+// the eight fp8 products of a layer: amax slot(s) of the A operand (Model::f8_aamax), its column layout and format, the weight
+// scale slot(s) (Model::f8_wamax: q k v o w1 w3 w2) and how the descales combine
+enum { F8P_QKV = 0, F8P_O = 1, F8P_W13 = 2, F8P_W2 = 3, F8P_W2_DX = 4, F8P_W13_DX = 5, F8P_O_DX = 6, F8P_QKV_DX = 7 };
+struct F8Op { int a_slot, layout, fmt, w_slot, n_w, desc_mode; };
+static const F8Op kF8Ops[8] = {
+  {0, F8_LAYOUT_PLAIN, F8_E4M3, 0, 3, 1},    // xn  . [Wq; Wk; Wv]^T
+  {1, F8_LAYOUT_PLAIN, F8_E4M3, 3, 1, 1},    // O   . Wo^T
+  {2, F8_LAYOUT_PLAIN, F8_E4M3, 4, 2, 1},    // hn  . [W1; W3]^T
+  {3, F8_LAYOUT_PLAIN, F8_E4M3, 6, 1, 1},    // g   . W2^T
+  {4, F8_LAYOUT_PLAIN, F8_E5M2, 6, 1, 2},    // dy  . W2
+  {5, F8_LAYOUT_SWIGLU, F8_E5M2, 4, 2, 2},   // [da | db] . [W1; W3]   (two gradients, two weights: K segments)
+  {7, F8_LAYOUT_PLAIN, F8_E5M2, 3, 1, 2},    // dh  . Wo
+  {8, F8_LAYOUT_SEGS, F8_E5M2, 0, 3, 2},     // [dq | dk | dv] . [Wq; Wk; Wv]
+};
+
+// One linear of the fp8 trunk.  `p` is the bf16 call (A = the bf16 operand [M][K], epilogue, outputs); the A operand is quantised
+// (its amax first unless the producer already left it in the slot), the product runs on the fp8 pipeline with weight copy `w8`.
+static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, const unsigned char* w8, long long ldw, bool amax_done = false) {
+  const F8Op& o = kF8Ops[which];
+  hipStream_t s = m->stream;
+  F8Cast c{};
+  c.src = p.A; c.ld_src = p.lda; c.rows = p.M; c.cols = p.K; c.rows_dev = p.m_dev; c.fmt = o.fmt; c.layout = o.layout;
+  c.seg_cols = o.layout == F8_LAYOUT_SEGS ? m->KV * m->hd : 0; c.seg_rep = m->H / m->KV;   // (dq | dk | dv: units of one kv group)
+  c.amax = m->f8_aamax + l * 16 + o.a_slot; c.dst = m->a8; c.ld_dst = p.K;
+  c.desc = m->f8_desc + (l * 8 + which) * 32; c.wamax = m->f8_wamax + l * 8 + o.w_slot; c.n_w = o.n_w; c.desc_mode = o.desc_mode;
+  c.w_rep = which == F8P_QKV ? m->H / m->KV : 1;
+  tic(m, "hbm_f8_cast", (amax_done ? 3.0 : 5.0) * p.M * (double)p.K);
+  if (!amax_done) RC(launch_f8_amax(c, s));
+  RC(launch_f8_cast(c, s));
+  toc(m);
+  p.A = m->a8; p.lda = p.K; p.B = w8; p.ldb = ldw;
+  p.f8 = o.fmt == F8_E5M2 ? 2 : 1; p.f8_desc = c.desc;
+  if (which == F8P_QKV) p.f8_seg_cols = m->KV * m->hd;
+  if (which == F8P_W13) p.f8_alt = 1;
+  if (which == F8P_W13_DX) p.f8_kb[0] = m->Ip / 128;
+  if (which == F8P_QKV_DX) { p.f8_kb[0] = m->H * m->hd / 128; p.f8_kb[1] = (m->H + m->KV) * m->hd / 128; }
+  if (p.alpha == 0.f) p.alpha = 1.f;
+  p.splitk = 1;
+  p.flags |= m->gemm_flags;
+  if (m->timer.enabled) tic(m, (std::string(tag) + "@8f").c_str(), 2.0 * p.M * p.N * (double)p.K);
+  const int rc = launch_gemm8p_f8(p, s);
+  toc(m);
+  return rc;
+}
+static inline const unsigned char* W8(Model* m, int64_t off) { return m->W8 + (off - m->w8_base); }
+static inline const unsigned char* W8T(Model* m, int64_t off) { return m->W8T + (off - m->w8_base); }
+
 static SmallParams small_params(Model* m) {
   SmallParams sp;
   sp.per_cos = m->P + m->o_pcos; sp.per_sin = m->P + m->o_psin;
@@ -834,7 +937,8 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     GemmParams p{};
     p.A = O_in ? O_in : a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
     p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
-    RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
+    if (m->fp8) RC(gemm_f8(m, l, F8P_O, "gemm_o_fwd", p, W8(m, m->lo[l].wo), D));
+    else RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
   }
   tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
   RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
@@ -843,13 +947,15 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     GemmParams p{};
     p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
     p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
-    RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
+    if (m->fp8) RC(gemm_f8(m, l, F8P_W13, "gemm_w13_fwd", p, W8(m, m->lo[l].w13), D));
+    else RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
   }
   {
     GemmParams p{};
     p.A = a.g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = xnext; p.ldc = D; p.c_f32 = 1;
     p.M = NT; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = a.h; p.ldr = D;
-    RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
+    if (m->fp8) RC(gemm_f8(m, l, F8P_W2, "gemm_w2_fwd", p, W8(m, m->lo[l].w2), Ip));
+    else RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
   }
   return RSYS_OK;
 }
@@ -910,6 +1016,10 @@ static int forward_trunk(Model* m) {
   const int* rpos = b.rope_pos;
   // fused item table F = E + Meta Wp^T + bp
   tic(m, "phase_embed");
+  if (m->fp8) {
+    RC(ensure_f8_weights(m));
+    HIP_CHECK(hipMemsetAsync(m->f8_aamax, 0, (size_t)m->L * 16 * 4, s));   // this pass's activation / gradient amax slots
+  }
   if (m->table_dirty) { RC(table_forward<T>(m)); m->table_dirty = false; }
   SmallParams sp = small_params(m);
   RC(launch_action_features<T>(b, sp, AT<T>(m->feat), s));
@@ -979,7 +1089,8 @@ static int forward_trunk(Model* m) {
       p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
       p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
-      RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV, "gemm_qkv_fwd", p, W8(m, m->lo[l].wqkv), D));
+      else RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
     }
     if (ft) {
       // q += 2 * La[:, :8] Bq^T, v += 2 * La[:, 8:] Bv^T (lora_scaling = 16/8, model.py:236-237,264-271).  RoPE is linear,
@@ -1476,7 +1587,8 @@ static int backward_trunk(Model* m) {
       if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
       RC(join_dw(m, DW_W13));   // the layer above's dW13 reads dab
-      RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_W2_DX, "gemm_w2_dx", p, W8T(m, m->lo[l].w2), D));
+      else RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
       RC(join_side(m));
     }
     if (!ft && !defer) {
@@ -1490,7 +1602,9 @@ static int backward_trunk(Model* m) {
       p.A = dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_W13_DX, "gemm_w13_dx", p, W8T(m, m->lo[l].w13), 2 * Ip));
+      else RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
+      if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 0], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
     RC(join_dw(m, DW_O));       // the layer above's dWo reads dht
@@ -1508,7 +1622,9 @@ static int backward_trunk(Model* m) {
       p.A = dht; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
       if (wt) p.B = WT<T>(m, m->lo[l].wo);
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_O_DX, "gemm_o_dx", p, W8T(m, m->lo[l].wo), D));
+      else RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
+      if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 1], m->dO, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
     }   // !top
@@ -1538,7 +1654,9 @@ static int backward_trunk(Model* m) {
       p.A = dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].wqkv); p.ldb = m->Nqkv; }
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
-      RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV_DX, "gemm_qkv_dx", p, W8T(m, m->lo[l].wqkv), m->Nqkv));
+      else RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
+      if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 2], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
     if (ft) {
@@ -1877,7 +1995,7 @@ int optimizer_step(Optimizer* o, float lr_factor, float clip, float grad_div) {
   const long long e_lo = m->cfg.finetune ? 0 : m->o_E, e_hi = m->cfg.finetune ? 0 : m->o_E + pad8((int64_t)m->TR * m->D);
   tic(m, "adamw", 32.0 * m->n_opt + (m->bf16_mode ? 2.0 * (m->n_opt - (e_hi - e_lo)) : 0.0));   // p, g, m, v read; p, m, v, zeroed g (+ bf16 shadow) written
   int rc;
-  if (!m->cfg.finetune) { m->wt_dirty = true; m->table_dirty = true; }   // (finetune: only the LoRA segment moves; base weights, their transposes and the fused table stay)
+  if (!m->cfg.finetune) { m->wt_dirty = true; m->table_dirty = true; m->w8_dirty = true; }   // (finetune: only the LoRA segment moves; base weights, their transposes and the fused table stay)
   if (m->bf16_mode)
     rc = launch_adamw<bf16>(m->P, m->G, o->mom, o->var, (bf16*)m->Sh, m->n_opt_decay, m->n_opt, o->lr * lr_factor, o->b1, o->b2,
                             o->eps, o->wd, o->step, ss, grad_div, clip, 1, m->stream, e_lo, e_hi);

@@ -78,6 +78,19 @@ struct Model {
   void* ShT = nullptr;       // bf16 mode: the trunk weight matrices of Sh, transposed ([in][out]), same offsets: the dx GEMMs then
                              // read row-major operands (256x256 LDS-DMA kernel); rebuilt lazily when wt_dirty
   bool wt_dirty = true;
+  // fp8 trunk (cfg.dtype == RSYS_DTYPE_FP8; f8.hip): bf16 arithmetic everywhere except the transformer blocks' linears, whose
+  // forward and dx products take tensor-wise scaled e4m3 / e5m2 operands (the reference's torchao recipe, transformer.py:671-676)
+  bool fp8 = false;
+  int64_t w8_base = 0;            // element offset of the first trunk weight: W8 / W8T hold [w8_base, end of the last layer's W2)
+  unsigned char* W8 = nullptr;    // e4m3 copies of the trunk's linear weights, row-major [out][in]: forward B operands
+  unsigned char* W8T = nullptr;   // transposed copies [in][out] (W13: K order [all w1 | all w3]): dx B operands
+  float* f8_wamax = nullptr;      // [L][8]: amax of q k v o w1 w3 w2 (this step's weights)
+  float* f8_aamax = nullptr;      // [L][16]: amax of xn O hn g | dy2 da db dh dq dk dv (this pass)
+  float* f8_desc = nullptr;       // [L][8 products][32]: descales the casts write for their consumer GEMMs (GemmParams::f8_desc)
+  unsigned char* a8 = nullptr;    // fp8 copy of the current product's A operand
+  void* f8_jobs = nullptr; int* f8_tile_job = nullptr; int* f8_tile_first = nullptr; int f8_ntiles = 0;
+  bool w8_dirty = true;
+  std::vector<void*> f8_keep;     // RSYS_F8_DEBUG_KEEP=1 (tests): per layer, copies of the three dx products' outputs (w13_dx, o_dx, qkv_dx)
   bool table_dirty = true;     // the fused item table F / FT must be rebuilt before the next forward: set by everything that changes a
                                // parameter or the metadata, and by the table-gradient pass (it borrows FT); clean between the
                                // micro-steps of one optimizer step, across finetune steps (frozen table) and across inference calls

@@ -27,7 +27,7 @@ from ._lib import check, lib
 ALL_MEDIUMS = [0, 1]
 ALL_METRICS = ["watch", "rating"]
 _METRICS3 = ["watch", "rating", "status"]
-DTYPES = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1}
+DTYPES = {"fp32": 0, "float32": 0, "f32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2, "float8": 2}   # fp8: bf16 + the float8 trunk linears (transformer.py:671-676)
 
 
 def _c_config(config, dtype, max_rows):
@@ -346,6 +346,26 @@ class RecommenderModel:
             out = np.empty(2 * n, np.int32)
         elif key == "embed.x0":
             out = np.empty((2 * n, D), np.float32)
+        elif key.startswith("act."):     # act.<layer>.<x|xn|qkv|O|h|hn|ab|g>: saved activations (bf16 ones come back widened to float32)
+            f = key.split(".")[2]
+            H, KV = self.config["num_heads"], self.config["num_kv_heads"]
+            Ip = (self.config["intermediate_dim"] + 15) // 16 * 16
+            cols = {"x": D, "h": D, "xn": D, "hn": D, "O": D, "qkv": (H + 2 * KV) * (D // H), "ab": 2 * Ip, "g": Ip}[f]
+            wide = f in ("x", "h") or self.dtype in ("fp32", "float32", "f32")
+            out = np.empty((2 * n, cols), np.float32 if wide else np.uint16)
+            check(lib().rsys_debug_get(self._h, key.encode(), out.ctypes.data, out.nbytes))
+            return out if wide else (out.astype(np.uint32) << 16).view(np.float32)
+        elif key.startswith("dw.") or key.startswith("f8keep."):   # bf16 operands the backward kept (widened to float32)
+            f = key.split(".")[2]
+            H, KV = self.config["num_heads"], self.config["num_kv_heads"]
+            Ip = (self.config["intermediate_dim"] + 15) // 16 * 16
+            cols = {"gxt": D, "dht": D, "dab": 2 * Ip, "dqkv": (H + 2 * KV) * (D // H)}.get(f, D)
+            out = np.empty((2 * n, cols), np.uint16)
+            check(lib().rsys_debug_get(self._h, key.encode(), out.ctypes.data, out.nbytes))
+            return (out.astype(np.uint32) << 16).view(np.float32)
+        elif key.startswith("f8."):
+            L = self.config["num_layers"]
+            out = np.empty({"f8.aamax": (L, 16), "f8.wamax": (L, 8), "f8.desc": (L, 8, 32)}[key], np.float32)
         elif key == "table.fused":
             out = np.empty((V + 1, D), np.float32)
         else:

@@ -53,6 +53,7 @@ def make_config(name="tiny", **over):
         # name: L, H, KV, D, I, S, V0, V1, M, K
         "tiny":  (2, 2, 1, 32, 88, 16, 30, 50, 12, 4),       # hd=16
         "hd64":  (2, 2, 1, 128, 352, 64, 120, 200, 20, 12),  # hd=64, GPU-kernel shaped
+        "f8t":   (2, 4, 2, 256, 384, 64, 120, 200, 20, 12),  # smallest shape the fp8 trunk takes (K tiles of 128, kv group of 128 columns)
         "cfg1":  (2, 4, 2, 64, 176, 32, 400, 600, 6148, 8),
         "cfg2":  (8, 4, 2, 256, 704, 256, 60000, 40000, 6148, 32),
         "cfg3":  (8, 8, 4, 512, 1408, 512, 120000, 80000, 6148, 64),

@@ -1,0 +1,178 @@
+"""GPU: the fp8 trunk (dtype="fp8": the reference's pretraining arithmetic, torchao "tensorwise" float8 linears under `transformers.`,
+transformer.py:671-676) against the numpy oracle run with the same recipe (oracle/model_np.py operand_round="fp8", oracle/fp8.py).
+PARITY UNPINNED against torchao itself (absent from the image): what these tests pin is that the HIP path computes the published
+recipe as restated -- and that it is the fp8 arithmetic, not bf16 (the two oracles differ by far more than HIP differs from its own)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TASK_W = [0.05, 0.2, 0.3, 0.25]
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _grad_errors(model, G_ref, names):
+    out = {}
+    for n in names:
+        g = model.grad(n)
+        scale = max(np.abs(G_ref[n]).max(), 1e-3 * np.sqrt((G_ref[n] ** 2).mean()) + 1e-12)
+        out[n] = float(np.abs(g - G_ref[n]).max() / max(scale, 1e-6))
+    return out
+
+
+def _rms(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum() / max((b ** 2).sum(), 1e-30)))
+
+
+def _split_ab(ab, Ip):
+    """[16 a | 16 b] column blocks -> (a, b)"""
+    r = ab.reshape(ab.shape[0], Ip // 16, 2, 16)
+    return r[:, :, 0, :].reshape(ab.shape[0], Ip), r[:, :, 1, :].reshape(ab.shape[0], Ip)
+
+
+def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
+    """Each of the eight fp8 products of a layer, fed with the HIP path's OWN stored operands, against the oracle's linear on those
+    operands: no error is carried from stage to stage, so the bounds are the output rounding (bf16: relative RMS ~ 1e-3) or the
+    accumulation (fp32 outputs: 1e-4) -- a wrong scale slot, weight copy, segment boundary or K order would be orders larger."""
+    monkeypatch.setenv("RSYS_F8_DEBUG_KEEP", "1")
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    rows, seed = 3, 31
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    ref = model_np.OracleModel(cfg, P, np.float64, operand_round="fp8")
+    Q = ref.q
+    model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    model(d, False, masks=(wm, rm))
+    L, D, H, KV = cfg["num_layers"], cfg["embed_dim"], cfg["num_heads"], cfg["num_kv_heads"]
+    hd, Ip, B, T = D // H, cfg["intermediate_dim"], rows, 2 * cfg["max_sequence_length"]
+    cos, sin = ref.cos[:T].astype(np.float64), ref.sin[:T].astype(np.float64)
+    get = lambda k: model.debug_get(k, rows).astype(np.float64)
+    worst_bf, worst_f32 = ("", 0.0), ("", 0.0)
+
+    def chk(tag, got, want, f32=False):
+        nonlocal worst_bf, worst_f32
+        e = _rms(got, want)
+        if f32:
+            worst_f32 = max(worst_f32, (tag, e), key=lambda t: t[1])
+        else:
+            worst_bf = max(worst_bf, (tag, e), key=lambda t: t[1])
+    for l in range(L):
+        p = f"transformers.layers.{l}."
+        xn = get(f"act.{l}.xn")
+        q = Q(model_np.apply_rope(ref.lin(xn, p + "attn.q_proj.weight").reshape(B, T, H, hd), cos, sin)).reshape(B * T, -1)
+        k = Q(model_np.apply_rope(ref.lin(xn, p + "attn.k_proj.weight").reshape(B, T, KV, hd), cos, sin)).reshape(B * T, -1)
+        v = Q(ref.lin(xn, p + "attn.v_proj.weight"))
+        chk(f"qkv_fwd[{l}]", get(f"act.{l}.qkv"), np.concatenate([q, k, v], 1))
+        h = get(f"act.{l}.x") + ref.lin(get(f"act.{l}.O"), p + "attn.output_proj.weight")
+        chk(f"o_fwd[{l}]", get(f"act.{l}.h"), h, f32=True)
+        hn = get(f"act.{l}.hn")
+        a = ref.lin(hn, p + "mlp.w1.weight"); b = ref.lin(hn, p + "mlp.w3.weight")
+        a_hip, b_hip = _split_ab(get(f"act.{l}.ab"), Ip)
+        chk(f"w1_fwd[{l}]", a_hip, Q(a)); chk(f"w3_fwd[{l}]", b_hip, Q(b))
+        chk(f"swiglu[{l}]", get(f"act.{l}.g"), Q(a / (1.0 + np.exp(-a)) * b))
+        if l + 1 < L:
+            chk(f"w2_fwd[{l}]", get(f"act.{l + 1}.x"), get(f"act.{l}.h") + ref.lin(get(f"act.{l}.g"), p + "mlp.w2.weight"), f32=True)
+        # backward: dY operands kept by the deferred weight gradients + the kept dx outputs
+        gg = ref.lin_dx(get(f"dw.{l}.gxt"), p + "mlp.w2.weight")
+        sig = 1.0 / (1.0 + np.exp(-a_hip))
+        da_hip, db_hip = _split_ab(get(f"dw.{l}.dab"), Ip)
+        chk(f"w2_dx.da[{l}]", da_hip, Q(gg * b_hip * (sig * (1.0 + a_hip * (1.0 - sig)))))
+        chk(f"w2_dx.db[{l}]", db_hip, Q(gg * a_hip * sig))
+        chk(f"w13_dx[{l}]", get(f"f8keep.{l}.0"), Q(ref.lin_dx(da_hip, p + "mlp.w1.weight") + ref.lin_dx(db_hip, p + "mlp.w3.weight")))
+        chk(f"o_dx[{l}]", get(f"f8keep.{l}.1"), Q(ref.lin_dx(get(f"dw.{l}.dht"), p + "attn.output_proj.weight")))
+        dqkv = get(f"dw.{l}.dqkv")
+        nq, nk = H * hd, KV * hd
+        chk(f"qkv_dx[{l}]", get(f"f8keep.{l}.2"), Q(ref.lin_dx(dqkv[:, :nq], p + "attn.q_proj.weight") + ref.lin_dx(dqkv[:, nq:nq + nk], p + "attn.k_proj.weight")
+                                                     + ref.lin_dx(dqkv[:, nq + nk:], p + "attn.v_proj.weight")))
+    print("stage-wise fp8 products: worst bf16-output stage", worst_bf, "worst fp32-output stage", worst_f32)
+    assert worst_bf[1] < 3e-3, worst_bf        # one bf16 rounding of the output: ~1.1e-3 relative RMS
+    assert worst_f32[1] < 1e-4, worst_f32
+    model.close()
+
+
+def test_fp8_trunk_vs_fp8_oracle():
+    """End to end.  Every quantisation step turns a bf16-ulp disagreement between the two implementations (summation order) into a
+    whole fp8 step on the few elements that sit at a rounding boundary, so the agreement after two layers and a backward pass is
+    percent-level by nature; the stage-wise test above is the sharp one.  Here: the result is finite, close to the fp8 oracle in
+    RMS, and clearly closer to it than the bf16 arithmetic is."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    rows, seed = 3, 31
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1)
+    wm, rm = synth.make_masks(cfg, rows, seed + 2)
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
+    res = {}
+    for mode in ("fp8", "bf16"):
+        ref = model_np.OracleModel(cfg, P, np.float64, operand_round=mode)
+        y, _ = ref.embed(dm)
+        l, G = ref.forward(dm, False, True, TASK_W)
+        res[mode] = (y, l, G)
+    y_ref, l_ref, G_ref = res["fp8"]
+    names = synth.trainable_names(cfg)
+    model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    losses = model(d, False, masks=(wm, rm))
+    y = model.trunk_output(rows)
+    e_y, gap_y = _rms(y, y_ref), _rms(res["bf16"][0], y_ref)
+    e_l = max(abs(a - b) / max(abs(b), 1.0) for a, b in zip(losses, l_ref))
+    ratios = {n: (_rms(model.grad(n), G_ref[n]), _rms(res["bf16"][2][n], G_ref[n])) for n in names}
+    worst = max(ratios.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1e-9))
+    print(f"fp8 end to end: trunk rms {e_y:.2e} (fp8 | bf16 oracles apart {gap_y:.2e}) losses {e_l:.2e}; gradient furthest from its oracle relative to the gap {worst}")
+    assert np.isfinite(y).all() and all(np.isfinite(model.grad(n)).all() for n in names)
+    assert e_y < 0.6 * gap_y and e_y < 6e-2, (e_y, gap_y)
+    assert e_l < 5e-2, (losses, l_ref)
+    for n, (e, gap) in ratios.items():
+        assert e < 0.75 * gap + 2e-2, (n, e, gap)
+    model.close()
+
+
+def test_fp8_is_refused_where_the_reference_does_not_use_it():
+    import recommendersystem_amd as ra
+    from oracle import synth
+    with pytest.raises(ra.RsysError):      # finetuning keeps bf16 linears (transformer.py:671: `if not config["finetune"]`)
+        ra.RecommenderModel(synth.make_config("f8t", finetune=True, finetune_metric="rating"), dtype="fp8", max_rows=2)
+    with pytest.raises(ra.RsysError):      # shapes the 128-element K tiles cannot take
+        ra.RecommenderModel(synth.make_config("hd64"), dtype="fp8", max_rows=2)
+
+
+def test_fp8_training_tracks_bf16():
+    """40 optimizer steps from the same initial state on the same batches: the fp8 loss curve stays inside the band of the bf16 one"""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16, learning_rate=2e-3)
+    rows = 4
+    P = synth.make_params(cfg, 5, "test")
+    batches = [synth.make_batch(cfg, rows, 100 + i) for i in range(8)]
+    masks = [synth.make_masks(cfg, rows, 200 + i) for i in range(8)]
+    curves = {}
+    for dtype in ("bf16", "fp8"):
+        model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+        model.load_state_dict(P)
+        opt = ra.create_optimizer(model, cfg)
+        model.set_loss_weights(TASK_W, 1)
+        cur = []
+        for step in range(40):
+            losses = model(batches[step % 8], False, masks=masks[step % 8])
+            opt.step(clip_max_norm=1.0)
+            cur.append(sum(w * l for w, l in zip(TASK_W, losses)))
+        curves[dtype] = np.array(cur)
+        model.close()
+    a, b = curves["bf16"], curves["fp8"]
+    print("weighted loss, steps 0 / 20 / 39: bf16", a[[0, 20, 39]], "fp8", b[[0, 20, 39]])
+    assert np.isfinite(b).all()
+    assert b[-8:].mean() < b[:8].mean()                       # it learns
+    assert abs(b[-8:].mean() - a[-8:].mean()) < 0.05 * abs(a[:8].mean() - a[-8:].mean()) + 0.02 * abs(a[-8:].mean()), (a[-8:].mean(), b[-8:].mean())
+    assert np.abs(b - a).max() < 0.2 * np.abs(a).max(), np.abs(b - a).max()     # (measured 0.11: step-to-step noise at this learning rate)

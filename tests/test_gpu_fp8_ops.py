@@ -45,11 +45,13 @@ def _get(lib, p, shape, dtype):
     return out
 
 
-def _segments(cols, layout, seg_cols):
+def _segments(cols, layout, seg_cols, seg_rep=1):
     """column index arrays of the amax segments, and the destination column of every source column"""
     c = np.arange(cols)
     if layout == 1:
-        return [c[c // seg_cols == s] for s in range(cols // seg_cols)], c
+        u = c // seg_cols
+        sg = np.where(u < seg_rep, 0, u - seg_rep + 1)
+        return [c[sg == s] for s in range(sg.max() + 1)], c
     if layout == 2:
         isb = (c >> 4) & 1
         dest = np.where(isb == 1, cols // 2, 0) + (c >> 5) * 16 + (c & 15)
@@ -58,8 +60,9 @@ def _segments(cols, layout, seg_cols):
 
 
 @pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("rows,cols,layout,seg_cols", [(300, 512, 0, 0), (257, 1536, 1, 512), (130, 2816, 2, 0), (64, 192, 1, 64)])
-def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols):
+@pytest.mark.parametrize("rows,cols,layout,seg_cols,seg_rep", [(300, 512, 0, 0, 1), (257, 1536, 1, 512, 1), (130, 2816, 2, 0, 1), (64, 192, 1, 64, 1),
+                                                                (200, 1024, 1, 256, 2), (100, 640, 1, 128, 3)])
+def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols, seg_rep):
     from oracle import fp8
     lib, L = _lib()
     rng = np.random.default_rng(rows + cols + fmt)
@@ -68,17 +71,18 @@ def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols):
     xb = _bf16_bits(x); xv = _bf16_val(xb)
     ld = cols + 16
     src = np.zeros((rows, ld), np.uint16); src[:, :cols] = xb
-    d_src = _dev(lib, src); d_dst = _empty(lib, rows * cols, 0x55); d_amax = _empty(lib, 16); d_desc = _empty(lib, 32)
+    d_src = _dev(lib, src); d_dst = _empty(lib, rows * cols, 0x55); d_amax = _empty(lib, 16); d_desc = _empty(lib, 128)
     wam = np.array([0.7, 1.9, 0.031, 5.0], np.float32)
     d_wam = _dev(lib, wam)
-    segs, dest = _segments(cols, layout, seg_cols)
+    segs, dest = _segments(cols, layout, seg_cols, seg_rep)
     mode = 2 if (fmt == 1 and layout != 0) else 1
     n_w = len(segs) if mode == 2 else 3
-    rc = lib.rsys_op_f8_quantize(d_src, ld, rows, cols, fmt, layout, seg_cols, d_dst, cols, d_amax, d_desc, d_wam, n_w, mode)
+    w_rep = seg_rep
+    rc = lib.rsys_op_f8_quantize(d_src, ld, rows, cols, fmt, layout, seg_cols, seg_rep, d_dst, cols, d_amax, d_desc, d_wam, n_w, w_rep, mode)
     assert rc == 0, L.last_error()
     amax = _get(lib, d_amax, (4,), np.float32)
     got = _get(lib, d_dst, (rows, cols), np.uint8)
-    desc = _get(lib, d_desc, (8,), np.float32)
+    desc = _get(lib, d_desc, (32,), np.float32)
     want = np.zeros((rows, cols), np.uint8)
     scales = []
     for si, cidx in enumerate(segs):
@@ -91,31 +95,33 @@ def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols):
     assert not (diff & ((got & 0x7F) != 0)).any() and not (diff & ((want & 0x7F) != 0)).any(), int(diff.sum())
     sw = fp8.scale_of(wam, fp8.E4M3)
     if mode == 1:
-        for i in range(n_w):
-            assert desc[i] == fp8.descale(scales[0], sw[i]), i
+        for u in range(n_w - 1 + w_rep):
+            assert desc[u] == fp8.descale(scales[0], sw[0 if u < w_rep else u - w_rep + 1]), u
     else:
         cj = [fp8.descale(scales[j], sw[j]) for j in range(len(segs))]
         assert desc[0] == cj[-1]
         for j in range(len(segs) - 1):
-            assert desc[4 + j] == np.float32(cj[j]) / np.float32(cj[j + 1])
+            assert desc[16 + j] == np.float32(cj[j]) / np.float32(cj[j + 1])
     for p in (d_src, d_dst, d_amax, d_desc, d_wam):
         lib.rsys_dev_free(p)
 
 
-@pytest.mark.parametrize("rows,cols,layout,seg_rows", [(512, 512, 0, 0), (1536, 512, 1, 512), (2816, 512, 2, 0), (512, 1408, 0, 0), (96, 68, 2, 0)])
-def test_weight_copies_are_bit_exact(rows, cols, layout, seg_rows):
+@pytest.mark.parametrize("rows,cols,layout,seg_rows,seg_rep", [(512, 512, 0, 0, 1), (1536, 512, 1, 512, 1), (2816, 512, 2, 0, 1), (512, 1408, 0, 0, 1), (96, 68, 2, 0, 1),
+                                                                (1024, 512, 1, 256, 2)])
+def test_weight_copies_are_bit_exact(rows, cols, layout, seg_rows, seg_rep):
     from oracle import fp8
     lib, L = _lib()
     rng = np.random.default_rng(rows * 3 + cols)
     w = (rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-3, 1, (rows, 1)))).astype(np.float32) * 0.05
     d_w = _dev(lib, w); d_dst = _empty(lib, rows * cols, 0x33); d_t = _empty(lib, rows * cols, 0x33); d_amax = _empty(lib, 16)
-    rc = lib.rsys_op_f8_weights(d_w, cols, rows, cols, layout, seg_rows, d_amax, d_dst, d_t, rows)
+    rc = lib.rsys_op_f8_weights(d_w, cols, rows, cols, layout, seg_rows, seg_rep, d_amax, d_dst, d_t, rows)
     assert rc == 0, L.last_error()
     amax = _get(lib, d_amax, (4,), np.float32)
     got = _get(lib, d_dst, (rows, cols), np.uint8); got_t = _get(lib, d_t, (cols, rows), np.uint8)
     r = np.arange(rows)
     if layout == 1:
-        seg = r // seg_rows; tcol = r
+        u = r // seg_rows
+        seg = np.where(u < seg_rep, 0, u - seg_rep + 1); tcol = r
     elif layout == 2:
         seg = (r >> 4) & 1; tcol = np.where(seg == 1, rows // 2, 0) + (r >> 5) * 16 + (r & 15)
     else:
@@ -149,7 +155,8 @@ def _grid_values(fmt, rng, shape, small):
     return codes, v
 
 
-def run_gemm_f8(M, N, K, a_fmt=0, c_f32=True, desc=(1.0,), seg_cols=0, alt=0, kseg=0, small=True, seed=0):
+def run_gemm_f8(M, N, K, a_fmt=0, c_f32=True, desc=(1.0,), seg_cols=0, alt=0, kb=(), small=True, seed=0):
+    """kb: K tiles (of 128) at which a new K segment begins; desc then holds one descale per segment"""
     lib, L = _lib()
     rng = np.random.default_rng(seed)
     Ac, Av = _grid_values(a_fmt, rng, (M, K), small)
@@ -158,28 +165,28 @@ def run_gemm_f8(M, N, K, a_fmt=0, c_f32=True, desc=(1.0,), seg_cols=0, alt=0, ks
         Av[0, :] = (np.arange(K) % 5 - 2) * 0.5; Bv[:, 0] = (np.arange(N) % 7 - 3) * 0.5
         from oracle import fp8
         Ac = fp8.encode_fp8(Av, a_fmt); Bc = fp8.encode_fp8(Bv, 0)
-    d = np.zeros(8, np.float32); d[:len(desc)] = desc
-    ratios = []
-    if kseg:
-        nseg = K // 128 // kseg
-        cj = list(desc[:nseg])
+    d = np.zeros(32, np.float32); d[:len(desc)] = desc
+    if kb:
+        cj = list(desc[:len(kb) + 1])
         d[:] = 0; d[0] = cj[-1]
-        for j in range(nseg - 1):
-            d[4 + j] = np.float32(cj[j]) / np.float32(cj[j + 1])
+        for j in range(len(kb)):
+            d[16 + j] = np.float32(cj[j]) / np.float32(cj[j + 1])
+    kbs = list(kb) + [0] * (3 - len(kb))
     dA = _dev(lib, Ac); dB = _dev(lib, Bc); dD = _dev(lib, d)
     ldc = (N + 7) // 8 * 8
     dC = _empty(lib, M * ldc * (4 if c_f32 else 2))
-    rc = lib.rsys_op_gemm_f8(dA, dB, dC, M, N, K, K, K, ldc, a_fmt, int(c_f32), dD, seg_cols, alt, kseg)
+    rc = lib.rsys_op_gemm_f8(dA, dB, dC, M, N, K, K, K, ldc, a_fmt, int(c_f32), dD, seg_cols, alt, kbs[0], kbs[1], kbs[2])
     assert rc == 0, L.last_error()
     raw = _get(lib, dC, (M, ldc), np.float32 if c_f32 else np.uint16)
     out = (raw if c_f32 else _bf16_val(raw))[:, :N]
     for p in (dA, dB, dC, dD):
         lib.rsys_dev_free(p)
     A64 = Av.astype(np.float64); B64 = Bv.astype(np.float64)
-    if kseg:
+    if kb:
         ref = np.zeros((M, N))
-        for j in range(K // 128 // kseg):
-            ks = slice(j * kseg * 128, (j + 1) * kseg * 128)
+        bounds = [0] + [b * 128 for b in kb] + [K]
+        for j in range(len(kb) + 1):
+            ks = slice(bounds[j], bounds[j + 1])
             ref += (A64[:, ks] @ B64[:, ks].T) * float(desc[j])
     else:
         col = np.arange(N)
@@ -209,9 +216,13 @@ def test_gemm_f8_segment_descales():
     np.testing.assert_array_equal(out, ref.astype(np.float32))
     out, ref = run_gemm_f8(300, 2816, 512, desc=(0.5, 4.0), alt=1, seed=2)                    # [16 w1 | 16 w3] column blocks
     np.testing.assert_array_equal(out, ref.astype(np.float32))
-    out, ref = run_gemm_f8(600, 512, 1536, a_fmt=1, desc=(0.5, 2.0, 0.125), kseg=4, seed=3)   # dq | dk | dv gradients (K segments)
+    out, ref = run_gemm_f8(600, 512, 1536, a_fmt=1, desc=(0.5, 2.0, 0.125), kb=(4, 8), seed=3)   # dq | dk | dv gradients (K segments)
     np.testing.assert_array_equal(out, ref.astype(np.float32))
-    out, ref = run_gemm_f8(600, 512, 2816, a_fmt=1, desc=(2.0, 0.25), kseg=11, seed=4)        # da | db
+    out, ref = run_gemm_f8(600, 512, 1024, a_fmt=1, desc=(0.5, 2.0, 0.125), kb=(4, 6), seed=5)   # grouped-query heads: dq twice as wide
+    np.testing.assert_array_equal(out, ref.astype(np.float32))
+    out, ref = run_gemm_f8(600, 512, 2816, a_fmt=1, desc=(2.0, 0.25), kb=(11,), seed=4)          # da | db
+    np.testing.assert_array_equal(out, ref.astype(np.float32))
+    out, ref = run_gemm_f8(512, 1024, 512, desc=(0.5, 0.5, 2.0, 0.25), seg_cols=256, seed=6)     # q (two units) | k | v output columns
     np.testing.assert_array_equal(out, ref.astype(np.float32))
 
 
@@ -235,9 +246,9 @@ def test_gemm_f8_quantised_normal_data(a_fmt):
     M, N, K = 1024, 512, 1536
     a = rng.standard_normal((M, K)).astype(np.float32); b = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
     qa, sa = fp8.quantize(a, a_fmt); qb, sb = fp8.quantize(b, 0)
-    d = np.zeros(8, np.float32); d[0] = fp8.descale(sa, sb)
+    d = np.zeros(32, np.float32); d[0] = fp8.descale(sa, sb)
     dA = _dev(lib, fp8.encode_fp8(qa, a_fmt)); dB = _dev(lib, fp8.encode_fp8(qb, 0)); dD = _dev(lib, d); dC = _empty(lib, M * N * 4)
-    assert lib.rsys_op_gemm_f8(dA, dB, dC, M, N, K, K, K, N, a_fmt, 1, dD, 0, 0, 0) == 0, L.last_error()
+    assert lib.rsys_op_gemm_f8(dA, dB, dC, M, N, K, K, K, N, a_fmt, 1, dD, 0, 0, 0, 0, 0) == 0, L.last_error()
     out = _get(lib, dC, (M, N), np.float32)
     for p in (dA, dB, dC, dD):
         lib.rsys_dev_free(p)
