@@ -221,7 +221,7 @@ int32_t rsys_op_embedding_scatter(const float* gx0, int64_t ldx, const int32_t* 
                                   int32_t V, int32_t D, float* gE, int32_t atomic);
 /* fp8 trunk (RSYS_DTYPE_FP8: the reference's torchao "tensorwise" float8 linears, transformer.py:671-676), unit-test access on
  * caller-provided device buffers.  fmt: 0 = e4m3, 1 = e5m2.
- * rsys_op_f8_quantize: amax_dev[seg] = max |src| per column segment (layout 0: one; 1: column units of seg_cols, the first seg_rep
+ * rsys_op_f8_quantize: amax_dev (64 shards of 32 floats; the maximum over the shards of element seg) = max |src| per column segment (layout 0: one; 1: column units of seg_cols, the first seg_rep
  *   units are segment 0 and every further unit its own segment -- q | k | v with grouped-query heads; 2: the [16 a | 16 b] column
  *   blocks of the W13 output, two segments), then dst = sat_rne(src * FMAX / amax) as fp8 bytes (layout 2: columns de-interleaved
  *   to [all a | all b]); src bf16 [rows][cols].  desc_mode 1 / 2 also writes the descales a consumer GEMM takes (1: desc[u] =

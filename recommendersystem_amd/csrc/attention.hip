@@ -303,6 +303,39 @@ __device__ __forceinline__ void attn_work(int n_groups, int n_inner, int& group,
   }
 }
 
+// largest magnitude among the elements of one 16-byte chunk of a T tile (fp8 trunk: amax of a tensor while it is written)
+template <typename T>
+__device__ __forceinline__ float chunk_amax(const uint4& v) {
+  if constexpr (is_bf16<T>::value) {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, v);
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf((float)h[k]));
+    return m;
+  } else {
+    const float4 f = __builtin_bit_cast(float4, v);
+    return fmaxf(fmaxf(fabsf(f.x), fabsf(f.y)), fmaxf(fabsf(f.z), fabsf(f.w)));
+  }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld, int tile_tok0, int T_len, int t, float* amax = nullptr) {
+  using C = ACfg<T, HD>;
+  constexpr int CPR = HD / C::E;
+  float am = 0.f;
+  for (int c = t; c < 64 * CPR; c += 256) {
+    const int row = c / CPR, ch = c % CPR;
+    if (tile_tok0 + row < T_len) {
+      const uint4 v = *(const uint4*)(Os + row * C::LDD + ch * C::E);
+      *(uint4*)(dst + (long long)row * ld + ch * C::E) = v;
+      if (amax != nullptr) am = fmaxf(am, chunk_amax<T>(v));
+    }
+  }
+  if (amax != nullptr) {
+    am = wave_max(am);
+    if ((t & 63) == 0) f8_amax_note(amax, am);
+  }
+}
+
 // ------------------------------------------------------------------------ forward
 template <typename T, int HD>
 __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
@@ -410,12 +443,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   }
   if (g == 0 && qv) p.lse[((long long)b * p.H + h) * p.T + q] = (m_run + log2f(l_run)) * (1.f / LOG2E);
   __syncthreads();
-  constexpr int CPR = HD / C::E;
-  for (int c = t; c < 64 * CPR; c += 256) {
-    const int row = c / CPR, ch = c % CPR;
-    if (qt * 64 + row < p.T)
-      *(uint4*)((T*)p.o + (tok0 + qt * 64 + row) * p.ldo + h * HD + ch * C::E) = *(const uint4*)(Os + row * C::LDD + ch * C::E);
-  }
+  copy_out_tile<T, HD>(Os, (T*)p.o + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, qt * 64, p.T, t, p.f8_amax);
 }
 
 template <typename T, int HD>
@@ -479,16 +507,6 @@ __device__ __forceinline__ void store_grad_tile(f32x4 (&acc)[HD / 16], bool rota
     for (int r = 0; r < 4; ++r) dst[r] = from_f32<T>(o[r]);
   }
 }
-template <typename T, int HD>
-__device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld, int tile_tok0, int T_len, int t) {
-  using C = ACfg<T, HD>;
-  constexpr int CPR = HD / C::E;
-  for (int c = t; c < 64 * CPR; c += 256) {
-    const int row = c / CPR, ch = c % CPR;
-    if (tile_tok0 + row < T_len) *(uint4*)(dst + (long long)row * ld + ch * C::E) = *(const uint4*)(Os + row * C::LDD + ch * C::E);
-  }
-}
-
 // ------------------------------------------------------------------------ backward: dK, dV (one workgroup per kv tile and kv head)
 template <typename T, int HD>
 __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_bwd_kv_kernel(AttnParams p) {
@@ -596,11 +614,11 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   for (int j = 0; j < HD / 16; ++j) dK[j] *= scale;
   store_grad_tile<T, HD>(dK, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
-  copy_out_tile<T, HD>(Os, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t);
+  copy_out_tile<T, HD>(Os, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 1 : nullptr);
   __syncthreads();
   store_grad_tile<T, HD>(dV, false, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
-  copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t);
+  copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
 }
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and head)
@@ -707,7 +725,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   for (int j = 0; j < HD / 16; ++j) dQ[j] *= scale;
   store_grad_tile<T, HD>(dQ, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
-  copy_out_tile<T, HD>(Os, (T*)p.dq + (tok0 + qt * 64) * p.ldg + h * HD, p.ldg, qt * 64, p.T, t);
+  copy_out_tile<T, HD>(Os, (T*)p.dq + (tok0 + qt * 64) * p.ldg + h * HD, p.ldg, qt * 64, p.T, t, p.f8_amax);
 }
 
 template <typename T, int HD>

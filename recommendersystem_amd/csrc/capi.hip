@@ -193,7 +193,7 @@ int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes)
     ARG_CHECK(l >= 0 && l < m->L && j >= 0 && j < 3, "f8keep: layer / product index");
     src = m->f8_keep[(size_t)l * 3 + j]; n = 2 * N * m->D * 2;
   }
-  else if (k == "f8.aamax" && m->fp8) { src = m->f8_aamax; n = (int64_t)m->L * 16 * 4; }
+  else if (k == "f8.aamax" && m->fp8) { src = m->f8_aamax; n = (int64_t)m->L * F8_AMAX_SHARDS * F8_AMAX_SHARD * 4; }
   else if (k == "f8.wamax" && m->fp8) { src = m->f8_wamax; n = (int64_t)m->L * 8 * 4; }
   else if (k == "f8.desc" && m->fp8) { src = m->f8_desc; n = (int64_t)m->L * 8 * 32 * 4; }
   else if (k == "top.cap") { ARG_CHECK(bytes == 4, "top.cap: one int32"); *(int32_t*)out = m->top_is_sparse ? m->ctop_cap : 0; return RSYS_OK; }
@@ -496,7 +496,7 @@ int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32
   c.src = src; c.ld_src = ld_src; c.rows = rows; c.cols = cols; c.fmt = fmt; c.layout = layout; c.seg_cols = seg_cols; c.seg_rep = seg_rep < 1 ? 1 : seg_rep;
   c.amax = amax_dev; c.dst = (unsigned char*)dst; c.ld_dst = ld_dst; c.desc = desc_dev; c.wamax = wamax_dev; c.n_w = n_w; c.w_rep = w_rep < 1 ? 1 : w_rep;
   c.desc_mode = desc_mode;
-  HIP_CHECK(hipMemsetAsync(amax_dev, 0, 16, nullptr));
+  HIP_CHECK(hipMemsetAsync(amax_dev, 0, (size_t)F8_AMAX_SHARDS * F8_AMAX_SHARD * 4, nullptr));
   int rc = launch_f8_amax(c, nullptr);
   if (!rc) rc = launch_f8_cast(c, nullptr);
   if (rc) return rc;

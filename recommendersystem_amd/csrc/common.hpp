@@ -88,6 +88,17 @@ __device__ __forceinline__ float block_max(float v, float* smem) {
   return r;
 }
 
+// fp8 trunk (f8.hip): running amax of a tensor while its producer writes it.  An amax slot is 64 shards one cache line apart
+// (F8_AMAX_SHARD floats; the reader takes the maximum over the shards); a workgroup adds to the shard of its block index and skips
+// the atomic when the shard already holds a value at least as large (the value only grows, so a stale read costs an atomic, never
+// a result).  m >= 0: the bit patterns of non-negative floats order like ints.
+constexpr int F8_AMAX_SHARDS = 64, F8_AMAX_SHARD = 32;
+__device__ __forceinline__ void f8_amax_note(float* slot, float m) {
+  float* p = slot + (blockIdx.x & (F8_AMAX_SHARDS - 1)) * F8_AMAX_SHARD;
+  if (m > __builtin_nontemporal_load(p)) atomicMax((int*)p, __float_as_int(m));
+}
+__device__ __forceinline__ float bf16_rounded(float v) { return (float)(bf16)v; }
+
 // Philox4x32-10 counter RNG (Salmon et al. 2011), used for masks and random init.
 struct Philox {
   uint32_t k0, k1;

@@ -187,9 +187,12 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* src) {
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
+thread_local float* g_f8_amax_next = nullptr;
+
 template <typename T, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
-                                                          long long rows, int D, const int* __restrict__ rows_dev, const int* __restrict__ in_rows) {
+                                                          long long rows, int D, const int* __restrict__ rows_dev, const int* __restrict__ in_rows,
+                                                          float* amax) {
   const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int l = threadIdx.x & 63;
   if (rows_dev != nullptr) {   // compact row set (compact.hip): rows [0, n) are live, rows [n, n rounded up to 256) are written as zeros
@@ -215,13 +218,20 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)D + 1e-5f);
   if (l == 0 && rstd) rstd[row] = r;
+  float am = 0.f;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + l) * 4;
     if (EXACT || c < D) {
       const float4 sc = *(const float4*)(scale + c);
-      store4<T>(y + row * D + c, v[j].x * r * sc.x, v[j].y * r * sc.y, v[j].z * r * sc.z, v[j].w * r * sc.w);
+      const float o0 = v[j].x * r * sc.x, o1 = v[j].y * r * sc.y, o2 = v[j].z * r * sc.z, o3 = v[j].w * r * sc.w;
+      store4<T>(y + row * D + c, o0, o1, o2, o3);
+      am = fmaxf(am, fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))));
     }
+  }
+  if (amax != nullptr) {   // fp8 trunk: amax of the (bf16) output while it is written -- the rounded amax is the amax of the rounded values
+    am = wave_max(am);
+    if (l == 0) f8_amax_note(amax, (float)from_f32<T>(am));
   }
 }
 
@@ -229,7 +239,8 @@ template <typename T>
 int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev, const int* in_rows) {
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
   const dim3 grid(div_up(rows, 4)), block(256);
-#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev, in_rows)
+  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;
+#define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev, in_rows, amax)
   if (D == 256) RSYS_NORM_FWD(1, true);
   else if (D == 512) RSYS_NORM_FWD(2, true);
   else if (D == 1024) RSYS_NORM_FWD(4, true);
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
                                                           float* part, long long rows, int D, const int* __restrict__ rows_dev,
-                                                          const int* __restrict__ resid_slot, const int* __restrict__ io_rows) {
+                                                          const int* __restrict__ resid_slot, const int* __restrict__ io_rows, float* amax) {
   extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (4 * D in deterministic mode: `part` set)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   // compact row set (compact.hip): rows [0, n) live, rows [n, n rounded up to 256) get zero outputs
   const long long n_live = rows_dev != nullptr ? (long long)*rows_dev : rows;
   if (rows_dev != nullptr) rows = min(rows, (n_live + 255) & ~255LL);
+  float am = 0.f;
   for (long long row = wave0; row < rows; row += nwaves) {
     if (row >= n_live) {
 #pragma unroll
@@ -306,8 +318,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
         o.z = r * gv[j].z - xv[j].z * k + rv[j].z; o.w = r * gv[j].w - xv[j].w * k + rv[j].w;
         *(float4*)(dx_out + xrow * D + c) = o;
         if (dx_out_t) store4<TO>(dx_out_t + xrow * D + c, o.x, o.y, o.z, o.w);   // operand copy for the next GEMMs (bf16 mode)
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
       }
     }
+  }
+  if (amax != nullptr) {   // fp8 trunk: amax of the operand copy (see rmsnorm_fwd_kernel)
+    am = wave_max(am);
+    if (l == 0) f8_amax_note(amax, (float)from_f32<TO>(am));
   }
   if (part != nullptr) {
     // deterministic: the four waves' sums side by side in LDS ([4][D], launcher), added in wave order, one partial row per workgroup
@@ -341,8 +358,9 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
   float* part = det_part((long long)grid.x * D);
+  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
-                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot, io_rows)
+                                                 rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot, io_rows, amax)
   if (D == 256) RSYS_NORM_BWD(1, true);
   else if (D == 512) RSYS_NORM_BWD(2, true);
   else if (D == 1024) RSYS_NORM_BWD(4, true);

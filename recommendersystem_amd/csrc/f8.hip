@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ src,
   const int nseg = f8_nseg(cols, layout, seg_cols, seg_rep);
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const float v = block_max(mx[sgi], red);
-    if (threadIdx.x == 0 && v > 0.f) atomic_max_pos(amax + sgi, v);
+    if (threadIdx.x == 0 && v > 0.f) f8_amax_note(amax + sgi, v);
   }
 }
 
@@ -98,9 +98,18 @@ template <typename T, int FMT>
 __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
   const int R = c.rows_dev ? min(*c.rows_dev, c.rows) : c.rows;
   const int nseg = f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep);
+  __shared__ float s_amax[4];
+  if (threadIdx.x < 64) {   // an amax slot is 64 shards (common.hpp f8_amax_note): lane j reads shard j
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = wave_max(i < nseg ? c.amax[threadIdx.x * F8_AMAX_SHARD + i] : 0.f);
+      if (threadIdx.x == 0) s_amax[i] = v;
+    }
+  }
+  __syncthreads();
   float sc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) sc[i] = i < nseg ? f8_scale_of(c.amax[i], FMT) : 0.f;
+  for (int i = 0; i < 4; ++i) sc[i] = i < nseg ? f8_scale_of(s_amax[i], FMT) : 0.f;
   if (blockIdx.x == 0 && threadIdx.x == 0 && c.desc != nullptr) {
     if (c.desc_mode == 1) {          // output-column units: one activation scale, n_w weight scales
       const float ia = 1.0f / sc[0];

@@ -61,6 +61,7 @@ struct GemmParams {
   int f8_kb[3];           // K is a run of segments quantised with different scales (dq | dk | dv, da | db): f8_kb[j] > 0 = the K tile
                           // (128 elements each) at which segment j + 1 begins; there the accumulators are multiplied by
                           // f8_desc[16 + j]; f8_desc[0] is the last segment's descale
+  float* f8_amax_out;     // EPI_SWIGLU: amax |g| -> slot [0]; EPI_SWIGLU_BWD: amax |da|, |db| -> slots [0], [1] (sharded slots, common.hpp f8_amax_note)
   int f8_rseg;            // split-K form: output ROW r takes f8_desc[r / f8_rseg] (rows of dY^T: segments of different scale); 0: f8_desc[0]
   const int* f8_rowmap;   // split-K form: output row r is added to row f8_rowmap[r] of C (de-interleaved dab^T rows back to W13's order)
 };

@@ -137,6 +137,8 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
         }
       }
     };
+    float amx0 = 0.f, amx1 = 0.f;   // fp8 trunk: running amax of the tensors this epilogue produces (rows / columns beyond the matrix repeat the last ones)
+    const bool want_amax = (ec == EPI_SWIGLU || ec == EPI_SWIGLU_BWD) && p.f8_amax_out != nullptr;
     auto finish = [&](auto I, const Pre& pre) __attribute__((always_inline))  {
       constexpr int i = decltype(I)::value;
       const bool rowok = FULL || lrow + 16 * i < p.M;
@@ -200,6 +202,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
             db[r] = v[j][r] * av[r] * sg;
           }
           const int oc = ((wn0 >> 4) + j) * 32 + ((fq & 1) << 4) + ((fq >> 1) << 3);
+          if (want_amax && (FULL || (rowok && wn0 + 16 * j + 4 * fq < p.N))) {   // (this lane's own 4 columns of dg, before the pair swap)
+            amx0 = fmaxf(amx0, fmaxf(fmaxf(fabsf(da[0]), fabsf(da[1])), fmaxf(fabsf(da[2]), fabsf(da[3]))));
+            amx1 = fmaxf(amx1, fmaxf(fmaxf(fabsf(db[0]), fabsf(db[1])), fmaxf(fabsf(db[2]), fabsf(db[3]))));
+          }
           store_pair(p.C, ro + (unsigned int)oc * 2u, rowok && oc < 2 * p.N, da, db);
         }
       } else if constexpr (ec == EPI_GELU) {
@@ -223,6 +229,10 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
         for (int r = 0; r < 4; ++r) {
           g0[r] = v[0][r] * __builtin_amdgcn_rcpf(1.f + __expf(-v[0][r])) * v[1][r];
           g1[r] = v[2][r] * __builtin_amdgcn_rcpf(1.f + __expf(-v[2][r])) * v[3][r];
+        }
+        if (want_amax && (FULL || rowok)) {   // (g0 / g1: this lane's 4 columns of blocks (0,1) / (2,3), before the pair swap)
+          if (FULL || wn0 + 4 * fq < p.N) amx0 = fmaxf(amx0, fmaxf(fmaxf(fabsf(g0[0]), fabsf(g0[1])), fmaxf(fabsf(g0[2]), fabsf(g0[3]))));
+          if (FULL || wn0 + 32 + 4 * fq < p.N) amx0 = fmaxf(amx0, fmaxf(fmaxf(fabsf(g1[0]), fabsf(g1[1])), fmaxf(fabsf(g1[2]), fabsf(g1[3]))));
         }
         const unsigned int ro = rowoff(i, p.ldc, 2), ro2 = rowoff(i, p.ldc2, 2);
         store_pair(p.C, ro + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1]);
@@ -262,6 +272,16 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
       if constexpr (i + 2 < 8) { request(std::integral_constant<int, i + 2>{}, pa); asm volatile("" ::: "memory"); }
       finish(std::integral_constant<int, i + 1>{}, pb);
     });
+    if constexpr (ec == EPI_SWIGLU || ec == EPI_SWIGLU_BWD) {
+      if (want_amax) {   // (the stored values are bf16: the amax of the rounded values is the rounded amax)
+        amx0 = wave_max(amx0);
+        if constexpr (ec == EPI_SWIGLU_BWD) amx1 = wave_max(amx1);
+        if ((threadIdx.x & 63) == 0) {
+          f8_amax_note(p.f8_amax_out, bf16_rounded(amx0));
+          if constexpr (ec == EPI_SWIGLU_BWD) f8_amax_note(p.f8_amax_out + 1, bf16_rounded(amx1));
+        }
+      }
+    }
   };
   auto run2 = [&](auto EC) __attribute__((always_inline))  {
     if constexpr (MODE == 1) run(EC, std::true_type{});

@@ -198,6 +198,9 @@ struct AttnParams {
   const void* dO; float* delta;   // delta [B][H][T] = rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   void *dq, *dk, *dv; long long ldg;     // un-rotated gradients, row-major views into dqkv
   const float *rope_cos, *rope_sin; const int* rope_pos;
+  // fp8 trunk: sharded amax slots (common.hpp f8_amax_note) of what the kernels write -- forward: |O| -> [0]; backward: |dq| -> [0],
+  // |dk| -> [1], |dv| -> [2]; nullptr: off
+  float* f8_amax;
 };
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s);
 template <typename T> int launch_attn_fwd(const AttnParams& p, hipStream_t s);
@@ -223,6 +226,10 @@ int launch_fill_normal(float* dst, long long n, float std, unsigned long long se
 template <typename T>
 int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float std, unsigned long long seed, hipStream_t s, long long row0 = 0);
 
+// When set, the next launch of rmsnorm_fwd (its T-typed output) / rmsnorm_bwd (its T-typed operand copy of dx) also adds the amax
+// of what it writes to this sharded slot (common.hpp f8_amax_note); the launcher clears it.  Same thread as the launch.
+extern thread_local float* g_f8_amax_next;
+
 // ---- fp8 trunk (f8.hip): torchao's tensor-wise dynamic scaling restated (transformer.py:671-676)
 enum { F8_E4M3 = 0, F8_E5M2 = 1 };
 enum { F8_LAYOUT_PLAIN = 0, F8_LAYOUT_SEGS = 1, F8_LAYOUT_SWIGLU = 2 };
@@ -232,7 +239,8 @@ struct F8Cast {
   const int* rows_dev;                    // optional device-side row count (rows up to the next multiple of 256 are zero-filled)
   int fmt, layout, seg_cols, seg_rep;     // SEGS: column units of seg_cols; the first seg_rep units are segment 0, every further unit its own
                                           // segment (q | k | v with grouped-query heads), <= 4 segments, each with its own amax; SWIGLU: [16 a | 16 b] blocks, 2 amaxes
-  float* amax;                            // device, one slot per segment: zero before launch_f8_amax; read by launch_f8_cast
+  float* amax;                            // device: consecutive sharded slots, one per segment (common.hpp f8_amax_note: element [shard * 32 + segment],
+                                          // 64 shards): zero before the producer / launch_f8_amax adds to it; read by launch_f8_cast
   unsigned char* dst; long long ld_dst;   // [rows][cols] (SWIGLU: columns de-interleaved to [all a | all b])
   // descales of the consumer GEMM (GemmParams::f8_desc), written by the cast: mode 1 = output-column units (this tensor's scale x
   // the weight scale of unit u: the first w_rep units take weight 0, unit u >= w_rep weight u - w_rep + 1; n_w weights), mode 2 = K

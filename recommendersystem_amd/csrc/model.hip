@@ -360,7 +360,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     const int64_t base = m->lo[0].wqkv, end = m->lo[L - 1].w2 + (int64_t)D * Ip;
     m->w8_base = base;
     DALLOC(m->W8, end - base); DALLOC(m->W8T, end - base);
-    DALLOC(m->f8_wamax, L * 8 * 4); DALLOC(m->f8_aamax, L * 16 * 4); DALLOC(m->f8_desc, L * 8 * 32 * 4);
+    DALLOC(m->f8_wamax, L * 8 * 4); DALLOC(m->f8_aamax, (int64_t)L * F8_AMAX_SHARDS * F8_AMAX_SHARD * 4); DALLOC(m->f8_desc, L * 8 * 32 * 4);
     DALLOC(m->a8, NT * std::max<int64_t>(2 * Ip, m->Nqkv));
     std::vector<F8WeightJob> jobs; std::vector<int> tile_job, tile_first;
     bool aligned = true;
@@ -882,6 +882,10 @@ static const F8Op kF8Ops[8] = {
   {8, F8_LAYOUT_SEGS, F8_E5M2, 0, 3, 2},     // [dq | dk | dv] . [Wq; Wk; Wv]
 };
 
+// sharded amax slot `slot` of layer l (common.hpp f8_amax_note): producers add to it, the cast reads it
+static inline float* f8_slot(Model* m, int l, int slot) { return m->f8_aamax + (int64_t)l * F8_AMAX_SHARDS * F8_AMAX_SHARD + slot; }
+enum { F8S_XN = 0, F8S_O = 1, F8S_HN = 2, F8S_G = 3, F8S_DY2 = 4, F8S_DAB = 5, F8S_DH = 7, F8S_DQKV = 8 };
+
 // One linear of the fp8 trunk.  `p` is the bf16 call (A = the bf16 operand [M][K], epilogue, outputs); the A operand is quantised
 // (its amax first unless the producer already left it in the slot), the product runs on the fp8 pipeline with weight copy `w8`.
 static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, const unsigned char* w8, long long ldw, bool amax_done = false) {
@@ -890,7 +894,7 @@ static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, co
   F8Cast c{};
   c.src = p.A; c.ld_src = p.lda; c.rows = p.M; c.cols = p.K; c.rows_dev = p.m_dev; c.fmt = o.fmt; c.layout = o.layout;
   c.seg_cols = o.layout == F8_LAYOUT_SEGS ? m->KV * m->hd : 0; c.seg_rep = m->H / m->KV;   // (dq | dk | dv: units of one kv group)
-  c.amax = m->f8_aamax + l * 16 + o.a_slot; c.dst = m->a8; c.ld_dst = p.K;
+  c.amax = f8_slot(m, l, o.a_slot); c.dst = m->a8; c.ld_dst = p.K;
   c.desc = m->f8_desc + (l * 8 + which) * 32; c.wamax = m->f8_wamax + l * 8 + o.w_slot; c.n_w = o.n_w; c.desc_mode = o.desc_mode;
   c.w_rep = which == F8P_QKV ? m->H / m->KV : 1;
   tic(m, "hbm_f8_cast", (amax_done ? 3.0 : 5.0) * p.M * (double)p.K);
@@ -937,24 +941,25 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     GemmParams p{};
     p.A = O_in ? O_in : a.O; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = a.h; p.ldc = D; p.c_f32 = 1;
     p.M = NT; p.N = D; p.K = D; p.epi = EPI_RESIDUAL; p.resid = a.x; p.ldr = D;
-    if (m->fp8) RC(gemm_f8(m, l, F8P_O, "gemm_o_fwd", p, W8(m, m->lo[l].wo), D));
+    if (m->fp8) RC(gemm_f8(m, l, F8P_O, "gemm_o_fwd", p, W8(m, m->lo[l].wo), D, true));   // (amax |O| came with the attention kernel)
     else RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
   }
   tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
+  if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_HN);
   RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
   toc(m);
   {
     GemmParams p{};
     p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
     p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
-    if (m->fp8) RC(gemm_f8(m, l, F8P_W13, "gemm_w13_fwd", p, W8(m, m->lo[l].w13), D));
+    if (m->fp8) { p.f8_amax_out = f8_slot(m, l, F8S_G); RC(gemm_f8(m, l, F8P_W13, "gemm_w13_fwd", p, W8(m, m->lo[l].w13), D, true)); }
     else RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
   }
   {
     GemmParams p{};
     p.A = a.g; p.lda = Ip; p.B = W<T>(m, m->lo[l].w2); p.ldb = Ip; p.C = xnext; p.ldc = D; p.c_f32 = 1;
     p.M = NT; p.N = D; p.K = Ip; p.epi = EPI_RESIDUAL; p.resid = a.h; p.ldr = D;
-    if (m->fp8) RC(gemm_f8(m, l, F8P_W2, "gemm_w2_fwd", p, W8(m, m->lo[l].w2), Ip));
+    if (m->fp8) RC(gemm_f8(m, l, F8P_W2, "gemm_w2_fwd", p, W8(m, m->lo[l].w2), Ip, true));   // (amax |g| came with the SwiGLU epilogue)
     else RC(gemm<T>(m, "gemm_w2_fwd", p, false, false, false));
   }
   return RSYS_OK;
@@ -1018,7 +1023,7 @@ static int forward_trunk(Model* m) {
   tic(m, "phase_embed");
   if (m->fp8) {
     RC(ensure_f8_weights(m));
-    HIP_CHECK(hipMemsetAsync(m->f8_aamax, 0, (size_t)m->L * 16 * 4, s));   // this pass's activation / gradient amax slots
+    HIP_CHECK(hipMemsetAsync(m->f8_aamax, 0, (size_t)m->L * F8_AMAX_SHARDS * F8_AMAX_SHARD * 4, s));   // this pass's activation / gradient amax slots
   }
   if (m->table_dirty) { RC(table_forward<T>(m)); m->table_dirty = false; }
   SmallParams sp = small_params(m);
@@ -1068,6 +1073,7 @@ static int forward_trunk(Model* m) {
     const bool top = m->top_is_sparse && l == m->L - 1;   // this layer runs in selected-first token order
     const int* rpos_l = top ? m->pos_p : rpos;
     tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
+    if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_XN);
     RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s, nullptr, top ? m->c_perm : nullptr));
     toc(m);
     const bool ft = m->cfg.finetune != 0;
@@ -1089,7 +1095,7 @@ static int forward_trunk(Model* m) {
       p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
       p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
-      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV, "gemm_qkv_fwd", p, W8(m, m->lo[l].wqkv), D));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV, "gemm_qkv_fwd", p, W8(m, m->lo[l].wqkv), D, true));
       else RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
     }
     if (ft) {
@@ -1105,6 +1111,7 @@ static int forward_trunk(Model* m) {
     AttnParams& apl = top ? ap_top : ap;
     apl.q = a.qkv; apl.k = AT<T>(a.qkv) + m->H * hd; apl.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; apl.ld = m->Nqkv;
     apl.o = a.O; apl.ldo = D; apl.lse = a.lse;
+    apl.f8_amax = m->fp8 ? f8_slot(m, l, F8S_O) : nullptr;
     tic(m, "attn_fwd");
     RC(launch_attn_fwd<T>(apl, s));
     toc(m);
@@ -1558,6 +1565,7 @@ static int backward_trunk(Model* m) {
                                  m->G + m->o_norm, m->ctop_cap, D, s, m->c_n));
   } else {
     tic(m, "hbm_rmsnorm_bwd", (4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT);
+    if (m->fp8) g_f8_amax_next = f8_slot(m, m->L - 1, F8S_DY2);   // the top layer's W2 takes this gradient as its dy
     RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
     toc(m);
   }
@@ -1587,7 +1595,7 @@ static int backward_trunk(Model* m) {
       if (wt) { p.B = WT<T>(m, m->lo[l].w2); p.ldb = D; }
       p.M = NT; p.N = Ip; p.K = D; p.epi = EPI_SWIGLU_BWD; p.C2 = a.ab; p.ldc2 = 2 * Ip;
       RC(join_dw(m, DW_W13));   // the layer above's dW13 reads dab
-      if (m->fp8) RC(gemm_f8(m, l, F8P_W2_DX, "gemm_w2_dx", p, W8T(m, m->lo[l].w2), D));
+      if (m->fp8) { p.f8_amax_out = f8_slot(m, l, F8S_DAB); RC(gemm_f8(m, l, F8P_W2_DX, "gemm_w2_dx", p, W8T(m, m->lo[l].w2), D, true)); }
       else RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
       RC(join_side(m));
     }
@@ -1602,13 +1610,14 @@ static int backward_trunk(Model* m) {
       p.A = dab; p.lda = 2 * Ip; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].w13); p.ldb = 2 * Ip; }
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
-      if (m->fp8) RC(gemm_f8(m, l, F8P_W13_DX, "gemm_w13_dx", p, W8T(m, m->lo[l].w13), 2 * Ip));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_W13_DX, "gemm_w13_dx", p, W8T(m, m->lo[l].w13), 2 * Ip, true));   // (amax |da|, |db| came with the SwiGLU-backward epilogue)
       else RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 0], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
     RC(join_dw(m, DW_O));       // the layer above's dWo reads dht
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
+    if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_DH);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     toc(m);
     if (!ft && !defer) {
@@ -1622,7 +1631,7 @@ static int backward_trunk(Model* m) {
       p.A = dht; p.lda = D; p.B = W<T>(m, m->lo[l].wo); p.ldb = D; p.C = m->dO; p.ldc = D;
       if (wt) p.B = WT<T>(m, m->lo[l].wo);
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
-      if (m->fp8) RC(gemm_f8(m, l, F8P_O_DX, "gemm_o_dx", p, W8T(m, m->lo[l].wo), D));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_O_DX, "gemm_o_dx", p, W8T(m, m->lo[l].wo), D, true));
       else RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 1], m->dO, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
@@ -1633,6 +1642,7 @@ static int backward_trunk(Model* m) {
     ap.dO = m->dO; ap.delta = m->delta;
     ap.dq = dqkv; ap.dk = AT<T>(dqkv) + m->H * hd; ap.dv = AT<T>(dqkv) + (m->H + m->KV) * hd; ap.ldg = m->Nqkv;
     RC(join_dw(m, DW_QKV));     // the layer above's dWqkv reads dqkv
+    ap.f8_amax = m->fp8 ? f8_slot(m, l, F8S_DQKV) : nullptr;
     tic(m, "attn_bwd");
     if (top) {   // selected-first token order of the last layer: its ids, tile maps, RoPE positions; dO is non-zero in the leading query tiles only
       AttnParams at = ap;
@@ -1654,7 +1664,7 @@ static int backward_trunk(Model* m) {
       p.A = dqkv; p.lda = m->Nqkv; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = m->dhn; p.ldc = D;
       if (wt) { p.B = WT<T>(m, m->lo[l].wqkv); p.ldb = m->Nqkv; }
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
-      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV_DX, "gemm_qkv_dx", p, W8T(m, m->lo[l].wqkv), m->Nqkv));
+      if (m->fp8) RC(gemm_f8(m, l, F8P_QKV_DX, "gemm_qkv_dx", p, W8T(m, m->lo[l].wqkv), m->Nqkv, true));
       else RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 2], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
@@ -1707,8 +1717,10 @@ static int backward_trunk(Model* m) {
       // ... and this layer's rows are in selected-first order: x is read at, and dx written to, the original token of each place
       RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->c_dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s,
                                nullptr, m->c_slot_p, m->c_perm));
-    else
+    else {
+      if (m->fp8 && l > 0) g_f8_amax_next = f8_slot(m, l - 1, F8S_DY2);   // the layer below takes this gradient as its W2's dy
       RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
+    }
     toc(m);
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);

@@ -85,7 +85,7 @@ struct Model {
   unsigned char* W8 = nullptr;    // e4m3 copies of the trunk's linear weights, row-major [out][in]: forward B operands
   unsigned char* W8T = nullptr;   // transposed copies [in][out] (W13: K order [all w1 | all w3]): dx B operands
   float* f8_wamax = nullptr;      // [L][8]: amax of q k v o w1 w3 w2 (this step's weights)
-  float* f8_aamax = nullptr;      // [L][16]: amax of xn O hn g | dy2 da db dh dq dk dv (this pass)
+  float* f8_aamax = nullptr;      // [L][64 shards][32]: sharded amax slots (common.hpp f8_amax_note) of xn O hn g | dy2 da db dh dq dk dv (this pass)
   float* f8_desc = nullptr;       // [L][8 products][32]: descales the casts write for their consumer GEMMs (GemmParams::f8_desc)
   unsigned char* a8 = nullptr;    // fp8 copy of the current product's A operand
   void* f8_jobs = nullptr; int* f8_tile_job = nullptr; int* f8_tile_first = nullptr; int f8_ntiles = 0;

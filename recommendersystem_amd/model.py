@@ -365,7 +365,7 @@ class RecommenderModel:
             return (out.astype(np.uint32) << 16).view(np.float32)
         elif key.startswith("f8."):
             L = self.config["num_layers"]
-            out = np.empty({"f8.aamax": (L, 16), "f8.wamax": (L, 8), "f8.desc": (L, 8, 32)}[key], np.float32)
+            out = np.empty({"f8.aamax": (L, 64, 32), "f8.wamax": (L, 8), "f8.desc": (L, 8, 32)}[key], np.float32)   # (aamax: [layer][shard][slot], take the max over the shards)
         elif key == "table.fused":
             out = np.empty((V + 1, D), np.float32)
         else:

@@ -94,6 +94,17 @@ def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
         nq, nk = H * hd, KV * hd
         chk(f"qkv_dx[{l}]", get(f"f8keep.{l}.2"), Q(ref.lin_dx(dqkv[:, :nq], p + "attn.q_proj.weight") + ref.lin_dx(dqkv[:, nq:nq + nk], p + "attn.k_proj.weight")
                                                      + ref.lin_dx(dqkv[:, nq + nk:], p + "attn.v_proj.weight")))
+    # the amax every producer left beside its output (RMSNorm fwd / bwd, attention fwd / bwd, the two SwiGLU epilogues) is exactly
+    # the amax of the tensor it stored
+    am = model.debug_get("f8.aamax", rows).max(1)               # [layer][slot]
+    nq, nk = H * hd, KV * hd
+    for l in range(L):
+        da_hip, db_hip = _split_ab(get(f"dw.{l}.dab"), Ip)
+        dqkv = get(f"dw.{l}.dqkv")
+        want = {0: get(f"act.{l}.xn"), 1: get(f"act.{l}.O"), 2: get(f"act.{l}.hn"), 3: get(f"act.{l}.g"), 4: get(f"dw.{l}.gxt"), 5: da_hip, 6: db_hip,
+                7: get(f"dw.{l}.dht"), 8: dqkv[:, :nq], 9: dqkv[:, nq:nq + nk], 10: dqkv[:, nq + nk:]}
+        for slot, t in want.items():
+            assert am[l, slot] == np.float32(np.abs(t).max()), (l, slot, am[l, slot], np.abs(t).max())
     print("stage-wise fp8 products: worst bf16-output stage", worst_bf, "worst fp32-output stage", worst_f32)
     assert worst_bf[1] < 3e-3, worst_bf        # one bf16 rounding of the output: ~1.1e-3 relative RMS
     assert worst_f32[1] < 1e-4, worst_f32

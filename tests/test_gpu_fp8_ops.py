@@ -71,7 +71,7 @@ def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols, seg_rep):
     xb = _bf16_bits(x); xv = _bf16_val(xb)
     ld = cols + 16
     src = np.zeros((rows, ld), np.uint16); src[:, :cols] = xb
-    d_src = _dev(lib, src); d_dst = _empty(lib, rows * cols, 0x55); d_amax = _empty(lib, 16); d_desc = _empty(lib, 128)
+    d_src = _dev(lib, src); d_dst = _empty(lib, rows * cols, 0x55); d_amax = _empty(lib, 64 * 32 * 4); d_desc = _empty(lib, 128)
     wam = np.array([0.7, 1.9, 0.031, 5.0], np.float32)
     d_wam = _dev(lib, wam)
     segs, dest = _segments(cols, layout, seg_cols, seg_rep)
@@ -80,7 +80,7 @@ def test_quantize_is_bit_exact(fmt, rows, cols, layout, seg_cols, seg_rep):
     w_rep = seg_rep
     rc = lib.rsys_op_f8_quantize(d_src, ld, rows, cols, fmt, layout, seg_cols, seg_rep, d_dst, cols, d_amax, d_desc, d_wam, n_w, w_rep, mode)
     assert rc == 0, L.last_error()
-    amax = _get(lib, d_amax, (4,), np.float32)
+    amax = _get(lib, d_amax, (64, 32), np.float32).max(0)      # an amax slot is 64 shards; element [shard][segment]
     got = _get(lib, d_dst, (rows, cols), np.uint8)
     desc = _get(lib, d_desc, (32,), np.float32)
     want = np.zeros((rows, cols), np.uint8)

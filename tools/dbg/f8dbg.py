@@ -45,7 +45,7 @@ for dt in ("fp8","bf16"):
         if "layers.0" in n or "layers" not in n:
             print("   grad", n, rel(model.grad(n), G_ref[n]), "oracles apart", rel(G_other[n], G_ref[n]))
     if dt=="fp8":
-        print("aamax", model.debug_get("f8.aamax", rows)[0][:4], "wamax", model.debug_get("f8.wamax", rows)[0])
+        print("aamax", model.debug_get("f8.aamax", rows).max(1)[0][:4], "wamax", model.debug_get("f8.wamax", rows)[0])
         xn = np.asarray(tc[0]["xn"]); print("oracle amax xn", np.abs(xn).max(), "O", np.abs(np.asarray(tc[0]["o"])).max(), "hn", np.abs(np.asarray(tc[0]["hn"])).max(), "g", np.abs(np.asarray(tc[0]["g"])).max())
         for nme in ("attn.q_proj","attn.k_proj","attn.v_proj","attn.output_proj","mlp.w1","mlp.w3","mlp.w2"):
             print(nme, np.abs(P[f"transformers.layers.0.{nme}.weight"]).max())
