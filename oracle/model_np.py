@@ -166,10 +166,12 @@ class OracleModel:
         operand_round="fp8": the same, and the transformer blocks' linears (q k v o w1 w3 w2: forward and input-gradient
         products) take tensor-wise dynamically scaled fp8 operands -- torchao's "tensorwise" float8 recipe the reference applies
         to `transformers.*` for pretraining (transformer.py:671-676), restated in oracle/fp8.py (parity unpinned against torchao
-        itself).  Weight gradients use the bf16 operands, as the HIP path's fp8 mode does."""
+        itself): forward, input-gradient and weight-gradient products.  `fp8_dw = False` afterwards: weight gradients from the
+        bf16 operands instead (the HIP path's RSYS_F8_DW=0 / deterministic mode)."""
         self.cfg = cfg
         self.dt = dtype
         self.fp8 = operand_round == "fp8"
+        self.fp8_dw = self.fp8
         if operand_round is None:
             self.q = lambda a: a
         else:
@@ -204,6 +206,17 @@ class OracleModel:
         qg, sg = fp8.quantize(np.asarray(g, np.float32), fp8.E5M2)
         qw, sw = fp8.quantize(np.asarray(self.P[name], np.float32), fp8.E4M3)
         return (qg.astype(self.dt) @ qw.astype(self.dt)) * self.dt(fp8.descale(sg, sw))
+
+    def lin_dw(self, g, x):
+        """dW = g^T x over all tokens (fp8 mode: e5m2 output gradient, e4m3 input, fp32 result -- torchao rounds this product to
+        bf16 before it is accumulated into the fp32 .grad; the HIP path and this oracle keep the fp32 sum)"""
+        g2 = g.reshape(-1, g.shape[-1]); x2 = x.reshape(-1, x.shape[-1])
+        if not (self.fp8 and self.fp8_dw):
+            return g2.T @ x2
+        from . import fp8
+        qg, sg = fp8.quantize(np.asarray(g2, np.float32), fp8.E5M2)
+        qx, sx = fp8.quantize(np.asarray(x2, np.float32), fp8.E4M3)
+        return (qg.astype(self.dt).T @ qx.astype(self.dt)) * self.dt(fp8.descale(sg, sx))
 
     # ---- embeddings
     def action_features(self, d):
@@ -306,18 +319,18 @@ class OracleModel:
             # out = h + g W2^T
             Q = self.q
             gxq = Q(gx)                                                 # the gradient as a GEMM operand
-            G[p + "mlp.w2.weight"] = fl(gxq).T @ fl(c["g"])
+            G[p + "mlp.w2.weight"] = self.lin_dw(gxq, c["g"])
             gg = self.lin_dx(gxq, p + "mlp.w2.weight")
             ga = Q(gg * c["b"] * (c["sig"] * (1.0 + c["a"] * (1.0 - c["sig"]))))
             gb = Q(gg * c["a"] * c["sig"])
-            G[p + "mlp.w1.weight"] = fl(ga).T @ fl(c["hn"])
-            G[p + "mlp.w3.weight"] = fl(gb).T @ fl(c["hn"])
+            G[p + "mlp.w1.weight"] = self.lin_dw(ga, c["hn"])
+            G[p + "mlp.w3.weight"] = self.lin_dw(gb, c["hn"])
             ghn = Q(self.lin_dx(ga, p + "mlp.w1.weight") + self.lin_dx(gb, p + "mlp.w3.weight"))
             dh, G[p + "mlp_norm.scale"] = rmsnorm_bwd(ghn, c["h"], P[p + "mlp_norm.scale"], c["r2"])
             gh = gx + dh
             ghq = Q(gh)
             # h = x + o Wo^T
-            G[p + "attn.output_proj.weight"] = fl(ghq).T @ fl(c["o"])
+            G[p + "attn.output_proj.weight"] = self.lin_dw(ghq, c["o"])
             go = Q(self.lin_dx(ghq, p + "attn.output_proj.weight")).reshape(B, T, H, hd)
             kk = np.repeat(c["k"], rep, axis=2); vv = np.repeat(c["v"], rep, axis=2)
             pr = c["pr"]
@@ -345,9 +358,9 @@ class OracleModel:
                 G[p + "attn.v_proj_lora_A.weight"] = fl(gva).T @ fl(c["xn"])
                 gxn = gxn + gqa @ self.W(p + "attn.q_proj_lora_A.weight") + gva @ self.W(p + "attn.v_proj_lora_A.weight")
             gxn = Q(gxn)
-            G[p + "attn.q_proj.weight"] = fl(gq).T @ fl(c["xn"])
-            G[p + "attn.k_proj.weight"] = fl(gk).T @ fl(c["xn"])
-            G[p + "attn.v_proj.weight"] = fl(gv).T @ fl(c["xn"])
+            G[p + "attn.q_proj.weight"] = self.lin_dw(gq, c["xn"])
+            G[p + "attn.k_proj.weight"] = self.lin_dw(gk, c["xn"])
+            G[p + "attn.v_proj.weight"] = self.lin_dw(gv, c["xn"])
             dx, G[p + "sa_norm.scale"] = rmsnorm_bwd(gxn, c["x"], P[p + "sa_norm.scale"], c["r1"])
             gx = gh + dx
         return gx

@@ -152,6 +152,87 @@ __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
   }
 }
 
+// The same cast for a tensor whose transposed copy is wanted too: one 128-row x 64-column tile per workgroup, the fp8 bytes pass
+// through LDS and leave a second time as 16-byte pieces along the rows (128 contiguous bytes per column and tile).
+template <typename T, int FMT>
+__global__ __launch_bounds__(256) void f8_cast_t_kernel(F8Cast c) {
+  __shared__ float s_amax[4];
+  __shared__ float s_xamax;
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64][144];   // [column][row], 16-byte aligned rows of 128 (+16: bank spread)
+  const int nseg = f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep);
+  const int t = threadIdx.x;
+  if (t < 64) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = wave_max(i < nseg ? c.amax[t * F8_AMAX_SHARD + i] : 0.f);
+      if (t == 0) s_amax[i] = v;
+    }
+    if (c.desc_dw != nullptr) { const float v = wave_max(c.xamax[t * F8_AMAX_SHARD]); if (t == 0) s_xamax = v; }
+  }
+  __syncthreads();
+  float sc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sc[i] = i < nseg ? f8_scale_of(s_amax[i], FMT) : 0.f;
+  if (blockIdx.x == 0 && t == 0) {
+    if (c.desc != nullptr && c.desc_mode == 1) {
+      const float ia = 1.0f / sc[0];
+      const int units = c.n_w - 1 + c.w_rep;
+      for (int u = 0; u < units; ++u) c.desc[u] = ia * (1.0f / f8_scale_of(c.wamax[u < c.w_rep ? 0 : u - c.w_rep + 1], F8_E4M3));
+    } else if (c.desc != nullptr && c.desc_mode == 2) {
+      float cj[4];
+      for (int j = 0; j < nseg; ++j) cj[j] = (1.0f / sc[j]) * (1.0f / f8_scale_of(c.wamax[j], F8_E4M3));
+      c.desc[0] = cj[nseg - 1];
+      for (int j = 0; j + 1 < nseg; ++j) c.desc[16 + j] = cj[j] / cj[j + 1];
+    }
+    if (c.desc_dw != nullptr) {   // weight-gradient product: row unit u of dY^T against the forward operand's scale
+      const float ix = 1.0f / f8_scale_of(s_xamax, F8_E4M3);
+      for (int u = 0; u < c.dw_units; ++u) {
+        const int sg = c.layout == F8_LAYOUT_SEGS ? (u < c.seg_rep ? 0 : u - c.seg_rep + 1) : (c.layout == F8_LAYOUT_SWIGLU ? u : 0);
+        c.desc_dw[u] = (1.0f / sc[sg]) * ix;
+      }
+    }
+  }
+  const int ct = c.cols >> 6;
+  const int r0 = (blockIdx.x / ct) * 128, c0 = (blockIdx.x % ct) * 64;
+  const T* src = (const T*)c.src;
+  const int half = c.cols >> 1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int it = t + 256 * k;            // 512 items: (row 0..127) x (16-column group 0..3)
+    const int rl = it >> 2, gq = it & 3;
+    const int col = c0 + gq * 16;
+    const int sg = f8_seg_of(col, c.layout, c.seg_cols, c.seg_rep);
+    const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (sg ? half : 0) + (col >> 5) * 16 : col;
+    const float s = sg == 0 ? sc[0] : (sg == 1 ? sc[1] : (sg == 2 ? sc[2] : sc[3]));
+    const T* p = src + (long long)(r0 + rl) * c.ld_src + col;
+    float v[16];
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[q] = (float)a[q] * s; v[8 + q] = (float)b[q] * s; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float4 a = *(const float4*)(p + 4 * q); v[4 * q] = a.x * s; v[4 * q + 1] = a.y * s; v[4 * q + 2] = a.z * s; v[4 * q + 3] = a.w * s; }
+    }
+    uint4 out;
+    out.x = f8_pack4<FMT>(v[0], v[1], v[2], v[3]); out.y = f8_pack4<FMT>(v[4], v[5], v[6], v[7]);
+    out.z = f8_pack4<FMT>(v[8], v[9], v[10], v[11]); out.w = f8_pack4<FMT>(v[12], v[13], v[14], v[15]);
+    *(uint4*)(c.dst + (long long)(r0 + rl) * c.ld_dst + dcol) = out;
+    const unsigned int w4[4] = {out.x, out.y, out.z, out.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[gq * 16 + q][rl] = (unsigned char)(w4[q >> 2] >> (8 * (q & 3)));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int it = t + 256 * k;            // 512 items: (column 0..63) x (16-row piece 0..7)
+    const int cl = it >> 3, rp = it & 7;
+    const int col = c0 + cl;
+    const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (((col >> 4) & 1) ? half : 0) + (col >> 5) * 16 + (col & 15) : col;
+    *(uint4*)(c.dst_t + (long long)dcol * c.ld_dst_t + r0 + rp * 16) = *(const uint4*)&tile[cl][rp * 16];
+  }
+}
+
 // ---- weights: fp32 master [rows][cols] -> e4m3 row-major copy + transposed copy, one 64 x 64 tile per workgroup, job table.
 // Row segments: qkv rows / seg_rows -> q | k | v; W13 rows in [16 w1 | 16 w3] blocks.
 __device__ __forceinline__ int f8w_seg(const F8WeightJob& j, int r) {
@@ -252,9 +333,18 @@ int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   ARG_CHECK(c.layout != F8_LAYOUT_SWIGLU || c.cols % 32 == 0, "fp8 cast: [16 a | 16 b] column blocks");
   ARG_CHECK(c.desc_mode == 0 || (c.desc != nullptr && c.wamax != nullptr && c.n_w >= 1 && c.n_w <= 4), "fp8 cast: descale job");
   ARG_CHECK(c.desc_mode != 1 || (c.w_rep >= 1 && c.n_w - 1 + c.w_rep <= 16), "fp8 cast: at most 16 output-column units");
+  const bool e5 = c.fmt == F8_E5M2;
+  if (c.dst_t != nullptr) {
+    ARG_CHECK(c.rows % 128 == 0 && c.cols % 64 == 0 && c.rows_dev == nullptr && c.ld_dst_t % 16 == 0 && c.ld_dst_t >= c.rows, "fp8 cast with a transposed copy: rows % 128, cols % 64");
+    ARG_CHECK(c.desc_dw == nullptr || (c.xamax != nullptr && c.dw_units >= 1 && c.dw_units <= 16), "fp8 cast: weight-gradient descale job");
+    const int grid_t = (c.rows / 128) * (c.cols / 64);
+    if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
+    else { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
+    HIP_CHECK(hipGetLastError());
+    return RSYS_OK;
+  }
   const long long total = (long long)c.rows * (c.cols >> 4);
   const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
-  const bool e5 = c.fmt == F8_E5M2;
   if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_kernel<float, F8_E5M2>), dim3(grid), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_kernel<float, F8_E4M3>), dim3(grid), dim3(256), 0, s, c); }
   else { if (e5) hipLaunchKernelGGL((f8_cast_kernel<bf16, F8_E5M2>), dim3(grid), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_kernel<bf16, F8_E4M3>), dim3(grid), dim3(256), 0, s, c); }
   HIP_CHECK(hipGetLastError());

@@ -62,8 +62,10 @@ struct GemmParams {
                           // (128 elements each) at which segment j + 1 begins; there the accumulators are multiplied by
                           // f8_desc[16 + j]; f8_desc[0] is the last segment's descale
   float* f8_amax_out;     // EPI_SWIGLU: amax |g| -> slot [0]; EPI_SWIGLU_BWD: amax |da|, |db| -> slots [0], [1] (sharded slots, common.hpp f8_amax_note)
-  int f8_rseg;            // split-K form: output ROW r takes f8_desc[r / f8_rseg] (rows of dY^T: segments of different scale); 0: f8_desc[0]
-  const int* f8_rowmap;   // split-K form: output row r is added to row f8_rowmap[r] of C (de-interleaved dab^T rows back to W13's order)
+  int f8_rseg;            // split-K form (weight gradients dW = dY8^T . X8): output ROW r takes f8_desc[r / f8_rseg] (the rows of dY^T come
+                          // in units of different scale: dq | dk | dv, da | db); 0: f8_desc[0]
+  int f8_rowmode;         // split-K form: 1 = the rows are the de-interleaved [all da | all db] gradient; row r is added to row
+                          // (i >> 4) * 32 + is_b * 16 + (i & 15) of C (W13's [16 w1 | 16 w3] row blocks), i = r - is_b * M / 2
 };
 
 // CT = compute type (bf16 -> v_mfma_f32_16x16x32_bf16, float -> v_mfma_f32_16x16x4_f32).
@@ -79,7 +81,7 @@ long long gemm_slab_need(const GemmParams& p, bool a_f32, bool b_f32, bool a_km,
 // pipeline (gemm8p.hip): a plan deals the products to the XCDs once, launches reuse it.  Products: bf16 K-major operands, fp32
 // C, EPI_ATOMIC (C must hold zeros or the sum so far).
 struct GemmGroupPlan;
-bool gemm8p_group_eligible(const GemmParams& p);
+bool gemm8p_group_eligible(const GemmParams& p);   // (p.f8 set: the fp8 split-K form, else the bf16 K-major form; one form per plan)
 int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out);
 void gemm8p_group_plan_destroy(GemmGroupPlan* pl);
 double gemm8p_group_flops(const GemmGroupPlan* pl);
@@ -89,6 +91,9 @@ int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s);
 // fp8 row-major operands on the persistent 256x256 pipeline (K tiles of 128 elements, v_mfma_f32_16x16x128_f8f6f4); p.f8 set
 bool gemm8p_f8_eligible(const GemmParams& p);
 int launch_gemm8p_f8(const GemmParams& p, hipStream_t s);
+// the same operands, split-K with fp32 atomics (EPI_ATOMIC): the fp8 trunk's weight gradients on K-contiguous (transposed) copies
+bool gemm8p_f8_splitk_eligible(const GemmParams& p);
+int launch_gemm8p_f8_splitk(const GemmParams& p, hipStream_t s);
 
 // short name of the kernel launch_gemm picks for this problem ("8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);

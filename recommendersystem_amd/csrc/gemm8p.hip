@@ -452,6 +452,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     float* const C = (float*)p.C;
     const int wm0 = em0 + wr * 128, wn0 = en0 + wc * 64;
     const int col = wn0 + l;
+    [[maybe_unused]] const cfloat_p f8d = (cfloat_p)p.f8_desc;
     auto stage_acc = [&](auto Q) __attribute__((always_inline)) {
       constexpr int q = decltype(Q)::value;
       static_for<2>([&](auto ii) { static_for<4>([&](auto j) {
@@ -471,9 +472,14 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
         for (int r = 0; r < 32; ++r) {
           const int row = wm0 + q * 32 + r;
           if (row < p.M) {
-            const float v = p.alpha * Cs[r * CS_LD + l];
+            float v = p.alpha * Cs[r * CS_LD + l];
+            int orow = row;
+            if constexpr (F8 != 0) {   // descale of the row's gradient tensor; de-interleaved rows back to W13's row blocks
+              v *= f8d[p.f8_rseg > 0 ? row / p.f8_rseg : 0];
+              if (p.f8_rowmode == 1) { const int half = p.M >> 1, isb = row >= half ? 1 : 0, i = row - isb * half; orow = ((i >> 4) << 5) + (isb << 4) + (i & 15); }
+            }
             if (p.slab != nullptr) p.slab[((long long)split_id * p.M + row) * p.N + col] = v;   // deterministic mode (gemm.hpp)
-            else atomicAdd(C + (long long)row * p.ldc + col, v);
+            else atomicAdd(C + (long long)orow * p.ldc + col, v);
           }
         }
       }
@@ -512,6 +518,19 @@ template <int F8>
 __global__ __launch_bounds__(512) void gemm8p_f8_kernel(GemmParams p) {
   gemm8p_body<false, false, false, F8>(p, blockIdx.x, gridDim.x, 0, 0);
 }
+// fp8 split-K (A = dY8^T e5m2, B = X8^T e4m3, both K-contiguous): one product per launch / many products per launch
+__global__ __launch_bounds__(512) void gemm8p_f8sk_kernel(GemmParams p) {
+  gemm8p_body<false, true, false, 2>(p, blockIdx.x, gridDim.x, 0, 0);
+}
+__global__ __launch_bounds__(512) void gemm8p_group_f8_kernel(const GemmParams* __restrict__ probs, const int* __restrict__ xcd_off,
+                                                              const unsigned int* __restrict__ work) {
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int o = xcd_off[xcd];
+  if (local >= xcd_off[xcd + 1] - o) return;
+  const unsigned int wk = work[o + local];     // product << 24 | split << 16 | tile
+  const GemmParams p = probs[wk >> 24];
+  gemm8p_body<false, true, true, 2>(p, blockIdx.x, gridDim.x, (int)(wk & 0xFFFFu), (int)((wk >> 16) & 0xFFu));
+}
 
 // Grouped K-major split-K launch: the weight gradients dW = dY^T X of MANY layers in one grid.  Each product alone is too small
 // for the chip (4 - 22 output tiles of 256^2 at cfg-3), all of them together are not.  The host deals the products to the 8
@@ -535,10 +554,11 @@ struct GemmGroupPlan {
   void* dev = nullptr;          // [probs | xcd_off | work]
   const GemmParams* d_probs = nullptr; const int* d_off = nullptr; const unsigned int* d_work = nullptr;
   int grid = 0, n = 0, splitk = 1;
+  bool f8 = false;
   double flops = 0.0;
 };
 
-bool gemm8p_group_eligible(const GemmParams& p) { return gemm8p_tn_eligible(p) && p.slab == nullptr; }
+bool gemm8p_group_eligible(const GemmParams& p) { return (p.f8 ? gemm8p_f8_splitk_eligible(p) : gemm8p_tn_eligible(p)) && p.slab == nullptr; }
 
 // Deals `n` (<= 128) K-major products (EPI_ATOMIC, fp32 C, zero or accumulating) to the XCDs and uploads the plan.  The plan
 // holds device pointers of the operands: it stays valid while those buffers do.  Synchronous (one small H2D copy).
@@ -549,11 +569,13 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   const int per_xcd = std::max(1, cus / 8);
   std::vector<int> tiles(n), ktiles(n);
   int ktmax = 0;
+  const bool f8 = probs[0].f8 != 0;
   for (int i = 0; i < n; ++i) {
-    ARG_CHECK(gemm8p_group_eligible(probs[i]), "grouped GEMM: product not eligible for the K-major LDS-DMA kernel");
+    ARG_CHECK((probs[i].f8 != 0) == f8, "grouped GEMM: fp8 and bf16 products in one plan");
+    ARG_CHECK(gemm8p_group_eligible(probs[i]), "grouped GEMM: product not eligible for the split-K LDS-DMA kernel");
     tiles[i] = ((probs[i].M + T8_BM - 1) / T8_BM) * ((probs[i].N + T8_BN - 1) / T8_BN);
     ARG_CHECK(tiles[i] < 65536, "grouped GEMM: too many tiles");
-    ktiles[i] = (probs[i].K + T8_BK - 1) / T8_BK;
+    ktiles[i] = f8 ? probs[i].K / 128 : (probs[i].K + T8_BK - 1) / T8_BK;
     ktmax = std::max(ktmax, ktiles[i]);
   }
   // products to XCDs: largest first onto the least loaded list (work = tiles x K tiles)
@@ -616,7 +638,7 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   ok = ok && hipMemcpy((void*)pl->d_off, off.data(), 9 * 4, hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy((void*)pl->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { hipFree(pl->dev); delete pl; set_error("grouped GEMM: plan upload failed"); return RSYS_ERR_HIP; }
-  pl->grid = 8 * longest; pl->n = n; pl->splitk = best_s; pl->flops = flops;
+  pl->grid = 8 * longest; pl->n = n; pl->splitk = best_s; pl->flops = flops; pl->f8 = f8;
   *out = pl;
   return RSYS_OK;
 }
@@ -625,7 +647,8 @@ double gemm8p_group_flops(const GemmGroupPlan* pl) { return pl->flops; }
 int gemm8p_group_splitk(const GemmGroupPlan* pl) { return pl->splitk; }
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s) {
   if (pl->grid <= 0) return RSYS_OK;
-  hipLaunchKernelGGL(gemm8p_group_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
+  if (pl->f8) hipLaunchKernelGGL(gemm8p_group_f8_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
+  else hipLaunchKernelGGL(gemm8p_group_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -745,6 +768,41 @@ int launch_gemm8p_f8(const GemmParams& p0, hipStream_t s) {
   else hipLaunchKernelGGL(gemm8p_f8_kernel<2>, grid, dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
+}
+
+bool gemm8p_f8_splitk_eligible(const GemmParams& p) {
+  if (p.f8 != 2 || p.f8_desc == nullptr) return false;
+  if (p.epi != EPI_ATOMIC || !p.c_f32 || p.k_dev != nullptr || p.m_dev != nullptr) return false;
+  if (p.K % 128 != 0 || p.K < 256 || p.lda % 16 != 0 || p.ldb % 16 != 0 || p.N % 8 != 0) return false;
+  if ((unsigned long long)p.M * p.lda >= (1ull << 32) || (unsigned long long)p.N * p.ldb >= (1ull << 32)) return false;
+  if (p.f8_rseg > 0 && (p.M + p.f8_rseg - 1) / p.f8_rseg > 16) return false;
+  if (p.f8_rowmode == 1 && p.M % 32 != 0) return false;
+  if (p.f8_rowmode != 0 && p.slab != nullptr) return false;   // (the ordered slab sum has no row map)
+  return true;
+}
+
+int launch_gemm8p_f8_splitk(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  ARG_CHECK(gemm8p_f8_splitk_eligible(p), "fp8 split-K GEMM: shape / operand layout not supported");
+  if (p.alpha == 0.f) p.alpha = 1.f;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  {   // K splits as for the bf16 row-major split-K form, in K tiles of 128
+    const int ktiles = p.K / 128;
+    int best = 8; double best_score = -1.0;
+    for (int sk = 8; sk <= 256; sk += 8) {
+      const int per = (ktiles + sk - 1) / sk;
+      if (per < 2 && sk > 8) break;
+      const long long wgs = (long long)tiles * sk;
+      const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+      const double score = eff * per / (per + 16.0);
+      if (score > best_score) { best_score = score; best = sk; }
+    }
+    p.splitk = best;
+  }
+  { const int rc_ = gemm_slab_begin(p, s); if (rc_ != RSYS_OK) return rc_; }
+  hipLaunchKernelGGL(gemm8p_f8sk_kernel, dim3(tiles * p.splitk), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return gemm_slab_end(p, s);
 }
 
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {

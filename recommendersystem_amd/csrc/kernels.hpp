@@ -246,6 +246,13 @@ struct F8Cast {
   // the weight scale of unit u: the first w_rep units take weight 0, unit u >= w_rep weight u - w_rep + 1; n_w weights), mode 2 = K
   // segments (this tensor's segment j x weight j; desc[0] = last, desc[16 + j] = ratios)
   float* desc; const float* wamax; int n_w; int w_rep; int desc_mode;
+  // optional transposed copy dst_t[c'][r] (ld_dst_t >= rows; rows % 128 == 0, cols % 64 == 0): the K-contiguous operand of the fp8
+  // weight gradient dW = dY8^T . X8 (K = tokens)
+  unsigned char* dst_t; long long ld_dst_t;
+  // optional descales of that weight-gradient product (GemmParams::f8_desc of launch_gemm8p_f8_splitk), written by the cast of the
+  // GRADIENT operand: desc_dw[u] = 1 / (s_this[segment of row unit u] * s_x), u < dw_units (units as in seg_cols / seg_rep; SWIGLU:
+  // two units), s_x from the sharded amax slot xamax of the forward operand
+  float* desc_dw; const float* xamax; int dw_units;
 };
 int launch_f8_amax(const F8Cast& c, hipStream_t s);
 int launch_f8_cast(const F8Cast& c, hipStream_t s);

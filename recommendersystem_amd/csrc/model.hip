@@ -381,6 +381,18 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       add(l, m->lo[l].w2, (int)D, Ip, F8_LAYOUT_PLAIN, 0, 6);
     }
     if (!aligned) { set_error("fp8 trunk: weight offsets are not 16-byte aligned in the fp8 copies"); return RSYS_ERR_ARG; }
+    static const int f8dw = getenv("RSYS_F8_DW") ? atoi(getenv("RSYS_F8_DW")) : 1;
+    m->f8_dw = f8dw != 0 && (2 * m->S) % 128 == 0;   // (K = tokens in tiles of 128)
+    if (m->f8_dw) {
+      m->f8_ldt = NT;
+      m->f8t.resize(L);
+      for (int l = 0; l < L; ++l) {
+        Model::F8T& t = m->f8t[l];
+        DALLOC(t.xn, D * NT); DALLOC(t.O, D * NT); DALLOC(t.hn, D * NT); DALLOC(t.g, (int64_t)Ip * NT);
+        DALLOC(t.gxt, D * NT); DALLOC(t.dab, (int64_t)2 * Ip * NT); DALLOC(t.dht, D * NT); DALLOC(t.dqkv, (int64_t)m->Nqkv * NT);
+      }
+      DALLOC(m->f8_desc_dw, L * 4 * 32 * 4);
+    }
     if (getenv("RSYS_F8_DEBUG_KEEP") && atoi(getenv("RSYS_F8_DEBUG_KEEP")) != 0) {   // stage-wise parity tests of the backward products
       m->f8_keep.assign((size_t)L * 3, nullptr);
       for (size_t i = 0; i < m->f8_keep.size(); ++i) DALLOC(m->f8_keep[i], NT * D * 2);
@@ -897,7 +909,19 @@ static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, co
   c.amax = f8_slot(m, l, o.a_slot); c.dst = m->a8; c.ld_dst = p.K;
   c.desc = m->f8_desc + (l * 8 + which) * 32; c.wamax = m->f8_wamax + l * 8 + o.w_slot; c.n_w = o.n_w; c.desc_mode = o.desc_mode;
   c.w_rep = which == F8P_QKV ? m->H / m->KV : 1;
-  tic(m, "hbm_f8_cast", (amax_done ? 3.0 : 5.0) * p.M * (double)p.K);
+  const bool tcopy = m->f8_dw && p.m_dev == nullptr && p.M % 128 == 0;
+  if (tcopy) {   // K-contiguous copy for the weight gradient; the gradient operand's cast also writes that product's descales
+    Model::F8T& t = m->f8t[l];
+    unsigned char* const dst_t[8] = {t.xn, t.O, t.hn, t.g, t.gxt, t.dab, t.dht, t.dqkv};
+    c.dst_t = dst_t[which]; c.ld_dst_t = m->f8_ldt;
+    if (which >= F8P_W2_DX) {
+      static const int x_slot[4] = {F8S_G, F8S_HN, F8S_O, F8S_XN};   // forward operand of w2, w13, o, qkv
+      c.desc_dw = m->f8_desc_dw + (l * 4 + (which - F8P_W2_DX)) * 32;
+      c.xamax = f8_slot(m, l, x_slot[which - F8P_W2_DX]);
+      c.dw_units = which == F8P_W13_DX ? 2 : (which == F8P_QKV_DX ? m->H / m->KV + 2 : 1);
+    }
+  }
+  tic(m, "hbm_f8_cast", ((amax_done ? 3.0 : 5.0) + (tcopy ? 1.0 : 0.0)) * p.M * (double)p.K);
   if (!amax_done) RC(launch_f8_amax(c, s));
   RC(launch_f8_cast(c, s));
   toc(m);
@@ -912,6 +936,30 @@ static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, co
   p.flags |= m->gemm_flags;
   if (m->timer.enabled) tic(m, (std::string(tag) + "@8f").c_str(), 2.0 * p.M * p.N * (double)p.K);
   const int rc = launch_gemm8p_f8(p, s);
+  toc(m);
+  return rc;
+}
+// weight gradient of linear `k` (0 w2, 1 w13, 2 o, 3 qkv) of layer l from the transposed fp8 copies: dW += q(dY)^T . q(X), K = tokens
+static GemmParams f8_dw_params(Model* m, int l, int k, int NT) {
+  const Model::F8T& t = m->f8t[l];
+  const int D = m->D, Ip = m->Ip;
+  GemmParams p{};
+  p.lda = p.ldb = m->f8_ldt; p.K = NT; p.c_f32 = 1; p.epi = EPI_ATOMIC; p.alpha = 1.f; p.f8 = 2;
+  p.f8_desc = m->f8_desc_dw + (l * 4 + k) * 32;
+  switch (k) {
+    case 0: p.A = t.gxt; p.B = t.g; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.M = D; p.N = Ip; break;
+    case 1: p.A = t.dab; p.B = t.hn; p.C = m->G + m->lo[l].w13; p.ldc = D; p.M = 2 * Ip; p.N = D; p.f8_rseg = Ip; p.f8_rowmode = 1; break;
+    case 2: p.A = t.dht; p.B = t.O; p.C = m->G + m->lo[l].wo; p.ldc = D; p.M = D; p.N = D; break;
+    default: p.A = t.dqkv; p.B = t.xn; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.M = m->Nqkv; p.N = D; p.f8_rseg = m->KV * m->hd; break;
+  }
+  return p;
+}
+static inline bool use_f8_dw(const Model* m) { return m->f8_dw && !m->deterministic && m->cur_rows * 2 * m->S % 128 == 0; }
+// one product at a time (layers whose products are large enough alone: the production shape)
+static int f8_dw_launch(Model* m, int l, int k, const char* tag, int NT) {
+  GemmParams p = f8_dw_params(m, l, k, NT);
+  if (m->timer.enabled) tic(m, (std::string(tag) + "@8fs").c_str(), 2.0 * p.M * p.N * (double)p.K);
+  const int rc = launch_gemm8p_f8_splitk(p, m->stream);
   toc(m);
   return rc;
 }
@@ -1509,7 +1557,8 @@ template <typename T>
 static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
   const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
   const bool top_compact = m->top_is_sparse;   // the last layer's W2 / W13 / Wo products ran on the compact rows already
-  const long long key = ((long long)top_compact << 56) | ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
+  const bool f8 = use_f8_dw(m);                 // fp8 trunk: the products read the transposed fp8 copies instead
+  const long long key = ((long long)f8 << 57) | ((long long)top_compact << 56) | ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
   auto it = m->dw_plans.find(key);
   if (it == m->dw_plans.end()) {
     std::vector<GemmParams> ps;
@@ -1522,6 +1571,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
         ps.push_back(p);
       };
       const bool full = !(top_compact && l == m->L - 1);
+      if (f8) { for (int k : {1, 0, 3, 2}) ps.push_back(f8_dw_params(m, l, k, NT)); continue; }
       if (full) add(o.dab, 2 * Ip, a.hn, D, m->G + m->lo[l].w13, D, 2 * Ip, D);       // dW13 += dab^T . hn
       if (full) add(o.gxt, D, a.g, Ip, m->G + m->lo[l].w2, Ip, D, Ip);                 // dW2  += gx^T . g
       add(o.dqkv, m->Nqkv, a.xn, D, m->G + m->lo[l].wqkv, D, m->Nqkv, D);              // dWqkv += dqkv^T . xn
@@ -1533,7 +1583,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
     RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl));
     it = m->dw_plans.emplace(key, pl).first;
   }
-  if (m->timer.enabled) tic(m, "gemm_dw_group@8g", gemm8p_group_flops(it->second));
+  if (m->timer.enabled) tic(m, f8 ? "gemm_dw_group@8gf" : "gemm_dw_group@8g", gemm8p_group_flops(it->second));
   int rc = launch_gemm8p_group(it->second, m->stream);
   toc(m);
   return rc;
@@ -1577,13 +1627,14 @@ static int backward_trunk(Model* m) {
   for (int l = m->L - 1; l >= 0; --l) {
     Model::LayerAct& a = m->la[l];
     const bool ft = m->cfg.finetune != 0;   // finetune: base weights are frozen, only the dx chain and the LoRA grads run
+    const bool f8dw = use_f8_dw(m);         // fp8 weight gradients: launched behind the cast of their gradient operand (inside the dx product)
     const bool top = ctop && l == m->L - 1;   // this layer's token-local part runs on the compact rows
     void* const dab = (defer && !top) ? m->dwb[l].dab : m->dab;
     void* const dqkv = defer ? m->dwb[l].dqkv : m->dqkv;
     if (defer) { if (!top) dht = AT<T>(m->dwb[l].dht); gxt_other = l > 0 ? AT<T>(m->dwb[l - 1].gxt) : AT<T>(m->gxa_t); }
     if (top) RC(top_tail_compact_bwd<T>(m, wt));
     if (!top) {
-    if (!ft && !defer) {
+    if (!ft && !defer && !f8dw) {
       GemmParams p{};  // dW2 += gx^T . g
       p.A = gxt; p.lda = D; p.B = a.g; p.ldb = Ip; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.c_f32 = 1;
       p.M = D; p.N = Ip; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1597,9 +1648,10 @@ static int backward_trunk(Model* m) {
       RC(join_dw(m, DW_W13));   // the layer above's dW13 reads dab
       if (m->fp8) { p.f8_amax_out = f8_slot(m, l, F8S_DAB); RC(gemm_f8(m, l, F8P_W2_DX, "gemm_w2_dx", p, W8T(m, m->lo[l].w2), D, true)); }
       else RC(gemm<T>(m, "gemm_w2_dx", p, false, false, !wt));
+      if (f8dw && !defer) RC(f8_dw_launch(m, l, 0, "gemm_w2_dw", NT));
       RC(join_side(m));
     }
-    if (!ft && !defer) {
+    if (!ft && !defer && !f8dw) {
       GemmParams p{};  // dW13 += dab^T . hn
       p.A = dab; p.lda = 2 * Ip; p.B = a.hn; p.ldb = D; p.C = m->G + m->lo[l].w13; p.ldc = D; p.c_f32 = 1;
       p.M = 2 * Ip; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1612,6 +1664,7 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = 2 * Ip; p.epi = EPI_STORE;
       if (m->fp8) RC(gemm_f8(m, l, F8P_W13_DX, "gemm_w13_dx", p, W8T(m, m->lo[l].w13), 2 * Ip, true));   // (amax |da|, |db| came with the SwiGLU-backward epilogue)
       else RC(gemm<T>(m, "gemm_w13_dx", p, false, false, !wt));
+      if (f8dw && !defer) RC(f8_dw_launch(m, l, 1, "gemm_w13_dw", NT));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 0], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
@@ -1620,7 +1673,7 @@ static int backward_trunk(Model* m) {
     if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_DH);
     RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
     toc(m);
-    if (!ft && !defer) {
+    if (!ft && !defer && !f8dw) {
       GemmParams p{};  // dWo += dh^T . O
       p.A = dht; p.lda = D; p.B = a.O; p.ldb = D; p.C = m->G + m->lo[l].wo; p.ldc = D; p.c_f32 = 1;
       p.M = D; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1633,6 +1686,7 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = D; p.epi = EPI_STORE;
       if (m->fp8) RC(gemm_f8(m, l, F8P_O_DX, "gemm_o_dx", p, W8T(m, m->lo[l].wo), D, true));
       else RC(gemm<T>(m, "gemm_o_dx", p, false, false, !wt));
+      if (f8dw && !defer) RC(f8_dw_launch(m, l, 2, "gemm_o_dw", NT));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 1], m->dO, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }
@@ -1653,7 +1707,7 @@ static int backward_trunk(Model* m) {
       RC(launch_attn_bwd<T>(ap, s));
     }
     toc(m);
-    if (!ft && !defer) {
+    if (!ft && !defer && !f8dw) {
       GemmParams p{};  // dWqkv += dqkv^T . xn
       p.A = dqkv; p.lda = m->Nqkv; p.B = a.xn; p.ldb = D; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.c_f32 = 1;
       p.M = m->Nqkv; p.N = D; p.K = NT; p.epi = EPI_ATOMIC;
@@ -1666,6 +1720,7 @@ static int backward_trunk(Model* m) {
       p.M = NT; p.N = D; p.K = m->Nqkv; p.epi = EPI_STORE;
       if (m->fp8) RC(gemm_f8(m, l, F8P_QKV_DX, "gemm_qkv_dx", p, W8T(m, m->lo[l].wqkv), m->Nqkv, true));
       else RC(gemm<T>(m, "gemm_qkv_dx", p, false, false, !wt));
+      if (f8dw && !defer) RC(f8_dw_launch(m, l, 3, "gemm_qkv_dw", NT));
       if (!m->f8_keep.empty()) HIP_CHECK(hipMemcpyAsync(m->f8_keep[l * 3 + 2], m->dhn, (size_t)NT * D * 2, hipMemcpyDeviceToDevice, s));
       RC(join_side(m));
     }

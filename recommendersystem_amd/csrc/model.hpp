@@ -90,6 +90,13 @@ struct Model {
   unsigned char* a8 = nullptr;    // fp8 copy of the current product's A operand
   void* f8_jobs = nullptr; int* f8_tile_job = nullptr; int* f8_tile_first = nullptr; int f8_ntiles = 0;
   bool w8_dirty = true;
+  // fp8 weight gradients dW = q_e5m2(dY)^T . q_e4m3(X): every cast also leaves a K-contiguous (transposed, [features][tokens]) copy
+  // per layer, consumed by the split-K fp8 form after (or, grouped, at the end of) the backward.  RSYS_F8_DW=0: bf16 operands instead.
+  bool f8_dw = false;
+  struct F8T { unsigned char *xn, *O, *hn, *g, *gxt, *dab, *dht, *dqkv; };
+  std::vector<F8T> f8t;
+  float* f8_desc_dw = nullptr;    // [L][4 products: w2 w13 o qkv][32]: row descales of the weight-gradient products
+  int64_t f8_ldt = 0;             // row stride of the transposed copies (tokens of a full batch)
   std::vector<void*> f8_keep;     // RSYS_F8_DEBUG_KEEP=1 (tests): per layer, copies of the three dx products' outputs (w13_dx, o_dx, qkv_dx)
   bool table_dirty = true;     // the fused item table F / FT must be rebuilt before the next forward: set by everything that changes a
                                // parameter or the metadata, and by the table-gradient pass (it borrows FT); clean between the

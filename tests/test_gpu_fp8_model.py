@@ -94,6 +94,15 @@ def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
         nq, nk = H * hd, KV * hd
         chk(f"qkv_dx[{l}]", get(f"f8keep.{l}.2"), Q(ref.lin_dx(dqkv[:, :nq], p + "attn.q_proj.weight") + ref.lin_dx(dqkv[:, nq:nq + nk], p + "attn.k_proj.weight")
                                                      + ref.lin_dx(dqkv[:, nq + nk:], p + "attn.v_proj.weight")))
+        # the seven weight gradients (fp32 sums) from the operands the two passes stored
+        grad = lambda n: model.grad(p + n).astype(np.float64)
+        chk(f"w2_dw[{l}]", grad("mlp.w2.weight"), ref.lin_dw(get(f"dw.{l}.gxt"), get(f"act.{l}.g")), f32=True)
+        chk(f"w1_dw[{l}]", grad("mlp.w1.weight"), ref.lin_dw(da_hip, hn), f32=True)
+        chk(f"w3_dw[{l}]", grad("mlp.w3.weight"), ref.lin_dw(db_hip, hn), f32=True)
+        chk(f"o_dw[{l}]", grad("attn.output_proj.weight"), ref.lin_dw(get(f"dw.{l}.dht"), get(f"act.{l}.O")), f32=True)
+        chk(f"q_dw[{l}]", grad("attn.q_proj.weight"), ref.lin_dw(dqkv[:, :nq], xn), f32=True)
+        chk(f"k_dw[{l}]", grad("attn.k_proj.weight"), ref.lin_dw(dqkv[:, nq:nq + nk], xn), f32=True)
+        chk(f"v_dw[{l}]", grad("attn.v_proj.weight"), ref.lin_dw(dqkv[:, nq + nk:], xn), f32=True)
     # the amax every producer left beside its output (RMSNorm fwd / bwd, attention fwd / bwd, the two SwiGLU epilogues) is exactly
     # the amax of the tensor it stored
     am = model.debug_get("f8.aamax", rows).max(1)               # [layer][slot]
