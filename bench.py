@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_PEAK_TFLOPS_FP8 = 5000.0   # dense fp8 (v_mfma_f32_16x16x128_f8f6f4), same guide: the fp8 kernel forms ("8f", "8fs", "8gf") are priced against this
 HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
@@ -28,6 +29,9 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
     "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
     "8g": "gemm8p_group_kernel",                          # the K-major pipeline, all layers' weight gradients in one grouped launch
+    "8f": "gemm8p_f8_kernel",                             # --dtype fp8: the persistent pipeline on e4m3 / e5m2 operands (K tiles of 128)
+    "8fs": "gemm8p_f8sk_kernel",                          # --dtype fp8: split-K weight gradients on transposed fp8 copies, one product per launch
+    "8gf": "gemm8p_group_f8_kernel",                      # --dtype fp8: the same, all layers' products in one grouped launch
     "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
@@ -36,6 +40,9 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
                 "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+                "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
+                "8fs": "gemm8p_f8sk_kernel (256x256 LDS-DMA, fp8 e5m2 x e4m3 on K-contiguous copies, split-K weight gradient)",
+                "8gf": "gemm8p_group_f8_kernel (the fp8 split-K form, grouped weight gradients of all layers)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 def _latest_traffic_file():
     """the newest committed PMC summary (profiles/r<round><letter>_pmc_traffic.json, written by tools/prof_round.sh)"""
@@ -408,8 +415,9 @@ def main():
             dom = max(var, key=lambda k: var[k]["ms"])
             a = var[dom]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS_FP8 if dom in ("8f", "8fs", "8gf") else MFMA_PEAK_TFLOPS
             roofline = {"bound": "mfma", "kernel": KERNEL_LABEL.get(dom, dom), "achieved": round(ach, 1),
-                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic_of(traffic_db, dom),
                         "traffic_source": (None if not traffic_db else {"file": "profiles/" + TRAFFIC_FILE, "git_blob": git_blob_id(os.path.join(ROOT, "profiles", TRAFFIC_FILE)),
                                                                         "note": "separate rocprofv3 --pmc passes of this workload (tools/prof_round.sh), read from the committed summary, not measured in this run"}),
@@ -439,6 +447,10 @@ def main():
             "roofline": roofline,
             "losses": [round(float(x), 4) for x in losses],
         }
+        if args.dtype in ("fp8", "float8"):
+            out["dtype_note"] = ("bf16 arithmetic with the transformer blocks' linears (forward, dx, dW) on tensor-wise dynamically scaled e4m3 / e5m2 "
+                                 "operands: the reference's pretraining arithmetic (transformer.py:671-676, torchao 'tensorwise'), restated -- parity "
+                                 "unpinned against torchao itself; step_mfma_frac* are still priced against the bf16 peak")
         if len(plain):
             q = lambda f: round(float(np.quantile(plain, f)), 3)
             out["ms_per_step_stats"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": int(len(plain)),

@@ -152,13 +152,21 @@ __global__ __launch_bounds__(256) void f8_cast_kernel(F8Cast c) {
   }
 }
 
-// The same cast for a tensor whose transposed copy is wanted too: one 128-row x 64-column tile per workgroup, the fp8 bytes pass
-// through LDS and leave a second time as 16-byte pieces along the rows (128 contiguous bytes per column and tile).
+// The same cast for a tensor whose transposed copy is wanted too.  One wave per 128-row x 128-column tile, lane = a 16 x 16 block
+// (row block l >> 3, column block l & 7): the lane converts its block four rows at a time -- 16-byte row-major stores -- and
+// transposes the 4 x 4 byte blocks in registers (v_perm_b32), so that after sixteen rows it holds, per column, the 16 bytes of its
+// rows and stores them as the transposed copy.  No LDS; a row is read in 256 contiguous bytes, both copies leave in 128-byte runs.
+__device__ __forceinline__ void f8_transpose4x4(unsigned int x0, unsigned int x1, unsigned int x2, unsigned int x3, unsigned int (&t)[4]) {
+  const unsigned int u0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), u1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+  const unsigned int v0 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), v1 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+  t[0] = __builtin_amdgcn_perm(v0, u0, 0x05040100u); t[1] = __builtin_amdgcn_perm(v0, u0, 0x07060302u);
+  t[2] = __builtin_amdgcn_perm(v1, u1, 0x05040100u); t[3] = __builtin_amdgcn_perm(v1, u1, 0x07060302u);
+}
+
 template <typename T, int FMT>
 __global__ __launch_bounds__(256) void f8_cast_t_kernel(F8Cast c) {
   __shared__ float s_amax[4];
   __shared__ float s_xamax;
-  __shared__ __attribute__((aligned(16))) unsigned char tile[64][144];   // [column][row], 16-byte aligned rows of 128 (+16: bank spread)
   const int nseg = f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep);
   const int t = threadIdx.x;
   if (t < 64) {
@@ -192,45 +200,48 @@ __global__ __launch_bounds__(256) void f8_cast_t_kernel(F8Cast c) {
       }
     }
   }
-  const int ct = c.cols >> 6;
-  const int r0 = (blockIdx.x / ct) * 128, c0 = (blockIdx.x % ct) * 64;
-  const T* src = (const T*)c.src;
-  const int half = c.cols >> 1;
+  const int ct = (c.cols + 127) >> 7;
+  const int tile = blockIdx.x * 4 + (t >> 6);
+  if (tile >= (c.rows >> 7) * ct) return;
+  const int l = t & 63;
+  const int r0 = (tile / ct) * 128 + (l >> 3) * 16, col = (tile % ct) * 128 + (l & 7) * 16;
+  if (col >= c.cols) return;
+  const int sg = f8_seg_of(col, c.layout, c.seg_cols, c.seg_rep);
+  const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (sg ? (c.cols >> 1) : 0) + (col >> 5) * 16 : col;
+  const float s = sg == 0 ? sc[0] : (sg == 1 ? sc[1] : (sg == 2 ? sc[2] : sc[3]));
+  const T* src = (const T*)c.src + (long long)r0 * c.ld_src + col;
+  unsigned char* dst = c.dst + (long long)r0 * c.ld_dst + dcol;
+  unsigned int acc[16][4];   // [column of the block][4 rows per dword]
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int it = t + 256 * k;            // 512 items: (row 0..127) x (16-column group 0..3)
-    const int rl = it >> 2, gq = it & 3;
-    const int col = c0 + gq * 16;
-    const int sg = f8_seg_of(col, c.layout, c.seg_cols, c.seg_rep);
-    const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (sg ? half : 0) + (col >> 5) * 16 : col;
-    const float s = sg == 0 ? sc[0] : (sg == 1 ? sc[1] : (sg == 2 ? sc[2] : sc[3]));
-    const T* p = src + (long long)(r0 + rl) * c.ld_src + col;
-    float v[16];
-    if constexpr (sizeof(T) == 2) {
-      const bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + 8);
+  for (int ch = 0; ch < 4; ++ch) {
+    unsigned int rw[4][4];   // [row of the chunk][4 columns per dword]
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { v[q] = (float)a[q] * s; v[8 + q] = (float)b[q] * s; }
-    } else {
+    for (int rr = 0; rr < 4; ++rr) {
+      const T* p = src + (long long)(ch * 4 + rr) * c.ld_src;
+      float v[16];
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + 8);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const float4 a = *(const float4*)(p + 4 * q); v[4 * q] = a.x * s; v[4 * q + 1] = a.y * s; v[4 * q + 2] = a.z * s; v[4 * q + 3] = a.w * s; }
+        for (int q = 0; q < 8; ++q) { v[q] = (float)a[q] * s; v[8 + q] = (float)b[q] * s; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 a = *(const float4*)(p + 4 * q); v[4 * q] = a.x * s; v[4 * q + 1] = a.y * s; v[4 * q + 2] = a.z * s; v[4 * q + 3] = a.w * s; }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rw[rr][g] = f8_pack4<FMT>(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+      *(uint4*)(dst + (long long)(ch * 4 + rr) * c.ld_dst) = make_uint4(rw[rr][0], rw[rr][1], rw[rr][2], rw[rr][3]);
     }
-    uint4 out;
-    out.x = f8_pack4<FMT>(v[0], v[1], v[2], v[3]); out.y = f8_pack4<FMT>(v[4], v[5], v[6], v[7]);
-    out.z = f8_pack4<FMT>(v[8], v[9], v[10], v[11]); out.w = f8_pack4<FMT>(v[12], v[13], v[14], v[15]);
-    *(uint4*)(c.dst + (long long)(r0 + rl) * c.ld_dst + dcol) = out;
-    const unsigned int w4[4] = {out.x, out.y, out.z, out.w};
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tile[gq * 16 + q][rl] = (unsigned char)(w4[q >> 2] >> (8 * (q & 3)));
-  }
-  __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+      unsigned int tq[4];
+      f8_transpose4x4(rw[0][g], rw[1][g], rw[2][g], rw[3][g], tq);
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int it = t + 256 * k;            // 512 items: (column 0..63) x (16-row piece 0..7)
-    const int cl = it >> 3, rp = it & 7;
-    const int col = c0 + cl;
-    const int dcol = c.layout == F8_LAYOUT_SWIGLU ? (((col >> 4) & 1) ? half : 0) + (col >> 5) * 16 + (col & 15) : col;
-    *(uint4*)(c.dst_t + (long long)dcol * c.ld_dst_t + r0 + rp * 16) = *(const uint4*)&tile[cl][rp * 16];
+      for (int j = 0; j < 4; ++j) acc[4 * g + j][ch] = tq[j];
+    }
   }
+  unsigned char* dt = c.dst_t + (long long)dcol * c.ld_dst_t + r0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) *(uint4*)(dt + (long long)j * c.ld_dst_t) = make_uint4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
 }
 
 // ---- weights: fp32 master [rows][cols] -> e4m3 row-major copy + transposed copy, one 64 x 64 tile per workgroup, job table.
@@ -337,7 +348,7 @@ int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   if (c.dst_t != nullptr) {
     ARG_CHECK(c.rows % 128 == 0 && c.cols % 64 == 0 && c.rows_dev == nullptr && c.ld_dst_t % 16 == 0 && c.ld_dst_t >= c.rows, "fp8 cast with a transposed copy: rows % 128, cols % 64");
     ARG_CHECK(c.desc_dw == nullptr || (c.xamax != nullptr && c.dw_units >= 1 && c.dw_units <= 16), "fp8 cast: weight-gradient descale job");
-    const int grid_t = (c.rows / 128) * (c.cols / 64);
+    const int grid_t = ((c.rows / 128) * ((c.cols + 127) / 128) + 3) / 4;
     if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
     else { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
     HIP_CHECK(hipGetLastError());

@@ -196,3 +196,58 @@ def test_fp8_training_tracks_bf16():
     assert b[-8:].mean() < b[:8].mean()                       # it learns
     assert abs(b[-8:].mean() - a[-8:].mean()) < 0.05 * abs(a[:8].mean() - a[-8:].mean()) + 0.02 * abs(a[-8:].mean()), (a[-8:].mean(), b[-8:].mean())
     assert np.abs(b - a).max() < 0.2 * np.abs(a).max(), np.abs(b - a).max()     # (measured 0.11: step-to-step noise at this learning rate)
+
+
+def test_fp8_deterministic_mode_is_bitwise_reproducible():
+    """amax is a maximum (order-free) and every other reduction takes the deterministic path of the bf16 mode; the weight gradients
+    then come from the bf16 operands through the ordered split-K slabs (the fp8 split-K form adds with float atomics)"""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16, deterministic=True)
+    rows = 3
+    P = synth.make_params(cfg, 9, "test")
+    batches = [synth.make_batch(cfg, rows, 60 + i) for i in range(2)]
+    masks = [synth.make_masks(cfg, rows, 70 + i) for i in range(2)]
+    names = synth.trainable_names(cfg)
+
+    def run():
+        model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+        model.load_state_dict(P)
+        opt = ra.create_optimizer(model, dict(cfg, learning_rate=1e-3))
+        model.set_loss_weights(TASK_W, 1)
+        out = []
+        for d, mk in zip(batches, masks):
+            out.append(list(model(d, False, masks=mk)) + [model.grad(n).copy() for n in names])
+            opt.step(clip_max_norm=1.0)
+        out.append([model.get_parameter(n).copy() for n in names])
+        model.close()
+        return out
+    a, b = run(), run()
+    for sa, sb in zip(a, b):
+        for x, y in zip(sa, sb):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_fp8_row_sharded_table_equals_replicated():
+    """the fp8 trunk under the row-sharded item table (world 1): the same losses and trunk gradients as the replicated model"""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    rows = 2
+    P = synth.make_params(cfg, 13, "test")
+    d = synth.make_batch(cfg, rows, 14); mk = synth.make_masks(cfg, rows, 15)
+    res = []
+    for shard in (None, (0, 1)):
+        c = dict(cfg)
+        if shard:
+            c["table_shard"] = shard
+        model = ra.RecommenderModel(c, dtype="fp8", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        losses = model(d, False, masks=mk)
+        res.append((losses, {n: model.grad(n).copy() for n in synth.trainable_names(cfg) if "transformers" in n}))
+        model.close()
+    (la, ga), (lb, gb) = res
+    assert np.allclose(la, lb, rtol=2e-3), (la, lb)
+    worst = max(float(np.abs(ga[n] - gb[n]).max() / max(np.abs(ga[n]).max(), 1e-6)) for n in ga)
+    assert worst < 5e-2, worst
