@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
   }
   if (amax != nullptr) {   // fp8 trunk: amax of the (bf16) output while it is written -- the rounded amax is the amax of the rounded values
-    am = wave_max(am);
-    if (l == 0) f8_amax_note(amax, (float)from_f32<T>(am));
+    am = wave_max(am);     // (one unconditional atomic per wave, nothing waits for it: a read-and-compare first cost 10 us per launch)
+    if (l == 0) atomicMax((int*)(amax + (blockIdx.x & (F8_AMAX_SHARDS - 1)) * F8_AMAX_SHARD), __float_as_int((float)from_f32<T>(am)));
   }
 }
 
