@@ -11,6 +11,10 @@ module RsysHIP
 
 const LIB = joinpath(@__DIR__, "..", "recommendersystem_amd", "librsys_hip.so")
 
+# RsysConfig.dtype (rsys.h RSYS_DTYPE_*): fp32 parity mode, the bf16 autocast arithmetic, or bf16 with the blocks' linears on
+# tensor-wise scaled fp8 operands -- what transformer.py:671-676 gets from torchao's convert_to_float8_training
+const DTYPE_FP32 = Int32(0); const DTYPE_BF16 = Int32(1); const DTYPE_FP8 = Int32(2)
+
 struct RsysConfig              # mirrors rsys_config (field order and types as in rsys.h)
     num_layers::Int32; num_heads::Int32; num_kv_heads::Int32; embed_dim::Int32; intermediate_dim::Int32
     max_sequence_length::Int32

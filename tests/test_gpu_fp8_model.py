@@ -251,3 +251,32 @@ def test_fp8_row_sharded_table_equals_replicated():
     assert np.allclose(la, lb, rtol=2e-3), (la, lb)
     worst = max(float(np.abs(ga[n] - gb[n]).max() / max(np.abs(ga[n]).max(), 1e-6)) for n in ga)
     assert worst < 5e-2, worst
+
+
+def test_fp8_at_the_benchmark_size_stays_close_to_bf16():
+    """cfg-3 at the benchmark's own batch (64 rows x 512; the grouped fp8 weight-gradient launch, grouped-query segments of the fused
+    QKV products, 65 536-token casts): the first step's losses and gradient norm from the same weights and batch stay within the fp8
+    noise of the bf16 arithmetic, and two steps later the loss has moved the same way"""
+    import recommendersystem_amd as ra
+    from recommendersystem_amd import workload
+    out = {}
+    for dtype in ("bf16", "fp8"):
+        cfg = workload.make_config("cfg3")
+        model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=64)
+        model.init_weights(0x1217); model.random_pretrained_embeddings(0x3E7A)
+        opt = ra.create_optimizer(model, cfg)
+        model.set_loss_weights(ra.make_task_weights(), 1)
+        d = workload.make_batch(cfg, 64, 0xD47A, mu=4.6, sigma=1.0)
+        losses = [model(d, False)]
+        gn = float(np.sqrt(sum(float((model.grad(n).astype(np.float64) ** 2).sum()) for n, _, tr in model.named_parameters() if tr and "transformers.layers" in n)))
+        for _ in range(2):
+            opt.step(lr_factor=1.0, clip_max_norm=1.0)
+            losses.append(model(d, False))
+        out[dtype] = (np.array(losses, np.float64), gn)
+        model.close()
+    (la, ga), (lb, gb) = out["bf16"], out["fp8"]
+    print("cfg-3 first-step losses bf16", la[0], "fp8", lb[0], "trunk gradient norm", ga, gb)
+    assert np.isfinite(lb).all()
+    assert np.abs(lb[0] - la[0]).max() <= 3e-2 * np.abs(la[0]).max(), (la[0], lb[0])
+    assert abs(gb - ga) <= 0.15 * ga, (ga, gb)
+    assert np.sign(lb[2] - lb[0]).tolist() == np.sign(la[2] - la[0]).tolist() or np.abs(lb[2] - la[2]).max() <= 5e-2 * np.abs(la[2]).max()

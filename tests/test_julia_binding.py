@@ -154,3 +154,11 @@ def test_struct_mirrors_have_the_headers_fields_in_order():
         assert [f for f, _ in c] == [f for f, _ in j], (cname, [f for f, _ in c], [f for f, _ in j])
         for (f, ct), (_, jt) in zip(c, j):
             assert norm_julia(ct) == norm_julia(jt), (cname, f, ct, jt)
+
+
+def test_dtype_constants_agree_with_the_header():
+    h = strip_comments(open(HEADER).read())
+    m = re.search(r"enum\s*\{\s*RSYS_DTYPE_FP32\s*=\s*(\d+),\s*RSYS_DTYPE_BF16\s*=\s*(\d+),\s*RSYS_DTYPE_FP8\s*=\s*(\d+)\s*\}", h)
+    j = re.sub(r"#.*", "", open(JULIA).read())
+    mj = re.search(r"const DTYPE_FP32 = Int32\((\d+)\); const DTYPE_BF16 = Int32\((\d+)\); const DTYPE_FP8 = Int32\((\d+)\)", j)
+    assert m and mj and m.groups() == mj.groups()
