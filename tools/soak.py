@@ -22,9 +22,10 @@ def vram():
 
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"   # "fp8": the reference's float8 trunk
 cfg = workload.make_config("cfg3", learning_rate=3e-4)
 rows = 64
-model = ra.RecommenderModel(cfg, device=0, dtype="bf16", max_rows=rows)
+model = ra.RecommenderModel(cfg, device=0, dtype=dtype, max_rows=rows)
 model.init_weights(0x1217); model.random_pretrained_embeddings(0x3E7A)
 opt = ra.create_optimizer(model, cfg)
 sched = LambdaLR(WSDScheduler(warmup_steps=200, total_steps=10 * steps, decay_ratio=0.1, final_ratio=0.1))
@@ -41,7 +42,7 @@ for s in range(steps):
         hist.append((s, [round(float(x), 4) for x in losses]))
         print(f"step {s:5d} losses {hist[-1][1]} lr factor {sched.factor():.3f} vram {vram():.2f} GiB", flush=True)
 m1 = vram()
-print(f"{steps} steps in {time.time() - t0:.1f}s; vram {m0:.2f} -> {m1:.2f} GiB")
+print(f"{dtype}: {steps} steps in {time.time() - t0:.1f}s; vram {m0:.2f} -> {m1:.2f} GiB")
 assert hist[-1][1][0] < hist[0][1][0] - 1.0 and hist[-1][1][2] < hist[0][1][2] - 1.0, "watch losses did not fall"
 assert abs(m1 - m0) < 0.25, "device memory grew"
 print("ok")
