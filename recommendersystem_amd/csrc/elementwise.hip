@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 
 template <typename T>
 int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev, const int* in_rows) {
+  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;   // (taken before any early return: never left for another launch)
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
   const dim3 grid(div_up(rows, 4)), block(256);
-  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;
 #define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev, in_rows, amax)
   if (D == 256) RSYS_NORM_FWD(1, true);
   else if (D == 512) RSYS_NORM_FWD(2, true);
@@ -355,10 +355,10 @@ template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
                            float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev,
                            const int* resid_slot, const int* io_rows = nullptr) {
+  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;   // (taken before any early return: never left for another launch)
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, 2048)), block(256);
   float* part = det_part((long long)grid.x * D);
-  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
                                                  rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot, io_rows, amax)
   if (D == 256) RSYS_NORM_BWD(1, true);
