@@ -280,3 +280,30 @@ def test_fp8_at_the_benchmark_size_stays_close_to_bf16():
     assert np.abs(lb[0] - la[0]).max() <= 3e-2 * np.abs(la[0]).max(), (la[0], lb[0])
     assert abs(gb - ga) <= 0.15 * ga, (ga, gb)
     assert np.sign(lb[2] - lb[0]).tolist() == np.sign(la[2] - la[0]).tolist() or np.abs(lb[2] - la[2]).max() <= 5e-2 * np.abs(la[2]).max()
+
+
+def test_fp8_partial_batch_equals_a_model_sized_for_it():
+    """a batch with fewer rows than the model was created for (the transposed fp8 copies keep the full batch's row stride, K stops at
+    the batch's tokens): same losses and weight gradients as a model created for that many rows"""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    P = synth.make_params(cfg, 17, "test")
+    d = synth.make_batch(cfg, 3, 18); mk = synth.make_masks(cfg, 3, 19)
+    big = synth.make_batch(cfg, 5, 20); mkb = synth.make_masks(cfg, 5, 21)
+    names = [n for n in synth.trainable_names(cfg) if "transformers.layers" in n]
+    res = []
+    for max_rows in (3, 5):
+        model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=max_rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        if max_rows == 5:
+            model(big, False, masks=mkb)        # a full batch first: stale tokens beyond the partial batch must not leak into K
+            model.zero_grad()
+        losses = model(d, False, masks=mk)
+        res.append((np.array(losses), {n: model.grad(n).copy() for n in names}))
+        model.close()
+    (la, ga), (lb, gb) = res
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    worst = max(float(np.abs(ga[n] - gb[n]).max() / max(np.abs(ga[n]).max(), 1e-9)) for n in names)
+    assert worst < 1e-4, worst      # (split-K atomics: summation order only)
