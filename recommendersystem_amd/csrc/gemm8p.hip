@@ -299,14 +299,14 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   using W10 = std::integral_constant<int, 10>;
   int pend = 0;
   typedef const __attribute__((address_space(4))) float* cfloat_p;   // scalar loads: no vector memory counter involved
-  int kseg_next = 0, kseg_idx = 0;
+  int kseg_next = -1, kseg_idx = 0;
   auto tile_body = [&](int kt) {
     const int bo = (kt & 1) << 16, bn = bo ^ 65536;
     if constexpr (F8 != 0) {
-      if (kt == kseg_next) {   // (never at kt = 0) a K segment with another scale begins: bring the sums so far into its units
+      if (kt == kseg_next) {   // a K segment with another scale begins: bring the sums so far into its units
         const float r = ((cfloat_p)p.f8_desc)[16 + kseg_idx];
         ++kseg_idx;
-        kseg_next = kseg_idx < 3 ? p.f8_kb[kseg_idx] : 0;
+        kseg_next = (kseg_idx < 3 && p.f8_kb[kseg_idx] > 0) ? p.f8_kb[kseg_idx] : -1;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -389,7 +389,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  kseg_next = F8 != 0 ? p.f8_kb[0] : 0; kseg_idx = 0;
+  kseg_next = (F8 != 0 && p.f8_kb[0] > 0) ? p.f8_kb[0] : -1; kseg_idx = 0;   // (-1: no boundary ahead)
   // B0, A0, B1 of K tile 0 have landed
   if (nt > 1) wait_vm(W10{}, pend); else wait_vm(W2{}, pend);
   T8_BARRIER();
