@@ -909,7 +909,7 @@ static int gemm_f8(Model* m, int l, int which, const char* tag, GemmParams p, co
   c.amax = f8_slot(m, l, o.a_slot); c.dst = m->a8; c.ld_dst = p.K;
   c.desc = m->f8_desc + (l * 8 + which) * 32; c.wamax = m->f8_wamax + l * 8 + o.w_slot; c.n_w = o.n_w; c.desc_mode = o.desc_mode;
   c.w_rep = which == F8P_QKV ? m->H / m->KV : 1;
-  const bool tcopy = m->f8_dw && p.m_dev == nullptr && p.M % 128 == 0;
+  const bool tcopy = m->f8_dw && m->f8_tcopies && p.m_dev == nullptr && p.M % 128 == 0;
   if (tcopy) {   // K-contiguous copy for the weight gradient; the gradient operand's cast also writes that product's descales
     Model::F8T& t = m->f8t[l];
     unsigned char* const dst_t[8] = {t.xn, t.O, t.hn, t.g, t.gxt, t.dab, t.dht, t.dqkv};
@@ -1917,6 +1917,7 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   m->drop_active = m->cfg.finetune && !evaluate && m->cfg.lora_dropout > 0.f;   // nn.Dropout is active in train() mode only
   m->drop_seed = seed ^ 0xD409ull; m->drop_step = step;
   m->top_is_sparse = m->sparse_top && !evaluate;
+  m->f8_tcopies = !evaluate;
   m->host_stream_syncs = 0; m->host_event_waits = 0;
   float tw[4];
   for (int i = 0; i < 4; ++i) tw[i] = task_w ? task_w[i] * grad_scale : 0.f;
@@ -1953,6 +1954,7 @@ static int infer_t(Model* m, int task, const int32_t* sel, int64_t n_sel, float*
   }
   const int64_t ntok = sel != nullptr ? n_sel : NT;
   ARG_CHECK(n == (task == 0 ? ntok * D : ntok), task == 0 ? "retrieval output has tokens*D floats" : "ranking output has one float per token");
+  m->f8_tcopies = false;
   HIP_CHECK(hipMemcpyAsync(b.m_tmid, b.tmid, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_matchedid, b.matchedid, N * 4, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipMemcpyAsync(b.m_status, b.status, N * 4, hipMemcpyDeviceToDevice, s));

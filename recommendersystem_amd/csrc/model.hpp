@@ -93,6 +93,7 @@ struct Model {
   // fp8 weight gradients dW = q_e5m2(dY)^T . q_e4m3(X): every cast also leaves a K-contiguous (transposed, [features][tokens]) copy
   // per layer, consumed by the split-K fp8 form after (or, grouped, at the end of) the backward.  RSYS_F8_DW=0: bf16 operands instead.
   bool f8_dw = false;
+  bool f8_tcopies = true;         // this pass is followed by a backward (forward-only passes skip the transposed copies)
   struct F8T { unsigned char *xn, *O, *hn, *g, *gxt, *dab, *dht, *dqkv; };
   std::vector<F8T> f8t;
   float* f8_desc_dw = nullptr;    // [L][4 products: w2 w13 o qkv][32]: row descales of the weight-gradient products
