@@ -299,7 +299,8 @@ def main():
     # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first tenth of the timed steps: ~300 event
     # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
     # (at least five instrumented steps once 20 are timed: two samples left the per-kernel entries swinging by 30 %)
-    n_instr = 0 if args.no_kernel_timing else (args.steps if args.detail else (max(5, args.steps // 10) if args.steps >= 20 else max(1, args.steps // 10)))
+    # (--detail: at most 20 steps -- every call site takes two timing events per step and the runtime's supply is bounded)
+    n_instr = 0 if args.no_kernel_timing else (min(args.steps, 20) if args.detail else (max(5, args.steps // 10) if args.steps >= 20 else max(1, args.steps // 10)))
     if n_instr:
         model.timing(True, serialize=True)
     ra.synchronize()

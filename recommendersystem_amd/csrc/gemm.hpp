@@ -42,6 +42,8 @@ struct GemmParams {
   void* C2; long long ldc2;
   // EPI_QKV_ROPE
   const float* rope_cos; const float* rope_sin;   // [pos][hd/2]
+  const float* rope_cs;                            // optional [pos][hd/2][2] = (cos, sin) interleaved: the register epilogue of the 256-wide
+                                                   // kernels then takes a lane's two pairs in ONE 16-byte load instead of two 8-byte ones
   const int* rope_pos;                             // optional per-row position, else row % T
   int T; int hd; int n_q; int n_k;                 // q cols = [0,n_q), k cols = [n_q,n_q+n_k), v after
   // EPI_TABLE

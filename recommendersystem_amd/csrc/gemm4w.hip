@@ -152,7 +152,7 @@ bool gemm4w_eligible(const GemmParams& p) {
   if ((unsigned long long)p.M * p.ldc * (cf ? 4 : 2) >= lim) return false;
   if (p.C2 != nullptr && (unsigned long long)p.M * p.ldc2 * 2 >= lim) return false;
   if (p.epi == EPI_RESIDUAL && (unsigned long long)p.M * p.ldr * 4 >= lim) return false;
-  if (p.epi == EPI_QKV_ROPE && p.alpha != 1.f) return false;
+  if (p.epi == EPI_QKV_ROPE && (p.alpha != 1.f || p.rope_cs == nullptr)) return false;
   if (p.epi == EPI_SWIGLU && (p.N % 32 != 0 || p.ldc2 % 8 != 0)) return false;
   return true;
 }

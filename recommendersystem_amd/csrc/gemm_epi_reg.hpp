@@ -122,8 +122,11 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const unsigned int off = (po & rope_m[j]) + rope_d[j];
-          const float2 c2 = ldf2(p.rope_cos, off), s2 = ldf2(p.rope_sin, off);
-          pre.f[j] = make_float4(c2.x, c2.y, s2.x, s2.y);
+          // interleaved table {cos p, sin p, cos p+1, sin p+1}: one 16-byte load per block (launcher: rope_cs is set).  No branch
+          // around a load here -- a uniform `if (table A) else (table B)` made hipcc drain the loads at every row block:
+          // qkv_fwd 0.98 -> 1.42 ms per step
+          const float4 v = ldf4(p.rope_cs, off * 2u);
+          pre.f[j] = make_float4(v.x, v.z, v.y, v.w);
         }
       } else if constexpr (ec == EPI_SWIGLU_BWD) {
         // saved a, b of dg column c live at (c>>4)*32 + (c&15) (+16) of the [a|b] rows: f[j] = {a (4 bf16), b (4 bf16)}.

@@ -38,7 +38,15 @@ static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st =
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
   if (t.used + 2 > t.pool.size()) {
-    for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); t.pool.push_back(e); }
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {   // (the runtime hands out a bounded number of timing events: ~10 K; stop measuring, keep running)
+        (void)hipGetLastError();
+        t.enabled = false;
+        return;
+      }
+      t.pool.push_back(e);
+    }
   }
   hipEvent_t e = t.pool[t.used++];
   hipEventRecord(e, st ? st : m->stream);
@@ -221,9 +229,12 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       float freq = 1.0f / powf(500000.0f, (float)(2 * k) / (float)hd);
       for (int t = 0; t < m->T; ++t) { float a = (float)t * freq; c[(size_t)t * half + k] = cosf(a); s[(size_t)t * half + k] = sinf(a); }
     }
-    DALLOC(m->rope_cos, c.size() * 4); DALLOC(m->rope_sin, s.size() * 4);
+    DALLOC(m->rope_cos, c.size() * 4); DALLOC(m->rope_sin, s.size() * 4); DALLOC(m->rope_cs, c.size() * 8);
     HIP_CHECK(hipMemcpy(m->rope_cos, c.data(), c.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(m->rope_sin, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> cs(c.size() * 2);
+    for (size_t i = 0; i < c.size(); ++i) { cs[2 * i] = c[i]; cs[2 * i + 1] = s[i]; }
+    HIP_CHECK(hipMemcpy(m->rope_cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
     m->rope_npos = m->T;
   }
   // batch blob: 27 raw arrays + masked copies
@@ -558,6 +569,12 @@ int model_set_rope(Model* m, const float* c, const float* s, int64_t n_pos) {
   size_t bytes = (size_t)n_pos * (m->hd / 2) * 4;
   HIP_CHECK(hipMemcpy(m->rope_cos, c, bytes, hipMemcpyHostToDevice));
   HIP_CHECK(hipMemcpy(m->rope_sin, s, bytes, hipMemcpyHostToDevice));
+  {
+    const size_t n = bytes / 4;
+    std::vector<float> cs(n * 2);
+    for (size_t i = 0; i < n; ++i) { cs[2 * i] = c[i]; cs[2 * i + 1] = s[i]; }
+    HIP_CHECK(hipMemcpy(m->rope_cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  }
   return RSYS_OK;
 }
 
@@ -1141,7 +1158,7 @@ static int forward_trunk(Model* m) {
       GemmParams p{};
       p.A = a.xn; p.lda = D; p.B = W<T>(m, m->lo[l].wqkv); p.ldb = D; p.C = a.qkv; p.ldc = m->Nqkv;
       p.M = NT; p.N = m->Nqkv; p.K = D; p.epi = EPI_QKV_ROPE;
-      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_cs = m->rope_cs; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       if (m->fp8) RC(gemm_f8(m, l, F8P_QKV, "gemm_qkv_fwd", p, W8(m, m->lo[l].wqkv), D, true));
       else RC(gemm<T>(m, "gemm_qkv_fwd", p, false, false, false));
@@ -1152,7 +1169,7 @@ static int forward_trunk(Model* m) {
       GemmParams p{};
       p.A = a.La; p.lda = 16; p.B = W<T>(m, m->lo[l].lb); p.ldb = 16; p.C = a.qkv; p.ldc = m->Nqkv;
       p.M = NT; p.N = m->Nqkv; p.K = 16; p.epi = EPI_QKV_ROPE; p.alpha = 2.f; p.accum = 1;
-      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
+      p.rope_cos = m->rope_cos; p.rope_sin = m->rope_sin; p.rope_cs = m->rope_cs; p.rope_pos = rpos_l; p.T = m->T; p.hd = hd;
       p.n_q = m->H * hd; p.n_k = m->KV * hd;
       RC(gemm<T>(m, "gemm_lora_b_fwd", p, false, false, false));
     }
