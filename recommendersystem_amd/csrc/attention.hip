@@ -332,7 +332,7 @@ __device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld,
   }
   if (amax != nullptr) {
     am = wave_max(am);
-    if ((t & 63) == 0) f8_amax_note(amax, am);
+    if ((t & 63) == 0) f8_amax_add(amax, am);
   }
 }
 

@@ -97,6 +97,11 @@ __device__ __forceinline__ void f8_amax_note(float* slot, float m) {
   float* p = slot + (blockIdx.x & (F8_AMAX_SHARDS - 1)) * F8_AMAX_SHARD;
   if (m > __builtin_nontemporal_load(p)) atomicMax((int*)p, __float_as_int(m));
 }
+// the same without looking first: one atomic nothing waits for (a load-and-compare in front of it would make the wave wait for
+// every vector-memory operation it still has in flight -- a GEMM epilogue's stores, a row kernel's last rows)
+__device__ __forceinline__ void f8_amax_add(float* slot, float m) {
+  atomicMax((int*)(slot + (blockIdx.x & (F8_AMAX_SHARDS - 1)) * F8_AMAX_SHARD), __float_as_int(m));
+}
 __device__ __forceinline__ float bf16_rounded(float v) { return (float)(bf16)v; }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011), used for masks and random init.

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   }
   if (amax != nullptr) {   // fp8 trunk: amax of the (bf16) output while it is written -- the rounded amax is the amax of the rounded values
     am = wave_max(am);     // (one unconditional atomic per wave, nothing waits for it: a read-and-compare first cost 10 us per launch)
-    if (l == 0) atomicMax((int*)(amax + (blockIdx.x & (F8_AMAX_SHARDS - 1)) * F8_AMAX_SHARD), __float_as_int((float)from_f32<T>(am)));
+    if (l == 0) f8_amax_add(amax, (float)from_f32<T>(am));
   }
 }
 
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   }
   if (amax != nullptr) {   // fp8 trunk: amax of the operand copy (see rmsnorm_fwd_kernel)
     am = wave_max(am);
-    if (l == 0) f8_amax_note(amax, (float)from_f32<TO>(am));
+    if (l == 0) f8_amax_add(amax, (float)from_f32<TO>(am));
   }
   if (part != nullptr) {
     // deterministic: the four waves' sums side by side in LDS ([4][D], launcher), added in wave order, one partial row per workgroup

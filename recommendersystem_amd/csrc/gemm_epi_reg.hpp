@@ -280,8 +280,8 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
         amx0 = wave_max(amx0);
         if constexpr (ec == EPI_SWIGLU_BWD) amx1 = wave_max(amx1);
         if ((threadIdx.x & 63) == 0) {
-          f8_amax_note(p.f8_amax_out, bf16_rounded(amx0));
-          if constexpr (ec == EPI_SWIGLU_BWD) f8_amax_note(p.f8_amax_out + 1, bf16_rounded(amx1));
+          f8_amax_add(p.f8_amax_out, bf16_rounded(amx0));   // (no read-and-compare first: it would drain the tile's stores)
+          if constexpr (ec == EPI_SWIGLU_BWD) f8_amax_add(p.f8_amax_out + 1, bf16_rounded(amx1));
         }
       }
     }

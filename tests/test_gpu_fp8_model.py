@@ -169,10 +169,11 @@ def test_fp8_is_refused_where_the_reference_does_not_use_it():
 
 
 def test_fp8_training_tracks_bf16():
-    """40 optimizer steps from the same initial state on the same batches: the fp8 loss curve stays inside the band of the bf16 one"""
+    """48 optimizer steps from the same initial state on the same batches: the smoothed fp8 loss curve stays inside a band around the
+    bf16 one (single steps of two runs differ by more than the two arithmetics do: float atomics, a small model, a high rate)"""
     import recommendersystem_amd as ra
     from oracle import synth
-    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16, learning_rate=2e-3)
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16, learning_rate=5e-4)
     rows = 4
     P = synth.make_params(cfg, 5, "test")
     batches = [synth.make_batch(cfg, rows, 100 + i) for i in range(8)]
@@ -184,19 +185,19 @@ def test_fp8_training_tracks_bf16():
         opt = ra.create_optimizer(model, cfg)
         model.set_loss_weights(TASK_W, 1)
         cur = []
-        for step in range(40):
+        for step in range(48):
             losses = model(batches[step % 8], False, masks=masks[step % 8])
             opt.step(clip_max_norm=1.0)
             cur.append(sum(w * l for w, l in zip(TASK_W, losses)))
         curves[dtype] = np.array(cur)
         model.close()
     a, b = curves["bf16"], curves["fp8"]
-    print("weighted loss, steps 0 / 20 / 39: bf16", a[[0, 20, 39]], "fp8", b[[0, 20, 39]])
+    sm = lambda x: np.convolve(x, np.ones(8) / 8.0, mode="valid")      # one pass over the 8 batches
+    sa, sb = sm(a), sm(b)
+    print("weighted loss (mean of 8 steps), start / middle / end: bf16", sa[[0, 20, -1]], "fp8", sb[[0, 20, -1]])
     assert np.isfinite(b).all()
-    assert b[-8:].mean() < b[:8].mean()                       # it learns
-    # (single steps of the two curves differ by up to ~0.7 at this learning rate, run to run as well: float atomics; the band is on the means)
-    assert abs(b[-8:].mean() - a[-8:].mean()) < 0.1 * abs(a[:8].mean() - a[-8:].mean()) + 0.05 * abs(a[-8:].mean()), (a[-8:].mean(), b[-8:].mean())
-    assert np.abs(b - a).max() < 0.2 * np.abs(a).max(), np.abs(b - a).max()     # (measured 0.11: step-to-step noise at this learning rate)
+    assert sb[-1] < 0.8 * sb[0]                                          # it learns
+    assert np.abs(sb - sa).max() < 0.15 * sa[0], (np.abs(sb - sa).max(), sa[0])
 
 
 def test_fp8_deterministic_mode_is_bitwise_reproducible():
