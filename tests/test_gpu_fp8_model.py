@@ -309,3 +309,54 @@ def test_fp8_partial_batch_equals_a_model_sized_for_it():
     assert np.allclose(la, lb, rtol=1e-5), (la, lb)
     worst = max(float(np.abs(ga[n] - gb[n]).max() / max(np.abs(ga[n]).max(), 1e-9)) for n in names)
     assert worst < 1e-4, worst      # (split-K atomics: summation order only)
+
+
+def test_fp8_data_parallel_buckets_on_two_concurrent_ranks():
+    """the fp8 trunk behind the data-parallel all-reduce with early gradient buckets (in-process rank group): the grouped fp8
+    weight-gradient launches run per bucket; every rank ends with the sum of the two ranks' own gradients"""
+    import threading
+
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    rows, world = 2, 2
+    P = synth.make_params(cfg, 23, "test")
+    batches = [synth.make_batch(cfg, rows, 24 + 10 * r) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, 25 + 10 * r) for r in range(world)]
+    names = synth.trainable_names(cfg)
+    single = []
+    for r in range(world):
+        model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+        model.load_state_dict(P); model.set_loss_weights(TASK_W, 1)
+        model(batches[r], False, masks=masks[r])
+        single.append({n: model.grad(n).astype(np.float64) for n in names})
+        model.close()
+    want = {n: single[0][n] + single[1][n] for n in names}
+    group = rdist.LocalGroup(world)
+    out = [None] * world; err = [None] * world
+
+    def rank_fn(r):
+        try:
+            comm = rdist.LocalComm(group, r)
+            model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+            model.load_state_dict(P); model.set_loss_weights(TASK_W, 1)
+            comm.begin_grad_sync(model)
+            model(batches[r], False, masks=masks[r])
+            comm.all_reduce_grads(model)
+            out[r] = {n: model.grad(n).astype(np.float64) for n in names}
+            model.close(); comm.close()
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    group.close()
+    for e in err:
+        if e is not None:
+            raise e
+    for r in range(world):
+        worst = max(float(np.abs(out[r][n] - want[n]).max() / max(np.abs(want[n]).max(), 1e-9)) for n in names)
+        assert worst < 2e-3, (r, worst)      # (float atomics of the split-K sums: order only)
