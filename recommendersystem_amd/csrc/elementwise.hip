@@ -456,6 +456,80 @@ __global__ __launch_bounds__(1024) void select_positions_kernel(SelectBatch sb, 
   wall = block_sum(wall, red);
   if (t == 0) { stats[0] = wsel; stats[1] = wall; if (npos_out) *npos_out = min(npos, topk); }
 }
+// The same selection by many workgroups: SEL_CHUNKS chunks per task count their positive weights (first kernel), every chunk then
+// ranks its positions behind the chunks before it (second kernel; the SEL_CHUNKS counts are summed by each workgroup itself).
+// One 1024-thread workgroup per task took 44 us at 32 768 positions (two strided passes); this takes two launches of ~4 us.
+constexpr int SEL_CHUNKS = 32;
+__global__ __launch_bounds__(256) void select_count_kernel(SelectBatch sb, int N, int* __restrict__ counts, float* __restrict__ wsums) {
+  __shared__ float red[16];
+  const int task = blockIdx.x / SEL_CHUNKS, ch = blockIdx.x % SEL_CHUNKS;
+  const float* __restrict__ w = sb.w[task];
+  const int per = (N + SEL_CHUNKS - 1) / SEL_CHUNKS, i0 = ch * per, i1 = min(N, i0 + per);
+  float cnt = 0.f, wall = 0.f;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) { const float x = w[i]; cnt += x > 0.f ? 1.f : 0.f; wall += x; }
+  cnt = block_sum(cnt, red);       // (counts <= 2^24: exact in float)
+  wall = block_sum(wall, red);
+  if (threadIdx.x == 0) { counts[blockIdx.x] = (int)cnt; wsums[blockIdx.x] = wall; }
+}
+__global__ __launch_bounds__(256) void select_place_kernel(SelectBatch sb, int N, int topk, const int* __restrict__ counts, const float* __restrict__ wsums,
+                                                           float* __restrict__ wsel_part) {
+  __shared__ int wave_tot[4];
+  __shared__ float red[16];
+  const int task = blockIdx.x / SEL_CHUNKS, ch = blockIdx.x % SEL_CHUNKS;
+  const float* __restrict__ w = sb.w[task];
+  int* idx = sb.idx[task];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  int before = 0, npos = 0;
+  for (int k = 0; k < SEL_CHUNKS; ++k) { const int v = counts[task * SEL_CHUNKS + k]; if (k < ch) before += v; npos += v; }
+  const int per = (N + SEL_CHUNKS - 1) / SEL_CHUNKS, i0 = ch * per, i1 = min(N, i0 + per);
+  float wsel = 0.f;
+  int rank0 = before;   // positives before the current 256-position stripe
+  for (int j0 = i0; j0 < i1; j0 += 256) {
+    const int i = j0 + t;
+    const float x = i < i1 ? w[i] : 0.f;
+    const int pos = x > 0.f ? 1 : 0;
+    int inc = pos;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+    __syncthreads();
+    if (l == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int v = wave_tot[k]; if (k < wv) base += v; tot += v; }
+    const int rank = rank0 + base + inc - pos;   // positives before position i
+    if (i < i1) {
+      const int slot = pos ? rank : npos + (i - rank);
+      if (slot < topk) { idx[slot] = i; wsel += x; }
+    }
+    rank0 += tot;
+  }
+  wsel = block_sum(wsel, red);
+  if (t == 0) wsel_part[blockIdx.x] = wsel;
+}
+__global__ void select_finish_kernel(SelectBatch sb, int ntask, int topk, const int* __restrict__ counts, const float* __restrict__ wsums,
+                                     const float* __restrict__ wsel_part) {
+  const int task = threadIdx.x;
+  if (task >= ntask) return;
+  int npos = 0; float wall = 0.f, wsel = 0.f;
+  for (int k = 0; k < SEL_CHUNKS; ++k) { npos += counts[task * SEL_CHUNKS + k]; wall += wsums[task * SEL_CHUNKS + k]; wsel += wsel_part[task * SEL_CHUNKS + k]; }
+  sb.stats[task][0] = wsel; sb.stats[task][1] = wall;
+  if (sb.npos[task]) *sb.npos[task] = min(npos, topk);
+}
+// scratch: 3 * 4 * SEL_CHUNKS words
+int launch_select_positions_chunked(int ntask, const float* const* w, int N, int topk, int* const* idx, float* const* stats, int* const* npos_out,
+                                    void* scratch, hipStream_t s) {
+  ARG_CHECK(topk <= N && ntask >= 1 && ntask <= 4 && scratch != nullptr, "select_positions: topk > N or more than 4 tasks");
+  SelectBatch sb{};
+  for (int i = 0; i < ntask; ++i) { sb.w[i] = w[i]; sb.idx[i] = idx[i]; sb.stats[i] = stats[i]; sb.npos[i] = npos_out[i]; }
+  int* counts = (int*)scratch; float* wsums = (float*)scratch + 4 * SEL_CHUNKS; float* wsel = (float*)scratch + 8 * SEL_CHUNKS;
+  hipLaunchKernelGGL(select_count_kernel, dim3(ntask * SEL_CHUNKS), dim3(256), 0, s, sb, N, counts, wsums);
+  hipLaunchKernelGGL(select_place_kernel, dim3(ntask * SEL_CHUNKS), dim3(256), 0, s, sb, N, topk, counts, wsums, wsel);
+  hipLaunchKernelGGL(select_finish_kernel, dim3(1), dim3(64), 0, s, sb, ntask, topk, counts, wsums, wsel);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats, int* npos_out, hipStream_t s) {
   const float* ws[1] = {w}; int* is[1] = {idx}; float* st[1] = {stats}; int* np[1] = {npos_out};
   return launch_select_positions_batch(1, ws, N, topk, is, st, np, s);

@@ -74,6 +74,9 @@ int launch_dropout(const T* src, T* dst, long long n, float p, unsigned long lon
 int launch_select_positions(const float* w, int N, int topk, int* idx, float* stats /*[2]: wsum_sel, wsum_all*/,
                             int* npos_out /*number of positive-weight rows selected (they come first)*/, hipStream_t s);
 // up to four independent selections (the four (medium, metric) tasks) in one launch, one workgroup each
+// the same by many workgroups (two small launches + a finishing one); scratch: 12 * 32 words of device memory
+int launch_select_positions_chunked(int ntask, const float* const* w, int N, int topk, int* const* idx, float* const* stats, int* const* npos_out,
+                                    void* scratch, hipStream_t s);
 int launch_select_positions_batch(int ntask, const float* const* w, int N, int topk, int* const* idx, float* const* stats,
                                   int* const* npos_out, hipStream_t s);
 

@@ -327,6 +327,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->dO, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
   DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
   DALLOC(m->sumsq, 64);
+  DALLOC(m->sel_scratch, 12 * 32 * 4);
   m->dLa = nullptr; m->dxl = nullptr;
   if (cfg->finetune) { DALLOC(m->dLa, NT * 16 * e); DALLOC(m->dxl, NT * D * e); }
   {
@@ -1498,7 +1499,9 @@ static int select_positions_all(Model* m) {
   const bool aside = aside_on && !m->sharded && !(m->timer.enabled && m->timer.serialize);   // (sharded: the early counts need them at once)
   hipStream_t s = aside ? m->side : m->stream;
   if (aside) { HIP_CHECK(hipEventRecord(m->ev_fork, m->stream)); HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
-  RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
+  static const bool chunked_on = !(getenv("RSYS_SELECT_CHUNKED") && atoi(getenv("RSYS_SELECT_CHUNKED")) == 0);   // (A/B)
+  if (chunked_on && N >= 4096) RC(launch_select_positions_chunked(4, ws, N, KB, is, sts, nps, m->sel_scratch, s));
+  else RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
   if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_bits, m->c_pre, m->c_n, s));
   if (aside) { HIP_CHECK(hipEventRecord(m->ev_sel, m->side)); m->sel_pending = true; }
   return RSYS_OK;

@@ -90,6 +90,7 @@ struct Model {
   unsigned char* a8 = nullptr;    // fp8 copy of the current product's A operand
   void* f8_jobs = nullptr; int* f8_tile_job = nullptr; int* f8_tile_first = nullptr; int f8_ntiles = 0;
   bool w8_dirty = true;
+  void* sel_scratch = nullptr;    // chunk counts / sums of the multi-workgroup position selection
   float* rope_cs = nullptr;       // [T][hd/2][2]: (cos, sin) interleaved copy of the RoPE tables for the QKV epilogue
   // fp8 weight gradients dW = q_e5m2(dY)^T . q_e4m3(X): every cast also leaves a K-contiguous (transposed, [features][tokens]) copy
   // per layer, consumed by the split-K fp8 form after (or, grouped, at the end of) the backward.  RSYS_F8_DW=0: bf16 operands instead.
