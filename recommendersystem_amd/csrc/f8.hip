@@ -54,10 +54,6 @@ __host__ __device__ __forceinline__ int f8_nseg(int n, int layout, int seg, int 
   return layout == F8_LAYOUT_SEGS ? n / seg - seg_rep + 1 : (layout == F8_LAYOUT_SWIGLU ? 2 : 1);
 }
 
-__device__ __forceinline__ void atomic_max_pos(float* slot, float v) {   // v >= 0: the bit patterns of non-negative floats order like ints
-  atomicMax((int*)slot, __float_as_int(v));
-}
-
 // ---- amax over column segments: thread = one group of 16 columns of one row per trip
 template <typename T>
 __global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ src, long long ld, int rows, int cols, const int* __restrict__ rows_dev,
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(256) void f8_weight_amax_kernel(const F8WeightJob* 
   const int nseg = f8_nseg(j.rows, j.layout, j.seg_rows, j.seg_rep);
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const float v = block_max(mx[sgi], red);
-    if (t == 0 && v > 0.f) atomic_max_pos(j.amax + sgi, v);
+    if (t == 0 && v > 0.f) atomicMax((int*)(j.amax + sgi), __float_as_int(v));   // (v >= 0: the bit patterns of non-negative floats order like ints)
   }
 }
 
