@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void f8_cast_t_kernel(F8Cast c) {
     }
   }
   const int ct = (c.cols + 127) >> 7;
-  const int tile = blockIdx.x * 4 + (t >> 6);
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (t >> 6);
   if (tile >= (c.rows >> 7) * ct) return;
   const int l = t & 63;
   const int r0 = (tile / ct) * 128 + (l >> 3) * 16, col = (tile % ct) * 128 + (l & 7) * 16;
@@ -344,9 +344,11 @@ int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   if (c.dst_t != nullptr) {
     ARG_CHECK(c.rows % 128 == 0 && c.cols % 64 == 0 && c.rows_dev == nullptr && c.ld_dst_t % 16 == 0 && c.ld_dst_t >= c.rows, "fp8 cast with a transposed copy: rows % 128, cols % 64");
     ARG_CHECK(c.desc_dw == nullptr || (c.xamax != nullptr && c.dw_units >= 1 && c.dw_units <= 16), "fp8 cast: weight-gradient descale job");
-    const int grid_t = ((c.rows / 128) * ((c.cols + 127) / 128) + 3) / 4;
-    if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
-    else { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E5M2>), dim3(grid_t), dim3(256), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E4M3>), dim3(grid_t), dim3(256), 0, s, c); }
+    static const int wpb = getenv("RSYS_DEBUG_F8_CAST_WAVES") ? atoi(getenv("RSYS_DEBUG_F8_CAST_WAVES")) : 4;   // waves (tiles) per workgroup: A/B
+    const int ntile_t = (c.rows / 128) * ((c.cols + 127) / 128);
+    const int grid_t = (ntile_t + wpb - 1) / wpb;
+    if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E5M2>), dim3(grid_t), dim3(64 * wpb), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E4M3>), dim3(grid_t), dim3(64 * wpb), 0, s, c); }
+    else { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E5M2>), dim3(grid_t), dim3(64 * wpb), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<bf16, F8_E4M3>), dim3(grid_t), dim3(64 * wpb), 0, s, c); }
     HIP_CHECK(hipGetLastError());
     return RSYS_OK;
   }
