@@ -29,7 +29,7 @@ typedef struct rsys_comm rsys_comm;
 /* RSYS_DTYPE_FP8: bf16 arithmetic with the transformer blocks' linears (q k v o w1 w3 w2: forward and input-gradient products) on
  * tensor-wise dynamically scaled fp8 operands -- the reference's pretraining arithmetic (transformer.py:671-676, torchao
  * "tensorwise": e4m3 inputs and weights, e5m2 output gradients); pretraining only, needs embed_dim % 128 == 0 >= 256,
- * intermediate_dim % 128 == 0, (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14 */
+ * (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14 (the hidden width is padded to a multiple of 128 inside) */
 enum { RSYS_DTYPE_FP32 = 0, RSYS_DTYPE_BF16 = 1, RSYS_DTYPE_FP8 = 2 };
 
 /* mirrors the config dict of train.py:535-560 (+ finetune keys of :520-524) */

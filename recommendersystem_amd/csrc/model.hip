@@ -175,9 +175,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
             "sampled_negatives needs the row-sharded table (table_shard_world >= 1)");
   if (cfg->dtype == RSYS_DTYPE_FP8) {
     ARG_CHECK(!cfg->finetune, "dtype fp8: the reference converts the trunk to float8 for pretraining only (transformer.py:671)");
-    ARG_CHECK(cfg->embed_dim % 128 == 0 && cfg->embed_dim >= 256 && cfg->intermediate_dim % 128 == 0 && cfg->num_heads > 0 && cfg->num_kv_heads > 0 &&
+    ARG_CHECK(cfg->embed_dim % 128 == 0 && cfg->embed_dim >= 256 && cfg->intermediate_dim >= 129 && cfg->num_heads > 0 && cfg->num_kv_heads > 0 &&
               (cfg->num_kv_heads * (cfg->embed_dim / cfg->num_heads)) % 128 == 0 && cfg->num_heads / cfg->num_kv_heads <= 14,
-              "dtype fp8 needs embed_dim % 128 == 0 (>= 256), intermediate_dim % 128 == 0, (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14");
+              "dtype fp8 needs embed_dim % 128 == 0 (>= 256), intermediate_dim > 128, (num_kv_heads * head_dim) % 128 == 0, num_heads / num_kv_heads <= 14");
   }
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -190,7 +190,8 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   m->fp8 = cfg->dtype == RSYS_DTYPE_FP8;
   m->esz = m->bf16_mode ? 2 : 4;
   m->L = cfg->num_layers; m->H = cfg->num_heads; m->KV = cfg->num_kv_heads; m->D = cfg->embed_dim;
-  m->I = cfg->intermediate_dim; m->Ip = (m->I + 15) / 16 * 16; m->S = cfg->max_sequence_length; m->T = 2 * m->S;
+  m->I = cfg->intermediate_dim; m->Ip = m->fp8 ? (m->I + 127) / 128 * 128 : (m->I + 15) / 16 * 16;   // (fp8: K tiles of 128 elements; padding rows / columns of W13 / W2 are zero)
+  m->S = cfg->max_sequence_length; m->T = 2 * m->S;
   m->V0 = cfg->vocab_0; m->V1 = cfg->vocab_1; m->V = m->V0 + m->V1; m->M = cfg->metadata_dim;
   m->Mp = (m->M + 63) / 64 * 64; m->K = cfg->mask_topk; m->hd = hd;
   m->Nqkv = (m->H + 2 * m->KV) * hd; m->rows_max = cfg->max_rows;

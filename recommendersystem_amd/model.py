@@ -349,7 +349,7 @@ class RecommenderModel:
         elif key.startswith("act."):     # act.<layer>.<x|xn|qkv|O|h|hn|ab|g>: saved activations (bf16 ones come back widened to float32)
             f = key.split(".")[2]
             H, KV = self.config["num_heads"], self.config["num_kv_heads"]
-            Ip = (self.config["intermediate_dim"] + 15) // 16 * 16
+            Ip = (self.config["intermediate_dim"] + 127) // 128 * 128 if self.dtype in ("fp8", "float8") else (self.config["intermediate_dim"] + 15) // 16 * 16
             cols = {"x": D, "h": D, "xn": D, "hn": D, "O": D, "qkv": (H + 2 * KV) * (D // H), "ab": 2 * Ip, "g": Ip}[f]
             wide = f in ("x", "h") or self.dtype in ("fp32", "float32", "f32")
             out = np.empty((2 * n, cols), np.float32 if wide else np.uint16)
@@ -358,7 +358,7 @@ class RecommenderModel:
         elif key.startswith("dw.") or key.startswith("f8keep."):   # bf16 operands the backward kept (widened to float32)
             f = key.split(".")[2]
             H, KV = self.config["num_heads"], self.config["num_kv_heads"]
-            Ip = (self.config["intermediate_dim"] + 15) // 16 * 16
+            Ip = (self.config["intermediate_dim"] + 127) // 128 * 128 if self.dtype in ("fp8", "float8") else (self.config["intermediate_dim"] + 15) // 16 * 16
             cols = {"gxt": D, "dht": D, "dab": 2 * Ip, "dqkv": (H + 2 * KV) * (D // H)}.get(f, D)
             out = np.empty((2 * n, cols), np.uint16)
             check(lib().rsys_debug_get(self._h, key.encode(), out.ctypes.data, out.nbytes))

@@ -35,26 +35,28 @@ def _split_ab(ab, Ip):
     return r[:, :, 0, :].reshape(ab.shape[0], Ip), r[:, :, 1, :].reshape(ab.shape[0], Ip)
 
 
-def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
+@pytest.mark.parametrize("hidden", [384, 352])   # 352: not a multiple of the 128-element K tile -- the hidden width is zero-padded inside
+def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch, hidden):
     """Each of the eight fp8 products of a layer, fed with the HIP path's OWN stored operands, against the oracle's linear on those
     operands: no error is carried from stage to stage, so the bounds are the output rounding (bf16: relative RMS ~ 1e-3) or the
     accumulation (fp32 outputs: 1e-4) -- a wrong scale slot, weight copy, segment boundary or K order would be orders larger."""
     monkeypatch.setenv("RSYS_F8_DEBUG_KEEP", "1")
     import recommendersystem_amd as ra
     from oracle import model_np, synth
-    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16, intermediate_dim=hidden)
     rows, seed = 3, 31
     P = synth.make_params(cfg, seed, "test")
     d = synth.make_batch(cfg, rows, seed + 1)
     wm, rm = synth.make_masks(cfg, rows, seed + 2)
     ref = model_np.OracleModel(cfg, P, np.float64, operand_round="fp8")
     Q = ref.q
+    I = hidden
     model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
     model.load_state_dict(P)
     model.set_loss_weights(TASK_W, 1)
     model(d, False, masks=(wm, rm))
     L, D, H, KV = cfg["num_layers"], cfg["embed_dim"], cfg["num_heads"], cfg["num_kv_heads"]
-    hd, Ip, B, T = D // H, cfg["intermediate_dim"], rows, 2 * cfg["max_sequence_length"]
+    hd, Ip, B, T = D // H, (cfg["intermediate_dim"] + 127) // 128 * 128, rows, 2 * cfg["max_sequence_length"]
     cos, sin = ref.cos[:T].astype(np.float64), ref.sin[:T].astype(np.float64)
     get = lambda k: model.debug_get(k, rows).astype(np.float64)
     worst_bf, worst_f32 = ("", 0.0), ("", 0.0)
@@ -77,15 +79,18 @@ def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
         chk(f"o_fwd[{l}]", get(f"act.{l}.h"), h, f32=True)
         hn = get(f"act.{l}.hn")
         a = ref.lin(hn, p + "mlp.w1.weight"); b = ref.lin(hn, p + "mlp.w3.weight")
-        a_hip, b_hip = _split_ab(get(f"act.{l}.ab"), Ip)
+        a_hip, b_hip = (t[:, :I] for t in _split_ab(get(f"act.{l}.ab"), Ip))
+        g_hip = get(f"act.{l}.g")
+        assert not g_hip[:, I:].any()                                  # (padding columns stay zero)
+        g_hip = g_hip[:, :I]
         chk(f"w1_fwd[{l}]", a_hip, Q(a)); chk(f"w3_fwd[{l}]", b_hip, Q(b))
-        chk(f"swiglu[{l}]", get(f"act.{l}.g"), Q(a / (1.0 + np.exp(-a)) * b))
+        chk(f"swiglu[{l}]", g_hip, Q(a / (1.0 + np.exp(-a)) * b))
         if l + 1 < L:
-            chk(f"w2_fwd[{l}]", get(f"act.{l + 1}.x"), get(f"act.{l}.h") + ref.lin(get(f"act.{l}.g"), p + "mlp.w2.weight"), f32=True)
+            chk(f"w2_fwd[{l}]", get(f"act.{l + 1}.x"), get(f"act.{l}.h") + ref.lin(g_hip, p + "mlp.w2.weight"), f32=True)
         # backward: dY operands kept by the deferred weight gradients + the kept dx outputs
         gg = ref.lin_dx(get(f"dw.{l}.gxt"), p + "mlp.w2.weight")
         sig = 1.0 / (1.0 + np.exp(-a_hip))
-        da_hip, db_hip = _split_ab(get(f"dw.{l}.dab"), Ip)
+        da_hip, db_hip = (t[:, :I] for t in _split_ab(get(f"dw.{l}.dab"), Ip))
         chk(f"w2_dx.da[{l}]", da_hip, Q(gg * b_hip * (sig * (1.0 + a_hip * (1.0 - sig)))))
         chk(f"w2_dx.db[{l}]", db_hip, Q(gg * a_hip * sig))
         chk(f"w13_dx[{l}]", get(f"f8keep.{l}.0"), Q(ref.lin_dx(da_hip, p + "mlp.w1.weight") + ref.lin_dx(db_hip, p + "mlp.w3.weight")))
@@ -96,7 +101,7 @@ def test_every_fp8_product_of_the_trunk_stage_by_stage(monkeypatch):
                                                      + ref.lin_dx(dqkv[:, nq + nk:], p + "attn.v_proj.weight")))
         # the seven weight gradients (fp32 sums) from the operands the two passes stored
         grad = lambda n: model.grad(p + n).astype(np.float64)
-        chk(f"w2_dw[{l}]", grad("mlp.w2.weight"), ref.lin_dw(get(f"dw.{l}.gxt"), get(f"act.{l}.g")), f32=True)
+        chk(f"w2_dw[{l}]", grad("mlp.w2.weight"), ref.lin_dw(get(f"dw.{l}.gxt"), g_hip), f32=True)
         chk(f"w1_dw[{l}]", grad("mlp.w1.weight"), ref.lin_dw(da_hip, hn), f32=True)
         chk(f"w3_dw[{l}]", grad("mlp.w3.weight"), ref.lin_dw(db_hip, hn), f32=True)
         chk(f"o_dw[{l}]", grad("attn.output_proj.weight"), ref.lin_dw(get(f"dw.{l}.dht"), get(f"act.{l}.O")), f32=True)
