@@ -451,7 +451,7 @@ def main():
         if args.dtype in ("fp8", "float8"):
             out["dtype_note"] = ("bf16 arithmetic with the transformer blocks' linears (forward, dx, dW) on tensor-wise dynamically scaled e4m3 / e5m2 "
                                  "operands: the reference's pretraining arithmetic (transformer.py:671-676, torchao 'tensorwise'), restated -- parity "
-                                 "unpinned against torchao itself; step_mfma_frac* are still priced against the bf16 peak")
+                                 "pinned to torch's float8 casts and torch._scaled_mm, not to torchao itself (absent); step_mfma_frac* are still priced against the bf16 peak")
         if len(plain):
             q = lambda f: round(float(np.quantile(plain, f)), 3)
             out["ms_per_step_stats"] = {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": int(len(plain)),

@@ -3,8 +3,10 @@
 The reference converts the transformer blocks' linears with torchao's "tensorwise" float8 recipe
 (/root/reference/notebooks/Training/transformer.py:671-676).  torchao is absent from this image, so this file restates the
 recipe it publishes (torchao.float8: `amax_to_scale`, `hp_tensor_to_float8_dynamic`, `Float8LinearConfig` defaults: input and
-weight e4m3, grad_output e5m2, one scale per tensor computed from this step's amax) -- PARITY UNPINNED against torchao itself.
-The rounding functions are pinned against torch's own float8 casts in tests/test_fp8_oracle.py.
+weight e4m3, grad_output e5m2, one scale per tensor computed from this step's amax).  Pinned in tests/test_fp8_oracle.py to the
+PyTorch primitives torchao's Float8Linear is made of, on the CPU: the rounding functions against torch's float8 casts (every grid
+point and tie), the three products of a linear (oracle/model_np.py lin / lin_dx / lin_dw) against torch._scaled_mm with inverse scales.
+NOT pinned (torchao itself is absent): the two-line amax -> scale formula and the format assignment, restated from its source.
 
     scale = float32(float64(FMAX) / max(float64(amax), 1e-12))        FMAX = 448 (e4m3fn), 57344 (e5m2)
     q(x)  = round-to-nearest-even(clamp(float32(x) * scale, -FMAX, FMAX)) on the fp8 grid

@@ -165,7 +165,7 @@ class OracleModel:
         is the reference's autocast arithmetic as the benchmarked mode computes it, for the tight bf16 parity check.
         operand_round="fp8": the same, and the transformer blocks' linears (q k v o w1 w3 w2: forward and input-gradient
         products) take tensor-wise dynamically scaled fp8 operands -- torchao's "tensorwise" float8 recipe the reference applies
-        to `transformers.*` for pretraining (transformer.py:671-676), restated in oracle/fp8.py (parity unpinned against torchao
+        to `transformers.*` for pretraining (transformer.py:671-676), restated in oracle/fp8.py (pinned to torch's float8 casts and torch._scaled_mm in tests/test_fp8_oracle.py; not against torchao
         itself): forward, input-gradient and weight-gradient products.  `fp8_dw = False` afterwards: weight gradients from the
         bf16 operands instead (the HIP path's RSYS_F8_DW=0 / deterministic mode)."""
         self.cfg = cfg

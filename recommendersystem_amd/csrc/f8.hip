@@ -3,7 +3,8 @@
 // The reference converts every nn.Linear under `transformers.` with torchao's "tensorwise" recipe before pretraining
 // (transformer.py:671-676: convert_to_float8_training(model, Float8LinearConfig.from_recipe_name("tensorwise"),
 // module_filter_fn = fqn.startswith("transformers."))).  torchao is not in this image, so what follows is a restatement
-// of its published recipe -- PARITY UNPINNED against torchao itself; oracle/model_np.py restates the same recipe in numpy:
+// of its published recipe; oracle/model_np.py restates the same recipe in numpy and is pinned on the CPU to torch's float8 casts
+// and torch._scaled_mm (the primitives torchao's Float8Linear calls); torchao's amax -> scale formula itself is restated, not pinned:
 //   forward   y  = (q_e4m3(x sx) . q_e4m3(W sw)^T) / (sx sw)      sx = 448 / amax|x|, sw = 448 / amax|W|   (per TENSOR, this step's values)
 //   backward  dx = (q_e5m2(dy sg) . q_e4m3(W sw))   / (sg sw)      sg = 57344 / amax|dy|
 //             dW = (q_e5m2(dy sg)^T . q_e4m3(x sx)) / (sg sx)

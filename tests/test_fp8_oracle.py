@@ -1,6 +1,7 @@
 """CPU: the fp8 restatement the GPU parity tests check against (oracle/fp8.py, oracle/model_np.py operand_round="fp8").
-torchao is absent from the image, so the recipe itself is PARITY UNPINNED; what can be pinned here is the rounding:
-OCP e4m3fn / e5m2 round-to-nearest-even against torch's own float8 casts, the byte codes, and the scale formula's published form."""
+torchao is absent from the image; what is pinned here are the PyTorch primitives its Float8Linear is made of: OCP
+e4m3fn / e5m2 round-to-nearest-even against torch's own float8 casts (and the byte codes), and the three products of a linear against
+torch._scaled_mm.  The amax -> scale formula is checked in its published form only."""
 import numpy as np
 import pytest
 
@@ -61,3 +62,53 @@ def test_oracle_fp8_mode_runs_and_differs_from_bf16_by_fp8_noise():
     _, G8b = o8b.forward(dm, False, True, tw)
     assert not np.array_equal(G8b[n], G8[n])                                        # weight gradients from bf16 operands: another arithmetic
     assert np.abs(G8b[n] - G8[n]).max() / np.abs(G8[n]).max() < 0.5
+
+
+def _bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).view(np.float32)
+
+
+def test_oracle_linears_match_torch_scaled_mm():
+    """The three products of a float8 linear as the oracle computes them (oracle/model_np.py lin / lin_dx / lin_dw) against PyTorch's own
+    primitives -- float8 casts and torch._scaled_mm with inverse scales and a bf16 output, the call torchao's Float8Linear makes --
+    on the CPU.  What stays restated from torchao's source, not pinned: the two-line amax -> scale formula and which tensors get
+    which format."""
+    torch = pytest.importorskip("torch")
+    if not hasattr(torch, "_scaled_mm"):
+        pytest.skip("no torch._scaled_mm")
+    from oracle import model_np
+    rng = np.random.default_rng(3)
+    T, Din, Dout = 96, 64, 48
+    x = _bf16_round(rng.standard_normal((T, Din)).astype(np.float32) * 1.7)
+    g = _bf16_round(rng.standard_normal((T, Dout)).astype(np.float32) * 3e-4)
+    W = (rng.standard_normal((Dout, Din)) * 0.04).astype(np.float32)
+    ora = model_np.OracleModel.__new__(model_np.OracleModel)            # only the linear helpers are exercised
+    ora.fp8 = True; ora.fp8_dw = True; ora.dt = np.float64; ora.P = {"w": W.astype(np.float64)}; ora.q = lambda a: a
+
+    def q8(t, fmt):
+        dt = torch.float8_e4m3fn if fmt == fp8.E4M3 else torch.float8_e5m2
+        s = torch.tensor(fp8.scale_of(float(np.abs(t).max()), fmt))
+        return (torch.from_numpy(t) * s).clamp(-fp8.fmax(fmt), fp8.fmax(fmt)).to(dt), (1.0 / s).float()
+
+    def colmajor(t):
+        return t.t().contiguous().t()
+
+    try:
+        x8, ix = q8(x, fp8.E4M3); w8, iw = q8(W, fp8.E4M3); g8, ig = q8(g, fp8.E5M2)
+        y = torch._scaled_mm(x8, colmajor(w8.t()), scale_a=ix, scale_b=iw, out_dtype=torch.bfloat16).float().numpy()        # x W^T
+        dx = torch._scaled_mm(g8, colmajor(w8), scale_a=ig, scale_b=iw, out_dtype=torch.bfloat16).float().numpy()           # g W
+        dw = torch._scaled_mm(g8.t().contiguous(), colmajor(x8), scale_a=ig, scale_b=ix, out_dtype=torch.float32).numpy()   # g^T x
+    except (RuntimeError, NotImplementedError) as e:                      # a build without the CPU kernel
+        pytest.skip(f"torch._scaled_mm unavailable on this CPU build: {e}")
+
+    def close_bf16(a, b):      # equal up to one bf16 rounding of the output (accumulation order at a rounding boundary)
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        ulp = np.maximum(np.abs(b), 1e-30) * 2.0 ** -7
+        return (np.abs(a - b) <= ulp).all() and (a != b).mean() < 0.1
+
+    assert close_bf16(_bf16_round(ora.lin(x.astype(np.float64), "w")), y)
+    assert close_bf16(_bf16_round(ora.lin_dx(g.astype(np.float64), "w")), dx)
+    ref_dw = ora.lin_dw(g.astype(np.float64), x.astype(np.float64))
+    assert np.abs(ref_dw - dw).max() <= 2e-6 * np.abs(ref_dw).max()

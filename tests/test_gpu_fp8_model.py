@@ -1,6 +1,7 @@
 """GPU: the fp8 trunk (dtype="fp8": the reference's pretraining arithmetic, torchao "tensorwise" float8 linears under `transformers.`,
 transformer.py:671-676) against the numpy oracle run with the same recipe (oracle/model_np.py operand_round="fp8", oracle/fp8.py).
-PARITY UNPINNED against torchao itself (absent from the image): what these tests pin is that the HIP path computes the published
+The oracle's rounding and linear products are pinned to torch's float8 casts and torch._scaled_mm (tests/test_fp8_oracle.py); torchao
+itself is absent from the image, so its amax -> scale formula is restated.  What these tests pin is that the HIP path computes the
 recipe as restated -- and that it is the fp8 arithmetic, not bf16 (the two oracles differ by far more than HIP differs from its own)."""
 import numpy as np
 import pytest

@@ -1,5 +1,5 @@
 """GPU: the fp8 trunk's kernels one by one through the C ABI (rsys_op_f8_quantize / rsys_op_f8_weights / rsys_op_gemm_f8) against
-the numpy restatement of torchao's tensor-wise recipe (oracle/fp8.py; parity unpinned against torchao itself, see there):
+the numpy restatement of torchao's tensor-wise recipe (oracle/fp8.py: pinned to torch's float8 casts and torch._scaled_mm on the CPU, torchao itself being absent):
 casts bit-exact, GEMMs exact on data whose products and sums are exact and to fp32 accumulation order on random data."""
 import ctypes as C
 
