@@ -259,3 +259,34 @@ def test_gemm_f8_quantised_normal_data(a_fmt):
     print("quantised normal data: kernel vs exact sum of the fp8 products", err, "; fp8 quantisation itself", qerr)
     assert err < 6e-5, err     # (measured 1.6e-5 .. 1.8e-5: the instruction's internal alignment, as above)
     assert qerr < 0.1
+
+
+@pytest.mark.parametrize("a_fmt", [0, 1])
+def test_gemm_f8_against_torch_scaled_mm_on_the_gpu(a_fmt):
+    """an independent checker on the device: PyTorch's own scaled fp8 matmul (hipBLASLt behind torch._scaled_mm) on the same bytes"""
+    torch = pytest.importorskip("torch")
+    if not (hasattr(torch, "_scaled_mm") and torch.cuda.is_available()):
+        pytest.skip("no torch._scaled_mm on this device")
+    from oracle import fp8
+    lib, L = _lib()
+    rng = np.random.default_rng(21 + a_fmt)
+    M, N, K = 512, 256, 1024
+    a = rng.standard_normal((M, K)).astype(np.float32); b = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    qa, sa = fp8.quantize(a, a_fmt); qb, sb = fp8.quantize(b, 0)
+    ca, cb = fp8.encode_fp8(qa, a_fmt), fp8.encode_fp8(qb, 0)
+    d = np.zeros(32, np.float32); d[0] = fp8.descale(sa, sb)
+    dA = _dev(lib, ca); dB = _dev(lib, cb); dD = _dev(lib, d); dC = _empty(lib, M * N * 2)
+    assert lib.rsys_op_gemm_f8(dA, dB, dC, M, N, K, K, K, N, a_fmt, 0, dD, 0, 0, 0, 0, 0) == 0, L.last_error()
+    out = _bf16_val(_get(lib, dC, (M, N), np.uint16))
+    for p in (dA, dB, dC, dD):
+        lib.rsys_dev_free(p)
+    try:
+        ta = torch.from_numpy(ca).cuda().view(torch.float8_e4m3fn if a_fmt == 0 else torch.float8_e5m2)
+        tb = torch.from_numpy(cb).cuda().view(torch.float8_e4m3fn)
+        ia = torch.tensor(1.0 / float(sa), dtype=torch.float32, device="cuda"); ib = torch.tensor(1.0 / float(sb), dtype=torch.float32, device="cuda")
+        want = torch._scaled_mm(ta, tb.t(), scale_a=ia, scale_b=ib, out_dtype=torch.bfloat16).float().cpu().numpy()
+    except (RuntimeError, NotImplementedError) as e:
+        pytest.skip(f"torch._scaled_mm not usable here: {e}")
+    ulp = np.maximum(np.abs(want), 1e-30) * 2.0 ** -7
+    assert (np.abs(out - want) <= ulp).all(), float(np.abs(out - want).max())      # one bf16 rounding of the output
+    assert (out != want).mean() < 0.2
