@@ -61,6 +61,12 @@ def _recv_frame(sock, max_header=MAX_HEADER, max_raw=None):
     return header, (_recv_exact(sock, nr) if nr else b"")
 
 
+def _is_loopback(addr):
+    """True for the loopback literals a single-node launcher passes as MASTER_ADDR (127.0.0.0/8, ::1, localhost)"""
+    a = (addr or "").strip().lower()
+    return a == "localhost" or a == "::1" or a.startswith("127.")
+
+
 def rendezvous_ports():
     """Candidate ports of rank 0's listener.  RSYS_RDZV_PORT names one (bench.py's own spawner sets it); under torchrun
     MASTER_PORT itself is held by the agent's store, so the candidates are the 16 ports after it and the handshake
@@ -98,14 +104,10 @@ class HostGroup:
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                # rank 0 listens on the rendezvous address only (127.0.0.1 under launch_local / torchrun --standalone), not on
-                # every interface; a MASTER_ADDR that is not an address of this host falls back to all interfaces
-                try:
-                    ls.bind((addr, port))
-                except (OSError, socket.gaierror) as e:
-                    if getattr(e, "errno", None) in (98, 48):      # EADDRINUSE: try the next port
-                        raise
-                    ls.bind(("", port))
+                # rank 0 listens on loopback only when the rendezvous address IS loopback (127.0.0.1 / localhost under
+                # launch_local / torchrun --standalone); for any other MASTER_ADDR -- e.g. a host name that /etc/hosts maps to
+                # 127.0.1.1 on rank 0 but to the real address elsewhere -- on every interface (the handshake token rejects strangers)
+                ls.bind((addr if _is_loopback(addr) else "", port))
             except OSError as e:
                 err = e
                 ls.close()

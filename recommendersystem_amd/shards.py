@@ -98,10 +98,11 @@ def _event_columns(events):
     """The events of one user as columns.  `prev_status` / `prev_rating`: the state of the same item before the event
     (`history_status` / `history_rating` of the importer, import_list.jl:624-635), NaN where the item is new to the user."""
     col = lambda key, dt: np.array([x[key] for x in events], dt) if events else np.zeros(0, dt)
-    prev = lambda key: np.array([np.nan if x[key] is None else x[key] for x in events], np.float64) if events else np.zeros(0, np.float64)
+    prev = lambda key, dt: np.array([np.nan if x[key] is None else x[key] for x in events], dt) if events else np.zeros(0, dt)
+    # prev_rating in the precision of `rating` (both Float32 in transformer.jl:129): 8.3 must compare equal to a history rating of 8.3
     return {"medium": col("medium", np.int64), "matchedid": col("matchedid", np.int64), "status": col("status", np.int64),
             "rating": col("rating", np.float32), "progress": col("progress", np.float32), "time": col("history_max_ts", np.float64),
-            "prev_status": prev("history_status"), "prev_rating": prev("history_rating")}
+            "prev_status": prev("history_status", np.float64), "prev_rating": prev("history_rating", np.float32)}
 
 
 def _target_masks(c):
@@ -113,7 +114,7 @@ def _target_masks(c):
     new_item = np.isnan(c["prev_status"])
     was_planned = (c["prev_status"] > 0) & (c["prev_status"] <= PLANNED_STATUS)      # (NaN compares false)
     watch = ((c["status"] == 0) & new_item) | ((c["status"] > PLANNED_STATUS) & (new_item | was_planned))
-    rating = (c["rating"] > 0) & ~(c["rating"].astype(np.float64) == c["prev_rating"])
+    rating = (c["rating"] > 0) & ~(c["rating"] == c["prev_rating"])                  # float32 against float32 (NaN: new item)
     status = (c["status"] > 0) & ~(c["status"].astype(np.float64) == c["prev_status"])
     return {"watch": watch, "rating": rating, "status": status}
 
@@ -238,7 +239,9 @@ def get_finetune_data(data, userid, num_items_0, max_seq_len=FINETUNE_SEQ_LEN):
     One row of `max_seq_len` tokens: the newest max_seq_len - 1 projected history tokens (context: no targets), then the test
     event, which alone is a target (same rules as the pretraining writer); every task's weights are normalised to sum 1."""
     assert len(data["test_items"]) <= NUM_TEST_ITEMS
-    history = project(tokenize(data["items"]))[-(max_seq_len - NUM_TEST_ITEMS):]
+    history = project(tokenize(data["items"]))
+    keep = max_seq_len - NUM_TEST_ITEMS
+    history = history[len(history) - keep:] if keep > 0 and len(history) > keep else (history if keep > 0 else [])   # ([-0:] is the whole list)
     d = _empty_record(max_seq_len)
     _write_events(d, 0, _event_columns(history), data["user"], userid, num_items_0, with_targets=False)
     _write_events(d, len(history), _event_columns(data["test_items"]), data["user"], userid, num_items_0, with_targets=True)

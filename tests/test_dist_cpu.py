@@ -122,6 +122,43 @@ def test_bench_gpus2_without_gpus_fails_cleanly_on_every_rank():
     assert p.stderr.count("ranks need one each") == 2
 
 
+def test_rank0_binds_loopback_only_for_a_loopback_master_addr(monkeypatch):
+    """with a host name as MASTER_ADDR (which rank 0's /etc/hosts may map to 127.0.1.1 while the other nodes resolve the
+    real address) rank 0 listens on every interface; only a loopback literal restricts the listener."""
+    import threading
+
+    from recommendersystem_amd import dist
+
+    assert dist._is_loopback("127.0.0.1") and dist._is_loopback("localhost") and dist._is_loopback("127.0.1.1")
+    assert not dist._is_loopback(socket.gethostname() or "node0") or socket.gethostname() == "localhost"
+    assert not dist._is_loopback("10.0.0.5") and not dist._is_loopback("")
+    port = _free_port()
+    for k, v in dict(MASTER_ADDR="some-node-name.invalid", MASTER_PORT=str(port), RSYS_RDZV_PORT=str(port), TORCHELASTIC_RUN_ID="bind").items():
+        monkeypatch.setenv(k, v)
+    groups = [None]; err = []
+
+    def rank0():
+        try:
+            groups[0] = dist.HostGroup(0, 2, timeout=20)
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+    t0 = threading.Thread(target=rank0); t0.start()
+    deadline = time.time() + 10
+    while True:                                       # rank 1 reaches the listener through loopback: it is bound to every interface
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1.0); break
+        except OSError:
+            assert time.time() < deadline and not err, err; time.sleep(0.05)
+    dist._send_frame(s, {"token": f"bind:{port}:2", "rank": 1})
+    assert dist._recv_frame(s)[0]["ok"] is True
+    t0.join(20)
+    assert not err, err
+    assert groups[0].listener.getsockname()[0] == "0.0.0.0"
+    s.close(); groups[0].listener.close()
+    for c in groups[0].peers:
+        c.close()
+
+
 def test_rendezvous_rejects_oversized_and_foreign_handshakes_without_allocating(monkeypatch):
     """rank 0 honoured two 32-bit length prefixes (up to 4 GiB each) before the token check, on every interface.  Now the
     first frame of a connection is capped (4 KB header, no payload) before anything is read, the listener binds the rendezvous

@@ -161,6 +161,27 @@ def test_get_data_label_rules():
     assert d2["time"].tolist() == [1.0]
 
 
+def test_rating_rule_compares_in_one_precision_and_finetune_keep_zero():
+    """a rating that float32 cannot represent (8.3) equal to its history rating is NOT a rating target
+    (transformer.jl:129 compares two Float32 values); and a finetune row with room for the test event only keeps no history."""
+    from recommendersystem_amd.shards import NUM_TEST_ITEMS, get_data, get_finetune_data
+    user = {"user": {"gender": 0, "source": 1}, "items": [
+        _event(1, 9, 12.0, 7, 8.3, hs=6, hr=8.3),       # same non-dyadic rating: status target only
+        _event(1, 11, 13.0, 7, 8.3, hs=7, hr=8.2),      # changed rating: rating target
+        _event(0, 4, 14.0, 6, 7.1, hs=6, hr=7.1),       # nothing changed: projected away
+    ]}
+    d = get_data(user, 7, num_items_0=100)
+    assert d["matchedid"].tolist() == [109, 111]
+    assert d["1.rating.weight"].tolist() == [0, 1] and d["token_mask_ids"].tolist() == [0, 1]
+    assert d["1.status.weight"].tolist() == [1, 0]
+    row = {"user": {"gender": None, "source": 0}, "items": [_event(0, 1, 1.0, 7, 5), _event(0, 2, 2.0, 7, 6)],
+           "test_items": [_event(1, 3, 3.0, 7, 9)]}
+    f = get_finetune_data(row, 3, 100, max_seq_len=NUM_TEST_ITEMS)
+    assert len(f["userid"]) == NUM_TEST_ITEMS and f["matchedid"].tolist() == [103]
+    f3 = get_finetune_data(row, 3, 100, max_seq_len=3)
+    assert f3["matchedid"].tolist() == [1, 2, 103]
+
+
 def test_optdate_and_media_table():
     from recommendersystem_amd.shards import MIN_TS, max_ts_of, media_embedding_matrix, optdate
     max_ts = max_ts_of("20250101\n")
