@@ -140,6 +140,10 @@ __device__ __forceinline__ void epi_item(const GemmParams& p, long long row, int
 // gemm8p_eligible: the problem satisfies that kernel's layout / size preconditions.
 bool gemm8p_eligible(const GemmParams& p);
 int launch_gemm8p(const GemmParams& p, hipStream_t s);
+// the same pipeline with one operand stream across the workgroup's output tiles and the epilogue overlapped with the next
+// tile's first K tile (gemm8c.hip): the epilogue classes of the training step; launch_gemm8p forwards eligible problems
+bool gemm8c_eligible(const GemmParams& p);
+int launch_gemm8c(const GemmParams& p, hipStream_t s);
 // the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
 bool gemm8p_tn_eligible(const GemmParams& p);
 int launch_gemm8p_tn(const GemmParams& p, hipStream_t s);

@@ -16,7 +16,9 @@ namespace rsys {
 // wm0 / wn0: first row / column of the wave's block; full: the whole workgroup tile lies inside the matrix.
 // MODE 1 / 0: the caller knows at compile time that the tile is full / an edge tile (the persistent kernel runs its
 // full tiles and its edge tiles in two separate loops); -1: decided by `full` at run time.
-template <int MODE = -1>
+// ECF >= 0: the epilogue class is known at compile time (gemm8c.hip: one kernel per class; EPI_QKV_ROPE there means the
+// implicit positions row % T), else it is p.epi.
+template <int MODE = -1, int ECF = -1>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[8][4], int wm0, int wn0, bool full,
                                               int fq, int fr) {
   auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
@@ -291,6 +293,7 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     else if constexpr (MODE == 0) run(EC, std::false_type{});
     else { if (full) run(EC, std::true_type{}); else run(EC, std::false_type{}); }
   };
+  if constexpr (ECF >= 0) { run2(std::integral_constant<int, ECF>{}); return; }
   switch (p.epi) {
     case EPI_STORE: run2(std::integral_constant<int, EPI_STORE>{}); break;
     case EPI_ACCUM: run2(std::integral_constant<int, EPI_ACCUM>{}); break;
