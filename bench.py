@@ -25,7 +25,8 @@ HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
 KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
-    "8p": "gemm8p_kernel<false, false>",                  # 256x256 LDS-DMA, persistent, row-major operands (gemm8p.hip)
+    "8c": "gemm8c_kernel",                                # 256x256 LDS-DMA, persistent, ONE operand stream across a workgroup's output tiles (gemm8c.hip; one instantiation per epilogue class)
+    "8p": "gemm8p_kernel<false, false>",                  # its predecessor: operand requests stop at the end of every output tile (gemm8p.hip; classes without an 8c kernel, RSYS_GEMM8C=0)
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
     "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
     "8g": "gemm8p_group_kernel",                          # the K-major pipeline, all layers' weight gradients in one grouped launch
@@ -37,7 +38,8 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
-KERNEL_LABEL = {"8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
+KERNEL_LABEL = {"8c": "gemm8c_kernel<epilogue class> (256x256 LDS-DMA, persistent, one operand stream per workgroup, row-major bf16)",
+                "8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
                 "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
                 "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
@@ -57,10 +59,10 @@ TRAFFIC_FILE = _latest_traffic_file()
 def traffic_of(db, variant):
     """HBM bytes per launch of the kernel from the committed PMC summary (profiles/<TRAFFIC_FILE>)."""
     sym = KERNEL_SYMBOL.get(variant)
-    for name, k in db.items():
-        if sym and sym in name:
-            return round(k["hbm_bytes_per_launch"])
-    return None
+    # a tag may stand for a family of instantiations (gemm8c_kernel<epilogue class>): launch-weighted mean over all of them
+    hits = [k for name, k in db.items() if sym and sym in name]
+    n = sum(k.get("launches", 1) for k in hits)
+    return round(sum(k["hbm_bytes_per_launch"] * k.get("launches", 1) for k in hits) / n) if n else None
 
 
 HBM_KERNEL_SYMBOL = {"hbm_gather": ["gather_items_kernel"], "hbm_scatter": ["seg_scatter_kernel", "seg_fixup_kernel"],   # (one call site, two launches)
@@ -359,7 +361,7 @@ def main():
         fl_rows256 = sum(2.0 * up(npos[2 * m_], 256) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
-                rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith("@8p")) else fl   # 256-row tiles
+                rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith(("@8p", "@8c"))) else fl   # 256-row tiles
         # the rating heads stop at their live rows too (tasks 1 and 3; one tag covers both launches)
         KBr = cfg["mask_topk"] * rows
         for tag, q in (("gemm_rating_fwd", 128), ("gemm_rating_dx", 128), ("gemm_rating_dw", 64)):
@@ -373,7 +375,7 @@ def main():
             top_cap, top_n = 0, 0
         if top_cap:
             for full in [k for k in rep if k.startswith("gemm_top_")]:
-                q = 256 if full.endswith("@8p") else (64 if full.split("@")[0].endswith("_dw") else 128)
+                q = 256 if full.endswith(("@8p", "@8c")) else (64 if full.split("@")[0].endswith("_dw") else 128)
                 rep[full]["flops"] *= min(top_cap, up(top_n, q)) / float(top_cap)
     losses = model.losses(False)
     assert all(np.isfinite(losses)), losses

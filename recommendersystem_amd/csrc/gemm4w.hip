@@ -68,6 +68,9 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmParams p) {
   const int m0 = tm * T4_BM, n0 = tn * T4_BN;
   if (p.m_dev != nullptr && m0 >= *p.m_dev) return;   // uniform: whole workgroup leaves
   const int nt = p.K / T4_BK;                          // launcher: K % 32 == 0
+#ifdef RSYS_4W_STAGGER   // tools/micro/gemm8c_dev.hip: the second workgroup of every CU starts (flags >> 16) naps late
+  if (blockIdx.x < 512 && ((blockIdx.x >> 3) & 32)) for (int k = 0; k < ((p.flags >> 16) & 0xFF); ++k) __builtin_amdgcn_s_sleep(32);
+#endif
 
   // ---- DMA source offsets.  A stage is 24 pieces of 1 KB (16 rows x 64 B): pieces 0..15 = A rows, 16..23 = B rows.
   // Wave w issues pieces w, w+4, ... (6 per K tile: 4 of A, 2 of B); lane l -> row 16 * piece + (l >> 2), slot l & 3.

@@ -1,22 +1,25 @@
 // bf16 MFMA GEMM for row-major operands, gfx950: C[M,N] = sum_k A[m][k] * B[n][k] -- the persistent 256x256 LDS-DMA pipeline of
-// gemm8p.hip (same tile, same LDS image, same four phases per K tile: read that header first) with the OUTPUT STREAM OVERLAPPED:
-//
-//  * one operand stream per workgroup.  The K tiles of all the output tiles a workgroup walks form one sequence g = 0, 1, 2, ...;
-//    phase P1 / P2 of K tile g request the second halves of K tile g + 1 and P3 / P4 the first halves of g + 2 WHATEVER output tile
-//    those belong to, so a new output tile finds its first K tile landed and its second one in flight (gemm8p stops requesting two
-//    K tiles before the end of a tile, bursts 128 KB per CU after it and waits for them: ~6 K of ~35 K cycles per tile at K = 512).
-//    The per-lane source offsets are the same for every tile (the tile origin is part of the wave-uniform buffer descriptor, whose
-//    num_records also bounds rows >= M / columns >= N of edge tiles: they read zeros and are never stored), the requests are
-//    unconditional (behind the last tile the descriptor is empty), so every vmcnt is a compile-time constant;
-//  * staged epilogue (classes without operand loads: plain store, SwiGLU).  The first K tile of the NEXT output tile starts its
-//    accumulator chains from the constant 0, so the registers of quadrant q of the finished tile are free for its MFMAs as soon as
-//    that quadrant has been converted and its stores issued: phase Pq of that K tile carries "epilogue piece q" in its load section,
-//    beside the partner wave's MFMA section (the two wave rows of a SIMD run one barrier apart).  The stores drain behind the
-//    following MFMAs; the counted waits allow for them (vector memory retires in issue order);
-//  * classes whose epilogue loads operands (residual, accumulate, table, SwiGLU backward, RoPE) keep the register epilogue of
-//    gemm_epi_reg.hpp between two tiles; the second halves of the next tile's K tile 1 are requested in front of it (run-ahead), so
-//    the stores of its last row blocks have until the second K tile to drain.
-// Full tiles and edge tiles run in two passes (edge epilogues mask their stores; see gemm8p.hip).
+// gemm8p.hip (same tile, same LDS image, same four phases per K tile: read that header first) with ONE OPERAND STREAM PER
+// WORKGROUP.  The K tiles of all the output tiles a workgroup walks form one sequence g = 0, 1, 2, ...; phases P1 / P2 of K tile g
+// request the second halves of K tile g + 1 and P3 / P4 the first halves of g + 2 WHATEVER output tile those belong to, so a new
+// output tile finds its first K tile landed and its second one in flight.  (gemm8p stops requesting two K tiles before the end
+// of a tile, bursts 128 KB per CU after it and waits for them with the MFMA pipe idle: without any epilogue this kernel runs the
+// step's K = 512 shapes at 1.26 - 1.49 PFLOP/s, the rate of its K loop at K = 8192; profiles/r4_gemm8c_no_epilogue_timing_only.log.)
+//  * The per-lane source offsets are the same for every tile: the tile origin is part of the wave-uniform buffer descriptor, whose
+//    num_records also bounds rows >= M / columns >= N of edge tiles (they read zeros and are never stored).  The requests are
+//    unconditional -- behind the last tile the descriptor is empty -- so every vmcnt is a compile-time constant, and a window
+//    advances by a few scalar selects per K tile (the next output tile's window is computed once per tile, outside the K loop).
+//  * Between two output tiles the register epilogue of gemm_epi_reg.hpp runs as in gemm8p, one kernel per epilogue class
+//    (straight-line code, exact vmcnt counts).  The second halves of the next tile's K tile 1 are requested in front of it
+//    (run-ahead), so the stores of its last row blocks have until the second K tile to drain; the accumulator chains of a tile's
+//    first K tile start from the constant 0 (no zero fill).
+//  * What was tried on top and is NOT here (tools/micro/gemm8c_dev.hip at commit "gemm8c: persistent 256x256 GEMM with one
+//    operand stream ...", logs profiles/r4_gemm8c_*.log): the epilogue cut into four quadrant pieces carried by the load sections
+//    of the next tile's first K tile (the C = 0 start frees a quadrant's registers as soon as it is stored).  Bit-identical, and
+//    no faster for outputs that stay in the Infinity Cache, 14 - 27 % SLOWER for outputs that go to HBM (N = 2816, 4096): vector
+//    memory retires in issue order per wave, so a wave that waits for its LDS-DMA also waits for every older store, and stores to
+//    HBM need longer than the two K tiles of prefetch the LDS allows.  Starting the workgroups of an XCD staggered in time changed
+//    nothing either: the output stream is bound per CU (bytes in flight / store latency), not by the CUs storing together.
 #include <algorithm>
 
 #include "gemm.hpp"
@@ -29,7 +32,7 @@ namespace {
 
 constexpr int C8_BM = 256, C8_BN = 256, C8_BK = 64;
 #ifndef C8_DEBUG
-#define C8_DEBUG 0   // timing-only builds of tools/micro/gemm8c_dev.hip: 1 = no epilogue at all (accumulators kept alive), 2 = staged pieces without their stores
+#define C8_DEBUG 0   // 1: timing-only build of tools/micro/gemm8c_dev.hip without any epilogue (accumulators kept alive): what the K loop alone takes
 #endif
 
 typedef __attribute__((ext_vector_type(4))) int c8_i32x4;
@@ -52,22 +55,12 @@ struct C8Cur {
 // position in the workgroup's run of output tiles: index and (row, column) of the tile, kept incrementally (no division per tile)
 struct C8Tile { int t, tm, tn; };
 
-// vector-memory operations a staged epilogue issues in phase ph (0..3) of the next tile's first K tile
-template <int EC, bool CF32>
-constexpr int c8_piece_ops(int ph) {
-  if (EC == EPI_STORE) return CF32 ? 8 : 4;
-  if (EC == EPI_SWIGLU) return (ph == 1 || ph == 3) ? 8 : 4;
-  return 0;
-}
-#ifndef C8_NO_STAGED   // (tools/micro/gemm8c_dev.hip builds a second binary without the staged epilogue: what the stream alone buys)
-template <int EC, bool CF32> constexpr bool c8_staged() { return EC == EPI_STORE || EC == EPI_SWIGLU; }
-#else
-template <int EC, bool CF32> constexpr bool c8_staged() { return false; }
-#endif
 // lower bound on the stores a register epilogue issues after its last load (see gemm8p.hip `pend`)
 template <int EC, bool CF32>
 constexpr int c8_pend() {
-  if (EC == EPI_ACCUM || EC == EPI_RESIDUAL || EC == EPI_SWIGLU_BWD) return 8;
+  if (EC == EPI_STORE) return CF32 ? 32 : 16;   // (no loads: all stores)
+  if (EC == EPI_SWIGLU) return 24;
+  if (EC == EPI_ACCUM || EC == EPI_RESIDUAL || EC == EPI_SWIGLU_BWD) return 8;   // (the stores of the last two row blocks)
   if (EC == EPI_TABLE) return 12;
   if (EC == EPI_QKV_ROPE) return CF32 ? 8 : 4;
   return 0;
@@ -78,10 +71,9 @@ template <int N> __device__ __forceinline__ void c8_wait_vm() { asm volatile("s_
 template <int EC, bool CF32>
 __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
-  const int t = threadIdx.x, l = t & 63;
+  const int t = threadIdx.x, l0 = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const int fq = l >> 4, fr = l & 15;
   const int bid = blockIdx.x, nblk = gridDim.x;
 
   // ---- the workgroup's run of output tiles (XCD-aware, as gemm8p.hip)
@@ -101,17 +93,28 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
 
   // ---- per-lane DMA source offsets, the same for every tile: instruction j of wave w fills the 1 KB piece (w*2+j) of a
   // half-tile = local rows (w*2+j)*8 + [0,8); lane l -> local row + (l>>3), stored slot l&7 (swizzle on the source side)
+  // and the fragment read offsets: lane (fq, fr) takes chunk kk*4+fq of local row base+fr.  All of it is derived from a fresh,
+  // opaque copy of the lane id after every epilogue, so that none of these 14 registers is held through one.
   unsigned int aoff[2][2], boff[2][2];   // [j][h]
+  int fq, fr, a_rd0, a_rd1, b_rd0, b_rd1;
+  auto lane_setup = [&]() __attribute__((always_inline)) {
+    int l = l0; asm volatile("" : "+v"(l));
+    fq = l >> 4; fr = l & 15;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int lr = (w * 2 + j) * 8 + (l >> 3);
-    const int c = (l & 7) ^ ((lr >> 1) & 7);
+    for (int j = 0; j < 2; ++j) {
+      const int lr = (w * 2 + j) * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      aoff[j][h] = (unsigned int)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned int)(p.lda * 2) + (unsigned int)(c * 16);
-      boff[j][h] = (unsigned int)((lr >> 5) * 64 + h * 32 + (lr & 31)) * (unsigned int)(p.ldb * 2) + (unsigned int)(c * 16);
+      for (int h = 0; h < 2; ++h) {
+        aoff[j][h] = (unsigned int)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned int)(p.lda * 2) + (unsigned int)(c * 16);
+        boff[j][h] = (unsigned int)((lr >> 5) * 64 + h * 32 + (lr & 31)) * (unsigned int)(p.ldb * 2) + (unsigned int)(c * 16);
+      }
     }
-  }
+    const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
+    a_rd0 = (wr * 64 + fr) * 128 + sw0; a_rd1 = (wr * 64 + fr) * 128 + sw1;
+    b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0; b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
+  };
+  lane_setup();
   unsigned char* const dma_base = smem + w * 2048;   // + buf*65536 + X*32768 + h*16384 + j*1024
   auto rsrc_of = [&](const char* base, unsigned int rec) __attribute__((always_inline)) -> c8_i32x4 {
     const unsigned long long a = (unsigned long long)base;
@@ -137,11 +140,6 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // ---- fragment read offsets: lane (fq, fr) takes chunk kk*4+fq of local row base+fr
-  const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
-  const int a_rd0 = (wr * 64 + fr) * 128 + sw0, a_rd1 = (wr * 64 + fr) * 128 + sw1;
-  const int b_rd0 = 32768 + (wc * 32 + fr) * 128 + sw0, b_rd1 = 32768 + (wc * 32 + fr) * 128 + sw1;
-
   f32x4 acc[8][4];
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
   auto read_a = [&](int bo, int h) __attribute__((always_inline)) {
@@ -159,28 +157,9 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     }
   };
   // 16 MFMAs of quadrant (ih, jh); C0: the chains start from the constant 0 (first K tile of an output tile)
-#ifndef C8_SHADOW
-#define C8_SHADOW 1   // bf16 plain-store class: convert quadrant q + 1 of the finished tile between the MFMAs of phase q (0: in the load section)
-#endif
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  u32x4 pkq[4];   // bf16 plain-store class: one converted quadrant (a 16-byte store per row block), made a phase before it is stored
-  auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t v; v[0] = (bf16)a; v[1] = (bf16)b;
-    return __builtin_bit_cast(unsigned int, v);
-  };
-  // row block ii of quadrant (ih, jh) of the FINISHED tile -> pkq[ii]: the lane's 8 consecutive bf16 columns after the pair swap
-  auto convert_rb = [&](auto IH, auto JH, auto II) __attribute__((always_inline)) {
-    constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value, ii = decltype(II)::value, i = ih * 4 + ii;
-    const f32x4 x = acc[i][jh * 2], y = acc[i][jh * 2 + 1];
-    auto r0 = __builtin_amdgcn_permlane16_swap(pk2(x[0], x[1]), pk2(y[0], y[1]), false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(pk2(x[2], x[3]), pk2(y[2], y[3]), false, false);
-    pkq[ii] = u32x4{r0[0], r1[0], r0[1], r1[1]};
-  };
-  auto mma_q = [&](auto IH, auto JH, auto C0, const bf16x8(&bf)[2][2], auto CIH, auto CJH) __attribute__((always_inline)) {
+  auto mma_q = [&](auto IH, auto JH, auto C0, const bf16x8(&bf)[2][2]) __attribute__((always_inline)) {
     constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
     constexpr bool c0 = decltype(C0)::value;
-    constexpr int cih = decltype(CIH)::value;   // >= 0: convert row block i of quadrant (cih, cjh) of the finished tile behind the MFMAs of row block i
     __builtin_amdgcn_s_setprio(1);
     static_for<4>([&](auto i) {
       static_for<2>([&](auto j) {
@@ -190,131 +169,55 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
           acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
         acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
       });
-      if constexpr (cih >= 0) convert_rb(CIH, CJH, i);
     });
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- staged epilogue pieces (full tiles only): quadrant (ih, jh) of the finished tile whose wave block starts at (wm0, wn0).
-  // Layout as gemm_epi_reg.hpp: acc[i][j][r] = C[wm0 + 16 i + fr][wn0 + 16 j + 4 fq + r].
-  unsigned int hold[8];   // SwiGLU: packed g of the quadrant that comes first of a block pair (2 dwords per row block)
-  auto st_pair_pk = [&](void* base, unsigned int off, unsigned int x0, unsigned int x1, unsigned int y0, unsigned int y1) __attribute__((always_inline)) {
-    auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-    if constexpr (C8_DEBUG == 2) asm volatile("" ::"v"(v), "v"(off));
-    else *(u32x4*)((char*)base + off) = v;
-  };
-  auto keep_acc = [&]() __attribute__((always_inline)) {
+  auto keep_acc = [&]() __attribute__((always_inline)) {   // (timing-only build: the MFMAs must not become dead code)
     static_for<8>([&](auto i) { static_for<4>([&](auto j) { const f32x4 v = acc[i][j]; asm volatile("" ::"v"(v)); }); });
   };
-  auto piece = [&](auto IH, auto JH, int wm0, int wn0) __attribute__((always_inline)) {
-    constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
-    if constexpr (C8_DEBUG == 1) { static_for<4>([&](auto ii) { static_for<2>([&](auto jj) { const f32x4 v = acc[ih * 4 + ii][jh * 2 + jj]; asm volatile("" ::"v"(v)); }); }); return; }
-    const int lrow = wm0 + fr;
-    const int c8 = wn0 + ((fq & 1) << 4) + ((fq >> 1) << 3) + jh * 32;   // first of the lane's 8 columns after the pair swap
-    if constexpr (EC == EPI_STORE) {
-      if constexpr (CF32) {
-        const int c4 = wn0 + 4 * fq + jh * 32;
-        static_for<4>([&](auto ii) {
-          constexpr int i = ih * 4 + decltype(ii)::value;
-          const unsigned int ro = (unsigned int)(lrow + 16 * i) * (unsigned int)(p.ldc * 4);
-          static_for<2>([&](auto jj) {
-            constexpr int j = jh * 2 + decltype(jj)::value;
-            const f32x4 v = acc[i][j];   // (launcher: alpha == 1)
-            *(f32x4*)((char*)p.C + ro + (unsigned int)(c4 + 16 * decltype(jj)::value) * 4u) = v;
-          });
-        });
-      } else if constexpr (C8_SHADOW) {
-        // (launcher: alpha == 1) the quadrant was converted between the MFMAs of the phase before (the first one right here)
-        if constexpr (ih == 0 && jh == 0) static_for<4>([&](auto ii) { convert_rb(IH, JH, ii); });
-        static_for<4>([&](auto ii) {
-          constexpr int i = ih * 4 + decltype(ii)::value;
-          const unsigned int ro = (unsigned int)(lrow + 16 * i) * (unsigned int)(p.ldc * 2);
-          if constexpr (C8_DEBUG == 2) asm volatile("" ::"v"(pkq[decltype(ii)::value]), "v"(ro));
-          else *(u32x4*)((char*)p.C + ro + (unsigned int)c8 * 2u) = pkq[decltype(ii)::value];
-        });
-      } else {
-        static_for<4>([&](auto ii) {
-          constexpr int i = ih * 4 + decltype(ii)::value;
-          const unsigned int ro = (unsigned int)(lrow + 16 * i) * (unsigned int)(p.ldc * 2);
-          const f32x4 x = acc[i][jh * 2], y = acc[i][jh * 2 + 1];
-          st_pair_pk(p.C, ro + (unsigned int)c8 * 2u, pk2(x[0], x[1]), pk2(x[2], x[3]), pk2(y[0], y[1]), pk2(y[2], y[3]));
-        });
-      }
-    } else if constexpr (EC == EPI_SWIGLU) {
-      // blocks (2 jh, 2 jh + 1) are a [16 a | 16 b] group: C gets [a|b] as is; g = silu(a) * b of block pairs (0,1) and (2,3)
-      // share a 16-byte store of C2, so the quadrant that comes first in phase order (jh 0 for ih 0, jh 1 for ih 1) holds its g
-      constexpr bool first = (ih == 0) ? (jh == 0) : (jh == 1);
-      const int gc = (wn0 >> 1) + ((fq & 1) << 4) + ((fq >> 1) << 3);
-      static_for<4>([&](auto ii) {
-        constexpr int k = decltype(ii)::value, i = ih * 4 + k;
-        const unsigned int ro = (unsigned int)(lrow + 16 * i) * (unsigned int)(p.ldc * 2);
-        const f32x4 a = acc[i][jh * 2], b = acc[i][jh * 2 + 1];
-        float g[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g[r] = a[r] * __builtin_amdgcn_rcpf(1.f + __expf(-a[r])) * b[r];
-        st_pair_pk(p.C, ro + (unsigned int)c8 * 2u, pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(b[0], b[1]), pk2(b[2], b[3]));
-        const unsigned int g0 = pk2(g[0], g[1]), g1 = pk2(g[2], g[3]);
-        if constexpr (first) { hold[2 * k] = g0; hold[2 * k + 1] = g1; }
-        else {
-          const unsigned int ro2 = (unsigned int)(lrow + 16 * i) * (unsigned int)(p.ldc2 * 2);
-          if constexpr (jh == 1) st_pair_pk(p.C2, ro2 + (unsigned int)gc * 2u, hold[2 * k], hold[2 * k + 1], g0, g1);   // x = blocks (0,1), y = (2,3)
-          else st_pair_pk(p.C2, ro2 + (unsigned int)gc * 2u, g0, g1, hold[2 * k], hold[2 * k + 1]);
-        }
-      });
-    }
-  };
 
-  // ---- one K tile.  n = window of K tile g + 1, s = of g + 2 (advanced by the caller).  Waits: P2 leaves the four half-tiles
-  // requested after A1(g) in flight (+ X2 operations of epilogue pieces / a register epilogue issued after it), P4 the three
-  // requested after B1(g+1) (+ X4).  PIECES: epilogue piece q of the previous tile (wave block at pm0, pn0) in phase q.
-  // DMA12 = false: B1 / A1 of g + 1 were requested ahead of a register epilogue.
+  // ---- one K tile.  cn = window of K tile g + 1, cs = of g + 2 (advanced by the caller).  Waits: P2 leaves the four half-tiles
+  // requested after A1(g) in flight, P4 the three requested after B1(g+1); X2 / X4 more where the stores of a register epilogue
+  // were issued after the guarded half-tile (they retire behind it).  C0: first K tile of an output tile.  DMA12 = false: B1 / A1
+  // of g + 1 were requested ahead of a register epilogue.
   C8Cur cn, cs;
   int bo = 0;
-  auto body = [&](auto C0, auto PIECES, auto DMA12, auto X2, auto X4, int pm0, int pn0) __attribute__((always_inline)) {
-    constexpr bool pieces = decltype(PIECES)::value, dma12 = decltype(DMA12)::value;
+  auto body = [&](auto C0, auto DMA12, auto X2, auto X4) __attribute__((always_inline)) {
+    constexpr bool dma12 = decltype(DMA12)::value;
     constexpr int x2 = decltype(X2)::value, x4 = decltype(X4)::value;
-    constexpr bool shadow = pieces && C8_SHADOW && EC == EPI_STORE && !CF32;
-    using CV1 = std::integral_constant<int, shadow ? 0 : -1>;   // row half of the quadrant converted in P1 (-1: none)
-    using CV2 = std::integral_constant<int, shadow ? 1 : -1>;   // ... in P2 and P3
     const int bn = bo ^ 65536;
     // P1
     read_b(bf0, bo, 0);
     read_a(bo, 0);
     if constexpr (dma12) stage_b(cn, I1{}, bn);
-    if constexpr (pieces) { piece(I0{}, I0{}, pm0, pn0); __builtin_amdgcn_sched_barrier(0); }
     C8_BARRIER();
-    mma_q(I0{}, I0{}, C0, bf0, CV1{}, I1{});   // (converts quadrant (0, 1) when staged)
+    mma_q(I0{}, I0{}, C0, bf0);
     C8_BARRIER();
     // P2
     read_b(bf1, bo, 1);
     if constexpr (dma12) stage_a(cn, I1{}, bn);
-    if constexpr (pieces) { piece(I0{}, I1{}, pm0, pn0); __builtin_amdgcn_sched_barrier(0); }
     c8_wait_vm<8 + x2>();
     C8_BARRIER();
-    mma_q(I0{}, I1{}, C0, bf1, CV2{}, I1{});   // (1, 1)
+    mma_q(I0{}, I1{}, C0, bf1);
     C8_BARRIER();
     // P3
     read_a(bo, 1);
     stage_b(cs, I0{}, bo);
-    if constexpr (pieces) { piece(I1{}, I1{}, pm0, pn0); __builtin_amdgcn_sched_barrier(0); }
     C8_BARRIER();
-    mma_q(I1{}, I1{}, C0, bf1, CV2{}, I0{});   // (1, 0)
+    mma_q(I1{}, I1{}, C0, bf1);
     C8_BARRIER();
     // P4
     stage_a(cs, I0{}, bo);
-    if constexpr (pieces) { piece(I1{}, I0{}, pm0, pn0); __builtin_amdgcn_sched_barrier(0); }
     c8_wait_vm<6 + x4>();
     C8_BARRIER();
-    mma_q(I1{}, I0{}, C0, bf0, std::integral_constant<int, -1>{}, I0{});
+    mma_q(I1{}, I0{}, C0, bf0);
     C8_BARRIER();
     bo = bn;
   };
   using T_ = std::true_type; using F_ = std::false_type;
   auto run_pass = [&](auto FULLC) __attribute__((always_inline)) {
     constexpr bool WANT = decltype(FULLC)::value;
-    constexpr bool STAGED = WANT && c8_staged<EC, CF32>();
     constexpr int PEND = WANT ? c8_pend<EC, CF32>() : 0;
     auto tile_full = [&](const C8Tile& x) __attribute__((always_inline)) -> bool {
       return x.tm * C8_BM + C8_BM <= p.M && x.tn * C8_BN + C8_BN <= p.N;
@@ -369,29 +272,25 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     if (wr == 1) C8_BARRIER();   // the second wave row runs one barrier behind the first
     auto step = [&]() __attribute__((always_inline)) { cn = cs; advance(cs); };
     using Z = std::integral_constant<int, 0>;
-    body(T_{}, F_{}, T_{}, Z{}, Z{}, 0, 0); step();
+    using PD = std::integral_constant<int, PEND>;
+    body(T_{}, T_{}, Z{}, Z{}); step();
 #pragma unroll 1
-    for (int kt = 1; kt < nt; ++kt) { body(F_{}, F_{}, T_{}, Z{}, Z{}, 0, 0); step(); }
+    for (int kt = 1; kt < nt; ++kt) { body(F_{}, T_{}, Z{}, Z{}); step(); }
     C8Tile tnext = next_tile(tile);
 #pragma unroll 1
     while (tnext.t < tile_end) {
       const int em0 = tile.tm * C8_BM, en0 = tile.tn * C8_BN;
       refresh_nx();
-      if constexpr (STAGED) {
-        constexpr int s1 = c8_piece_ops<EC, CF32>(0), s2 = c8_piece_ops<EC, CF32>(1), s3 = c8_piece_ops<EC, CF32>(2), s4 = c8_piece_ops<EC, CF32>(3);
-        body(T_{}, T_{}, T_{}, std::integral_constant<int, s1 + s2>{}, std::integral_constant<int, s1 + s2 + s3 + s4>{}, em0 + wr * 128, en0 + wc * 64); step();
-        body(F_{}, F_{}, T_{}, std::integral_constant<int, s2 + s3 + s4>{}, Z{}, 0, 0); step();
-      } else {
-        // run-ahead: second halves of the next K tile but one (their LDS slots were last read a phase ago), then the register epilogue
-        stage_b(cn, I1{}, bo ^ 65536); stage_a(cn, I1{}, bo ^ 65536);
-        if constexpr (C8_DEBUG == 1) keep_acc(); else
-        epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
-        if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): edge epilogues leave masked loads "pending" for hipcc
-        body(T_{}, F_{}, F_{}, std::integral_constant<int, PEND>{}, std::integral_constant<int, PEND>{}, 0, 0); step();
-        body(F_{}, F_{}, T_{}, std::integral_constant<int, PEND>{}, Z{}, 0, 0); step();
-      }
+      // run-ahead: second halves of the next K tile but one (their LDS slots were last read a phase ago), then the register epilogue
+      stage_b(cn, I1{}, bo ^ 65536); stage_a(cn, I1{}, bo ^ 65536);
+      if constexpr (C8_DEBUG == 1) keep_acc(); else
+      epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+      if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): edge epilogues leave masked loads "pending" for hipcc
+      lane_setup();
+      body(T_{}, F_{}, PD{}, PD{}); step();
+      body(F_{}, T_{}, PD{}, Z{}); step();
 #pragma unroll 1
-      for (int kt = 2; kt < nt; ++kt) { body(F_{}, F_{}, T_{}, Z{}, Z{}, 0, 0); step(); }
+      for (int kt = 2; kt < nt; ++kt) { body(F_{}, T_{}, Z{}, Z{}); step(); }
       tile = tnext;
       tnext = next_tile(tile);
     }
@@ -403,11 +302,6 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
   };
-  {   // timing experiment (tools/micro/gemm8c_dev.hip): workgroup j of an XCD starts (j % groups) * naps sleeps late, so that the
-      // workgroups' epilogues (the HBM-bound part of a tile) do not all fall into the same microseconds
-    const int groups = (p.flags >> 8) & 0xFF, naps = (p.flags >> 16) & 0xFF;
-    if (groups > 1) { const int d = ((bid >> 3) % groups) * naps; for (int k = 0; k < d; ++k) __builtin_amdgcn_s_sleep(32); }
-  }
   run_pass(std::true_type{});
   run_pass(std::false_type{});
 }

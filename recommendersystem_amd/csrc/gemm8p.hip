@@ -805,13 +805,18 @@ int launch_gemm8p_f8_splitk(const GemmParams& p0, hipStream_t s) {
   return gemm_slab_end(p, s);
 }
 
+// the one-stream form of this pipeline (gemm8c.hip) takes the epilogue classes it has kernels for; RSYS_GEMM8C=0: A/B switch
+bool gemm8p_forwards_to_8c(const GemmParams& p) {
+  static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
+  static const int use_8c = getenv("RSYS_GEMM8C") ? atoi(getenv("RSYS_GEMM8C")) : 1;
+  return use_8c && dbg == 0 && p.epi != 99 && gemm8c_eligible(p);
+}
+
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
   p.flags |= dbg;
-  // the overlapped form of this pipeline (gemm8c.hip) for the epilogue classes it has kernels for; RSYS_GEMM8C=0: A/B
-  static const int use_8c = getenv("RSYS_GEMM8C") ? atoi(getenv("RSYS_GEMM8C")) : 1;
-  if (use_8c && dbg == 0 && p.epi != 99 && gemm8c_eligible(p)) return launch_gemm8c(p, s);
+  if (gemm8p_forwards_to_8c(p0)) return launch_gemm8c(p0, s);
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
   hipLaunchKernelGGL(gemm8p_kernel<false>, dim3((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cu_count())), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());

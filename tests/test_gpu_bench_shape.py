@@ -28,7 +28,17 @@ def _perturb_scales(model, seed):
             model.set_parameter(n, (1.0 if n.endswith(".scale") else 0.0) + 0.1 * rng.standard_normal(shape).astype(np.float32))
 
 
-def test_bench_shape_step_vs_cpp_oracle():
+def _scale_trunk_to_order_one(model):
+    """init weights are N(0, 0.006) (model.py:5-12); bring every trunk / head matrix to N(0, 1 / fan_in) -- attention logits and
+    MLP pre-activations of order one, so that no gradient is a cancellation residue of the rounding noise"""
+    for n, shape, tr in model.named_parameters():
+        if tr and len(shape) == 2 and (n.startswith("transformers.") or n.startswith("rating_head.") or n.startswith("action_embedding.linear")):
+            model.set_parameter(n, model.get_parameter(n) * np.float32(1.0 / (0.006 * np.sqrt(shape[-1]))))
+
+
+def _cfg3_step(weights, with_exact):
+    """the step bench.py times (cfg-3, 64 rows, bf16) on the HIP path and on the oracle's C++ step with the same storage roundings
+    (and, with_exact, on the unrounded C++ step: how far bf16 arithmetic itself is from fp32 on each tensor)"""
     import recommendersystem_amd as ra
     from oracle import cpu_step, model_np, synth, train_np
     cfg = synth.make_config("cfg3")
@@ -40,6 +50,8 @@ def test_bench_shape_step_vs_cpp_oracle():
     model.init_weights(0x1217)
     model.random_pretrained_embeddings(0x3E7A)
     _perturb_scales(model, 3)
+    if weights == "order_one":
+        _scale_trunk_to_order_one(model)
     P = {k: v for k, v in model.state_dict(include_frozen=True).items() if not k.startswith("watch_head.")}
     names = synth.trainable_names(cfg)
     model.set_loss_weights(tw, 1)
@@ -51,47 +63,114 @@ def test_bench_shape_step_vs_cpp_oracle():
     model.close()
 
     dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
-    norm_gpu = float(np.sqrt(sum(float((G[n].astype(np.float64) ** 2).sum()) for n in names)))
-    # the exact (unrounded) step first: how far bf16 arithmetic itself is from fp32 on each tensor
-    ex = cpu_step.CpuStep(cfg, P, lr=lr)
-    _, ex_G = ex.forward_backward(dm, tw)
-    ex_G = {n: ex_G[n].copy() for n in names}
-    del ex
+    ex_G = None
+    if with_exact:
+        ex = cpu_step.CpuStep(cfg, P, lr=lr)
+        _, ex_G = ex.forward_backward(dm, tw)
+        ex_G = {n: ex_G[n].copy() for n in names}
+        del ex
     cs = cpu_step.CpuStep(cfg, P, lr=lr, operand_round="bf16")
     ref_losses, ref_G = cs.forward_backward(dm, tw)
     ref_G = {n: ref_G[n].copy() for n in names}
     ref_norm = cs.clip_adamw()
+    ref_P = {n: cs.P[n].copy() for n in names}
+    del cs
     cpu_step.release()
+    return dict(cfg=cfg, names=names, lr=lr, losses=losses, G=G, Pn=Pn, ex_G=ex_G, ref_losses=ref_losses, ref_G=ref_G, ref_norm=ref_norm, ref_P=ref_P)
 
-    e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(losses, ref_losses)]
-    mx = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-    l2 = lambda a, b: float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-60)))
-    table = sorted(((mx(G[n], ref_G[n]), l2(G[n], ref_G[n]), mx(G[n], ex_G[n]), mx(ref_G[n], ex_G[n]), n) for n in names), reverse=True)
-    print("bench-shape parity: losses", losses, "oracle", ref_losses, "rel", e_l)
-    print("  grad norm", norm_gpu, "oracle", ref_norm)
-    print("  worst gradients: max|hip - oracle_bf16| / max, rel L2, max|hip - exact| / max, max|oracle_bf16 - exact| / max")
-    for r in table[:6]:
-        print("    %.3e %.3e %.3e %.3e %s" % r)
-    assert max(e_l) <= 5e-3, (losses, ref_losses)
-    assert abs(norm_gpu - ref_norm) <= 1e-2 * ref_norm, (norm_gpu, ref_norm)
-    # every named gradient within the bf16-rounded-oracle bound (5e-2 of the tensor's max).  The q / k projections of the upper
-    # layers are the exception the bound was not made for: rows of dS sum to zero, so the keys' common component cancels in the
-    # signal but not in the rounding noise of the bf16 dS operand, and two bf16 evaluations of the same formula (this path, the
-    # rounded oracle) land as far from each other as each is from the exact step.  There the HIP gradient must be as close to
-    # the EXACT fp32 gradient as the rounded restatement is (within a factor 2: measured 1.1 - 1.6 over runs whose summation orders
-    # differ), and within 1e-1 of the rounded one.
-    for e_r, e_l2, e_x, e_rx, n in table:
-        assert e_r <= 5e-2 or (e_r <= 1e-1 and e_x <= 2.0 * e_rx and ("q_proj" in n or "k_proj" in n)), (n, e_r, e_l2, e_x, e_rx)
+
+_mx = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+_l2 = lambda a, b: float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-60)))
+
+
+@pytest.fixture(scope="module")
+def init_scale_step():
+    return _cfg3_step("init", with_exact=True)
+
+
+def _check_losses_norm_and_update(r):
+    names, lr = r["names"], r["lr"]
+    e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(r["losses"], r["ref_losses"])]
+    norm_gpu = float(np.sqrt(sum(float((r["G"][n].astype(np.float64) ** 2).sum()) for n in names)))
+    print("bench-shape parity: losses", r["losses"], "oracle", r["ref_losses"], "rel", e_l)
+    print("  grad norm", norm_gpu, "oracle", r["ref_norm"])
+    assert max(e_l) <= 5e-3, (r["losses"], r["ref_losses"])
+    assert abs(norm_gpu - r["ref_norm"]) <= 1e-2 * r["ref_norm"], (norm_gpu, r["ref_norm"])
     # one fused clip + AdamW step.  The first Adam step moves every element by lr * g / (|g| + eps) ~ +-lr: elements whose two
     # gradients disagree in sign (|g| within the bf16 noise of zero) differ by 2 lr, all the others by ~lr * eps / |g|
     flips, total, worst = 0, 0, 0.0
     for n in names:
-        diff = np.abs(Pn[n] - cs.P[n])
+        diff = np.abs(r["Pn"][n] - r["ref_P"][n])
         worst = max(worst, float(diff.max()))
         flips += int((diff > 0.5 * lr).sum()); total += diff.size
     print(f"  parameters after clip + AdamW: max |diff| {worst:.3e} (lr {lr}), {flips} of {total} elements moved the other way")
     assert worst <= 2.0 * lr * 1.02 + 1e-7, worst
     assert flips <= 0.02 * total, (flips, total)
+
+
+def test_bench_shape_step_vs_cpp_oracle(init_scale_step):
+    r = init_scale_step
+    names, G, ref_G, ex_G = r["names"], r["G"], r["ref_G"], r["ex_G"]
+    table = sorted(((_mx(G[n], ref_G[n]), _l2(G[n], ref_G[n]), _mx(G[n], ex_G[n]), _mx(ref_G[n], ex_G[n]), n) for n in names), reverse=True)
+    print("  worst gradients: max|hip - oracle_bf16| / max, rel L2, max|hip - exact| / max, max|oracle_bf16 - exact| / max")
+    for row in table[:6]:
+        print("    %.3e %.3e %.3e %.3e %s" % row)
+    _check_losses_norm_and_update(r)
+    # every named gradient within the bf16-rounded-oracle bound (5e-2 of the tensor's max).  The q / k projections of the upper
+    # layers are the exception the bound was not made for AT INITIALISATION-SCALE WEIGHTS: rows of dS sum to zero, so the keys'
+    # common component cancels in the signal but not in the rounding noise of the bf16 dS operand, and two bf16 evaluations of the
+    # same formula (this path, the rounded oracle) land as far from each other as each is from the exact step.  There the HIP
+    # gradient must be as close to the EXACT fp32 gradient as the rounded restatement is (within a factor 2: measured 1.1 - 1.6 over
+    # runs whose summation orders differ), and within 1e-1 of the rounded one.  The independent checks of exactly those tensors
+    # are the two tests below: order-one weights (no cancellation: the unrelaxed bound for every tensor) and the two token orders
+    # of the last layer's attention against each other.
+    for e_r, e_l2, e_x, e_rx, n in table:
+        assert e_r <= 5e-2 or (e_r <= 1e-1 and e_x <= 2.0 * e_rx and ("q_proj" in n or "k_proj" in n)), (n, e_r, e_l2, e_x, e_rx)
+
+
+def test_bench_shape_step_with_order_one_weights_vs_cpp_oracle():
+    """the same step with trunk / head matrices of order 1 / sqrt(fan_in): the attention logits are of
+    order one, the q / k gradients are signal, and EVERY named gradient -- all q / k projections included -- must meet the
+    unrelaxed bound against the C++ oracle with the same storage roundings."""
+    r = _cfg3_step("order_one", with_exact=False)
+    table = sorted(((_mx(r["G"][n], r["ref_G"][n]), _l2(r["G"][n], r["ref_G"][n]), n) for n in r["names"]), reverse=True)
+    print("  order-one weights, worst gradients: max|hip - oracle_bf16| / max, rel L2")
+    for row in table[:8]:
+        print("    %.3e %.3e %s" % row)
+    qk = [row for row in table if "q_proj" in row[2] or "k_proj" in row[2]]
+    print("  worst q / k projection:", "%.3e %.3e %s" % qk[0])
+    _check_losses_norm_and_update(r)
+    for e_r, e_l2, n in table:
+        assert e_r <= 5e-2, (n, e_r, e_l2)
+
+
+def test_last_layer_token_orders_agree_on_qk_gradients(init_scale_step, tmp_path):
+    """the last layer's attention in selected-first token order (default) and in plain token order
+    (RSYS_TOP_ORDER=0, its own process: the switch is read once) are two summation orders of the same arithmetic.  Their q / k
+    gradients of layer 7 -- the tensors the exemption above is about -- must lie within the rounded oracle's own distance from the
+    exact gradient of each other (bound: 1.5 x), and every other tensor of that layer within 3e-2."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "token_order.npz")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "_bench_shape_worker.py"), out, root], check=True,
+                   env=dict(os.environ, RSYS_TOP_ORDER="0"), cwd=root, timeout=600)
+    z = np.load(out)
+    r = init_scale_step
+    assert np.allclose(z["losses"], r["losses"], rtol=2e-3), (z["losses"], r["losses"])
+    L = r["cfg"]["num_layers"] - 1
+    for k in z.files:
+        if not k.startswith("g/"):
+            continue
+        n = k[2:]
+        e01 = _mx(z[k], r["G"][n])
+        noise = _mx(r["ref_G"][n], r["ex_G"][n])
+        print(f"  {n}: token order vs selected-first {e01:.3e}, rounded oracle vs exact {noise:.3e}")
+        if f"layers.{L}.attn.q_proj" in n or f"layers.{L}.attn.k_proj" in n:
+            assert e01 <= 1.5 * noise + 1e-3, (n, e01, noise)
+        else:
+            assert e01 <= 3e-2, (n, e01)
 
 
 def test_cfg4_own_size_sharded_step_equals_replicated():
@@ -160,6 +239,7 @@ def test_cfg4_own_size_sharded_step_equals_replicated():
         for n in names:
             g_ref, p_ref = (G_ref[n][lo:hi], P_ref[n][lo:hi]) if n == E_NAME else (G_ref[n], P_ref[n])
             e = float(np.abs(G[n] - g_ref).max() / max(np.abs(G_ref[n]).max(), 1e-30))
+            worst_p = max(worst_p, float(np.abs(Pn[n] - p_ref).max()))   # (every parameter, q / k projections included: 2 lr bound)
             if "q_proj" in n or "k_proj" in n:
                 # (the replicated model runs its last layer on the compact, selected-first token order, the sharded ranks in token
                 # order: two summation orders of a gradient whose bf16 noise is ~5e-2 of its maximum at initialisation -- see (a))
@@ -167,7 +247,6 @@ def test_cfg4_own_size_sharded_step_equals_replicated():
                 continue
             if e > worst_g[1]:
                 worst_g = (n, e)
-            worst_p = max(worst_p, float(np.abs(Pn[n] - p_ref).max()))
     print(f"cfg-4 own size, world {world}: losses {worst_l:.2e}, worst gradient {worst_g}, q / k projections {worst_qk:.2e}, parameters max |diff| {worst_p:.2e} (lr {lr})")
     assert worst_l <= 2e-3, worst_l                  # measured by tools/rehearse_sharded.py: 3e-5
     assert worst_g[1] <= 5e-2, worst_g

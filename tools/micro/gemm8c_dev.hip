@@ -1,8 +1,13 @@
 // Development harness of gemm8c.hip: every epilogue class on the training step's shapes, checked bit for bit against gemm8p.hip
 // (same MFMA order, same epilogue arithmetic) and timed against it, interleaved in one process.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude tools/micro/gemm8c_dev.hip -o gpurun_out/gemm8c_dev && gpurun_out/gemm8c_dev [reps]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude tools/micro/gemm8c_dev.hip -o tools/micro/bin/gemm8c_dev && tools/micro/bin/gemm8c_dev [reps]
+// -DC8_DEBUG=1: timing-only build without any epilogue (the outputs then differ, of course): what the K loops alone take.
 #include "../../recommendersystem_amd/csrc/gemm8p.hip"
 #include "../../recommendersystem_amd/csrc/gemm8c.hip"
+#ifdef DEV_WITH_4W
+#define RSYS_4W_STAGGER 1
+#include "../../recommendersystem_amd/csrc/gemm4w.hip"
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -55,7 +60,6 @@ static void run(const char* name, int M, int N, int K, int epi, int c_f32, int r
   auto prep = [&](int which) {
     GemmParams q = p;
     q.C = b.C[which];
-    if (which && getenv("C8_STAGGER")) { int g = 0, n = 0; sscanf(getenv("C8_STAGGER"), "%d,%d", &g, &n); q.flags |= (g << 8) | (n << 16); }
     if (epi == EPI_SWIGLU || epi == EPI_TABLE) q.C2 = b.C2[which];
     if (epi == EPI_SWIGLU_BWD) q.C2 = b.E;   // saved [a|b] (bf16 [M][2N], filled below)
     return q;
@@ -97,6 +101,22 @@ static void run(const char* name, int M, int N, int K, int epi, int c_f32, int r
       float t = 0; hipEventElapsedTime(&t, e0, e1);
       if (round < 2 || t < ms[which]) ms[which] = t;   // (rounds 0 and 1 are warm-up: min of the last four)
     }
+#ifdef DEV_WITH_4W
+  if (gemm4w_eligible(prep(1))) {
+    for (int naps : {0, 2, 4, 6, 9, 12}) {
+      GemmParams q = prep(1); q.flags |= naps << 16;
+      float best = 1e30f;
+      for (int round = 0; round < 3; ++round) {
+        launch_gemm4w(q, nullptr);
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < reps; ++i) launch_gemm4w(q, nullptr);
+        hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
+        float t = 0; hipEventElapsedTime(&t, e0, e1); best = std::min(best, t);
+      }
+      printf("   4w naps %2d: %8.1f us\n", naps, best * 1000 / reps);
+    }
+  }
+#endif
   const double rowsd = m_dev_rows >= 0 ? std::min(M, (m_dev_rows + 255) / 256 * 256) : M;
   const double fl = 2.0 * rowsd * N * K;
   printf("%-12s M=%6d N=%6d K=%5d : 8p %8.1f us %7.1f TF/s | 8c %8.1f us %7.1f TF/s | x%.3f\n", name, M, N, K, ms[0] * 1000 / reps, fl / (ms[0] / reps) * 1e-9,
