@@ -91,6 +91,45 @@ def flops_per_interaction(cfg, B, attention_density=1.0):
             + 6 * (D * D + D) * 2 * K / S)
 
 
+def extra_leg(ra, synth, cfg_name, dtype, rows, warmup, steps):
+    """ms per step and interactions/s of one more configuration: resident batch, no per-kernel events, one GPU"""
+    from recommendersystem_amd.train import WSDScheduler, LambdaLR
+    cfg = synth.make_config(cfg_name)
+    S = cfg["max_sequence_length"]
+    model = ra.RecommenderModel(cfg, device=0, dtype=dtype, max_rows=rows)
+    try:
+        model.init_weights(0x1217)
+        model.random_pretrained_embeddings(0x3E7A)
+        opt = ra.create_optimizer(model, cfg)
+        sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
+        for _ in range(2000):
+            sched.step()
+        model.set_loss_weights(ra.make_task_weights(), 1)
+        model.mask_seed = 0x3A5C
+        model.upload(synth.make_batch(cfg, rows, 0xD47A, mu=4.6, sigma=1.0))
+
+        def step():
+            model.forward_resident(False)
+            opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=1.0)
+            sched.step()
+        for _ in range(warmup):
+            step()
+        ra.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ra.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        losses = model.losses(False)
+        assert all(np.isfinite(losses)), losses
+        fpi = flops_per_interaction(cfg, rows)
+        return {"ms_per_step": round(ms, 3), "interactions_per_sec": round(rows * S / (ms * 1e-3), 1), "steps": steps, "warmup": warmup, "dtype": dtype,
+                "rows_per_gpu": rows, "workload": f"{cfg_name}: D={cfg['embed_dim']} L={cfg['num_layers']} S={S} K={cfg['mask_topk']}",
+                "step_mfma_frac": round(rows * S / (ms * 1e-3) * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+    finally:
+        model.close()
+
+
 def git_blob_id(path):
     """the id `git hash-object` gives the file (the GPU box has no .git): which committed PMC summary a line quotes"""
     import hashlib
@@ -218,6 +257,8 @@ def main():
                     help="row-sharded table only: classes sampled per rank and medium for the watch heads (0 = full soft-max)")
     ap.add_argument("--deterministic", action="store_true", help="bitwise reproducible steps (rsys_model_set_deterministic): what the fixed summation order costs")
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short legs at other configurations (cfg-2, the reference's production shape in bf16 and fp8) that the default line carries in `other_configs`")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
     args = ap.parse_args()
@@ -489,10 +530,27 @@ def main():
                 print(f"  {k:22s} {v['ms'] / n_instr:8.3f} ms/step  {v['count'] // n_instr:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, 1, args.cpu_rows)
+        # the numbers README / DESIGN quote for other configurations, under the same clock as `value`: short
+        # resident-batch legs after the cfg-3 measurement; `value`, `config` and everything above describe cfg-3 in bf16 only
+        default_run = (world == 1 and args.config == "cfg3" and args.dtype == "bf16" and rows == 64 and args.layers is None and not sharded
+                       and not args.deterministic and not args.detail and not args.no_kernel_timing)
+        if default_run and not args.no_extra_legs:
+            model.close(); model = None
+            legs = {}
+            for key, cname, dt, warm, k in (("cfg2_bf16", "cfg2", "bf16", 5, 20), ("prod_bf16", "prod", "bf16", 2, 5), ("prod_fp8", "prod", "fp8", 3, 10)):
+                try:
+                    legs[key] = extra_leg(ra, synth, cname, dt, 64, warm, k)
+                except Exception as e:   # noqa: BLE001  (a failing leg must not lose the headline line)
+                    legs[key] = {"error": str(e)[:200]}
+            legs["note"] = ("train step (fwd + bwd + fused clip/AdamW) on one resident synthetic batch of 64 rows per configuration, un-instrumented; "
+                            "prod = the reference's production shape (D=2048 L=8 S=1024 I=5632 K=128, transformer.py:535-560, 200 K items); "
+                            "fp8 = the opt-in torchao-style tensorwise trunk (parity unpinned for torchao's scale formula; the compact top is off in that mode)")
+            out["other_configs"] = legs
         print(json.dumps(out), file=json_out, flush=True)
     if comm is not None:
         comm.close()
-    model.close()
+    if model is not None:
+        model.close()
     hg.close()
 
 
