@@ -52,8 +52,6 @@ struct GemmParams {
   // deterministic split-K (Model::deterministic): instead of float atomics into C every K split stores its partial tile into
   // slab[split][M][N] (slab_floats = capacity); the launcher clears the slab, and sums the splits in index order into C afterwards
   float* slab; long long slab_floats;
-  int nt_out;       // gemm8c.hip, classes STORE / SWIGLU / TABLE: bit 0 = C, bit 1 = C2 are written with non-temporal stores (outputs far
-                    // larger than the Infinity Cache that no kernel reads back soon: they would only evict what the next kernels read)
   int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
                     // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip)
   // fp8 operands (launch_gemm8p_f8, the fp8 trunk of f8.hip): f8 = 1: A is e4m3, 2: A is e5m2; B is always e4m3.  lda / ldb / K

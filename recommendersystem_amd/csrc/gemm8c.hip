@@ -68,7 +68,7 @@ constexpr int c8_pend() {
 
 template <int N> __device__ __forceinline__ void c8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EC, bool CF32, int NTC = 0>
+template <int EC, bool CF32>
 __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l0 = t & 63;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       // run-ahead: second halves of the next K tile but one (their LDS slots were last read a phase ago), then the register epilogue
       stage_b(cn, I1{}, bo ^ 65536); stage_a(cn, I1{}, bo ^ 65536);
       if constexpr (C8_DEBUG == 1) keep_acc(); else
-      epilogue_regs<WANT ? 1 : 0, EC, NTC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+      epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
       if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): edge epilogues leave masked loads "pending" for hipcc
       lane_setup();
       body(T_{}, F_{}, PD{}, PD{}); step();
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       const int em0 = tile.tm * C8_BM, en0 = tile.tn * C8_BN;
       if (wr == 0) C8_BARRIER();   // rejoin (equal barrier counts)
       if constexpr (C8_DEBUG == 1) keep_acc(); else
-      epilogue_regs<WANT ? 1 : 0, EC, NTC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+      epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
       if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
   };
@@ -331,20 +331,13 @@ int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   switch (p.epi) {
     case EPI_STORE:
       if (p.c_f32) hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, true>), grid, blk, 0, s, p);
-      else if (p.nt_out & 1) hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, false, 1>), grid, blk, 0, s, p);
       else hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, false>), grid, blk, 0, s, p);
       break;
-    case EPI_SWIGLU:
-      if (p.nt_out & 1) hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false, 1>), grid, blk, 0, s, p);
-      else hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false>), grid, blk, 0, s, p);
-      break;
+    case EPI_SWIGLU: hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false>), grid, blk, 0, s, p); break;
     case EPI_RESIDUAL: hipLaunchKernelGGL((gemm8c_kernel<EPI_RESIDUAL, true>), grid, blk, 0, s, p); break;
     case EPI_ACCUM: hipLaunchKernelGGL((gemm8c_kernel<EPI_ACCUM, true>), grid, blk, 0, s, p); break;
     case EPI_SWIGLU_BWD: hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU_BWD, false>), grid, blk, 0, s, p); break;
-    case EPI_TABLE:
-      if (p.nt_out == 3) hipLaunchKernelGGL((gemm8c_kernel<EPI_TABLE, true, 3>), grid, blk, 0, s, p);
-      else hipLaunchKernelGGL((gemm8c_kernel<EPI_TABLE, true>), grid, blk, 0, s, p);
-      break;
+    case EPI_TABLE: hipLaunchKernelGGL((gemm8c_kernel<EPI_TABLE, true>), grid, blk, 0, s, p); break;
     case EPI_QKV_ROPE: hipLaunchKernelGGL((gemm8c_kernel<EPI_QKV_ROPE, false>), grid, blk, 0, s, p); break;
     default: set_error("gemm8c: epilogue class without a kernel"); return RSYS_ERR_ARG;
   }

@@ -18,10 +18,7 @@ namespace rsys {
 // full tiles and its edge tiles in two separate loops); -1: decided by `full` at run time.
 // ECF >= 0: the epilogue class is known at compile time (gemm8c.hip: one kernel per class; EPI_QKV_ROPE there means the
 // implicit positions row % T), else it is p.epi.
-// NTC: cache policy of the output stores, a compile-time choice per kernel: bit 0 = C, bit 1 = C2 leave with non-temporal
-// stores (outputs far larger than the 256 MB Infinity Cache that nothing reads back soon -- the saved [a|b] of the SwiGLU MLP,
-// the fused item table: profiles/r4_gemm8c_store_cache_policy.log; outputs the next kernel reads keep the default policy).
-template <int MODE = -1, int ECF = -1, int NTC = 0>
+template <int MODE = -1, int ECF = -1>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[8][4], int wm0, int wn0, bool full,
                                               int fq, int fr) {
   auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
@@ -60,23 +57,22 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
     auto ldf2 = [&](const void* base, unsigned int off) __attribute__((always_inline)) -> float2  { return *(const float2*)((const char*)base + off); };
     // x: 4 values of block jx at columns .. + 4 fq + r, y: the same of the partner block.  After the swaps lane rows
     // (fq) 0/2 hold 8 consecutive columns of x's block, rows 1/3 of y's.  Every lane takes part in the swaps.
-    auto store_pair = [&](void* base, unsigned int off, bool ok, const float (&x)[4], const float (&y)[4], bool nt = false) __attribute__((always_inline))  {
+    auto store_pair = [&](void* base, unsigned int off, bool ok, const float (&x)[4], const float (&y)[4]) __attribute__((always_inline))  {
       unsigned int x0 = pk2(x[0], x[1]), x1 = pk2(x[2], x[3]), y0 = pk2(y[0], y[1]), y1 = pk2(y[2], y[3]);
       auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
       auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
       if (FULL || ok) {
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-        if (nt) __builtin_nontemporal_store(v, (u32x4*)((char*)base + off)); else *(u32x4*)((char*)base + off) = v;
+        *(u32x4*)((char*)base + off) = v;   // (nontemporal stores measured 3 % slower in the step)
       }
     };
-    auto store_f32 = [&](void* base, unsigned int off, bool ok, const float (&x)[4], bool nt = false) __attribute__((always_inline))  {
+    auto store_f32 = [&](void* base, unsigned int off, bool ok, const float (&x)[4]) __attribute__((always_inline))  {
       if (FULL || ok) {
         const f32x4 v = {x[0], x[1], x[2], x[3]};
-        if (nt) __builtin_nontemporal_store(v, (f32x4*)((char*)base + off)); else *(f32x4*)((char*)base + off) = v;
+        *(f32x4*)((char*)base + off) = v;
       }
     };
-    constexpr bool ntc = (NTC & 1) != 0, ntc2 = (NTC & 2) != 0;
     auto unpack4 = [](float lo, float hi, float (&o)[4]) __attribute__((always_inline)) {
       const bf16x4 q = __builtin_bit_cast(bf16x4, make_float2(lo, hi));
 #pragma unroll
@@ -244,25 +240,25 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
           if (FULL || wn0 + 32 + 4 * fq < p.N) amx0 = fmaxf(amx0, fmaxf(fmaxf(fabsf(g1[0]), fabsf(g1[1])), fmaxf(fabsf(g1[2]), fabsf(g1[3]))));
         }
         const unsigned int ro = rowoff(i, p.ldc, 2), ro2 = rowoff(i, p.ldc2, 2);
-        store_pair(p.C, ro + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1], ntc);
-        store_pair(p.C, ro + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3], ntc);
+        store_pair(p.C, ro + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1]);
+        store_pair(p.C, ro + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3]);
         const int gc = (wn0 >> 1) + ((fq & 1) << 4) + ((fq >> 1) << 3);
-        store_pair(p.C2, ro2 + (unsigned int)gc * 2u, rowok && gc * 2 < p.N, g0, g1, ntc2);
+        store_pair(p.C2, ro2 + (unsigned int)gc * 2u, rowok && gc * 2 < p.N, g0, g1);
       } else if constexpr (ec == EPI_TABLE) {
         const unsigned int ro = rowoff(i, p.ldc, 4), ro2 = rowoff(i, p.ldc2, 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store_f32(p.C, ro + (unsigned int)(c4 + 16 * j) * 4u, rowok && c4 + 16 * j < p.N, v[j], ntc);
-        store_pair(p.C2, ro2 + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1], ntc2);
-        store_pair(p.C2, ro2 + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3], ntc2);
+        for (int j = 0; j < 4; ++j) store_f32(p.C, ro + (unsigned int)(c4 + 16 * j) * 4u, rowok && c4 + 16 * j < p.N, v[j]);
+        store_pair(p.C2, ro2 + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1]);
+        store_pair(p.C2, ro2 + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3]);
       } else {
         if (outf32) {
           const unsigned int ro = rowoff(i, p.ldc, 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) store_f32(p.C, ro + (unsigned int)(c4 + 16 * j) * 4u, rowok && c4 + 16 * j < p.N, v[j], ntc);
+          for (int j = 0; j < 4; ++j) store_f32(p.C, ro + (unsigned int)(c4 + 16 * j) * 4u, rowok && c4 + 16 * j < p.N, v[j]);
         } else {
           const unsigned int ro = rowoff(i, p.ldc, 2);
-          store_pair(p.C, ro + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1], ntc);
-          store_pair(p.C, ro + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3], ntc);
+          store_pair(p.C, ro + (unsigned int)c8 * 2u, rowok && c8 < p.N, v[0], v[1]);
+          store_pair(p.C, ro + (unsigned int)(c8 + 32) * 2u, rowok && c8 + 32 < p.N, v[2], v[3]);
         }
       }
     };

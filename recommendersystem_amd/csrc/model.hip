@@ -855,22 +855,12 @@ template <typename T> static inline T* WT(Model* m, int64_t off) { return (T*)m-
 // Fused item table F = E + Meta Wp^T + bp over all V + 1 rows (model.py:120-133): f32 copy for the token gather, T copy as the
 // tied watch-head operand.  (At cfg-3 this is 782 x 2 tiles of 256 x 256 = 6.1 per CU; sending the rows beyond whole rounds
 // to the 128 x 128 kernel in a second launch was measured: 1.32 -> 1.18 + 0.12 ms, not worth the second code path.)
-// Outputs that are much larger than the 256 MB Infinity Cache and that no kernel reads back soon leave the 256 x 256 GEMM with
-// non-temporal stores (GemmParams::nt_out): written with the default policy they only evict what the next kernels read
-// (profiles/r4_gemm8c_store_cache_policy.log: 12 - 14 % on such outputs, nothing or a loss on outputs the next kernel consumes).
-// RSYS_NT_OUT = bit mask of the call sites it is allowed for (1: the SwiGLU MLP's saved [a|b], 2: the fused item table; default 3).
-static bool nt_out_wanted(int site_bit, long long bytes) {
-  static const int mask = getenv("RSYS_NT_OUT") ? atoi(getenv("RSYS_NT_OUT")) : 3;
-  return (mask & site_bit) != 0 && bytes >= (192ll << 20);
-}
-
 template <typename T>
 static int table_forward(Model* m) {
   GemmParams p{};
   p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
   p.M = m->TR; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
   p.C2 = m->FT; p.ldc2 = m->D;
-  if (nt_out_wanted(2, (long long)m->TR * m->D * 6)) p.nt_out = 3;   // F (token gather: sparse rows) and its T copy (logits GEMM, a whole trunk later)
   return gemm<T>(m, "gemm_table_fwd", p, false, false, false);
 }
 
@@ -1029,7 +1019,6 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     GemmParams p{};
     p.A = a.hn; p.lda = D; p.B = W<T>(m, m->lo[l].w13); p.ldb = D; p.C = a.ab; p.ldc = 2 * Ip;
     p.M = NT; p.N = 2 * Ip; p.K = D; p.epi = EPI_SWIGLU; p.C2 = a.g; p.ldc2 = Ip;
-    if (nt_out_wanted(1, (long long)NT * 2 * Ip * 2)) p.nt_out = 1;   // the saved [a|b] is read again in the backward only; g (the next GEMM's operand) keeps the default policy
     if (m->fp8) { p.f8_amax_out = f8_slot(m, l, F8S_G); RC(gemm_f8(m, l, F8P_W13, "gemm_w13_fwd", p, W8(m, m->lo[l].w13), D, true)); }
     else RC(gemm<T>(m, "gemm_w13_fwd", p, false, false, false));
   }
