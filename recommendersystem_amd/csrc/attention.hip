@@ -151,6 +151,56 @@ __device__ __forceinline__ void first_stage(f32x4 (&S)[4], const T* X, const typ
   }
 }
 
+// The same two stages for R query heads that share one kv head (grouped-query attention) and the same 16 tokens per wave: the
+// K (V^T, ...) fragment of the staged tile is read from LDS ONCE and feeds R MFMAs.
+template <typename T, int HD, int R>
+__device__ __forceinline__ void first_stage_r(f32x4 (&S)[R][4], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int l) {
+  using C = ACfg<T, HD>;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) S[r][i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < C::NDS; ++s) {
+      const typename AMma<T>::Frag x = frag_rows<T>(X, C::LDD, 16 * i, s * C::KS, l);
+#pragma unroll
+      for (int r = 0; r < R; ++r) S[r][i] = AMma<T>::mma(x, f[r][s], S[r][i]);
+    }
+  }
+}
+template <typename T, int HD, int R>
+__device__ __forceinline__ void acc_second_stage_r(f32x4 (&acc)[R][HD / 16], const f32x4 (&P)[R][4], const T* X, int l) {
+  using C = ACfg<T, HD>;
+  if constexpr (is_bf16<T>::value) {
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      bf16x8 pf[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) pf[r] = pack8(P[r][2 * t2], P[r][2 * t2 + 1]);
+#pragma unroll
+      for (int jd = 0; jd < HD / 16; ++jd) {
+        const bf16x8 x = frag_tr(X, C::LDD, 32 * t2, 16 * jd, l);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][jd] = AMma<bf16>::mma(x, pf[r], acc[r][jd]);
+      }
+    }
+  } else {
+    const int g = l >> 4, fr = l & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float* xr = X + (16 * i + 4 * g + rr) * C::LDD + fr;
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd) {
+          const float x = xr[16 * jd];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][jd] = AMma<float>::mma(x, P[r][i][rr], acc[r][jd]);
+        }
+      }
+  }
+}
+
 // ---- staging ----------------------------------------------------------------------------------------------
 template <typename T, int HD> struct TileRegs { uint4 v[(64 * HD * sizeof(T) / 16 + 255) / 256]; };
 
@@ -337,8 +387,11 @@ __device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld,
 }
 
 // ------------------------------------------------------------------------ forward
-template <typename T, int HD>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
+// R = query heads per workgroup: the R heads of one kv head's group at the SAME 64 tokens (R = 1: one head).  They share the
+// staged K / V tile, every K and V^T fragment read, the tile maps and -- the mask depends on the tokens only -- the mask
+// predicates; soft-max statistics and the output accumulators are per head.
+template <typename T, int HD, int R>
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : 2) : 1) void attn_fwd_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -347,25 +400,30 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int* ak = (int*)(Vs + 2 * C::TILE);         // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
-  attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
-  const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
+  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, grp, inner);
+  const int b = grp / p.KV, kvh = grp % p.KV, h0 = kvh * (p.H / p.KV) + (inner / nt) * R, qt = inner % nt;
   if (p.q_active != nullptr && qt >= p.q_active[b]) return;   // nobody reads this query tile's output (uniform: whole workgroup)
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
   const float c2 = rsqrtf((float)HD) * LOG2E;        // scores are handled in log2 units
   const int q = qt * 64 + w * 16 + fr;               // this lane's query
   const bool qv = q < p.T;
-  typename M::Frag qf[C::NDS];
-  {
-    const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + h * HD;
+  typename M::Frag qf[R][C::NDS];
 #pragma unroll
-    for (int s = 0; s < C::NDS; ++s) qf[s] = frag_global<T>(qrow, s * C::KS, HD, l);
+  for (int r = 0; r < R; ++r) {
+    const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + (h0 + r) * HD;
+#pragma unroll
+    for (int s = 0; s < C::NDS; ++s) qf[r][s] = frag_global<T>(qrow, s * C::KS, HD, l);
   }
   const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
-  float m_run = -1e30f, l_run = 0.f;
-  f32x4 oacc[HD / 16];
+  float m_run[R], l_run[R];
+  f32x4 oacc[R][HD / 16];
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) oacc[j] = f32x4{0, 0, 0, 0};
+  for (int r = 0; r < R; ++r) {
+    m_run[r] = -1e30f; l_run[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < HD / 16; ++j) oacc[r][j] = f32x4{0, 0, 0, 0};
+  }
   zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t);
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);   // kv tiles this wave's 16 queries take part in
@@ -396,54 +454,80 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     const T* Kc = Ks + cur * C::TILE;
     const T* Vc = Vs + cur * C::TILE;
     if ((wbits >> kt) & 1u) {   // (a wave whose 16 queries have no allowed key in this tile leaves its state untouched)
-    f32x4 S[4];
-    first_stage<T, HD>(S, Kc, qf, l);
+    f32x4 S[R][4];
+    first_stage_r<T, HD, R>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
+      // allowed(q, kv) <=> key[kv] == key[q] without its tm bits, or key[kv] == key[q] (mask_tile): one predicate per score
+      // position, applied to every head
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mask_tile<true>(S[i], ak + cur * 64, nullptr, 16 * i, aq0, aq, g, -1e30f);
-    }
-    float tmax = -1e30f;
+      for (int i = 0; i < 4; ++i) {
+        const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
+        const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool ok = aa[rr] == aq0 || aa[rr] == aq;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, S[i][r]);
-    tmax = quad_rows_max(tmax);
-    const float m_new = fmaxf(m_run, tmax * c2);
-    const float mu_old = fmaxf(m_run, -1e20f), mu_new = fmaxf(m_new, -1e20f);
-    const float alpha = fexp2(mu_old - mu_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = fexp2(fmaf(S[i][r], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
-        S[i][r] = pv;
-        psum += pv;
+          for (int r = 0; r < R; ++r) S[r][i][rr] = ok ? S[r][i][rr] : -1e30f;
+        }
       }
-    psum = quad_rows_sum(psum);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    }
 #pragma unroll
-    for (int j = 0; j < HD / 16; ++j) oacc[j] *= alpha;
-    acc_second_stage<T, HD>(oacc, S, Vc, l);
+    for (int r = 0; r < R; ++r) {
+      float tmax = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) tmax = fmaxf(tmax, S[r][i][rr]);
+      tmax = quad_rows_max(tmax);
+      const float m_new = fmaxf(m_run[r], tmax * c2);
+      const float mu_old = fmaxf(m_run[r], -1e20f), mu_new = fmaxf(m_new, -1e20f);
+      const float alpha = fexp2(mu_old - mu_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float pv = fexp2(fmaf(S[r][i][rr], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
+          S[r][i][rr] = pv;
+          psum += pv;
+        }
+      psum = quad_rows_sum(psum);
+      l_run[r] = l_run[r] * alpha + psum;
+      m_run[r] = m_new;
+#pragma unroll
+      for (int j = 0; j < HD / 16; ++j) oacc[r][j] *= alpha;
+    }
+    acc_second_stage_r<T, HD, R>(oacc, S, Vc, l);
     }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
     kt = nxt;
   }
-  // O^T (rows d, col q) -> row-major through LDS, then 16-byte row stores
-  T* Os = Ks;   // [64][LDD]
-  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  // O^T (rows d, col q) -> row-major through LDS (head r in the r-th staged-tile slot), then 16-byte row stores
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) {
-    T* dst = Os + (w * 16 + fr) * C::LDD + 16 * j + 4 * g;
+  for (int r = 0; r < R; ++r) {
+    T* Os = Ks + r * C::TILE;   // [64][LDD]   (R <= 4: the four staged-tile slots)
+    const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[r] = from_f32<T>(oacc[j][r] * inv);
+    for (int j = 0; j < HD / 16; ++j) {
+      T* dst = Os + (w * 16 + fr) * C::LDD + 16 * j + 4 * g;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dst[rr] = from_f32<T>(oacc[r][j][rr] * inv);
+    }
+    if (g == 0 && qv) p.lse[((long long)b * p.H + h0 + r) * p.T + q] = (m_run[r] + log2f(l_run[r])) * (1.f / LOG2E);
   }
-  if (g == 0 && qv) p.lse[((long long)b * p.H + h) * p.T + q] = (m_run + log2f(l_run)) * (1.f / LOG2E);
   __syncthreads();
-  copy_out_tile<T, HD>(Os, (T*)p.o + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, qt * 64, p.T, t, p.f8_amax);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    copy_out_tile<T, HD>(Ks + r * C::TILE, (T*)p.o + (tok0 + qt * 64) * p.ldo + (h0 + r) * HD, p.ldo, qt * 64, p.T, t, p.f8_amax);
+}
+
+// query heads per workgroup of the forward / dQ kernels: the whole group of a kv head when that is 2 (every configuration of
+// H / KV = 2), else 1.  RSYS_ATTN_PAIR=0: one head per workgroup (A/B switch).
+static int attn_heads_per_wg(const AttnParams& p) {
+  static const int pair = getenv("RSYS_ATTN_PAIR") ? atoi(getenv("RSYS_ATTN_PAIR")) : 1;
+  return (pair && p.H / p.KV == 2 && p.hd <= 64) ? 2 : 1;   // (head_dim 128: two heads' accumulators cost a wave per SIMD)
 }
 
 template <typename T, int HD>
@@ -452,10 +536,12 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
   const size_t sm = sizeof(T) * 4 * C::TILE + 384 * sizeof(int);
   static bool set = false;
   if (!set) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     set = true;
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm, s, p);
+  if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 2>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 1>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -621,9 +707,9 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
 }
 
-// ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and head)
-template <typename T, int HD>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void attn_bwd_q_kernel(AttnParams p) {
+// ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
+template <typename T, int HD, int R>
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : 2) : 1) void attn_bwd_q_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -632,46 +718,48 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int* ak = (int*)(Vs + 2 * C::TILE);    // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
-  attn_work(p.B * p.KV, (p.H / p.KV) * nt, grp, inner);
-  const int b = grp / p.KV, kvh = grp % p.KV, h = kvh * (p.H / p.KV) + inner / nt, qt = inner % nt;
+  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, grp, inner);
+  const int b = grp / p.KV, kvh = grp % p.KV, h0 = kvh * (p.H / p.KV) + (inner / nt) * R, qt = inner % nt;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
   if (p.q_active != nullptr && qt >= p.q_active[b]) {   // dO of these queries is identically zero: so is dQ (uniform: whole workgroup)
     constexpr int CPRZ = HD / C::E;
-    for (int c = t; c < 64 * CPRZ; c += 256) {
-      const int row = c / CPRZ, ch = c % CPRZ;
-      if (qt * 64 + row < p.T) *(uint4*)((T*)p.dq + (tok0 + qt * 64 + row) * p.ldg + h * HD + ch * C::E) = make_uint4(0, 0, 0, 0);
+    for (int c = t; c < 64 * CPRZ * R; c += 256) {
+      const int r = c / (64 * CPRZ), cc = c % (64 * CPRZ), row = cc / CPRZ, ch = cc % CPRZ;
+      if (qt * 64 + row < p.T) *(uint4*)((T*)p.dq + (tok0 + qt * 64 + row) * p.ldg + (h0 + r) * HD + ch * C::E) = make_uint4(0, 0, 0, 0);
     }
     return;
   }
   const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
   const int q = qt * 64 + w * 16 + fr;
   const bool qv = q < p.T;
-  typename M::Frag qf[C::NDS], dof[C::NDS];
-  {
+  typename M::Frag qf[R][C::NDS], dof[R][C::NDS];
+  float dl[R], lse2[R];
+  f32x4 dQ[R][HD / 16];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int h = h0 + r;
     const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + h * HD;
     const T* drow = (const T*)p.dO + (tok0 + min(q, p.T - 1)) * p.ldo + h * HD;
 #pragma unroll
-    for (int s = 0; s < C::NDS; ++s) { qf[s] = frag_global<T>(qrow, s * C::KS, HD, l); dof[s] = frag_global<T>(drow, s * C::KS, HD, l); }
-  }
-  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
-  const long long so = ((long long)b * p.H + h) * p.T + min(q, p.T - 1);
-  // delta = rowsum(dO * O) of this lane's query: the four lanes that share a query hold disjoint quarters of d in their
-  // fragments.  Written out for the dK/dV kernel, which runs after this one.
-  float dl = 0.f;
-  {
+    for (int s = 0; s < C::NDS; ++s) { qf[r][s] = frag_global<T>(qrow, s * C::KS, HD, l); dof[r][s] = frag_global<T>(drow, s * C::KS, HD, l); }
+    const long long so = ((long long)b * p.H + h) * p.T + min(q, p.T - 1);
+    // delta = rowsum(dO * O) of this lane's query: the four lanes that share a query hold disjoint quarters of d in their
+    // fragments.  Written out for the dK/dV kernel, which runs after this one.
+    float d_ = 0.f;
     const T* orow = (const T*)p.o + (tok0 + min(q, p.T - 1)) * p.ldo + h * HD;
 #pragma unroll
-    for (int s = 0; s < C::NDS; ++s) dl += frag_dot(dof[s], frag_global<T>(orow, s * C::KS, HD, l));
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
-    if (!qv) dl = 0.f;
-    if (g == 0 && qv) p.delta[so] = dl;
-  }
-  const float lse2 = qv ? p.lse[so] * LOG2E : 0.f;
-  f32x4 dQ[HD / 16];
+    for (int s = 0; s < C::NDS; ++s) d_ += frag_dot(dof[r][s], frag_global<T>(orow, s * C::KS, HD, l));
+    d_ += __shfl_xor(d_, 16, 64);
+    d_ += __shfl_xor(d_, 32, 64);
+    if (!qv) d_ = 0.f;
+    if (g == 0 && qv) p.delta[so] = d_;
+    dl[r] = d_;
+    lse2[r] = qv ? p.lse[so] * LOG2E : 0.f;
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) dQ[j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < HD / 16; ++j) dQ[r][j] = f32x4{0, 0, 0, 0};
+  }
+  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
@@ -699,20 +787,32 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     const T* Kc = Ks + cur * C::TILE;
     const T* Vc = Vs + cur * C::TILE;
     if ((wbits >> kt) & 1u) {
-    f32x4 S[4], dP[4];
-    first_stage<T, HD>(S, Kc, qf, l);      // S^T[kv][q]
-    first_stage<T, HD>(dP, Vc, dof, l);    // dP^T[kv][q]
-    const bool fullt = (fullbits >> kt) & 1u;
+    f32x4 S[R][4], dP[R][4];
+    first_stage_r<T, HD, R>(S, Kc, qf, l);      // S^T[kv][q]
+    first_stage_r<T, HD, R>(dP, Vc, dof, l);    // dP^T[kv][q]
+    if (!((fullbits >> kt) & 1u)) {   // one predicate per score position, applied to every head (mask_tile)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (!fullt) mask_tile<true>(S[i], ak + cur * 64, nullptr, 16 * i, aq0, aq, g, -1e30f);
+      for (int i = 0; i < 4; ++i) {
+        const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
+        const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = fexp2(fmaf(S[i][r], c2, -lse2));
-        dP[i][r] = pv * (dP[i][r] - dl);   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool ok = aa[rr] == aq0 || aa[rr] == aq;
+#pragma unroll
+          for (int r = 0; r < R; ++r) S[r][i][rr] = ok ? S[r][i][rr] : -1e30f;
+        }
       }
     }
-    acc_second_stage<T, HD>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float pv = fexp2(fmaf(S[r][i][rr], c2, -lse2[r]));
+          dP[r][i][rr] = pv * (dP[r][i][rr] - dl[r]);   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
+        }
+    acc_second_stage_r<T, HD, R>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
     }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
@@ -720,12 +820,16 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     kt = nxt;
   }
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(q, p.T - 1)] : min(q, p.T - 1);
-  T* Os = Ks;
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) dQ[j] *= scale;
-  store_grad_tile<T, HD>(dQ, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int j = 0; j < HD / 16; ++j) dQ[r][j] *= scale;
+    store_grad_tile<T, HD>(dQ[r], true, p.rope_cos, p.rope_sin, pos, Ks + r * C::TILE, w, l);   // (head r in the r-th staged-tile slot)
+  }
   __syncthreads();
-  copy_out_tile<T, HD>(Os, (T*)p.dq + (tok0 + qt * 64) * p.ldg + h * HD, p.ldg, qt * 64, p.T, t, p.f8_amax);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    copy_out_tile<T, HD>(Ks + r * C::TILE, (T*)p.dq + (tok0 + qt * 64) * p.ldg + (h0 + r) * HD, p.ldg, qt * 64, p.T, t, p.f8_amax);
 }
 
 template <typename T, int HD>
@@ -736,12 +840,16 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   static bool set = false;
   if (!set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_kv));
-    HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
+    HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
+    HIP_CHECK(hipFuncSetAttribute((const void*)attn_bwd_q_kernel<T, HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_q));
     set = true;
   }
   // the dQ kernel also produces delta = rowsum(dO * O), which the dK/dV kernel reads
-  hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
+  if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 2>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_q, s, p);
+  else hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 1>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
   HIP_CHECK(hipGetLastError());
+  // (two adjacent kv tiles per workgroup -- Q / dO staging and every fragment read shared by 32 keys per wave -- measured 6 % slower:
+  // 254 registers, two waves per SIMD; profiles/r4_ab_attn_dkv_two_key_tiles.log)
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), sm_kv, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
