@@ -187,7 +187,6 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* src) {
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
-thread_local float* g_f8_amax_next = nullptr;
 
 template <typename T, int NJ, bool EXACT>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* y, float* rstd,
@@ -236,8 +235,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 }
 
 template <typename T>
-int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev, const int* in_rows) {
-  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;   // (taken before any early return: never left for another launch)
+int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev, const int* in_rows,
+                       float* f8_amax) {
+  float* const amax = f8_amax;
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm: D must be a multiple of 4 and <= 2048");
   const dim3 grid(div_up(rows, 4)), block(256);
 #define RSYS_NORM_FWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, NJ, EX>), grid, block, 0, s, x, scale, y, rstd, rows, D, rows_dev, in_rows, amax)
@@ -253,8 +253,8 @@ int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, lo
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
-template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*);
-template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*, const int*);
+template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*, float*);
+template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*, const int*, float*);
 
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
 template <typename TG, typename TO, int NJ, bool EXACT>
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
 template <typename TG, typename TO>
 static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, const float* rstd, const float* resid,
                            float* dx_out, TO* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev,
-                           const int* resid_slot, const int* io_rows = nullptr) {
-  float* const amax = g_f8_amax_next; g_f8_amax_next = nullptr;   // (taken before any early return: never left for another launch)
+                           const int* resid_slot, const int* io_rows = nullptr, float* f8_amax = nullptr) {
+  float* const amax = f8_amax;
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
   static const int grid_cap = getenv("RSYS_DEBUG_NORM_BWD_GRID") ? atoi(getenv("RSYS_DEBUG_NORM_BWD_GRID")) : 1024;   // (every workgroup ends with D atomics onto the same D scale gradients: 512-1024 workgroups 1.39-1.45 ms per step at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37)
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, grid_cap)), block(256);
@@ -378,18 +378,18 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
 template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
                        float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev, const int* resid_slot,
-                       const int* io_rows) {
-  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, resid_slot, io_rows);
+                       const int* io_rows, float* f8_amax) {
+  return rmsnorm_bwd_any<T, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, resid_slot, io_rows, f8_amax);
 }
-template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*, const int*);
-template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, const int*, const int*);
+template int launch_rmsnorm_bwd<bf16>(const bf16*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, const int*, const int*, float*);
+template int launch_rmsnorm_bwd<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, const int*, const int*, float*);
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev) {
-  return rmsnorm_bwd_any<float, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, nullptr);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev, float* f8_amax) {
+  return rmsnorm_bwd_any<float, T>(g, x, scale, rstd, resid_grad, dx_out, dx_out_t, dscale, rows, D, s, rows_dev, nullptr, nullptr, f8_amax);
 }
-template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*);
-template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*);
+template int launch_rmsnorm_bwd_f32<bf16>(const float*, const float*, const float*, const float*, const float*, float*, bf16*, float*, long long, int, hipStream_t, const int*, float*);
+template int launch_rmsnorm_bwd_f32<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, long long, int, hipStream_t, const int*, float*);
 
 // --------------------------------------------------------------------- dropout (LoRA input, finetune)
 template <typename T>

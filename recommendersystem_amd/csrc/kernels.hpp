@@ -52,7 +52,8 @@ int launch_gather_items(const BatchDev& b, const float* F32, int V, int D, float
 // written as zeros, the rest is left alone (compact.hip)
 template <typename T>
 int launch_rmsnorm_fwd(const float* x, const float* scale, T* y, float* rstd, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
-                       const int* in_rows = nullptr /* output row r is computed from input row in_rows[r] */);
+                       const int* in_rows = nullptr /* output row r is computed from input row in_rows[r] */,
+                       float* f8_amax = nullptr /* fp8 trunk: sharded amax slot of the output (common.hpp f8_amax_add) */);
 
 // dx_out = resid_grad + d/dx rmsnorm ; dscale += column sums (atomic)
 // dx_out_t (optional): T-typed copy of dx_out, the A operand of the GEMMs that consume it
@@ -60,11 +61,13 @@ template <typename T>
 int launch_rmsnorm_bwd(const T* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
                        float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
                        const int* resid_slot = nullptr /* resid_grad is compact: row resid_slot[row] of it, zero where -1 */,
-                       const int* io_rows = nullptr /* x is read at, and dx_out / dx_out_t written to, row io_rows[row] (g, rstd, resid_slot: row) */);
+                       const int* io_rows = nullptr /* x is read at, and dx_out / dx_out_t written to, row io_rows[row] (g, rstd, resid_slot: row) */,
+                       float* f8_amax = nullptr /* fp8 trunk: sharded amax slot of dx_out_t */);
 // same with an f32 incoming gradient (final norm: gy is f32)
 template <typename T>
 int launch_rmsnorm_bwd_f32(const float* g, const float* x, const float* scale, const float* rstd, const float* resid_grad,
-                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr);
+                           float* dx_out, T* dx_out_t, float* dscale, long long rows, int D, hipStream_t s, const int* rows_dev = nullptr,
+                           float* f8_amax = nullptr);
 
 // dst = (accumulate ? dst : 0) + src * mask / (1 - p), mask ~ Bernoulli(1-p) from Philox(seed, stream)(element index):
 // nn.Dropout of the LoRA input (model.py:238,265,269); the backward pass regenerates the same mask
@@ -231,7 +234,6 @@ int launch_fill_normal_t(T* dst, long long rows, int cols, long long ld, float s
 
 // When set, the next launch of rmsnorm_fwd (its T-typed output) / rmsnorm_bwd (its T-typed operand copy of dx) also adds the amax
 // of what it writes to this sharded slot (common.hpp f8_amax_note); the launcher clears it.  Same thread as the launch.
-extern thread_local float* g_f8_amax_next;
 
 // ---- fp8 trunk (f8.hip): torchao's tensor-wise dynamic scaling restated (transformer.py:671-676)
 enum { F8_E4M3 = 0, F8_E5M2 = 1 };

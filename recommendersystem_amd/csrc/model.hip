@@ -1012,8 +1012,7 @@ static int layer_tail_dense(Model* m, int l, const void* O_in = nullptr /* atten
     else RC(gemm<T>(m, "gemm_o_fwd", p, false, false, false));
   }
   tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
-  if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_HN);
-  RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s));
+  RC(launch_rmsnorm_fwd<T>(a.h, m->P + m->lo[l].mlp, AT<T>(a.hn), a.rstd2, NT, D, s, nullptr, nullptr, m->fp8 ? f8_slot(m, l, F8S_HN) : nullptr));
   toc(m);
   {
     GemmParams p{};
@@ -1140,8 +1139,7 @@ static int forward_trunk(Model* m) {
     const bool top = m->top_is_sparse && l == m->L - 1;   // this layer runs in selected-first token order
     const int* rpos_l = top ? m->pos_p : rpos;
     tic(m, "hbm_rmsnorm_fwd", (4.0 + sizeof(T)) * D * NT);
-    if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_XN);
-    RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s, nullptr, top ? m->c_perm : nullptr));
+    RC(launch_rmsnorm_fwd<T>(a.x, m->P + m->lo[l].sa, AT<T>(a.xn), a.rstd1, NT, D, s, nullptr, top ? m->c_perm : nullptr, m->fp8 ? f8_slot(m, l, F8S_XN) : nullptr));
     toc(m);
     const bool ft = m->cfg.finetune != 0;
     T* xnd = AT<T>(a.xn);   // LoRA input: dropout(x) in a training pass (model.py:265,269), else x itself
@@ -1601,6 +1599,10 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
     GemmGroupPlan* pl = nullptr;
     ++m->host_stream_syncs;   // (first use of this layer range / batch size only)
     HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (m->dw_plans.size() >= 8) {   // (a plan bakes the row count in: a loader with many distinct last-batch sizes must not grow this without bound)
+      for (auto& kv : m->dw_plans) gemm8p_group_plan_destroy(kv.second);
+      m->dw_plans.clear();
+    }
     RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl));
     it = m->dw_plans.emplace(key, pl).first;
   }
@@ -1636,8 +1638,8 @@ static int backward_trunk(Model* m) {
                                  m->G + m->o_norm, m->ctop_cap, D, s, m->c_n));
   } else {
     tic(m, "hbm_rmsnorm_bwd", (4.0 + 4.0 + 4.0 + (cp ? 2.0 : 0.0)) * D * NT);
-    if (m->fp8) g_f8_amax_next = f8_slot(m, m->L - 1, F8S_DY2);   // the top layer's W2 takes this gradient as its dy
-    RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s));
+    RC(launch_rmsnorm_bwd_f32<T>(m->gy, m->xL, m->P + m->o_norm, m->rstdf, nullptr, gx, cp ? gxt : nullptr, m->G + m->o_norm, NT, D, s, nullptr,
+                                 m->fp8 ? f8_slot(m, m->L - 1, F8S_DY2) : nullptr));   // (fp8: the top layer's W2 takes this gradient as its dy)
     toc(m);
   }
   AttnParams ap{};
@@ -1691,8 +1693,8 @@ static int backward_trunk(Model* m) {
     }
     RC(join_dw(m, DW_O));       // the layer above's dWo reads dht
     tic(m, "hbm_rmsnorm_bwd", nb_bytes);
-    if (m->fp8) g_f8_amax_next = f8_slot(m, l, F8S_DH);
-    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s));
+    RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.h, m->P + m->lo[l].mlp, a.rstd2, gx, m->dh, cp ? dht : nullptr, m->G + m->lo[l].mlp, NT, D, s, nullptr, nullptr, nullptr,
+                             m->fp8 ? f8_slot(m, l, F8S_DH) : nullptr));
     toc(m);
     if (!ft && !defer && !f8dw) {
       GemmParams p{};  // dWo += dh^T . O
@@ -1794,8 +1796,8 @@ static int backward_trunk(Model* m) {
       RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->c_dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s,
                                nullptr, m->c_slot_p, m->c_perm));
     else {
-      if (m->fp8 && l > 0) g_f8_amax_next = f8_slot(m, l - 1, F8S_DY2);   // the layer below takes this gradient as its W2's dy
-      RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s));
+      RC(launch_rmsnorm_bwd<T>(AT<T>(m->dhn), a.x, m->P + m->lo[l].sa, a.rstd1, m->dh, gx_other, cp ? gxt_other : nullptr, m->G + m->lo[l].sa, NT, D, s, nullptr, nullptr, nullptr,
+                               (m->fp8 && l > 0) ? f8_slot(m, l - 1, F8S_DY2) : nullptr));   // (fp8: the layer below takes this gradient as its W2's dy)
     }
     toc(m);
     std::swap(gx, gx_other);
