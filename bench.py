@@ -33,7 +33,6 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8f": "gemm8p_f8_kernel",                             # --dtype fp8: the persistent pipeline on e4m3 / e5m2 operands (K tiles of 128)
     "8fs": "gemm8p_f8sk_kernel",                          # --dtype fp8: split-K weight gradients on transposed fp8 copies, one product per launch
     "8gf": "gemm8p_group_f8_kernel",                      # --dtype fp8: the same, all layers' products in one grouped launch
-    "4w": "gemm4w_kernel",                                # 256x128, two workgroups per CU (gemm4w.hip)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
@@ -41,7 +40,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8c": "gemm8c_kernel<epilogue class> (256x256 LDS-DMA, persistent, one operand stream per workgroup, row-major bf16)",
                 "8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
-                "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)", "4w": "gemm4w_kernel (256x128, 2 workgroups/CU)",
+                "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)",
                 "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
                 "8fs": "gemm8p_f8sk_kernel (256x256 LDS-DMA, fp8 e5m2 x e4m3 on K-contiguous copies, split-K weight gradient)",
                 "8gf": "gemm8p_group_f8_kernel (the fp8 split-K form, grouped weight gradients of all layers)",

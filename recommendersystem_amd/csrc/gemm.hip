@@ -471,15 +471,16 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   return gemm_slab_end(q, s);
 }
 
-// which kernel a row-major bf16 problem goes to: 0 = 128x128 register-staged (this file), 2 = 256x256 LDS-DMA (gemm8p.hip),
-// 3 = 256x128 two-per-CU (gemm4w.hip).  RSYS_GEMM_KERNEL=1 / 2 / 3 forces one of them where it is eligible (tests, A/B timing).
+// which kernel a row-major bf16 problem goes to: 0 = 128x128 register-staged (this file), 2 = 256x256 LDS-DMA (gemm8c.hip for the
+// epilogue classes it has kernels for, else gemm8p.hip).  RSYS_GEMM_KERNEL=1 / 2 forces one of them where it is eligible (tests,
+// A/B timing).  (The 256x128 two-per-CU sibling of rounds 1-3 left the library: slower than gemm8c on every shape of the step,
+// profiles/r4_gemm4w_two_per_cu_stagger.log; its source is kept under tools/micro/ for measurements.)
 static int pick_rowmajor_kernel(const GemmParams& p) {
   const char* e = getenv("RSYS_GEMM_KERNEL");
   const int hint = e ? atoi(e) : 0;
   if (hint == 1) return 0;
-  const bool e8 = gemm8p_eligible(p), e4 = gemm4w_eligible(p);
+  const bool e8 = gemm8p_eligible(p);
   if (hint == 2) return e8 ? 2 : 0;
-  if (hint == 3) return e4 ? 3 : 0;
   const int Me = (p.m_dev != nullptr && p.m_expect > 0) ? std::min(p.M, p.m_expect) : p.M;   // rows the launch is expected to compute
   const long long t256 = (long long)((Me + 255) / 256) * ((p.N + 255) / 256);
   if (e8 && t256 >= 128) return 2;   // at least half the CUs get a 256x256 tile
@@ -513,7 +514,6 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32) {
     const int k = pick_rowmajor_kernel(p);
     if (k == 2) return gemm8p_forwards_to_8c(p) ? "8c" : "8p";
-    if (k == 3) return "4w";
   }
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return "8s";
@@ -550,7 +550,6 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
     if (!a_km && !b_km && !a_f32 && !b_f32) {
       const int k = pick_rowmajor_kernel(p);
       if (k == 2) return launch_gemm8p(p, s);
-      if (k == 3) return launch_gemm4w(p, s);
     }
     if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return launch_gemm8p_tn(p, s);
   }

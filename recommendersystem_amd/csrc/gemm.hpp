@@ -97,7 +97,7 @@ int launch_gemm8p_f8(const GemmParams& p, hipStream_t s);
 bool gemm8p_f8_splitk_eligible(const GemmParams& p);
 int launch_gemm8p_f8_splitk(const GemmParams& p, hipStream_t s);
 
-// short name of the kernel launch_gemm picks for this problem ("8c", "8p", "8t", "8s", "4w", "nt", "nn", "tn"): timing tags
+// short name of the kernel launch_gemm picks for this problem ("8c", "8p", "8t", "8s", "nt", "nn", "tn"): timing tags
 const char* gemm_kernel_name(const GemmParams& p, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km);
 
 }  // namespace rsys

@@ -808,7 +808,8 @@ int launch_gemm8p_f8_splitk(const GemmParams& p0, hipStream_t s) {
 // the one-stream form of this pipeline (gemm8c.hip) takes the epilogue classes it has kernels for; RSYS_GEMM8C=0: A/B switch
 bool gemm8p_forwards_to_8c(const GemmParams& p) {
   static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
-  static const int use_8c = getenv("RSYS_GEMM8C") ? atoi(getenv("RSYS_GEMM8C")) : 1;
+  const char* e = getenv("RSYS_GEMM8C");   // (read per call: the GEMM tests switch between the two kernels inside one process)
+  const int use_8c = e ? atoi(e) : 1;
   return use_8c && dbg == 0 && p.epi != 99 && gemm8c_eligible(p);
 }
 

@@ -1,7 +1,7 @@
 // Fused GEMM epilogues, LDS-staged form: used by the 128x128 kernel (gemm.hip), which passes its accumulators through
 // LDS and hands every lane W consecutive columns of one output row; epi_item applies the epilogue to those W values and
 // writes them with 16-byte accesses.  (The 256-wide kernels write straight from registers: gemm_epi_reg.hpp.)
-// Also declares the launchers of the LDS-DMA kernels (gemm8p.hip, gemm4w.hip) for the dispatcher in gemm.hip.
+// Also declares the launchers of the LDS-DMA kernels (gemm8p.hip, gemm8c.hip) for the dispatcher in gemm.hip.
 #pragma once
 #include <utility>
 
@@ -154,8 +154,5 @@ int launch_gemm8p_nt_splitk(const GemmParams& p, hipStream_t s);
 int gemm8p_splits(const GemmParams& p, bool k_major);            // K splits the two split-K forms choose (gemm8p.hip)
 int gemm_slab_begin(const GemmParams& p, hipStream_t s);         // deterministic split-K: clear the slab / sum it into C (gemm.hip)
 int gemm_slab_end(const GemmParams& p, hipStream_t s);
-// row-major bf16 operands, 256x128 tiles, two workgroups per CU (gemm4w.hip)
-bool gemm4w_eligible(const GemmParams& p);
-int launch_gemm4w(const GemmParams& p, hipStream_t s);
 
 }  // namespace rsys

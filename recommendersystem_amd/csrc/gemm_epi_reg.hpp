@@ -1,4 +1,4 @@
-// Register-resident epilogue of the LDS-DMA GEMM kernels (gemm8p.hip, gemm4w.hip): every wave owns a 128x64 block
+// Register-resident epilogue of the LDS-DMA GEMM kernels (gemm8p.hip, gemm8c.hip): every wave owns a 128x64 block
 // of the output as 8x4 MFMA 16x16 accumulator blocks of the TRANSPOSED product (B fragment as the first MFMA
 // operand), so lane (fq, fr) = (lane >> 4, lane & 15) holds FOUR CONSECUTIVE COLUMNS of one row:
 //   acc[i][j][r] = C[wm0 + 16 i + fr][wn0 + 16 j + 4 fq + r].

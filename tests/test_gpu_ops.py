@@ -109,11 +109,14 @@ def test_gemm_bf16_with_f32_source_and_splitk(a_km, b_km):
                                    # more tiles than CUs: the 256x256 kernel walks 2-3 tiles per workgroup (full and edge passes)
                                    (9000, 2816, 192), (16384, 1408, 128), (33000, 776, 256)])
 @pytest.mark.parametrize("c_f32", [True, False])
-@pytest.mark.parametrize("kern", ["2", "3"])
+@pytest.mark.parametrize("kern", ["8c", "8p"])
 def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
-    """LDS-DMA kernels (gemm8p.hip / gemm4w.hip), forced: exact on asymmetric integer data for even / odd K-tile counts,
-    ragged edges (clamped source rows, guarded stores), f32 and bf16 outputs; and it must agree with the 128x128 kernel."""
-    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)   # 2: 256x256 (gemm8p.hip), 3: 256x128, two workgroups per CU (gemm4w.hip)
+    """The 256x256 LDS-DMA kernels, forced -- gemm8c.hip (one operand stream across a workgroup's tiles: the default) and its
+    predecessor gemm8p.hip (RSYS_GEMM8C=0; still the kernel of the epilogue classes without an 8c instantiation): exact on asymmetric
+    integer data for even / odd K-tile counts, ragged edges (rows / columns beyond the matrix read as zeros or clamped, guarded
+    stores), f32 and bf16 outputs; and it must agree with the 128x128 kernel."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    monkeypatch.setenv("RSYS_GEMM8C", "1" if kern == "8c" else "0")
     out, ref = run_gemm(1, M, N, K, False, False, c_f32=c_f32, integer=True, seed=M + N + K)
     if c_f32:
         np.testing.assert_array_equal(out, ref.astype(np.float32))
@@ -136,13 +139,14 @@ def test_gemm_rowmajor_splitk_lds_dma_kernel(M, N, K):
 
 
 @pytest.mark.parametrize("rows", [0, 1, 256, 300, 717, 1280, 2048, 5000])
-@pytest.mark.parametrize("kern", ["1", "2"])
+@pytest.mark.parametrize("kern", ["1", "2", "2p"])
 def test_gemm_device_side_row_count(monkeypatch, rows, kern):
     """Head GEMMs run over "the rows selected on the device" (GemmParams.m_dev): the 256x256 kernel walks row tiles in
     its persistent tile loop (gemm8p_kernel<false>), the 128x128 kernel drops whole workgroups.  Rows below the count are exact; rows
     past the last started tile keep their previous contents."""
     from recommendersystem_amd import _lib
-    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern)
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", kern[0])
+    monkeypatch.setenv("RSYS_GEMM8C", "0" if kern == "2p" else "1")   # 2: gemm8c.hip, 2p: gemm8p.hip
     lib = _lib.lib()
     M, N, K = 2048, 2056, 192
     rng = np.random.default_rng(rows)
@@ -162,7 +166,7 @@ def test_gemm_device_side_row_count(monkeypatch, rows, kern):
     ref = _bf16_round((A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32))
     live = min(rows, M)
     np.testing.assert_array_equal(out[:live], ref[:live])
-    tile = 256 if kern == "2" else 128
+    tile = 256 if kern[0] == "2" else 128
     started = min(M, (live + tile - 1) // tile * tile)
     assert (raw[started:] == 0x4300).all()
 

@@ -1,3 +1,4 @@
+// (Measurement only since round 4: not part of librsys_hip.so.  tools/micro/gemm8c_dev.hip at commit 278633b timed it against gemm8c.)
 // bf16 MFMA GEMM for row-major operands, gfx950: C[M,N] = sum_k A[m][k] * B[n][k] -- the short-K sibling of
 // gemm8p.hip.  The training step's GEMMs have K = 512..2816 and write as many bytes as they read: with one
 // 256x256 workgroup per CU the prologue (first tiles from HBM) and the epilogue (the output burst) of every tile
@@ -14,9 +15,9 @@
 // LDS image of a stage: rows of 64 B (32 k), 16-byte chunk c of row r at r*64 + ((c ^ ((-(r>>2)) & 3)) << 4): with
 // the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) every group covers all 64 banks.  LDS-DMA writes
 // lane-linear, so the permutation is applied to the per-lane SOURCE address.
-#include "gemm.hpp"
-#include "gemm_epi.hpp"
-#include "gemm_epi_reg.hpp"
+#include "../../recommendersystem_amd/csrc/gemm.hpp"
+#include "../../recommendersystem_amd/csrc/gemm_epi.hpp"
+#include "../../recommendersystem_amd/csrc/gemm_epi_reg.hpp"
 
 namespace rsys {
 
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmParams p) {
 
 }  // namespace
 
+bool gemm4w_eligible(const GemmParams& p);
+int launch_gemm4w(const GemmParams& p, hipStream_t s);
 bool gemm4w_eligible(const GemmParams& p) {
   if (p.splitk > 1 || p.epi == EPI_ATOMIC || p.k_dev != nullptr || p.accum) return false;
   if (p.K % T4_BK != 0) return false;

@@ -16,7 +16,7 @@ for _ in range(36):
     K = int(rng.choice([128, 192, 256, 512, 576, 1024, 1408, 2816]))
     cases.append((M, N, K))
 for (M, N, K) in cases:
-    for kern, env in (("8p", {"RSYS_GEMM_KERNEL": "2"}), ("4w", {"RSYS_GEMM_KERNEL": "3"})):
+    for kern, env in (("8c", {"RSYS_GEMM_KERNEL": "2", "RSYS_GEMM8C": "1"}), ("8p", {"RSYS_GEMM_KERNEL": "2", "RSYS_GEMM8C": "0"})):
         os.environ.update(env)
         for rep in range(2):
             out, ref = T.run_gemm(1, M, N, K, False, False, c_f32=bool(rep), integer=True, seed=M + N + K + rep)
