@@ -201,6 +201,51 @@ __device__ __forceinline__ void acc_second_stage_r(f32x4 (&acc)[R][HD / 16], con
   }
 }
 
+// One 16-token block (i) of the first stage / one 32-token half (t2 = blocks 2 t2, 2 t2 + 1) of the second stage: the backward
+// kernels need no row maximum (they exponentiate against the stored log-sum-exp), so they run the two stages per half and keep
+// only two score blocks per head alive instead of four.
+// (S enters with its initial value: zero, or a row / lane constant that the chain then carries -- the dP chains start from -delta, so
+// dS = P * (dP - delta) needs no subtraction)
+template <typename T, int HD, int R>
+__device__ __forceinline__ void first_stage_block_r(f32x4 (&S)[R], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int i, int l) {
+  using C = ACfg<T, HD>;
+#pragma unroll
+  for (int s = 0; s < C::NDS; ++s) {
+    const typename AMma<T>::Frag x = frag_rows<T>(X, C::LDD, 16 * i, s * C::KS, l);
+#pragma unroll
+    for (int r = 0; r < R; ++r) S[r] = AMma<T>::mma(x, f[r][s], S[r]);
+  }
+}
+template <typename T, int HD, int R>
+__device__ __forceinline__ void acc_second_stage_half_r(f32x4 (&acc)[R][HD / 16], const f32x4 (&P)[R][2], const T* X, int t2, int l) {
+  using C = ACfg<T, HD>;
+  if constexpr (is_bf16<T>::value) {
+    bf16x8 pf[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pf[r] = pack8(P[r][0], P[r][1]);
+#pragma unroll
+    for (int jd = 0; jd < HD / 16; ++jd) {
+      const bf16x8 x = frag_tr(X, C::LDD, 32 * t2, 16 * jd, l);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][jd] = AMma<bf16>::mma(x, pf[r], acc[r][jd]);
+    }
+  } else {
+    const int g = l >> 4, fr = l & 15;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float* xr = X + (16 * (2 * t2 + ii) + 4 * g + rr) * C::LDD + fr;
+#pragma unroll
+        for (int jd = 0; jd < HD / 16; ++jd) {
+          const float x = xr[16 * jd];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][jd] = AMma<float>::mma(x, P[r][ii][rr], acc[r][jd]);
+        }
+      }
+  }
+}
+
 // ---- staging ----------------------------------------------------------------------------------------------
 template <typename T, int HD> struct TileRegs { uint4 v[(64 * HD * sizeof(T) / 16 + 255) / 256]; };
 
@@ -614,17 +659,17 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
   const int kv = kvt * 64 + w * 16 + fr;       // this lane's key/value token
   const bool kvv = kv < p.T;
-  typename M::Frag kf[C::NDS], vf[C::NDS];
+  typename M::Frag kf[1][C::NDS], vf[1][C::NDS];
   {
     const T* krow = (const T*)p.k + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
     const T* vrow = (const T*)p.v + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
 #pragma unroll
-    for (int s = 0; s < C::NDS; ++s) { kf[s] = frag_global<T>(krow, s * C::KS, HD, l); vf[s] = frag_global<T>(vrow, s * C::KS, HD, l); }
+    for (int s = 0; s < C::NDS; ++s) { kf[0][s] = frag_global<T>(krow, s * C::KS, HD, l); vf[0][s] = frag_global<T>(vrow, s * C::KS, HD, l); }
   }
   const int akv = kvv ? token_key(p.uid[tok0 + kv], p.tm[tok0 + kv]) : KEY_NO_K;
-  f32x4 dK[HD / 16], dV[HD / 16];
+  f32x4 dK[1][HD / 16], dV[1][HD / 16];
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) { dK[j] = f32x4{0, 0, 0, 0}; dV[j] = f32x4{0, 0, 0, 0}; }
+  for (int j = 0; j < HD / 16; ++j) { dK[0][j] = f32x4{0, 0, 0, 0}; dV[0][j] = f32x4{0, 0, 0, 0}; }
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Qs + i * C::TILE, t); zero_pad_cols<T, HD>(dOs + i * C::TILE, t); }
   const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
   const unsigned int act = qa >= 32 ? ~0u : ((1u << qa) - 1u);   // query tiles whose dO can be non-zero
@@ -669,25 +714,30 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     const T* Qc = Qs + cur * C::TILE;
     const T* dOc = dOs + cur * C::TILE;
     if ((wbits >> (it & 31)) & 1u) {   // (nothing to add for a wave whose 16 keys no query of this tile may see)
-    f32x4 S[4], dP[4];
-    first_stage<T, HD>(S, Qc, kf, l);      // S[q][kv]: rows q (registers), col kv (lane)
-    first_stage<T, HD>(dP, dOc, vf, l);    // dP[q][kv]
     const bool fullt = (fullbits >> (it & 31)) & 1u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
-      const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
-      const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-      if (!fullt) mask_tile<false>(S[i], q0s + cur * 64, q1s + cur * 64, 16 * i, akv, 0, g, -1e30f);
+    for (int t2 = 0; t2 < 2; ++t2) {   // 32 queries at a time: both stages, two score blocks alive (no row maximum is needed here)
+      f32x4 P2[1][2], dS2[1][2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = fexp2(fmaf(S[i][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
-        S[i][r] = pv;
-        dP[i][r] = pv * (dP[i][r] - dd[r]);   // (the 1/sqrt(hd) factor of dS is applied once to dK at the end)
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * t2 + ii;
+        const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
+        const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+        f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP[1] = {f32x4{-d4.x, -d4.y, -d4.z, -d4.w}};   // (rows = queries: the chain starts from -delta[q])
+        first_stage_block_r<T, HD, 1>(S, Qc, kf, i, l);      // S[q][kv]: rows q (registers), col kv (lane)
+        first_stage_block_r<T, HD, 1>(dP, dOc, vf, i, l);    // dP[q][kv] - delta[q]
+        if (!fullt) mask_tile<false>(S[0], q0s + cur * 64, q1s + cur * 64, 16 * i, akv, 0, g, -1e30f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = fexp2(fmaf(S[0][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
+          P2[0][ii][r] = pv;
+          dS2[0][ii][r] = pv * dP[0][r];   // (the 1/sqrt(hd) factor of dS is applied once to dK at the end)
+        }
       }
+      acc_second_stage_half_r<T, HD, 1>(dV, P2, dOc, t2, l);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
+      acc_second_stage_half_r<T, HD, 1>(dK, dS2, Qc, t2, l);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
     }
-    acc_second_stage<T, HD>(dV, S, dOc, l);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
-    acc_second_stage<T, HD>(dK, dP, Qc, l);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
     }
     if (nxt < end) lstore(cur ^ 1);
     __syncthreads();
@@ -697,12 +747,12 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
   T* Os = Qs;
 #pragma unroll
-  for (int j = 0; j < HD / 16; ++j) dK[j] *= scale;
-  store_grad_tile<T, HD>(dK, true, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  for (int j = 0; j < HD / 16; ++j) dK[0][j] *= scale;
+  store_grad_tile<T, HD>(dK[0], true, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
   copy_out_tile<T, HD>(Os, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 1 : nullptr);
   __syncthreads();
-  store_grad_tile<T, HD>(dV, false, p.rope_cos, p.rope_sin, pos, Os, w, l);
+  store_grad_tile<T, HD>(dV[0], false, p.rope_cos, p.rope_sin, pos, Os, w, l);
   __syncthreads();
   copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
 }
@@ -787,32 +837,38 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     const T* Kc = Ks + cur * C::TILE;
     const T* Vc = Vs + cur * C::TILE;
     if ((wbits >> kt) & 1u) {
-    f32x4 S[R][4], dP[R][4];
-    first_stage_r<T, HD, R>(S, Kc, qf, l);      // S^T[kv][q]
-    first_stage_r<T, HD, R>(dP, Vc, dof, l);    // dP^T[kv][q]
-    if (!((fullbits >> kt) & 1u)) {   // one predicate per score position, applied to every head (mask_tile)
+    const bool partial = !((fullbits >> kt) & 1u);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
-        const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int t2 = 0; t2 < 2; ++t2) {   // 32 keys at a time: both stages, two score blocks per head alive
+      f32x4 dS[R][2];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const bool ok = aa[rr] == aq0 || aa[rr] == aq;
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * t2 + ii;
+        f32x4 S[R], dP[R];
 #pragma unroll
-          for (int r = 0; r < R; ++r) S[r][i][rr] = ok ? S[r][i][rr] : -1e30f;
+        for (int r = 0; r < R; ++r) { S[r] = f32x4{0, 0, 0, 0}; dP[r] = f32x4{-dl[r], -dl[r], -dl[r], -dl[r]}; }
+        first_stage_block_r<T, HD, R>(S, Kc, qf, i, l);      // S^T[kv][q]
+        first_stage_block_r<T, HD, R>(dP, Vc, dof, i, l);    // dP^T[kv][q] - delta[q]
+        if (partial) {   // one predicate per score position, applied to every head (mask_tile)
+          const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
+          const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool ok = aa[rr] == aq0 || aa[rr] == aq;
+#pragma unroll
+            for (int r = 0; r < R; ++r) S[r][rr] = ok ? S[r][rr] : -1e30f;
+          }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float pv = fexp2(fmaf(S[r][rr], c2, -lse2[r]));
+            dS[r][ii][rr] = pv * dP[r][rr];   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
+          }
       }
+      acc_second_stage_half_r<T, HD, R>(dQ, dS, Kc, t2, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float pv = fexp2(fmaf(S[r][i][rr], c2, -lse2[r]));
-          dP[r][i][rr] = pv * (dP[r][i][rr] - dl[r]);   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
-        }
-    acc_second_stage_r<T, HD, R>(dQ, dP, Kc, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
     }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
