@@ -246,3 +246,54 @@ def test_row_sharded_table_is_bitwise_reproducible_too():
     with pytest.raises(ra.RsysError):
         c = dict(cfg, deterministic=True); c["table_shard"] = (0, 1); c["sampled_softmax"] = 8
         ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+
+
+def test_benchmark_size_attention_backward_is_bitwise_reproducible():
+    """rsys_op_attention at the benchmark's shape (64 rows of 1024 tokens, 8 heads on 4 kv heads, hd 64: the paired-head
+    kernels), sixteen times on the same operands: O, the log-sum-exp and dQ/dK/dV must come back identical every time.  The
+    kernels have no atomics, so anything else is a fault: in round 4 sixteen queries x one column of dQ came back with the
+    o2*cos product of the un-rotation missing about once per three launches, when the build still let the compiler pack that
+    arithmetic into v_pk_fma_f32 with a crossed low half (csrc/Makefile, profiles/r4_attn_dq_packed_f32_glitch.log)."""
+    import ctypes as C
+    from recommendersystem_amd import _lib, workload
+    lib = _lib.lib()
+    cfg = workload.make_config("cfg3")
+    B, S, H, KV = 64, cfg["max_sequence_length"], cfg["num_heads"], cfg["num_kv_heads"]
+    hd, T = cfg["embed_dim"] // H, 2 * S
+    d = workload.make_batch(cfg, B, 0xD47A, mu=4.6, sigma=1.0)
+    rng = np.random.default_rng(0)
+    uid = np.repeat(np.asarray(d["userid"], np.int32).reshape(-1), 2)
+    tm = np.repeat((np.asarray(d["token_mask_ids"]).reshape(-1) * (rng.random(B * S) < 0.1)).astype(np.int32), 2)
+    Nq = (H + 2 * KV) * hd
+    held = []
+
+    def dev(a):
+        p = C.c_void_p()
+        _lib.check(lib.rsys_dev_alloc(C.byref(p), a.nbytes))
+        lib.rsys_dev_h2d(p, a.ctypes.data, a.nbytes)
+        held.append(p)
+        return p
+
+    bf = lambda a: (np.ascontiguousarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    qkv, dO = dev(bf(rng.standard_normal((B * T, Nq)))), dev(bf(rng.standard_normal((B * T, H * hd))))
+    d_uid, d_tm = dev(uid), dev(tm)
+    ang = np.outer(np.arange(T, dtype=np.float32), 1.0 / (500000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd)))
+    cos, sin = dev(np.cos(ang).astype(np.float32)), dev(np.sin(ang).astype(np.float32))
+    O, dq, lse = dev(np.zeros((B * T, H * hd), np.uint16)), dev(np.zeros((B * T, Nq), np.uint16)), dev(np.zeros((B, H, T), np.float32))
+    first = None
+    try:
+        for rep in range(16):
+            _lib.check(lib.rsys_op_attention(1, B, T, H, KV, hd, qkv, d_uid, d_tm, O, lse, dO, dq, cos, sin))
+            got = [np.empty((B * T, H * hd), np.uint16), np.empty((B * T, Nq), np.uint16), np.empty((B, H, T), np.float32)]
+            for a, p in zip(got, (O, dq, lse)):
+                lib.rsys_dev_d2h(a.ctypes.data, p, a.nbytes)
+            if first is None:
+                first = got
+                assert np.abs(got[2]).max() > 0 and (got[1] != 0).any()
+                continue
+            for name, a, b in zip(("O", "dqkv", "lse"), first, got):
+                bad = np.argwhere(a != b)
+                assert len(bad) == 0, f"launch {rep}: {name} differs from launch 0 in {len(bad)} elements, first at {bad[0].tolist()}"
+    finally:
+        for p in held:
+            lib.rsys_dev_free(p)
