@@ -335,6 +335,24 @@ int launch_f8_amax(const F8Cast& c, hipStream_t s) {
   return RSYS_OK;
 }
 
+__global__ __launch_bounds__(256) void round_bf16_accum_kernel(float4* __restrict__ stage, float4* __restrict__ dst, long long n4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = stage[i];
+    float4 d = dst[i];
+    d.x += (float)(bf16)v.x; d.y += (float)(bf16)v.y; d.z += (float)(bf16)v.z; d.w += (float)(bf16)v.w;
+    dst[i] = d;
+    stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+int launch_round_bf16_accum(float* stage, float* dst, long long n, hipStream_t s) {
+  if (n <= 0) return RSYS_OK;
+  ARG_CHECK(n % 4 == 0 && ((uintptr_t)stage | (uintptr_t)dst) % 16 == 0, "round_bf16_accum: n % 4 == 0 and 16-byte aligned buffers");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(round_bf16_accum_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, (float4*)stage, (float4*)dst, n4);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   ARG_CHECK(c.cols % 16 == 0 && c.rows > 0 && c.ld_dst % 16 == 0, "fp8 cast: columns in groups of 16");
   ARG_CHECK(c.layout != F8_LAYOUT_SEGS || (c.seg_cols % 16 == 0 && c.cols % c.seg_cols == 0 && c.seg_rep >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) >= 1 && f8_nseg(c.cols, c.layout, c.seg_cols, c.seg_rep) <= 4), "fp8 cast: at most 4 column segments");

@@ -260,6 +260,8 @@ struct F8Cast {
   float* desc_dw; const float* xamax; int dw_units;
 };
 int launch_f8_amax(const F8Cast& c, hipStream_t s);
+// dst[i] += float(bf16(stage[i])); stage[i] = 0   (n % 4 == 0, both 16-byte aligned)
+int launch_round_bf16_accum(float* stage, float* dst, long long n, hipStream_t s);
 int launch_f8_cast(const F8Cast& c, hipStream_t s);
 struct F8WeightJob {
   const float* src; long long ld; int rows, cols;   // fp32 master [rows][cols]

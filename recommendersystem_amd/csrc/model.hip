@@ -405,6 +405,12 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
         DALLOC(t.gxt, D * NT); DALLOC(t.dab, (int64_t)2 * Ip * NT); DALLOC(t.dht, D * NT); DALLOC(t.dqkv, (int64_t)m->Nqkv * NT);
       }
       DALLOC(m->f8_desc_dw, L * 4 * 32 * 4);
+      if (getenv("RSYS_F8_DW_ROUND_BF16") && atoi(getenv("RSYS_F8_DW_ROUND_BF16")) != 0) {
+        m->f8_dw_stage_base = m->lo[0].wqkv;
+        const int64_t n = m->lo[L - 1].w2 + pad8((int64_t)D * Ip) - m->f8_dw_stage_base;
+        DALLOC(m->f8_dw_stage, n * 4);
+        HIP_CHECK(hipMemset(m->f8_dw_stage, 0, n * 4));
+      }
     }
     if (getenv("RSYS_F8_DEBUG_KEEP") && atoi(getenv("RSYS_F8_DEBUG_KEEP")) != 0) {   // stage-wise parity tests of the backward products
       m->f8_keep.assign((size_t)L * 3, nullptr);
@@ -965,13 +971,21 @@ static GemmParams f8_dw_params(Model* m, int l, int k, int NT) {
   GemmParams p{};
   p.lda = p.ldb = m->f8_ldt; p.K = NT; p.c_f32 = 1; p.epi = EPI_ATOMIC; p.alpha = 1.f; p.f8 = 2;
   p.f8_desc = m->f8_desc_dw + (l * 4 + k) * 32;
+  float* G = m->f8_dw_stage ? m->f8_dw_stage - m->f8_dw_stage_base : m->G;   // (staged: f8_dw_round_accum moves it to the gradient)
   switch (k) {
-    case 0: p.A = t.gxt; p.B = t.g; p.C = m->G + m->lo[l].w2; p.ldc = Ip; p.M = D; p.N = Ip; break;
-    case 1: p.A = t.dab; p.B = t.hn; p.C = m->G + m->lo[l].w13; p.ldc = D; p.M = 2 * Ip; p.N = D; p.f8_rseg = Ip; p.f8_rowmode = 1; break;
-    case 2: p.A = t.dht; p.B = t.O; p.C = m->G + m->lo[l].wo; p.ldc = D; p.M = D; p.N = D; break;
-    default: p.A = t.dqkv; p.B = t.xn; p.C = m->G + m->lo[l].wqkv; p.ldc = D; p.M = m->Nqkv; p.N = D; p.f8_rseg = m->KV * m->hd; break;
+    case 0: p.A = t.gxt; p.B = t.g; p.C = G + m->lo[l].w2; p.ldc = Ip; p.M = D; p.N = Ip; break;
+    case 1: p.A = t.dab; p.B = t.hn; p.C = G + m->lo[l].w13; p.ldc = D; p.M = 2 * Ip; p.N = D; p.f8_rseg = Ip; p.f8_rowmode = 1; break;
+    case 2: p.A = t.dht; p.B = t.O; p.C = G + m->lo[l].wo; p.ldc = D; p.M = D; p.N = D; break;
+    default: p.A = t.dqkv; p.B = t.xn; p.C = G + m->lo[l].wqkv; p.ldc = D; p.M = m->Nqkv; p.N = D; p.f8_rseg = m->KV * m->hd; break;
   }
   return p;
+}
+// RSYS_F8_DW_ROUND_BF16: gradient[lo, hi) += bf16(staged product sums), stage back to zero (layers l_lo .. l_hi: their four weight
+// tensors are contiguous, layers ascending)
+static int f8_dw_round_accum(Model* m, int l_lo, int l_hi) {
+  if (!m->f8_dw_stage) return RSYS_OK;
+  const int64_t lo = m->lo[l_lo].wqkv, hi = m->lo[l_hi].w2 + pad8((int64_t)m->D * m->Ip);
+  return launch_round_bf16_accum(m->f8_dw_stage + (lo - m->f8_dw_stage_base), m->G + lo, hi - lo, m->stream);
 }
 static inline bool use_f8_dw(const Model* m) { return m->f8_dw && !m->deterministic && m->cur_rows * 2 * m->S % 128 == 0; }
 // one product at a time (layers whose products are large enough alone: the production shape)
@@ -1609,6 +1623,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
   if (m->timer.enabled) tic(m, f8 ? "gemm_dw_group@8gf" : "gemm_dw_group@8g", gemm8p_group_flops(it->second));
   int rc = launch_gemm8p_group(it->second, m->stream);
   toc(m);
+  if (rc == RSYS_OK && f8) rc = f8_dw_round_accum(m, l_lo, l_hi);
   return rc;
 }
 
@@ -1802,6 +1817,7 @@ static int backward_trunk(Model* m) {
     toc(m);
     std::swap(gx, gx_other);
     std::swap(gxt, gxt_other);
+    if (f8dw && !defer && !ft) RC(f8_dw_round_accum(m, l, l));   // (the layer's four products were launched one by one above)
     if (defer && !m->grad_bucket_hook && l == 0) RC(grouped_weight_grads<T>(m, 0, m->L - 1));   // all layers' products in one launch
     if (m->grad_bucket_hook && !ft) {
       // weight gradients of layers l .. bucket_top are final (the four tensors of a layer are contiguous, layers ascending)

@@ -100,6 +100,11 @@ struct Model {
   std::vector<F8T> f8t;
   float* f8_desc_dw = nullptr;    // [L][4 products: w2 w13 o qkv][32]: row descales of the weight-gradient products
   int64_t f8_ldt = 0;             // row stride of the transposed copies (tokens of a full batch)
+  // RSYS_F8_DW_ROUND_BF16=1: every fp8 weight-gradient product is summed (fp32, all its split-K parts) into dw_stage, rounded to
+  // bf16 once and only then added to the fp32 gradient -- what autograd does under autocast, where the product's output tensor is
+  // bf16 and param.grad is fp32.  Default: the fp32 sum goes to the gradient unrounded.
+  float* f8_dw_stage = nullptr;   // [trunk weights of all layers], zero between products
+  int64_t f8_dw_stage_base = 0;   // offset (in the flat buffers) of its first element
   std::vector<void*> f8_keep;     // RSYS_F8_DEBUG_KEEP=1 (tests): per layer, copies of the three dx products' outputs (w13_dx, o_dx, qkv_dx)
   bool table_dirty = true;     // the fused item table F / FT must be rebuilt before the next forward: set by everything that changes a
                                // parameter or the metadata, and by the table-gradient pass (it borrows FT); clean between the

@@ -317,6 +317,45 @@ def test_fp8_partial_batch_equals_a_model_sized_for_it():
     assert worst < 1e-4, worst      # (split-K atomics: summation order only)
 
 
+def test_fp8_weight_gradients_rounded_to_bf16_before_the_accumulate(monkeypatch):
+    """RSYS_F8_DW_ROUND_BF16=1 (what autograd does under autocast -- the product's output tensor is bf16, param.grad fp32):
+    each weight-gradient product is summed over all its split-K parts in fp32, rounded to bf16 ONCE and then added to the gradient.
+    After one pass from zero gradients every trunk weight gradient is a bf16 number, namely the rounding of the default mode's; a
+    second pass without zero_grad adds a second rounded product (gradient accumulation) instead of re-rounding the sum."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    P = synth.make_params(cfg, 23, "test")
+    d = synth.make_batch(cfg, 4, 24); mk = synth.make_masks(cfg, 4, 25)
+    names = [n for n in synth.trainable_names(cfg) if "transformers.layers" in n]
+    mats = [n for n in names if any(k in n for k in ("q_proj", "k_proj", "v_proj", "output_proj", "w1", "w2", "w3"))]
+    assert len(mats) == 7 * cfg["num_layers"], mats
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RSYS_F8_DW_ROUND_BF16", flag)
+        model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=4)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        model(d, False, masks=mk)
+        once = {n: model.grad(n).copy() for n in names}
+        model(d, False, masks=mk)
+        twice = {n: model.grad(n).copy() for n in names}
+        res[flag] = (once, twice)
+        model.close()
+    (g0, g0b), (g1, g1b) = res["0"], res["1"]
+    is_bf16 = lambda a: bool(((np.ascontiguousarray(a, np.float32).view(np.uint32) & 0xFFFF) == 0).all())
+    for n in mats:
+        assert is_bf16(g1[n]), n
+        assert not is_bf16(g0[n]), n                       # (so the check above is not vacuous)
+        tol = 2.0 ** -8 * np.abs(g0[n]) + 1e-5 * np.abs(g0[n]).max()   # half a bf16 step + the split-K summation order
+        assert (np.abs(g1[n] - g0[n]) <= tol).all(), (n, float(np.abs(g1[n] - g0[n]).max()))
+        # accumulation: a second rounded product on top of the first (the sum of two bf16 numbers need not be one)
+        assert np.abs(g1b[n] - 2 * g1[n]).max() <= 2.0 ** -7 * np.abs(g1[n]).max(), n
+    for n in names:
+        if n not in mats:                                  # norm weights: not products of the fp8 linears, untouched by the switch
+            assert np.allclose(g1[n], g0[n], rtol=1e-4, atol=1e-6 * np.abs(g0[n]).max()), n
+
+
 def test_fp8_data_parallel_buckets_on_two_concurrent_ranks():
     """the fp8 trunk behind the data-parallel all-reduce with early gradient buckets (in-process rank group): the grouped fp8
     weight-gradient launches run per bucket; every rank ends with the sum of the two ranks' own gradients"""
