@@ -120,7 +120,7 @@ int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
 int32_t rsys_item_table(rsys_model* m, float* out, int64_t n);
 /* on != 0: every float sum of the training step gets a fixed order (split-K partial tiles summed in split order, reductions through
  * per-workgroup partials instead of float atomics), so a step -- losses, gradients, updated parameters -- is bitwise reproducible
- * from run to run; costs a few percent of the step.  Replicated or row-sharded table with the full soft-max (not the sampled one).  (The reference's CUDA path is not reproducible:
+ * from run to run; costs a few percent of the step.  Replicated or row-sharded table, full or sampled soft-max.  (The reference's CUDA path is not reproducible:
  * its embedding backward and split-K reductions use atomics too.) */
 int32_t rsys_model_set_deterministic(rsys_model* m, int32_t on);
 /* inference forward -- model.py:531-538; task 0 = retrieval (out: rows*2S*D), 1 = ranking (out: rows*2S) */

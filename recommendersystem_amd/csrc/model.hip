@@ -778,8 +778,6 @@ static int det_slab_for(Model* m, long long need, GemmParams& p) {
   return RSYS_OK;
 }
 int model_set_deterministic(Model* m, int on) {
-  ARG_CHECK(!on || !m->sharded || m->cfg.sampled_negatives == 0,
-            "deterministic mode covers the full soft-max (replicated or row-sharded table); the sampled soft-max's target-class gradients use float atomics");
   HIP_CHECK(hipSetDevice(m->device));
   if (on && m->det_part == nullptr) {
     const long long KB = (long long)m->K * m->rows_max;

@@ -153,7 +153,7 @@ struct Model {
   bool tok_index_valid = false;
   // deterministic mode (rsys_model_set_deterministic): every float sum of the step has a fixed order -- split-K partial tiles go
   // to det_slab and are added in split order, the reduction kernels write per-workgroup partials to det_part (kernels.hpp
-  // DetScratch) -- so a step is bitwise reproducible; replicated item table only
+  // DetScratch) -- so a step is bitwise reproducible (replicated or row-sharded table, full or sampled soft-max)
   bool deterministic = false;
   float* det_slab = nullptr; long long det_slab_floats = 0;
   float* det_part = nullptr; long long det_part_floats = 0;

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl
                                                         const float* __restrict__ metaC, const float* __restrict__ gmax,
                                                         const float* __restrict__ sneg, const float* __restrict__ tl,
                                                         const int* __restrict__ nlive, const int* __restrict__ pre, int rank,
-                                                        float* loss_out, float* dt) {
+                                                        float* loss_out, float* dt, float* part) {
   const int row = blockIdx.x, t = threadIdx.x;
   if (row >= ((*nlive + 255) & ~255)) return;
   T* lr = logits + (long long)row * ldl;
@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void ss_finish_kernel(T* logits, long long ldl
   const int tgt = __float_as_int(metaC[4LL * row]) - col0;
   if (t == 0) {
     dt[row] = coef * (__expf(tl[row] - lse) - 1.f);
-    if (row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) atomicAdd(loss_out, (lse - tl[row]) * lw);
+    if (row >= pre[rank] && row < pre[rank + 1] && lw != 0.f) {
+      if (part != nullptr) part[row] = (lse - tl[row]) * lw;   // deterministic mode: the rows' terms are added in row order afterwards
+      else atomicAdd(loss_out, (lse - tl[row]) * lw);
+    }
   }
   for (int c = t; c < (int)ldl; c += 256) {
     float g = 0.f;
@@ -490,6 +493,45 @@ __global__ void ss_target_grad_kernel(const T* __restrict__ EwC, const T* __rest
   const T* a = EwC + (long long)row * D; const T* b = Floc + (long long)tgt * D;
   float* gf = gE_loc + (long long)tgt * D; float* ge = dEwC + (long long)row * D;
   for (int c = l; c < D; c += 64) { atomicAdd(&gf[c], g * to_f32(a[c])); ge[c] += g * to_f32(b[c]); }
+}
+
+// The same without atomics (deterministic mode): the FIRST live row of a target class adds the terms of all rows that share it, in
+// row order, and is the only writer of that class's gradient row; every row still adds its own d(selected row).  One wave per live
+// row; the lanes sweep the row list 64 at a time (a compare and a ballot per 64 rows), D <= 64 * DMAX.
+template <typename T, int DMAX>
+__global__ void ss_target_grad_ordered_kernel(const T* __restrict__ EwC, const T* __restrict__ Floc, int D, int len, int col0,
+                                              const float* __restrict__ metaC, const float* __restrict__ dt, const int* __restrict__ nlive,
+                                              float* gE_loc, float* dEwC) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  const int n = *nlive;
+  if (row >= n) return;
+  const int tgt = __float_as_int(metaC[4LL * row]) - col0;
+  if (tgt < 0 || tgt >= len) return;
+  const float g = dt[row];
+  const T* b = Floc + (long long)tgt * D;
+  if (g != 0.f) { float* ge = dEwC + (long long)row * D; for (int c = l; c < D; c += 64) ge[c] += g * to_f32(b[c]); }
+  for (int r0 = 0; r0 < row; r0 += 64) {   // an earlier row with this target: that one adds for all of them
+    const int r = r0 + l;
+    if (__ballot(r < row && __float_as_int(metaC[4LL * r]) - col0 == tgt) != 0ull) return;
+  }
+  float acc[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) acc[k] = 0.f;
+  for (int r0 = row & ~63; r0 < n; r0 += 64) {
+    const int r = r0 + l;
+    unsigned long long hit = __ballot(r >= row && r < n && __float_as_int(metaC[4LL * r]) - col0 == tgt);
+    while (hit != 0ull) {
+      const int rr = r0 + __ffsll((long long)hit) - 1;
+      hit &= hit - 1;
+      const float gr = dt[rr];
+      const T* a = EwC + (long long)rr * D;
+#pragma unroll
+      for (int k = 0; k < DMAX; ++k) { const int c = l + 64 * k; if (c < D) acc[k] += gr * to_f32(a[c]); }
+    }
+  }
+  float* gf = gE_loc + (long long)tgt * D;
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) { const int c = l + 64 * k; if (c < D) gf[c] += acc[k]; }
 }
 
 template <typename T>
@@ -519,15 +561,24 @@ template <typename T>
 int launch_ss_finish(T* logits, long long ldl, int n_s, int n_tot, int len, int col0, const int* cols, const float* metaC, const float* gmax,
                      const float* sneg, const float* tl, const int* nlive, const int* pre, int rank, float* loss_out,
                      float* dt, int grid_rows, hipStream_t s) {
+  float* part = g_det.part != nullptr && (long long)grid_rows <= g_det.cap ? g_det.part : nullptr;   // deterministic mode (kernels.hpp DetScratch)
+  if (g_det.part != nullptr && part == nullptr) { set_error("sampled soft-max: deterministic scratch too small"); return RSYS_ERR_STATE; }
+  if (part != nullptr) HIP_CHECK(hipMemsetAsync(part, 0, (size_t)grid_rows * 4, s));   // (rows without a term write nothing)
   hipLaunchKernelGGL((ss_finish_kernel<T>), dim3(grid_rows), dim3(256), 0, s, logits, ldl, n_s, n_tot, len, col0, cols, metaC, gmax, sneg, tl,
-                     nlive, pre, rank, loss_out, dt);
+                     nlive, pre, rank, loss_out, dt, part);
   HIP_CHECK(hipGetLastError());
+  if (part != nullptr) return launch_reduce_parts(part, grid_rows, 1, 1, loss_out, s);
   return RSYS_OK;
 }
 template <typename T>
 int launch_ss_target_grad(const T* EwC, const T* Floc, int D, int len, int col0, const float* metaC, const float* dt, const int* nlive,
                           float* gE_loc, float* dEwC, int grid_rows, hipStream_t s) {
-  hipLaunchKernelGGL((ss_target_grad_kernel<T>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, dt, nlive, gE_loc, dEwC);
+  if (g_det.part != nullptr) {   // deterministic mode
+    ARG_CHECK(D <= 64 * 32, "sampled soft-max, deterministic mode: embed_dim <= 2048");
+    if (D <= 64 * 8) hipLaunchKernelGGL((ss_target_grad_ordered_kernel<T, 8>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, dt, nlive, gE_loc, dEwC);
+    else hipLaunchKernelGGL((ss_target_grad_ordered_kernel<T, 32>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, dt, nlive, gE_loc, dEwC);
+  } else
+    hipLaunchKernelGGL((ss_target_grad_kernel<T>), dim3(div_up(grid_rows, 4)), dim3(256), 0, s, EwC, Floc, D, len, col0, metaC, dt, nlive, gE_loc, dEwC);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }

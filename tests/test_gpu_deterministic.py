@@ -88,7 +88,7 @@ def test_fused_clip_adamw_equals_the_separate_passes_bit_for_bit():
     assert worst <= 1e-6, worst
 
 
-def test_deterministic_finetune_step_and_sampled_softmax_refusal():
+def test_deterministic_finetune_step():
     import recommendersystem_amd as ra
     from oracle import synth
     cfg = synth.make_config("hd64", mask_rate=0.2, finetune=True, finetune_metric="rating")
@@ -99,8 +99,6 @@ def test_deterministic_finetune_step_and_sampled_softmax_refusal():
     a = _three_steps(cfg, P, batches, masks, "bf16", True)
     b = _three_steps(cfg, P, batches, masks, "bf16", True)
     assert _bitwise(a, b)
-    with pytest.raises(Exception):       # (the sampled soft-max keeps float atomics on shared target rows; the full one is covered below)
-        ra.RecommenderModel(dict(synth.make_config("hd64"), table_shard=(0, 1), sampled_softmax=8, deterministic=True), dtype="bf16", max_rows=2)
 
 
 def test_benchmark_size_steps_are_bitwise_reproducible():
@@ -187,11 +185,14 @@ def test_data_parallel_step_on_two_concurrent_ranks_is_bitwise_reproducible():
             assert np.array_equal(a[r][2][n], a[0][2][n]), (r, n)      # and the ranks agree with each other
 
 
-def test_row_sharded_table_is_bitwise_reproducible_too():
-    """Deterministic mode on the row-sharded table (full soft-max): the vocabulary-parallel heads sum their loss terms in row order,
-    their split-K gradient goes through ordered slabs, the row exchange adds requester by requester and the in-process group
-    reduces in rank order -- two runs of two optimizer steps on two concurrent ranks end with the same bits on every rank.  The
-    sampled soft-max (float atomics on shared target rows) is still refused."""
+@pytest.mark.parametrize("sampled", [0, 24])
+def test_row_sharded_table_is_bitwise_reproducible_too(sampled):
+    """Deterministic mode on the row-sharded table: the vocabulary-parallel heads sum their loss terms in row order, their split-K
+    gradient goes through ordered slabs, the row exchange adds requester by requester and the in-process group reduces in rank
+    order -- two runs of two optimizer steps on two concurrent ranks end with the same bits on every rank.  sampled > 0: the
+    sampled soft-max, whose target-class gradient rows (shared by the rows with the same target) are then added by the first such
+    row in row order (ss_target_grad_ordered_kernel) instead of by float atomics; a third run in the default mode shows that the
+    ordered form computes the same gradients up to the order of the sums."""
     import threading
 
     import recommendersystem_amd as ra
@@ -205,14 +206,16 @@ def test_row_sharded_table_is_bitwise_reproducible_too():
     masks = [[synth.make_masks(cfg, rows, 50 + 10 * r + i) for i in range(2)] for r in range(world)]
     names = synth.trainable_names(cfg)
 
-    def run():
+    def run(deterministic=True):
         group = rdist.LocalGroup(world)
         out = [None] * world; err = [None] * world
 
         def rank(r):
             try:
                 comm = rdist.LocalComm(group, r)
-                c = dict(cfg, deterministic=True); c["table_shard"] = (r, world)
+                c = dict(cfg, deterministic=deterministic); c["table_shard"] = (r, world)
+                if sampled:
+                    c["sampled_softmax"] = sampled
                 m = ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
                 m.set_shard_comm(comm)
                 lo, hi = m.table_rows()
@@ -243,9 +246,21 @@ def test_row_sharded_table_is_bitwise_reproducible_too():
     a, b = run(), run()
     for r in range(world):
         assert _bitwise(a[r], b[r]), r
-    with pytest.raises(ra.RsysError):
-        c = dict(cfg, deterministic=True); c["table_shard"] = (0, 1); c["sampled_softmax"] = 8
-        ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+    if sampled:
+        c = run(deterministic=False)
+        shared = 0
+        for r in range(world):
+            for (la, ga), (lc, gc) in zip(a[r][0], c[r][0]):
+                assert np.allclose(la, lc, rtol=2e-3), (la, lc)
+                for n in names:
+                    assert np.abs(ga[n] - gc[n]).max() <= 2e-2 * max(np.abs(gc[n]).max(), 1e-6), n
+        for i in range(2):         # (and the case the ordered kernel exists for did occur: live rows that share a watch target)
+            for med in (0, 1):
+                lab = np.concatenate([np.asarray(batches[r][i][f"{med}.watch.label"]).reshape(-1) for r in range(world)])
+                wgt = np.concatenate([np.asarray(batches[r][i][f"{med}.watch.weight"]).reshape(-1) for r in range(world)])
+                live = lab[wgt > 0]
+                shared += int(len(live) - len(np.unique(live)))
+        assert shared > 0
 
 
 def test_benchmark_size_attention_backward_is_bitwise_reproducible():
