@@ -51,7 +51,11 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
 template <typename T> struct AMma;
 template <> struct AMma<bf16> {
   static constexpr int KS = 32;   // contraction per MFMA
-  static constexpr int PAD = 8;
+  // rows of 64 + 16 elements = 160 bytes: by the guide's lane groups the natural ds_read_b128 fragments and both ds_read_b64_tr_b16
+  // reads of a transposed fragment are then free of bank conflicts (144-byte rows: 2x the cycles on both; 224-byte rows are free of
+  // them too but cost a workgroup per CU).  Measured on one box: dK/dV 311 -> 302 us, forward and dQ unchanged -- the kernels wait on
+  // dependencies, not on the LDS array (profiles/r4_ab_attn_lds_row_padding.log).
+  static constexpr int PAD = 16;
   using Frag = bf16x8;
   static __device__ __forceinline__ Frag zero() { Frag f; for (int i = 0; i < 8; ++i) f[i] = (bf16)0.f; return f; }
   static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -344,6 +348,63 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   if (t < 4) p.qmap16[(b * nt + qt) * 4 + t] = any16[t];
 }
 
+// Heaviest-first launch orders (AttnParams::order_q / order_k).  blockIdx.y = 0: the q-side kernels (work of a slot = kv tiles its
+// q tile visits; tiles beyond q_active: none), 1: the dK/dV kernel (q tiles its kv tile is visited by).  One workgroup per list of
+// attn_work (blockIdx.x = XCD, or the single list of the fallback); rank = slots with more work + equal ones before it (stable, so
+// the order is a function of the maps alone).
+static int attn_heads_per_wg(const AttnParams& p);
+__global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, int identity) {
+  extern __shared__ int ocnt[];   // [chunks of 64 slots + 1][34]: slots per (chunk, key), then their exclusive prefixes; last row: totals / bases
+  const int side = blockIdx.y, nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
+  const int n_inner = side == 0 ? (p.H / p.KV / R) * nt : nt;
+  int* out = side == 0 ? p.order_q : p.order_k;
+  if (out == nullptr) return;
+  const bool lists = (n_groups & 7) == 0;
+  const int ns = lists ? (n_groups >> 3) * n_inner : n_groups * n_inner, xcd = blockIdx.x;
+  if (!lists && xcd > 0) return;
+  out += lists ? xcd * ns : 0;
+  if (identity) { for (int sl = threadIdx.x; sl < ns; sl += 256) out[sl] = sl; return; }
+  const int nch = (ns + 63) >> 6, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  auto key_of = [&](int sl) -> int {
+    if (sl >= ns) return 33;   // (padding of the last chunk: a key of its own)
+    const int group = lists ? (sl / n_inner) * 8 + xcd : sl / n_inner, tile = (sl % n_inner) % nt, b = group / p.KV;
+    const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
+    if (side == 0) return tile < qa ? __popc(p.qmap[b * nt + tile]) : 0;
+    return __popc(p.kmap[b * nt + tile] & (qa >= 32 ? ~0u : ((1u << qa) - 1u)));
+  };
+  auto same_key = [&](int k) -> unsigned long long {   // lanes of this wave that hold the same key
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) { const unsigned long long bb = __ballot((k >> bit) & 1); m &= ((k >> bit) & 1) ? bb : ~bb; }
+    return m;
+  };
+  for (int i = threadIdx.x; i < (nch + 1) * 34; i += 256) ocnt[i] = 0;
+  __syncthreads();
+  for (int c = w; c < nch; c += 4) {
+    const int k = key_of(c * 64 + l);
+    const unsigned long long m = same_key(k);
+    if ((m & ((1ull << l) - 1ull)) == 0ull) ocnt[c * 34 + k] = __popcll(m);   // (the first lane of each key of the chunk)
+  }
+  __syncthreads();
+  if (threadIdx.x < 34) {
+    const int k = threadIdx.x;
+    int run = 0;
+    for (int c = 0; c < nch; ++c) { const int n = ocnt[c * 34 + k]; ocnt[c * 34 + k] = run; run += n; }
+    ocnt[nch * 34 + k] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // heaviest first: the base of key k = slots with a larger key
+    int acc = 0;
+    for (int k = 32; k >= 0; --k) { const int n = ocnt[nch * 34 + k]; ocnt[nch * 34 + k] = acc; acc += n; }
+  }
+  __syncthreads();
+  for (int c = w; c < nch; c += 4) {
+    const int sl = c * 64 + l, k = key_of(sl);
+    const unsigned long long m = same_key(k);
+    if (sl < ns) out[ocnt[nch * 34 + k] + ocnt[c * 34 + k] + __popcll(m & ((1ull << l) - 1ull))] = sl;
+  }
+}
+
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
   const size_t bytes = sizeof(unsigned int) * p.B * ((p.T + 63) / 64);
@@ -356,6 +417,12 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipMemsetAsync(p.kmap16, 0, bytes * 4, s));
   }
   hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
+  if (p.order_q != nullptr || p.order_k != nullptr) {
+    const int R = attn_heads_per_wg(p), nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
+    const int ns_max = ((n_groups & 7) == 0 ? (n_groups >> 3) : n_groups) * (p.H / p.KV) * nt;
+    // (a list beyond one workgroup's LDS: keep the plain order -- the kernels read an identity permutation)
+    hipLaunchKernelGGL(attn_order_kernel, dim3((n_groups & 7) == 0 ? 8 : 1, 2), dim3(256), (size_t)(std::min((ns_max + 63) / 64, 400) + 1) * 34 * 4, s, p, R, (ns_max + 63) / 64 > 400 ? 1 : 0);
+  }
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
@@ -386,15 +453,20 @@ __device__ __forceinline__ void mask_tile(f32x4& S, const int* ks, const int* ks
 // (row, kv head) group read the same K/V (forward, dQ) or Q/dO (dK/dV) tiles, so a group is kept on ONE XCD: its tiles
 // are fetched from HBM once instead of once per XCD (rocprofv3 FETCH_SIZE: 2.9x the algorithmic bytes before).
 // 1-D grid of n_groups * n_inner workgroups; falls back to the plain order when n_groups is not a multiple of 8.
-__device__ __forceinline__ void attn_work(int n_groups, int n_inner, int& group, int& inner) {
+// order (optional): per XCD list (or one list in the fallback) the slots sorted heaviest first (attn_order_kernel): workgroups are
+// dispatched in blockIdx order, so the long ones start first and the short ones fill the tail of the launch.
+__device__ __forceinline__ void attn_work(int n_groups, int n_inner, const int* __restrict__ order, int& group, int& inner) {
   const int bid = blockIdx.x;
   if ((n_groups & 7) == 0) {
-    const int xcd = bid & 7, slot = bid >> 3;
+    const int xcd = bid & 7;
+    int slot = bid >> 3;
+    if (order != nullptr) slot = order[xcd * ((n_groups >> 3) * n_inner) + slot];
     group = (slot / n_inner) * 8 + xcd;
     inner = slot % n_inner;
   } else {
-    group = bid / n_inner;
-    inner = bid % n_inner;
+    const int slot = order != nullptr ? order[bid] : bid;
+    group = slot / n_inner;
+    inner = slot % n_inner;
   }
 }
 
@@ -445,7 +517,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   int* ak = (int*)(Vs + 2 * C::TILE);         // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
-  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, grp, inner);
+  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
   const int b = grp / p.KV, kvh = grp % p.KV, h0 = kvh * (p.H / p.KV) + (inner / nt) * R, qt = inner % nt;
   if (p.q_active != nullptr && qt >= p.q_active[b]) return;   // nobody reads this query tile's output (uniform: whole workgroup)
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
@@ -598,8 +670,16 @@ static int check_attn(const AttnParams& p, size_t esz) {
   return RSYS_OK;
 }
 
+// RSYS_ATTN_ORDER=0: plain launch order (A/B switch of the heaviest-first orders)
+static AttnParams attn_order_switch(const AttnParams& p0) {
+  static const bool on = !(getenv("RSYS_ATTN_ORDER") && atoi(getenv("RSYS_ATTN_ORDER")) == 0);
+  AttnParams p = p0;
+  if (!on) p.order_q = p.order_k = nullptr;
+  return p;
+}
 template <typename T>
-int launch_attn_fwd(const AttnParams& p, hipStream_t s) {
+int launch_attn_fwd(const AttnParams& p0, hipStream_t s) {
+  const AttnParams p = attn_order_switch(p0);
   int rc = check_attn(p, sizeof(T));
   if (rc) return rc;
   switch (p.hd) {
@@ -652,7 +732,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   int* q1s = q0s + 128;                         // [2][64] query keys
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   int grp, kvt;
-  attn_work(p.B * p.KV, nt, grp, kvt);
+  attn_work(p.B * p.KV, nt, p.order_k, grp, kvt);
   const int b = grp / p.KV, kvh = grp % p.KV;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
@@ -768,7 +848,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   int* ak = (int*)(Vs + 2 * C::TILE);    // [2][64] token keys of the staged K/V tile
   const int nt = (p.T + 63) / 64;
   int grp, inner;
-  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, grp, inner);
+  attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
   const int b = grp / p.KV, kvh = grp % p.KV, h0 = kvh * (p.H / p.KV) + (inner / nt) * R, qt = inner % nt;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
   const long long tok0 = (long long)b * p.T;
@@ -912,7 +992,8 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
 }
 
 template <typename T>
-int launch_attn_bwd(const AttnParams& p, hipStream_t s) {
+int launch_attn_bwd(const AttnParams& p0, hipStream_t s) {
+  const AttnParams p = attn_order_switch(p0);
   int rc = check_attn(p, sizeof(T));
   if (rc) return rc;
   ARG_CHECK(p.H / p.KV <= 8, "attention: at most 8 query heads per kv head");

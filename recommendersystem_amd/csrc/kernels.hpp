@@ -207,6 +207,10 @@ struct AttnParams {
   // fp8 trunk: sharded amax slots (common.hpp f8_amax_note) of what the kernels write -- forward: |O| -> [0]; backward: |dq| -> [0],
   // |dk| -> [1], |dv| -> [2]; nullptr: off
   float* f8_amax;
+  // optional: heaviest-first launch orders, written by launch_attn_tilemap from the maps (attn_order_kernel) and read by the kernels'
+  // blockIdx -> work mapping: order_q [B * H * ceil(T/64)] for the forward / dQ kernels (work = kv tiles of the q tile), order_k
+  // [B * KV * ceil(T/64)] for the dK/dV kernel (work = q tiles of the kv tile).  nullptr: plain order.
+  int *order_q, *order_k;
 };
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s);
 template <typename T> int launch_attn_fwd(const AttnParams& p, hipStream_t s);
