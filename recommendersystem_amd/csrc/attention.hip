@@ -756,24 +756,28 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   const unsigned int bits = p.kmap[b * nt + kvt] & act, fullbits = p.kmap_full[b * nt + kvt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.kmap16[(b * nt + kvt) * 4 + w]);   // q tiles that may see this wave's 16 keys
 
-  TileRegs<T, HD> rq, rdo;
-  float rl = 0.f, rd = 0.f; int ra = 0;
-  auto gload = [&](int it) {   // it = head-in-group * 32 + q tile
+  // Staging runs TWO items ahead of the arithmetic: an item's global loads have a whole iteration (one item of another workgroup's
+  // arithmetic would not cover their latency) before they are stored to LDS, and that store is in LDS one barrier before its use.
+  // Two register sets, used alternately (the loop below is unrolled by two so that each stays in fixed registers).
+  struct ItemRegs { TileRegs<T, HD> rq, rdo; float rl, rd; int ra; };
+  ItemRegs R0, R1;
+  R0.rl = R0.rd = R1.rl = R1.rd = 0.f; R0.ra = R1.ra = 0;
+  auto gload = [&](ItemRegs& r, int it) {   // it = head-in-group * 32 + q tile
     const int h = kvh * rep + (it >> 5), qt = it & 31;
     const int nv = min(64, p.T - qt * 64);
-    tile_load<T, HD>(rq, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
-    tile_load<T, HD>(rdo, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
+    tile_load<T, HD>(r.rq, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
+    tile_load<T, HD>(r.rdo, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
     if (t < 64) {
       const bool v = t < nv;
       const long long o = ((long long)b * p.H + h) * p.T + qt * 64 + (v ? t : 0);
-      rl = v ? p.lse[o] * LOG2E : 0.f; rd = v ? p.delta[o] : 0.f;
-      ra = v ? token_key(p.uid[tok0 + qt * 64 + t], p.tm[tok0 + qt * 64 + t]) : KEY_NO_Q;
+      r.rl = v ? p.lse[o] * LOG2E : 0.f; r.rd = v ? p.delta[o] : 0.f;
+      r.ra = v ? token_key(p.uid[tok0 + qt * 64 + t], p.tm[tok0 + qt * 64 + t]) : KEY_NO_Q;
     }
   };
-  auto lstore = [&](int buf) {
-    tile_store<T, HD>(rq, Qs + buf * C::TILE, t);
-    tile_store<T, HD>(rdo, dOs + buf * C::TILE, t);
-    if (t < 64) { lse2[buf * 64 + t] = rl; dls[buf * 64 + t] = rd; q0s[buf * 64 + t] = ra & ~4095; q1s[buf * 64 + t] = ra; }
+  auto lstore = [&](const ItemRegs& r, int buf) {
+    tile_store<T, HD>(r.rq, Qs + buf * C::TILE, t);
+    tile_store<T, HD>(r.rdo, dOs + buf * C::TILE, t);
+    if (t < 64) { lse2[buf * 64 + t] = r.rl; dls[buf * 64 + t] = -r.rd; q0s[buf * 64 + t] = r.ra & ~4095; q1s[buf * 64 + t] = r.ra; }   // (dls holds -delta: what the dP chains start from)
   };
   auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
     int hh = from >> 5, qt = from & 31;
@@ -786,11 +790,12 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   };
   const int end = rep * 32;
   int it = next_item(0), cur = 0;
-  if (it < end) { gload(it); lstore(0); }
+  int nxt = it < end ? next_item(it + 1) : end, nxt2 = nxt < end ? next_item(nxt + 1) : end;   // the items staged one and two ahead
+  if (it < end) { gload(R0, it); lstore(R0, 0); }
+  if (nxt < end) gload(R1, nxt);
   __syncthreads();
-  while (it < end) {
-    const int nxt = next_item(it + 1);
-    if (nxt < end) gload(nxt);
+  auto step = [&](ItemRegs& rload, const ItemRegs& rstore) {   // rstore holds item nxt; item nxt2 is loaded into rload
+    if (nxt2 < end) gload(rload, nxt2);
     const T* Qc = Qs + cur * C::TILE;
     const T* dOc = dOs + cur * C::TILE;
     if ((wbits >> (it & 31)) & 1u) {   // (nothing to add for a wave whose 16 keys no query of this tile may see)
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
         const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
         const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
-        f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP[1] = {f32x4{-d4.x, -d4.y, -d4.z, -d4.w}};   // (rows = queries: the chain starts from -delta[q])
+        f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP[1] = {f32x4{d4.x, d4.y, d4.z, d4.w}};   // (rows = queries: the chain starts from -delta[q])
         first_stage_block_r<T, HD, 1>(S, Qc, kf, i, l);      // S[q][kv]: rows q (registers), col kv (lane)
         first_stage_block_r<T, HD, 1>(dP, dOc, vf, i, l);    // dP[q][kv] - delta[q]
         if (!fullt) mask_tile<false>(S[0], q0s + cur * 64, q1s + cur * 64, 16 * i, akv, 0, g, -1e30f);
@@ -819,10 +824,15 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
       acc_second_stage_half_r<T, HD, 1>(dK, dS2, Qc, t2, l);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
     }
     }
-    if (nxt < end) lstore(cur ^ 1);
+    if (nxt < end) lstore(rstore, cur ^ 1);
     __syncthreads();
     cur ^= 1;
-    it = nxt;
+    it = nxt; nxt = nxt2; nxt2 = nxt2 < end ? next_item(nxt2 + 1) : end;
+  };
+  while (it < end) {
+    step(R0, R1);
+    if (it >= end) break;
+    step(R1, R0);
   }
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
   T* Os = Qs;
