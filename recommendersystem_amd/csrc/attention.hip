@@ -276,6 +276,41 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, HD>& r, T* dst, int
     if (c < N) *(uint4*)(dst + (c / CPR) * C::LDD + (c % CPR) * C::E) = r.v[k];
   }
 }
+// The same tile through a buffer descriptor: the per-thread byte offsets are loop invariant (TileOffs, computed once per kernel), the
+// tile's origin is a scalar offset, and rows past the end of the sequence come back as zeros from the descriptor's bounds check --
+// no per-load address arithmetic, predicate or zero fill in the staging loops, which are bound by instruction issue
+// (profiles/r4_attn_dkv_item_loop_phases.log).
+typedef __attribute__((ext_vector_type(4))) int at_i32x4;
+extern "C" __device__ at_i32x4 rsys_at_buffer_load_b128(at_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+extern "C" __device__ int rsys_at_buffer_load_b32(at_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+// base .. base + bytes is what a load may touch (wave-uniform); bytes < 2^31
+__device__ __forceinline__ at_i32x4 at_rsrc(const void* base, long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  at_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)((a >> 32) & 0xFFFFu));   // stride 0
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;                                                               // raw buffer, 32-bit data format
+  return r;
+}
+template <typename T, int HD> struct TileOffs { int v[(64 * HD * sizeof(T) / 16 + 255) / 256]; };
+template <typename T, int HD>
+__device__ __forceinline__ void tile_offsets(TileOffs<T, HD>& o, long long ld, int t) {
+  using C = ACfg<T, HD>;
+  constexpr int CPR = HD / C::E, N = 64 * CPR;
+#pragma unroll
+  for (int k = 0; k < (N + 255) / 256; ++k) {
+    const int c = t + 256 * k;
+    o.v[k] = c < N ? (int)(((c / CPR) * ld + (c % CPR) * C::E) * (long long)sizeof(T)) : 0x7FFFFFF0;   // (no chunk: out of every range, reads zeros)
+  }
+}
+template <typename T, int HD>
+__device__ __forceinline__ void tile_load_buf(TileRegs<T, HD>& r, at_i32x4 rsrc, const TileOffs<T, HD>& o, int soffset) {
+  using C = ACfg<T, HD>;
+  constexpr int N = 64 * (HD / C::E);
+#pragma unroll
+  for (int k = 0; k < (N + 255) / 256; ++k) r.v[k] = __builtin_bit_cast(uint4, rsys_at_buffer_load_b128(rsrc, o.v[k], soffset, 0));
+}
 template <typename T, int HD>
 __device__ __forceinline__ void zero_pad_cols(T* dst, int t) {
   using C = ACfg<T, HD>;
@@ -544,21 +579,29 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t);
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);   // kv tiles this wave's 16 queries take part in
-  const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
-  const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
+  // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
+  const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  const at_i32x4 v_rs = at_rsrc((const T*)p.v + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  TileOffs<T, HD> kv_of;
+  tile_offsets<T, HD>(kv_of, p.ld, t);
+  const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
 
   TileRegs<T, HD> rk, rv;
   int ra = 0;
   auto gload = [&](int kt) {
-    const int nv = min(64, p.T - kt * 64);
-    tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    if (t < 64) ra = t < nv ? token_key(p.uid[tok0 + kt * 64 + t], p.tm[tok0 + kt * 64 + t]) : KEY_NO_K;
+    const int so = (int)(kt * 64 * p.ld * sizeof(T));
+    tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
+    tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    if (w0) {
+      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, kt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, kt * 256, 0);
+      ra = kt * 64 + l < p.T ? token_key(u, m_) : KEY_NO_K;
+    }
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) ak[buf * 64 + t] = ra;
+    if (w0) ak[buf * 64 + l] = ra;
   };
 
   int kt = next_bit(bits, 0);
@@ -759,25 +802,39 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   // Staging runs TWO items ahead of the arithmetic: an item's global loads have a whole iteration (one item of another workgroup's
   // arithmetic would not cover their latency) before they are stored to LDS, and that store is in LDS one barrier before its use.
   // Two register sets, used alternately (the loop below is unrolled by two so that each stays in fixed registers).
-  struct ItemRegs { TileRegs<T, HD> rq, rdo; float rl, rd; int ra; };
+  struct ItemRegs { TileRegs<T, HD> rq, rdo; int x, y, z; };   // x, y, z (wave 0): log-sum-exp, -delta and key of row l
   ItemRegs R0, R1;
-  R0.rl = R0.rd = R1.rl = R1.rd = 0.f; R0.ra = R1.ra = 0;
+  R0.x = R1.x = R0.y = R1.y = R0.z = R1.z = 0;
+  // Q / dO of the kv head's query heads, rows of this sequence: [T][rep * HD] windows of the row-major tensors
+  const at_i32x4 q_rs = at_rsrc((const T*)p.q + tok0 * p.ld + kvh * rep * HD, ((long long)(p.T - 1) * p.ld + rep * HD) * sizeof(T));
+  const at_i32x4 do_rs = at_rsrc((const T*)p.dO + tok0 * p.ldo + kvh * rep * HD, ((long long)(p.T - 1) * p.ldo + rep * HD) * sizeof(T));
+  TileOffs<T, HD> q_of, do_of;
+  tile_offsets<T, HD>(q_of, p.ld, t);
+  tile_offsets<T, HD>(do_of, p.ldo, t);
+  // [rep][T] windows of lse / delta (a row past T of a head reads the next head's, finite and masked; of the last head: zero), [T] of uid / tm
+  const at_i32x4 lse_rs = at_rsrc(p.lse + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  const at_i32x4 dl_rs = at_rsrc(p.delta + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  // wave 0 (a wave-uniform branch) stages the 64 rows' scalars.  (One array per wave instead -- log-sum-exp, -delta, keys on waves 0, 1, 2 --
+  // was measured 7 % SLOWER: three more uniform branches per item in every wave; profiles/r4_ab_attn_staging.log)
+  const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
   auto gload = [&](ItemRegs& r, int it) {   // it = head-in-group * 32 + q tile
-    const int h = kvh * rep + (it >> 5), qt = it & 31;
+    const int hh = it >> 5, qt = it & 31;
     const int nv = min(64, p.T - qt * 64);
-    tile_load<T, HD>(r.rq, (const T*)p.q + (tok0 + qt * 64) * p.ld + h * HD, p.ld, t, nv);
-    tile_load<T, HD>(r.rdo, (const T*)p.dO + (tok0 + qt * 64) * p.ldo + h * HD, p.ldo, t, nv);
-    if (t < 64) {
-      const bool v = t < nv;
-      const long long o = ((long long)b * p.H + h) * p.T + qt * 64 + (v ? t : 0);
-      r.rl = v ? p.lse[o] * LOG2E : 0.f; r.rd = v ? p.delta[o] : 0.f;
-      r.ra = v ? token_key(p.uid[tok0 + qt * 64 + t], p.tm[tok0 + qt * 64 + t]) : KEY_NO_Q;
+    tile_load_buf<T, HD>(r.rq, q_rs, q_of, (int)((qt * 64 * p.ld + hh * HD) * sizeof(T)));
+    tile_load_buf<T, HD>(r.rdo, do_rs, do_of, (int)((qt * 64 * p.ldo + hh * HD) * sizeof(T)));
+    if (w0) {   // (rows past the sequence: the next head's finite values or zero, all masked, and the key of no query)
+      const int so = (hh * p.T + qt * 64) * 4;
+      r.x = __builtin_bit_cast(int, __builtin_bit_cast(float, rsys_at_buffer_load_b32(lse_rs, 4 * l, so, 0)) * LOG2E);
+      r.y = rsys_at_buffer_load_b32(dl_rs, 4 * l, so, 0) ^ 0x80000000;   // -delta: what the dP chains start from
+      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, qt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, qt * 256, 0);
+      r.z = l < nv ? token_key(u, m_) : KEY_NO_Q;
     }
   };
   auto lstore = [&](const ItemRegs& r, int buf) {
     tile_store<T, HD>(r.rq, Qs + buf * C::TILE, t);
     tile_store<T, HD>(r.rdo, dOs + buf * C::TILE, t);
-    if (t < 64) { lse2[buf * 64 + t] = r.rl; dls[buf * 64 + t] = -r.rd; q0s[buf * 64 + t] = r.ra & ~4095; q1s[buf * 64 + t] = r.ra; }   // (dls holds -delta: what the dP chains start from)
+    if (w0) { ((int*)lse2)[buf * 64 + l] = r.x; ((int*)dls)[buf * 64 + l] = r.y; q0s[buf * 64 + l] = r.z & ~4095; q1s[buf * 64 + l] = r.z; }
   };
   auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
     int hh = from >> 5, qt = from & 31;
@@ -903,20 +960,28 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
-  const T* kbase = (const T*)p.k + tok0 * p.ld + kvh * HD;
-  const T* vbase = (const T*)p.v + tok0 * p.ld + kvh * HD;
+  // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
+  const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  const at_i32x4 v_rs = at_rsrc((const T*)p.v + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  TileOffs<T, HD> kv_of;
+  tile_offsets<T, HD>(kv_of, p.ld, t);
+  const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
   TileRegs<T, HD> rk, rv;
   int ra = 0;
   auto gload = [&](int kt) {
-    const int nv = min(64, p.T - kt * 64);
-    tile_load<T, HD>(rk, kbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    tile_load<T, HD>(rv, vbase + (long long)kt * 64 * p.ld, p.ld, t, nv);
-    if (t < 64) ra = t < nv ? token_key(p.uid[tok0 + kt * 64 + t], p.tm[tok0 + kt * 64 + t]) : KEY_NO_K;
+    const int so = (int)(kt * 64 * p.ld * sizeof(T));
+    tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
+    tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    if (w0) {
+      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, kt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, kt * 256, 0);
+      ra = kt * 64 + l < p.T ? token_key(u, m_) : KEY_NO_K;
+    }
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (t < 64) ak[buf * 64 + t] = ra;
+    if (w0) ak[buf * 64 + l] = ra;
   };
   int kt = next_bit(bits, 0), cur = 0;
   if (kt < nt) { gload(kt); lstore(0); }
