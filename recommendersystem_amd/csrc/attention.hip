@@ -484,6 +484,16 @@ __device__ __forceinline__ void mask_tile(f32x4& S, const int* ks, const int* ks
   }
 }
 
+// The lane is the key and the rows are queries, one compare per pair: key b0 meets query key q iff (q & bmask) == b0, where bmask
+// keeps the query's tm bits only when the key has tm bits of its own (b0 & 4095 != 0: visible to queries of the same tm only; else
+// to every query of the user: q without its tm bits == b0).  ks: the rows' full query keys.
+__device__ __forceinline__ void mask_tile_key(f32x4& S, const int* ks, int tok0, int b0, int bmask, int g, float fill) {
+  const int4 a4 = *(const int4*)(ks + tok0 + 4 * g);
+  const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[r] = ((aa[r] & bmask) == b0) ? S[r] : fill;
+}
+
 // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each); all workgroups of one
 // (row, kv head) group read the same K/V (forward, dQ) or Q/dO (dK/dV) tiles, so a group is kept on ONE XCD: its tiles
 // are fetched from HBM once instead of once per XCD (rocprofv3 FETCH_SIZE: 2.9x the algorithmic bytes before).
@@ -771,8 +781,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   T* dOs = Qs + 2 * C::TILE;             // [2][64 q][LDD]
   float* lse2 = (float*)(dOs + 2 * C::TILE);   // [2][64]
   float* dls = lse2 + 128;                      // [2][64]
-  int* q0s = (int*)(dls + 128);                 // [2][64] query keys without tm
-  int* q1s = q0s + 128;                         // [2][64] query keys
+  int* q1s = (int*)(dls + 128);                 // [2][64] query keys
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   int grp, kvt;
   attn_work(p.B * p.KV, nt, p.order_k, grp, kvt);
@@ -790,6 +799,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     for (int s = 0; s < C::NDS; ++s) { kf[0][s] = frag_global<T>(krow, s * C::KS, HD, l); vf[0][s] = frag_global<T>(vrow, s * C::KS, HD, l); }
   }
   const int akv = kvv ? token_key(p.uid[tok0 + kv], p.tm[tok0 + kv]) : KEY_NO_K;
+  const int akmask = (akv & 4095) == 0 ? ~4095 : ~0;   // (mask_tile_key)
   f32x4 dK[1][HD / 16], dV[1][HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[0][j] = f32x4{0, 0, 0, 0}; dV[0][j] = f32x4{0, 0, 0, 0}; }
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   auto lstore = [&](const ItemRegs& r, int buf) {
     tile_store<T, HD>(r.rq, Qs + buf * C::TILE, t);
     tile_store<T, HD>(r.rdo, dOs + buf * C::TILE, t);
-    if (w0) { ((int*)lse2)[buf * 64 + l] = r.x; ((int*)dls)[buf * 64 + l] = r.y; q0s[buf * 64 + l] = r.z & ~4095; q1s[buf * 64 + l] = r.z; }
+    if (w0) { ((int*)lse2)[buf * 64 + l] = r.x; ((int*)dls)[buf * 64 + l] = r.y; q1s[buf * 64 + l] = r.z; }
   };
   auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
     int hh = from >> 5, qt = from & 31;
@@ -869,7 +879,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
         f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP[1] = {f32x4{d4.x, d4.y, d4.z, d4.w}};   // (rows = queries: the chain starts from -delta[q])
         first_stage_block_r<T, HD, 1>(S, Qc, kf, i, l);      // S[q][kv]: rows q (registers), col kv (lane)
         first_stage_block_r<T, HD, 1>(dP, dOc, vf, i, l);    // dP[q][kv] - delta[q]
-        if (!fullt) mask_tile<false>(S[0], q0s + cur * 64, q1s + cur * 64, 16 * i, akv, 0, g, -1e30f);
+        if (!fullt) mask_tile_key(S[0], q1s + cur * 64, 16 * i, akv, akmask, g, -1e30f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = fexp2(fmaf(S[0][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
@@ -1046,7 +1056,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 template <typename T, int HD>
 static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   using C = ACfg<T, HD>;
-  const size_t sm_kv = sizeof(T) * 4 * C::TILE + 512 * 4;
+  const size_t sm_kv = sizeof(T) * 4 * C::TILE + 384 * 4;
   const size_t sm_q = sizeof(T) * 4 * C::TILE + 384 * 4;
   static bool set = false;
   if (!set) {
