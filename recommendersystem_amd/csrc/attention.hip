@@ -283,6 +283,8 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, HD>& r, T* dst, int
 typedef __attribute__((ext_vector_type(4))) int at_i32x4;
 extern "C" __device__ at_i32x4 rsys_at_buffer_load_b128(at_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 extern "C" __device__ int rsys_at_buffer_load_b32(at_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+typedef __attribute__((ext_vector_type(2))) int at_i32x2;
+extern "C" __device__ at_i32x2 rsys_at_buffer_load_b64(at_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
 // base .. base + bytes is what a load may touch (wave-uniform); bytes < 2^31
 __device__ __forceinline__ at_i32x4 at_rsrc(const void* base, long long bytes) {
   const unsigned long long a = (unsigned long long)base;
@@ -330,34 +332,54 @@ __device__ __forceinline__ int next_bit(unsigned int bits, int from) {  // lowes
 // time: allowed(q, kv) <=> key[kv] == key[q] or key[kv] == key[q] without its tm bits (token_key below), so a (query,
 // 64 keys) step is two compares, an OR and a ballot.  Exact: "some" bits may not miss a pair, "only" bits may not claim one.
 __device__ __forceinline__ int token_key(int uid, int tm);
+extern "C" __device__ int rsys_at_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");   // v_writelane_b32
 __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   __shared__ unsigned int any_bits, any16[4], kany[32];   // kany[j]: bit kg = keys 16 kg .. +15 of kv tile j meet a query of this tile
   __shared__ int cnt[32];
+  __shared__ unsigned short kcols[32][64][4];   // [kv tile][key][query group of 16]: the key's bits against this q tile, written out as words
+  __shared__ int keys[2048];                    // the row's token keys (one round of loads instead of a dependent load per kv tile)
   const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x, l = t & 63, w = t >> 6;
   const int nt = (p.T + 63) / 64;
   const long long base = (long long)b * p.T;
   if (t == 0) any_bits = 0u;
   if (t < 4) any16[t] = 0u;
   if (t < 32) { cnt[t] = 0; kany[t] = 0u; }
+  for (int i = t; i < nt * 64; i += 256) keys[i] = i < p.T ? token_key(p.uid[base + i], p.tm[base + i]) : KEY_NO_K;
   // lane i < 16 of wave w holds the key of query qt*64 + w*16 + i
   int myq = KEY_NO_Q;
   if (l < 16) { const int q = qt * 64 + w * 16 + l; if (q < p.T) myq = token_key(p.uid[base + q], p.tm[base + q]); }
-  int aq[16], aq0[16];
+  int aq[16];   // (scalars; the key without its tm bits is one scalar AND away: keeping both arrays spilled scalar registers)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { aq[i] = __builtin_amdgcn_readlane(myq, i); aq0[i] = aq[i] & ~4095; }
+  for (int i = 0; i < 16; ++i) aq[i] = __builtin_amdgcn_readlane(myq, i);
   __syncthreads();
   unsigned int wany = 0u;
   for (int j = 0; j < nt; ++j) {
-    const int kv = j * 64 + l;
-    const int ak = kv < p.T ? token_key(p.uid[base + kv], p.tm[base + kv]) : KEY_NO_K;
+    const int ak = keys[j * 64 + l];
     bool mine = false;     // this key meets one of the wave's queries
     int n = 0;             // allowed pairs of this (q group, kv tile), wave-uniform
+    unsigned long long qrow = 0ull;   // lane i < 16: the 64 keys of tile j that query w*16 + i may see
+    unsigned int kcol = 0u;           // bit i: this lane's key is seen by query w*16 + i
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const bool hit = ak == aq[i] || ak == aq0[i];
+      const bool hit = ak == aq[i] || ak == (aq[i] & ~4095);
       mine |= hit;
       n += __builtin_popcountll(__ballot(hit));
     }
+    if (n) {   // (wave-uniform; a (query group, kv tile) pair without an allowed pair keeps zero bits and skips this second pass)
+      int qlo = 0, qhi = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool hit = ak == aq[i] || ak == (aq[i] & ~4095);
+        const unsigned long long hb = __ballot(hit);
+        qlo = rsys_at_writelane((int)(unsigned int)hb, i, qlo);            // lane i <- query i's row of key bits
+        qhi = rsys_at_writelane((int)(unsigned int)(hb >> 32), i, qhi);
+        kcol |= hit ? (1u << i) : 0u;
+      }
+      qrow = ((unsigned long long)(unsigned int)qhi << 32) | (unsigned int)qlo;
+    }
+    // the pair bits the attention kernels mask with (AttnParams::qbits / kbits): every (q tile, kv tile), visited or not
+    if (l < 16) p.qbits[(((long long)b * nt + qt) * nt + j) * 64 + w * 16 + l] = qrow;
+    kcols[j][l][w] = (unsigned short)kcol;
     if (n) {
       wany |= 1u << j;
       const unsigned long long km = __ballot(mine);
@@ -369,6 +391,8 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   }
   if (l == 0) { any16[w] = wany; atomicOr(&any_bits, wany); }
   __syncthreads();
+  for (int c = t; c < nt * 64; c += 256)   // kbits[b][kv tile c / 64][qt][key c % 64]: 512-byte runs
+    p.kbits[(((long long)b * nt + (c >> 6)) * nt + qt) * 64 + (c & 63)] = *(const unsigned long long*)kcols[c >> 6][c & 63];
   if (t < nt) {
     const bool any = (any_bits >> t) & 1u, full = cnt[t] == 4096;
     if (any) atomicOr(&p.kmap[b * nt + t], 1u << qt);
@@ -442,6 +466,7 @@ __global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, in
 
 int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
+  ARG_CHECK(p.qbits != nullptr && p.kbits != nullptr, "attention: the pair-bit buffers (AttnParams::qbits / kbits) are required");
   const size_t bytes = sizeof(unsigned int) * p.B * ((p.T + 63) / 64);
   if (p.maps_zero_base != nullptr) {
     HIP_CHECK(hipMemsetAsync(p.maps_zero_base, 0, p.maps_zero_bytes, s));
@@ -462,38 +487,26 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
   return RSYS_OK;
 }
 
-// masks one accumulator tile in place: rows = tokens tok0+4g+r with ids read from LDS against the lane's own ids.
 // allowed(q, kv) = uid equal AND (tm[kv] == 0 OR tm equal).  With the token key a = uid << 12 | tm (host-checked:
-// 0 <= uid < 2^19, 0 <= tm < 4096) this is  a[kv] == (a[q] & ~4095)  OR  a[kv] == a[q]: two compares, one scalar OR
-// and the select -- three vector ops per score (the xor / and-or form took five).
-// LANE_IS_Q: the lane is the query (b0 = its key without tm, b1 = its key) and the rows are keys (ks = their keys,
-// staged with the tile); else the lane is the key (b0 holds its key) and the rows are queries (ks = their b0, ks2 = b1).
+// 0 <= uid < 2^19, 0 <= tm < 4096) this is  a[kv] == (a[q] & ~4095)  OR  a[kv] == a[q].  The compares run ONCE per step and map set, in
+// attn_tilemap_kernel, which keeps their outcome as pair bits (AttnParams::qbits / kbits); the attention kernels mask from those.
 __device__ __forceinline__ int token_key(int uid, int tm) { return (int)(((unsigned int)uid << 12) | (unsigned int)tm); }
-template <bool LANE_IS_Q>
-__device__ __forceinline__ void mask_tile(f32x4& S, const int* ks, const int* ks2, int tok0, int b0, int b1, int g, float fill) {
-  const int4 a4 = *(const int4*)(ks + tok0 + 4 * g);
-  const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
-  if (LANE_IS_Q) {
+// Masks from the precomputed pair bits: `word` = the lane's 64-bit row of the (q tile, kv tile) bit matrix, already shifted right by
+// 4 g, so that the partner of the lane's score (block i, register rr) is bit 16 i + rr: a signed one-bit extract gives 0 / -1 and a
+// bit-field insert picks the score or the fill -- two VALU instructions per score, the extract shared by the R heads, no key reads.
+template <int R>
+__device__ __forceinline__ void mask_bits_block(f32x4 (&S)[R], unsigned long long word, int i, float fill) {
+  const int src = (int)(i < 2 ? (unsigned int)word : (unsigned int)(word >> 32));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[r] = (aa[r] == b0 || aa[r] == b1) ? S[r] : fill;
-  } else {
-    const int4 c4 = *(const int4*)(ks2 + tok0 + 4 * g);
-    const int cc[4] = {c4.x, c4.y, c4.z, c4.w};
+  for (int rr = 0; rr < 4; ++rr) {
+    const int m = __builtin_amdgcn_sbfe(src, 16 * (i & 1) + rr, 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[r] = (b0 == aa[r] || b0 == cc[r]) ? S[r] : fill;
+    for (int r = 0; r < R; ++r) {
+      const float sv = S[r][rr];   // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+      S[r][rr] = __builtin_bit_cast(float, (__builtin_bit_cast(int, sv) & m) | (__builtin_bit_cast(int, fill) & ~m));
+    }
   }
 }
-
-// The lane is the key and the rows are queries, one compare per pair: key b0 meets query key q iff (q & bmask) == b0, where bmask
-// keeps the query's tm bits only when the key has tm bits of its own (b0 & 4095 != 0: visible to queries of the same tm only; else
-// to every query of the user: q without its tm bits == b0).  ks: the rows' full query keys.
-__device__ __forceinline__ void mask_tile_key(f32x4& S, const int* ks, int tok0, int b0, int bmask, int g, float fill) {
-  const int4 a4 = *(const int4*)(ks + tok0 + 4 * g);
-  const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) S[r] = ((aa[r] & bmask) == b0) ? S[r] : fill;
-}
-
 // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each); all workgroups of one
 // (row, kv head) group read the same K/V (forward, dQ) or Q/dO (dK/dV) tiles, so a group is kept on ONE XCD: its tiles
 // are fetched from HBM once instead of once per XCD (rocprofv3 FETCH_SIZE: 2.9x the algorithmic bytes before).
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ks = (T*)smem_raw;                       // [2][64][LDD]
   T* Vs = Ks + 2 * C::TILE;                   // [2][64][LDD]
-  int* ak = (int*)(Vs + 2 * C::TILE);         // [2][64] token keys of the staged K/V tile
+  unsigned long long* ab = (unsigned long long*)(Vs + 2 * C::TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
@@ -577,7 +590,6 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) qf[r][s] = frag_global<T>(qrow, s * C::KS, HD, l);
   }
-  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   float m_run[R], l_run[R];
   f32x4 oacc[R][HD / 16];
 #pragma unroll
@@ -592,26 +604,24 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
   const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
   const at_i32x4 v_rs = at_rsrc((const T*)p.v + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
-  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  // the pair bits of this q tile against every kv tile: [nt][64 queries] words (AttnParams::qbits)
+  const at_i32x4 qb_rs = at_rsrc(p.qbits + ((long long)b * nt + qt) * nt * 64, (long long)nt * 64 * 8);
   TileOffs<T, HD> kv_of;
   tile_offsets<T, HD>(kv_of, p.ld, t);
   const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
 
   TileRegs<T, HD> rk, rv;
-  int ra = 0;
+  unsigned long long rb = 0ull;
   auto gload = [&](int kt) {
     const int so = (int)(kt * 64 * p.ld * sizeof(T));
     tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
     tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
-    if (w0) {
-      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, kt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, kt * 256, 0);
-      ra = kt * 64 + l < p.T ? token_key(u, m_) : KEY_NO_K;
-    }
+    if (w0) rb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(qb_rs, 8 * l, kt * 512, 0));   // query l's keys of tile kt
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (w0) ak[buf * 64 + l] = ra;
+    if (w0) ab[buf * 64 + l] = rb;
   };
 
   int kt = next_bit(bits, 0);
@@ -627,17 +637,19 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     f32x4 S[R][4];
     first_stage_r<T, HD, R>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
-      // allowed(q, kv) <=> key[kv] == key[q] without its tm bits, or key[kv] == key[q] (mask_tile): one predicate per score
-      // position, applied to every head
+      // the lane's query against the tile's 64 keys: one extracted bit per score position, applied to every head (mask_bits_block)
+      const unsigned long long wq = ab[cur * 64 + w * 16 + fr] >> (4 * g);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
-        const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
+        const int src = (int)(i < 2 ? (unsigned int)wq : (unsigned int)(wq >> 32));
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const bool ok = aa[rr] == aq0 || aa[rr] == aq;
+          const int m = __builtin_amdgcn_sbfe(src, 16 * (i & 1) + rr, 1);
 #pragma unroll
-          for (int r = 0; r < R; ++r) S[r][i][rr] = ok ? S[r][i][rr] : -1e30f;
+          for (int r = 0; r < R; ++r) {
+            const float sv = S[r][i][rr];   // (a copy: see mask_bits_block)
+            S[r][i][rr] = __builtin_bit_cast(float, (__builtin_bit_cast(int, sv) & m) | (__builtin_bit_cast(int, -1e30f) & ~m));
+          }
         }
       }
     }
@@ -718,6 +730,7 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
 
 static int check_attn(const AttnParams& p, size_t esz) {
   ARG_CHECK(p.T % 8 == 0 && (p.T + 63) / 64 <= 32, "attention: T must be a multiple of 8 and <= 2048");
+  ARG_CHECK(p.qbits != nullptr && p.kbits != nullptr, "attention: the pair-bit buffers (AttnParams::qbits / kbits) are required");
   ARG_CHECK(p.H % p.KV == 0, "attention: H % KV");
   ARG_CHECK((p.ld * esz) % 16 == 0 && (p.hd * esz) % 16 == 0, "attention: 16-byte row alignment");
   return RSYS_OK;
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   T* dOs = Qs + 2 * C::TILE;             // [2][64 q][LDD]
   float* lse2 = (float*)(dOs + 2 * C::TILE);   // [2][64]
   float* dls = lse2 + 128;                      // [2][64]
-  int* q1s = (int*)(dls + 128);                 // [2][64] query keys
+  unsigned long long* kbs = (unsigned long long*)(dls + 128);   // [2][64] pair bits of the 64 keys against the staged item's queries
   const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
   int grp, kvt;
   attn_work(p.B * p.KV, nt, p.order_k, grp, kvt);
@@ -798,8 +811,6 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) { kf[0][s] = frag_global<T>(krow, s * C::KS, HD, l); vf[0][s] = frag_global<T>(vrow, s * C::KS, HD, l); }
   }
-  const int akv = kvv ? token_key(p.uid[tok0 + kv], p.tm[tok0 + kv]) : KEY_NO_K;
-  const int akmask = (akv & 4095) == 0 ? ~4095 : ~0;   // (mask_tile_key)
   f32x4 dK[1][HD / 16], dV[1][HD / 16];
 #pragma unroll
   for (int j = 0; j < HD / 16; ++j) { dK[0][j] = f32x4{0, 0, 0, 0}; dV[0][j] = f32x4{0, 0, 0, 0}; }
@@ -812,9 +823,9 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   // Staging runs TWO items ahead of the arithmetic: an item's global loads have a whole iteration (one item of another workgroup's
   // arithmetic would not cover their latency) before they are stored to LDS, and that store is in LDS one barrier before its use.
   // Two register sets, used alternately (the loop below is unrolled by two so that each stays in fixed registers).
-  struct ItemRegs { TileRegs<T, HD> rq, rdo; int x, y, z; };   // x, y, z (wave 0): log-sum-exp, -delta and key of row l
+  struct ItemRegs { TileRegs<T, HD> rq, rdo; int x, y; unsigned long long kb; };   // (wave 0) x, y: log-sum-exp and -delta of query l; kb: pair bits of key l
   ItemRegs R0, R1;
-  R0.x = R1.x = R0.y = R1.y = R0.z = R1.z = 0;
+  R0.x = R1.x = R0.y = R1.y = 0; R0.kb = R1.kb = 0ull;
   // Q / dO of the kv head's query heads, rows of this sequence: [T][rep * HD] windows of the row-major tensors
   const at_i32x4 q_rs = at_rsrc((const T*)p.q + tok0 * p.ld + kvh * rep * HD, ((long long)(p.T - 1) * p.ld + rep * HD) * sizeof(T));
   const at_i32x4 do_rs = at_rsrc((const T*)p.dO + tok0 * p.ldo + kvh * rep * HD, ((long long)(p.T - 1) * p.ldo + rep * HD) * sizeof(T));
@@ -824,27 +835,26 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   // [rep][T] windows of lse / delta (a row past T of a head reads the next head's, finite and masked; of the last head: zero), [T] of uid / tm
   const at_i32x4 lse_rs = at_rsrc(p.lse + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
   const at_i32x4 dl_rs = at_rsrc(p.delta + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
-  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  // the pair bits of this kv tile against every q tile: [nt][64 keys] words (AttnParams::kbits)
+  const at_i32x4 kb_rs = at_rsrc(p.kbits + ((long long)b * nt + kvt) * nt * 64, (long long)nt * 64 * 8);
   // wave 0 (a wave-uniform branch) stages the 64 rows' scalars.  (One array per wave instead -- log-sum-exp, -delta, keys on waves 0, 1, 2 --
   // was measured 7 % SLOWER: three more uniform branches per item in every wave; profiles/r4_ab_attn_staging.log)
   const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
   auto gload = [&](ItemRegs& r, int it) {   // it = head-in-group * 32 + q tile
     const int hh = it >> 5, qt = it & 31;
-    const int nv = min(64, p.T - qt * 64);
     tile_load_buf<T, HD>(r.rq, q_rs, q_of, (int)((qt * 64 * p.ld + hh * HD) * sizeof(T)));
     tile_load_buf<T, HD>(r.rdo, do_rs, do_of, (int)((qt * 64 * p.ldo + hh * HD) * sizeof(T)));
     if (w0) {   // (rows past the sequence: the next head's finite values or zero, all masked, and the key of no query)
       const int so = (hh * p.T + qt * 64) * 4;
       r.x = __builtin_bit_cast(int, __builtin_bit_cast(float, rsys_at_buffer_load_b32(lse_rs, 4 * l, so, 0)) * LOG2E);
       r.y = rsys_at_buffer_load_b32(dl_rs, 4 * l, so, 0) ^ 0x80000000;   // -delta: what the dP chains start from
-      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, qt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, qt * 256, 0);
-      r.z = l < nv ? token_key(u, m_) : KEY_NO_Q;
+      r.kb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(kb_rs, 8 * l, qt * 512, 0));   // key l against the 64 queries
     }
   };
   auto lstore = [&](const ItemRegs& r, int buf) {
     tile_store<T, HD>(r.rq, Qs + buf * C::TILE, t);
     tile_store<T, HD>(r.rdo, dOs + buf * C::TILE, t);
-    if (w0) { ((int*)lse2)[buf * 64 + l] = r.x; ((int*)dls)[buf * 64 + l] = r.y; q1s[buf * 64 + l] = r.z; }
+    if (w0) { ((int*)lse2)[buf * 64 + l] = r.x; ((int*)dls)[buf * 64 + l] = r.y; kbs[buf * 64 + l] = r.kb; }
   };
   auto next_item = [&](int from) {   // items are (head, q tile) pairs in order; returns rep*32 when exhausted
     int hh = from >> 5, qt = from & 31;
@@ -867,6 +877,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
     const T* dOc = dOs + cur * C::TILE;
     if ((wbits >> (it & 31)) & 1u) {   // (nothing to add for a wave whose 16 keys no query of this tile may see)
     const bool fullt = (fullbits >> (it & 31)) & 1u;
+    const unsigned long long wk = kbs[cur * 64 + w * 16 + fr] >> (4 * g);   // the lane's key against the item's 64 queries (mask_bits_block)
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {   // 32 queries at a time: both stages, two score blocks alive (no row maximum is needed here)
       f32x4 P2[1][2], dS2[1][2];
@@ -879,7 +890,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
         f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP[1] = {f32x4{d4.x, d4.y, d4.z, d4.w}};   // (rows = queries: the chain starts from -delta[q])
         first_stage_block_r<T, HD, 1>(S, Qc, kf, i, l);      // S[q][kv]: rows q (registers), col kv (lane)
         first_stage_block_r<T, HD, 1>(dP, dOc, vf, i, l);    // dP[q][kv] - delta[q]
-        if (!fullt) mask_tile_key(S[0], q1s + cur * 64, 16 * i, akv, akmask, g, -1e30f);
+        if (!fullt) mask_bits_block<1>(S, wk, i, -1e30f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = fexp2(fmaf(S[0][r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
@@ -922,7 +933,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ks = (T*)smem_raw;                  // [2][64 kv][LDD]
   T* Vs = Ks + 2 * C::TILE;              // [2][64 kv][LDD]
-  int* ak = (int*)(Vs + 2 * C::TILE);    // [2][64] token keys of the staged K/V tile
+  unsigned long long* ab = (unsigned long long*)(Vs + 2 * C::TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
@@ -966,32 +977,29 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) dQ[r][j] = f32x4{0, 0, 0, 0};
   }
-  const int aq = qv ? token_key(p.uid[tok0 + q], p.tm[tok0 + q]) : KEY_NO_Q, aq0 = aq & ~4095;
   for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
   const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
   const at_i32x4 v_rs = at_rsrc((const T*)p.v + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
-  const at_i32x4 uid_rs = at_rsrc(p.uid + tok0, (long long)p.T * 4), tm_rs = at_rsrc(p.tm + tok0, (long long)p.T * 4);
+  // the pair bits of this q tile against every kv tile: [nt][64 queries] words (AttnParams::qbits)
+  const at_i32x4 qb_rs = at_rsrc(p.qbits + ((long long)b * nt + qt) * nt * 64, (long long)nt * 64 * 8);
   TileOffs<T, HD> kv_of;
   tile_offsets<T, HD>(kv_of, p.ld, t);
   const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
   TileRegs<T, HD> rk, rv;
-  int ra = 0;
+  unsigned long long rb = 0ull;
   auto gload = [&](int kt) {
     const int so = (int)(kt * 64 * p.ld * sizeof(T));
     tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
     tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
-    if (w0) {
-      const int u = rsys_at_buffer_load_b32(uid_rs, 4 * l, kt * 256, 0), m_ = rsys_at_buffer_load_b32(tm_rs, 4 * l, kt * 256, 0);
-      ra = kt * 64 + l < p.T ? token_key(u, m_) : KEY_NO_K;
-    }
+    if (w0) rb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(qb_rs, 8 * l, kt * 512, 0));   // query l's keys of tile kt
   };
   auto lstore = [&](int buf) {
     tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
     tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
-    if (w0) ak[buf * 64 + l] = ra;
+    if (w0) ab[buf * 64 + l] = rb;
   };
   int kt = next_bit(bits, 0), cur = 0;
   if (kt < nt) { gload(kt); lstore(0); }
@@ -1003,6 +1011,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     const T* Vc = Vs + cur * C::TILE;
     if ((wbits >> kt) & 1u) {
     const bool partial = !((fullbits >> kt) & 1u);
+    const unsigned long long wq = ab[cur * 64 + w * 16 + fr] >> (4 * g);   // the lane's query against the tile's 64 keys (mask_bits_block)
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {   // 32 keys at a time: both stages, two score blocks per head alive
       f32x4 dS[R][2];
@@ -1014,16 +1023,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
         for (int r = 0; r < R; ++r) { S[r] = f32x4{0, 0, 0, 0}; dP[r] = f32x4{-dl[r], -dl[r], -dl[r], -dl[r]}; }
         first_stage_block_r<T, HD, R>(S, Kc, qf, i, l);      // S^T[kv][q]
         first_stage_block_r<T, HD, R>(dP, Vc, dof, i, l);    // dP^T[kv][q] - delta[q]
-        if (partial) {   // one predicate per score position, applied to every head (mask_tile)
-          const int4 a4 = *(const int4*)(ak + cur * 64 + 16 * i + 4 * g);
-          const int aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const bool ok = aa[rr] == aq0 || aa[rr] == aq;
-#pragma unroll
-            for (int r = 0; r < R; ++r) S[r][rr] = ok ? S[r][rr] : -1e30f;
-          }
-        }
+        if (partial) mask_bits_block<R>(S, wq, i, -1e30f);   // one extracted bit per score position, applied to every head
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 template <typename T, int HD>
 static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   using C = ACfg<T, HD>;
-  const size_t sm_kv = sizeof(T) * 4 * C::TILE + 384 * 4;
+  const size_t sm_kv = sizeof(T) * 4 * C::TILE + 512 * 4;
   const size_t sm_q = sizeof(T) * 4 * C::TILE + 384 * 4;
   static bool set = false;
   if (!set) {

@@ -550,11 +550,14 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   p.ld = (long long)(H + 2 * KV) * hd;
   p.o = O; p.ldo = (long long)H * hd; p.lse = lse; p.uid = uid; p.tm = tm;
   unsigned int* maps = nullptr; float* delta = nullptr;
+  unsigned long long* pairbits = nullptr;
   HIP_CHECK(hipMalloc((void**)&maps, sizeof(unsigned int) * (12 * B * nt + (size_t)B * (H + KV) * nt)));
+  HIP_CHECK(hipMalloc((void**)&pairbits, sizeof(unsigned long long) * 2 * (size_t)B * nt * nt * 64));
   HIP_CHECK(hipMalloc((void**)&delta, sizeof(float) * B * H * T));
   p.qmap = maps; p.kmap = maps + B * nt; p.qmap_full = maps + 2 * B * nt; p.kmap_full = maps + 3 * B * nt; p.delta = delta;
   p.qmap16 = maps + 4 * B * nt; p.kmap16 = maps + 8 * B * nt;
   p.order_q = (int*)(maps + 12 * B * nt); p.order_k = p.order_q + (size_t)B * H * nt;
+  p.qbits = pairbits; p.kbits = pairbits + (size_t)B * nt * nt * 64;
   p.dO = dO; p.dq = dqkv; p.dk = (unsigned char*)dqkv + (size_t)H * hd * e;
   p.dv = (unsigned char*)dqkv + (size_t)(H + KV) * hd * e; p.ldg = p.ld;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = nullptr;
@@ -564,7 +567,7 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
     rc = dtype == RSYS_DTYPE_BF16 ? launch_attn_bwd<bf16>(p, nullptr) : launch_attn_bwd<float>(p, nullptr);
   }
   hipError_t e2 = hipDeviceSynchronize();
-  hipFree(maps); hipFree(delta);
+  hipFree(maps); hipFree(delta); hipFree(pairbits);
   if (rc) return rc;
   HIP_CHECK(e2);
   return RSYS_OK;

@@ -272,6 +272,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     m->maps_zero_bytes = (size_t)(7 * mb);
     const int64_t nt = (m->T + 63) / 64;
     DALLOC(m->attn_order_q, (int64_t)m->rows_max * m->H * nt * 4); DALLOC(m->attn_order_k, (int64_t)m->rows_max * m->KV * nt * 4);
+    DALLOC(m->attn_qbits, (int64_t)m->rows_max * nt * nt * 64 * 8); DALLOC(m->attn_kbits, (int64_t)m->rows_max * nt * nt * 64 * 8);
   }
   m->la.resize(m->L);
   for (int l = 0; l < m->L; ++l) {
@@ -370,6 +371,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       m->qmap_p = (unsigned int*)(base + 7 * mb); m->qmap16_p = (unsigned int*)(base + 8 * mb);
       const int64_t nt = (m->T + 63) / 64;
       DALLOC(m->attn_order_q_p, (int64_t)m->rows_max * m->H * nt * 4); DALLOC(m->attn_order_k_p, (int64_t)m->rows_max * m->KV * nt * 4);
+      DALLOC(m->attn_qbits_p, (int64_t)m->rows_max * nt * nt * 64 * 8); DALLOC(m->attn_kbits_p, (int64_t)m->rows_max * nt * nt * 64 * 8);
     }
   }
   if (m->fp8) {
@@ -1135,7 +1137,7 @@ static int forward_trunk(Model* m) {
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   ap.maps_zero_base = m->kmap; ap.maps_zero_bytes = m->maps_zero_bytes;
-  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k;
+  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
   AttnParams ap_top = ap;   // the last layer under the compact top: selected-first token order, its own tile maps, leading query tiles only
@@ -1147,7 +1149,7 @@ static int forward_trunk(Model* m) {
     ap_top.qmap = m->qmap_p; ap_top.kmap = m->kmap_p; ap_top.qmap_full = m->qmap_full_p; ap_top.kmap_full = m->kmap_full_p;
     ap_top.qmap16 = m->qmap16_p; ap_top.kmap16 = m->kmap16_p;
     ap_top.maps_zero_base = m->kmap_p;
-    ap_top.order_q = m->attn_order_q_p; ap_top.order_k = m->attn_order_k_p;
+    ap_top.order_q = m->attn_order_q_p; ap_top.order_k = m->attn_order_k_p; ap_top.qbits = m->attn_qbits_p; ap_top.kbits = m->attn_kbits_p;
     ap_top.q_active = m->c_qact;   // (the launch orders put the query tiles beyond it last)
     RC(launch_attn_tilemap(ap_top, s));
   }
@@ -1220,7 +1222,7 @@ static int materialise_output_t(Model* m) {
   AttnParams ap{};
   ap.B = m->cur_rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_p; ap.tm = m->tm_p; ap.qmap = m->qmap_p; ap.kmap = m->kmap_p; ap.qmap_full = m->qmap_full_p; ap.kmap_full = m->kmap_full_p;
-  ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p; ap.order_q = m->attn_order_q_p; ap.order_k = m->attn_order_k_p;
+  ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p; ap.order_q = m->attn_order_q_p; ap.order_k = m->attn_order_k_p; ap.qbits = m->attn_qbits_p; ap.kbits = m->attn_kbits_p;
   ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
   ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
   RC(launch_attn_fwd<T>(ap, m->stream));
@@ -1664,7 +1666,7 @@ static int backward_trunk(Model* m) {
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
-  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k;
+  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
   int bucket_top = m->L - 1;
   for (int l = m->L - 1; l >= 0; --l) {
@@ -1745,7 +1747,7 @@ static int backward_trunk(Model* m) {
       AttnParams at = ap;
       at.uid = m->uid_p; at.tm = m->tm_p; at.rope_pos = m->pos_p; at.q_active = m->c_qact;
       at.qmap = m->qmap_p; at.kmap = m->kmap_p; at.qmap_full = m->qmap_full_p; at.kmap_full = m->kmap_full_p; at.qmap16 = m->qmap16_p; at.kmap16 = m->kmap16_p;
-      at.order_q = m->attn_order_q_p; at.order_k = m->attn_order_k_p;
+      at.order_q = m->attn_order_q_p; at.order_k = m->attn_order_k_p; at.qbits = m->attn_qbits_p; at.kbits = m->attn_kbits_p;
       RC(launch_attn_bwd<T>(at, s));
     } else {
       RC(launch_attn_bwd<T>(ap, s));

@@ -204,6 +204,7 @@ struct Model {
   // permuted places; *_p maps: the attention tile maps of that order.  la[L-1].{xn, rstd1, qkv, O, lse} are stored in permuted order.
   int *c_perm = nullptr, *uid_p = nullptr, *tm_p = nullptr, *pos_p = nullptr, *c_slot_p = nullptr, *c_sel_p = nullptr, *c_qact = nullptr;
   unsigned int *qmap_p = nullptr, *kmap_p = nullptr, *qmap_full_p = nullptr, *kmap_full_p = nullptr, *qmap16_p = nullptr, *kmap16_p = nullptr;
+  unsigned long long *attn_qbits = nullptr, *attn_kbits = nullptr, *attn_qbits_p = nullptr, *attn_kbits_p = nullptr;   // pair bits of the two map sets (AttnParams::qbits / kbits)
   int *attn_order_q = nullptr, *attn_order_k = nullptr, *attn_order_q_p = nullptr, *attn_order_k_p = nullptr;   // heaviest-first launch orders of the two map sets (AttnParams::order_q / order_k)
   bool table_grads_pending = false;
   // the item-table gradient rows of medium m are known to be zero (just zeroed by zero_grad / AdamW and not written since):
