@@ -925,6 +925,202 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
   copy_out_tile<T, HD>(Os, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
 }
 
+
+// ------------------------------------------------------------------------ dK, dV with LDS-DMA staging (bf16, head_dim 64)
+// The same kernel with the Q / dO tiles brought in by `buffer_load ... lds` (no staging registers, no LDS stores) into UNPADDED tiles:
+// a 64-column bf16 row is 128 bytes = 8 chunks of 16, chunk c of row r sits in slot c ^ (r & 7).  By the guide's lane groups that
+// layout is free of bank conflicts for the natural ds_read_b128 fragments and for both ds_read_b64_tr_b16 reads (as the 160-byte rows
+// are), it is what a DMA instruction can fill (1 KB = 8 consecutive rows, the swizzle applied on the SOURCE side: the lane that fills
+// slot s of row r loads chunk s ^ (r & 7)), and it makes a tile 8 KB: 34 KB per workgroup and ~110 registers -- four workgroups per CU.
+extern "C" __device__ void rsys_at_buffer_load_lds(at_i32x4 rsrc, LDS_AS unsigned int* lds, int size, int voffset, int soffset, int offset,
+                                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+// store_grad_tile / copy_out_tile on one such 8 KB tile (the epilogue stages through a tile buffer it no longer needs)
+__device__ __forceinline__ void store_grad_tile_sw(f32x4 (&acc)[4], bool rotate, const float* rope_cos, const float* rope_sin, int pos, bf16* Os, int w, int l) {
+  const int g = l >> 4, fr = l & 15, row = w * 16 + fr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float o[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+    if (rotate) {
+      const int d2 = (16 * j + 4 * g) >> 1;
+      const float2 cc = *(const float2*)(rope_cos + pos * 32 + d2);
+      const float2 ss = *(const float2*)(rope_sin + pos * 32 + d2);
+      const float a0 = o[0] * cc.x + o[1] * ss.x, a1 = -o[0] * ss.x + o[1] * cc.x;
+      const float b0 = o[2] * cc.y + o[3] * ss.y, b1 = -o[2] * ss.y + o[3] * cc.y;
+      o[0] = a0; o[1] = a1; o[2] = b0; o[3] = b1;
+    }
+    const int col = 16 * j + 4 * g;
+    bf16* dst = Os + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = (bf16)o[r];
+  }
+}
+__device__ __forceinline__ void copy_out_tile_sw(const bf16* Os, bf16* dst, long long ld, int tile_tok0, int T_len, int t, float* amax = nullptr) {
+  float am = 0.f;
+#pragma unroll
+  for (int c = t; c < 512; c += 256) {
+    const int row = c >> 3, ch = c & 7;
+    if (tile_tok0 + row < T_len) {
+      const uint4 v = *(const uint4*)(Os + row * 64 + ((ch ^ (row & 7)) << 3));
+      *(uint4*)(dst + (long long)row * ld + ch * 8) = v;
+      if (amax != nullptr) am = fmaxf(am, chunk_amax<bf16>(v));
+    }
+  }
+  if (amax != nullptr) {
+    am = wave_max(am);
+    if ((t & 63) == 0) f8_amax_add(amax, am);
+  }
+}
+__device__ __forceinline__ bf16x8 frag_rows_sw(const bf16* tile, int row0, int k0, int l) {
+  const int row = row0 + (l & 15), ch = (k0 >> 3) + (l >> 4);
+  return *(const bf16x8*)(tile + row * 64 + ((ch ^ (row & 7)) << 3));
+}
+__device__ __forceinline__ bf16x8 frag_tr_sw(const bf16* tile, int tok0, int d0, int l) {
+  const int g = l >> 4, i = l & 15;
+  const int row = tok0 + 4 * g + (i >> 2), col = d0 + 4 * (i & 3);
+  const bf16* a = tile + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
+  bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)a);
+  bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(a + 16 * 64));   // (row + 16: the same slot permutation)
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
+  constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
+  using T = bf16;
+  using C = ACfg<T, HD>;
+  // (The compiler orders an LDS read behind a pending LDS-DMA unless it can tell the two apart, so each item starts with a wait for the
+  // next item's DMA it has just issued; the other three workgroups of the CU run meanwhile.  Telling them apart was tried -- one LDS
+  // object per buffer and the item loop unrolled by two: no wait, but 158 registers = three workgroups per CU and 209 against 198 us, or
+  // 30 spilled registers at four; profiles/r4_ab_attn_kv_dma.log.)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Qs = (T*)smem_raw;                  // [2][64 q][64] swizzled
+  T* dOs = Qs + 2 * TB;                  // [2][64 q][64] swizzled
+  float* lse2 = (float*)(dOs + 2 * TB);  // [2][64]
+  float* dls = lse2 + 128;               // [2][64]
+  unsigned long long* kbs = (unsigned long long*)(dls + 128);   // [2][64]
+  const int rep = p.H / p.KV, nt = (p.T + 63) / 64;
+  int grp, kvt;
+  attn_work(p.B * p.KV, nt, p.order_k, grp, kvt);
+  const int b = grp / p.KV, kvh = grp % p.KV;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, g = l >> 4, fr = l & 15;
+  const long long tok0 = (long long)b * p.T;
+  const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
+  const int kv = kvt * 64 + w * 16 + fr;       // this lane's key/value token
+  bf16x8 kf[2], vf[2];
+  {
+    const T* krow = (const T*)p.k + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
+    const T* vrow = (const T*)p.v + (tok0 + min(kv, p.T - 1)) * p.ld + kvh * HD;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { kf[s] = frag_global<T>(krow, s * 32, HD, l); vf[s] = frag_global<T>(vrow, s * 32, HD, l); }
+  }
+  f32x4 dK[1][4], dV[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dK[0][j] = f32x4{0, 0, 0, 0}; dV[0][j] = f32x4{0, 0, 0, 0}; }
+  const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
+  const unsigned int act = qa >= 32 ? ~0u : ((1u << qa) - 1u);
+  const unsigned int bits = p.kmap[b * nt + kvt] & act, fullbits = p.kmap_full[b * nt + kvt];
+  const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.kmap16[(b * nt + kvt) * 4 + w]);
+  const at_i32x4 q_rs = at_rsrc((const T*)p.q + tok0 * p.ld + kvh * rep * HD, ((long long)(p.T - 1) * p.ld + rep * HD) * sizeof(T));
+  const at_i32x4 do_rs = at_rsrc((const T*)p.dO + tok0 * p.ldo + kvh * rep * HD, ((long long)(p.T - 1) * p.ldo + rep * HD) * sizeof(T));
+  const at_i32x4 lse_rs = at_rsrc(p.lse + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  const at_i32x4 dl_rs = at_rsrc(p.delta + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  const at_i32x4 kb_rs = at_rsrc(p.kbits + ((long long)b * nt + kvt) * nt * 64, (long long)nt * 64 * 8);
+  const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
+  // wave w fills rows 16 w .. 16 w + 15 of each tile with two DMA instructions (8 rows = 1 KB each): per-lane source offsets, fixed
+  int qv_[2], dv_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = 16 * w + 8 * k + (l >> 3), ch = (l & 7) ^ (row & 7);
+    qv_[k] = (int)((row * p.ld + ch * 8) * sizeof(T));
+    dv_[k] = (int)((row * p.ldo + ch * 8) * sizeof(T));
+  }
+  int sx = 0, sy = 0; unsigned long long skb = 0ull;   // (wave 0) the next item's row scalars on their way to LDS
+  auto stage = [&](int it, int buf) {   // it = head-in-group * 32 + q tile
+    const int hh = it >> 5, qt = it & 31;
+    const int qso = (int)((qt * 64 * p.ld + hh * HD) * sizeof(T)), dso = (int)((qt * 64 * p.ldo + hh * HD) * sizeof(T));
+    unsigned char* qd = (unsigned char*)(Qs + buf * TB) + (16 * w) * 128;
+    unsigned char* dd = (unsigned char*)(dOs + buf * TB) + (16 * w) * 128;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      rsys_at_buffer_load_lds(q_rs, (LDS_AS unsigned int*)(qd + k * 1024), 16, qv_[k], qso, 0, 0);
+      rsys_at_buffer_load_lds(do_rs, (LDS_AS unsigned int*)(dd + k * 1024), 16, dv_[k], dso, 0, 0);
+    }
+    if (w0) {
+      const int so = (hh * p.T + qt * 64) * 4;
+      sx = __builtin_bit_cast(int, __builtin_bit_cast(float, rsys_at_buffer_load_b32(lse_rs, 4 * l, so, 0)) * LOG2E);
+      sy = rsys_at_buffer_load_b32(dl_rs, 4 * l, so, 0) ^ 0x80000000;   // -delta
+      skb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(kb_rs, 8 * l, qt * 512, 0));
+    }
+  };
+  auto publish = [&](int buf) {   // the scalars into LDS; every DMA of this wave landed
+    if (w0) { ((int*)lse2)[buf * 64 + l] = sx; ((int*)dls)[buf * 64 + l] = sy; kbs[buf * 64 + l] = skb; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto next_item = [&](int from) {
+    int hh = from >> 5, qt = from & 31;
+    while (hh < rep) {
+      const int n = next_bit(bits, qt);
+      if (n < nt) return hh * 32 + n;
+      ++hh; qt = 0;
+    }
+    return rep * 32;
+  };
+  const int end = rep * 32;
+  int it = next_item(0), cur = 0;
+  if (it < end) { stage(it, 0); publish(0); }
+  __syncthreads();
+  while (it < end) {
+    const int nxt = next_item(it + 1);
+    if (nxt < end) stage(nxt, cur ^ 1);   // (the other buffer: every wave left it before the barrier that ended the previous item)
+    const T* Qc = Qs + cur * TB;
+    const T* dOc = dOs + cur * TB;
+    if ((wbits >> (it & 31)) & 1u) {
+      const bool fullt = (fullbits >> (it & 31)) & 1u;
+      const unsigned long long wk = kbs[cur * 64 + w * 16 + fr] >> (4 * g);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        f32x4 P2[2], dS2[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * t2 + ii;
+          const float4 l4 = *(const float4*)(lse2 + cur * 64 + 16 * i + 4 * g);
+          const float4 d4 = *(const float4*)(dls + cur * 64 + 16 * i + 4 * g);
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+          f32x4 S[1] = {f32x4{0, 0, 0, 0}}, dP = f32x4{d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            S[0] = AMma<bf16>::mma(frag_rows_sw(Qc, 16 * i, 32 * s2, l), kf[s2], S[0]);       // S[q][kv]
+            dP = AMma<bf16>::mma(frag_rows_sw(dOc, 16 * i, 32 * s2, l), vf[s2], dP);          // dP[q][kv] - delta[q]
+          }
+          if (!fullt) mask_bits_block<1>(S, wk, i, -1e30f);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = fexp2(fmaf(S[0][r], c2, -ll[r]));
+            P2[ii][r] = pv;
+            dS2[ii][r] = pv * dP[r];
+          }
+        }
+        const bf16x8 pf = pack8(P2[0], P2[1]), sf = pack8(dS2[0], dS2[1]);
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) {
+          dV[0][jd] = AMma<bf16>::mma(frag_tr_sw(dOc, 32 * t2, 16 * jd, l), pf, dV[0][jd]);   // dV^T[d][kv] += dO^T[d][q] P[q][kv]
+          dK[0][jd] = AMma<bf16>::mma(frag_tr_sw(Qc, 32 * t2, 16 * jd, l), sf, dK[0][jd]);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+        }
+      }
+    }
+    if (nxt < end) publish(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    it = nxt;
+  }
+  const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dK[0][j] *= scale;
+  store_grad_tile_sw(dK[0], true, p.rope_cos, p.rope_sin, pos, Qs, w, l);    // (dK through one Q buffer, dV through the other: one barrier fewer)
+  store_grad_tile_sw(dV[0], false, p.rope_cos, p.rope_sin, pos, Qs + TB, w, l);
+  __syncthreads();
+  copy_out_tile_sw(Qs, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 1 : nullptr);
+  copy_out_tile_sw(Qs + TB, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
+}
+
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
 template <typename T, int HD, int R>
 __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : 2) : 1) void attn_bwd_q_kernel(AttnParams p) {
@@ -1071,6 +1267,14 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
   // (two adjacent kv tiles per workgroup -- Q / dO staging and every fragment read shared by 32 keys per wave -- measured 6 % slower:
   // 254 registers, two waves per SIMD; profiles/r4_ab_attn_dkv_two_key_tiles.log)
+  if constexpr (is_bf16<T>::value && HD == 64) {
+    static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);   // A/B switch
+    if (dma) {
+      hipLaunchKernelGGL(attn_bwd_kv_dma_kernel, dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), 4 * 64 * 64 * 2 + 512 * 4, s, p);
+      HIP_CHECK(hipGetLastError());
+      return RSYS_OK;
+    }
+  }
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, HD>), dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), sm_kv, s, p);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
