@@ -111,6 +111,28 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int ld, int tok0, in
   bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(a + 16 * ld));
   return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// The same fragments from an UNPADDED bf16 tile of 64 columns whose 16-byte chunks are XOR-swizzled (chunk c of row r in slot c ^ (r & 7)):
+// free of bank conflicts for both kinds of read, and what one LDS-DMA instruction can fill (attn_*_dma_kernel below).
+__device__ __forceinline__ bf16x8 frag_rows_sw(const bf16* tile, int row0, int k0, int l) {
+  const int row = row0 + (l & 15), ch = (k0 >> 3) + (l >> 4);
+  return *(const bf16x8*)(tile + row * 64 + ((ch ^ (row & 7)) << 3));
+}
+__device__ __forceinline__ bf16x8 frag_tr_sw(const bf16* tile, int tok0, int d0, int l) {
+  const int g = l >> 4, i = l & 15;
+  const int row = tok0 + 4 * g + (i >> 2), col = d0 + 4 * (i & 3);
+  const bf16* a = tile + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
+  bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)a);
+  bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(a + 16 * 64));   // (row + 16: the same slot permutation)
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <typename T, bool SW>
+__device__ __forceinline__ typename AMma<T>::Frag frag_rows_x(const T* tile, int ld, int row0, int k0, int l) {
+  if constexpr (SW) return frag_rows_sw(tile, row0, k0, l); else return frag_rows<T>(tile, ld, row0, k0, l);
+}
+template <bool SW>
+__device__ __forceinline__ bf16x8 frag_tr_x(const bf16* tile, int ld, int tok0, int d0, int l) {
+  if constexpr (SW) return frag_tr_sw(tile, tok0, d0, l); else return frag_tr(tile, ld, tok0, d0, l);
+}
 __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
   bf16x8 o;
   o[0] = (bf16)lo[0]; o[1] = (bf16)lo[1]; o[2] = (bf16)lo[2]; o[3] = (bf16)lo[3];
@@ -157,7 +179,7 @@ __device__ __forceinline__ void first_stage(f32x4 (&S)[4], const T* X, const typ
 
 // The same two stages for R query heads that share one kv head (grouped-query attention) and the same 16 tokens per wave: the
 // K (V^T, ...) fragment of the staged tile is read from LDS ONCE and feeds R MFMAs.
-template <typename T, int HD, int R>
+template <typename T, int HD, int R, bool SW = false>
 __device__ __forceinline__ void first_stage_r(f32x4 (&S)[R][4], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int l) {
   using C = ACfg<T, HD>;
 #pragma unroll
@@ -166,13 +188,13 @@ __device__ __forceinline__ void first_stage_r(f32x4 (&S)[R][4], const T* X, cons
     for (int r = 0; r < R; ++r) S[r][i] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) {
-      const typename AMma<T>::Frag x = frag_rows<T>(X, C::LDD, 16 * i, s * C::KS, l);
+      const typename AMma<T>::Frag x = frag_rows_x<T, SW>(X, C::LDD, 16 * i, s * C::KS, l);
 #pragma unroll
       for (int r = 0; r < R; ++r) S[r][i] = AMma<T>::mma(x, f[r][s], S[r][i]);
     }
   }
 }
-template <typename T, int HD, int R>
+template <typename T, int HD, int R, bool SW = false>
 __device__ __forceinline__ void acc_second_stage_r(f32x4 (&acc)[R][HD / 16], const f32x4 (&P)[R][4], const T* X, int l) {
   using C = ACfg<T, HD>;
   if constexpr (is_bf16<T>::value) {
@@ -183,7 +205,7 @@ __device__ __forceinline__ void acc_second_stage_r(f32x4 (&acc)[R][HD / 16], con
       for (int r = 0; r < R; ++r) pf[r] = pack8(P[r][2 * t2], P[r][2 * t2 + 1]);
 #pragma unroll
       for (int jd = 0; jd < HD / 16; ++jd) {
-        const bf16x8 x = frag_tr(X, C::LDD, 32 * t2, 16 * jd, l);
+        const bf16x8 x = frag_tr_x<SW>(X, C::LDD, 32 * t2, 16 * jd, l);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r][jd] = AMma<bf16>::mma(x, pf[r], acc[r][jd]);
       }
@@ -210,17 +232,17 @@ __device__ __forceinline__ void acc_second_stage_r(f32x4 (&acc)[R][HD / 16], con
 // only two score blocks per head alive instead of four.
 // (S enters with its initial value: zero, or a row / lane constant that the chain then carries -- the dP chains start from -delta, so
 // dS = P * (dP - delta) needs no subtraction)
-template <typename T, int HD, int R>
+template <typename T, int HD, int R, bool SW = false>
 __device__ __forceinline__ void first_stage_block_r(f32x4 (&S)[R], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int i, int l) {
   using C = ACfg<T, HD>;
 #pragma unroll
   for (int s = 0; s < C::NDS; ++s) {
-    const typename AMma<T>::Frag x = frag_rows<T>(X, C::LDD, 16 * i, s * C::KS, l);
+    const typename AMma<T>::Frag x = frag_rows_x<T, SW>(X, C::LDD, 16 * i, s * C::KS, l);
 #pragma unroll
     for (int r = 0; r < R; ++r) S[r] = AMma<T>::mma(x, f[r][s], S[r]);
   }
 }
-template <typename T, int HD, int R>
+template <typename T, int HD, int R, bool SW = false>
 __device__ __forceinline__ void acc_second_stage_half_r(f32x4 (&acc)[R][HD / 16], const f32x4 (&P)[R][2], const T* X, int t2, int l) {
   using C = ACfg<T, HD>;
   if constexpr (is_bf16<T>::value) {
@@ -229,7 +251,7 @@ __device__ __forceinline__ void acc_second_stage_half_r(f32x4 (&acc)[R][HD / 16]
     for (int r = 0; r < R; ++r) pf[r] = pack8(P[r][0], P[r][1]);
 #pragma unroll
     for (int jd = 0; jd < HD / 16; ++jd) {
-      const bf16x8 x = frag_tr(X, C::LDD, 32 * t2, 16 * jd, l);
+      const bf16x8 x = frag_tr_x<SW>(X, C::LDD, 32 * t2, 16 * jd, l);
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r][jd] = AMma<bf16>::mma(x, pf[r], acc[r][jd]);
     }
@@ -561,18 +583,59 @@ __device__ __forceinline__ void copy_out_tile(const T* Os, T* dst, long long ld,
   }
 }
 
+extern "C" __device__ void rsys_at_buffer_load_lds(at_i32x4 rsrc, LDS_AS unsigned int* lds, int size, int voffset, int soffset, int offset,
+                                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+// store_grad_tile / copy_out_tile on one such 8 KB tile (the epilogue stages through a tile buffer it no longer needs)
+__device__ __forceinline__ void store_grad_tile_sw(f32x4 (&acc)[4], bool rotate, const float* rope_cos, const float* rope_sin, int pos, bf16* Os, int w, int l) {
+  const int g = l >> 4, fr = l & 15, row = w * 16 + fr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float o[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+    if (rotate) {
+      const int d2 = (16 * j + 4 * g) >> 1;
+      const float2 cc = *(const float2*)(rope_cos + pos * 32 + d2);
+      const float2 ss = *(const float2*)(rope_sin + pos * 32 + d2);
+      const float a0 = o[0] * cc.x + o[1] * ss.x, a1 = -o[0] * ss.x + o[1] * cc.x;
+      const float b0 = o[2] * cc.y + o[3] * ss.y, b1 = -o[2] * ss.y + o[3] * cc.y;
+      o[0] = a0; o[1] = a1; o[2] = b0; o[3] = b1;
+    }
+    const int col = 16 * j + 4 * g;
+    bf16* dst = Os + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = (bf16)o[r];
+  }
+}
+__device__ __forceinline__ void copy_out_tile_sw(const bf16* Os, bf16* dst, long long ld, int tile_tok0, int T_len, int t, float* amax = nullptr) {
+  float am = 0.f;
+#pragma unroll
+  for (int c = t; c < 512; c += 256) {
+    const int row = c >> 3, ch = c & 7;
+    if (tile_tok0 + row < T_len) {
+      const uint4 v = *(const uint4*)(Os + row * 64 + ((ch ^ (row & 7)) << 3));
+      *(uint4*)(dst + (long long)row * ld + ch * 8) = v;
+      if (amax != nullptr) am = fmaxf(am, chunk_amax<bf16>(v));
+    }
+  }
+  if (amax != nullptr) {
+    am = wave_max(am);
+    if ((t & 63) == 0) f8_amax_add(amax, am);
+  }
+}
 // ------------------------------------------------------------------------ forward
 // R = query heads per workgroup: the R heads of one kv head's group at the SAME 64 tokens (R = 1: one head).  They share the
 // staged K / V tile, every K and V^T fragment read, the tile maps and -- the mask depends on the tokens only -- the mask
 // predicates; soft-max statistics and the output accumulators are per head.
-template <typename T, int HD, int R>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : 2) : 1) void attn_fwd_kernel(AttnParams p) {
+// DMA (bf16, head_dim 64): the K / V tiles arrive by LDS-DMA in unpadded XOR-swizzled tiles (frag_rows_sw), as in attn_bwd_kv_dma_kernel.
+template <typename T, int HD, int R, bool DMA = false>
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : (DMA ? 3 : 2)) : 1) void attn_fwd_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
+  static_assert(!DMA || (is_bf16<T>::value && HD == 64), "LDS-DMA staging: bf16, head_dim 64");
+  constexpr int TILE = DMA ? 64 * 64 : C::TILE;   // elements of a staged tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ks = (T*)smem_raw;                       // [2][64][LDD]
-  T* Vs = Ks + 2 * C::TILE;                   // [2][64][LDD]
-  unsigned long long* ab = (unsigned long long*)(Vs + 2 * C::TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
+  T* Ks = (T*)smem_raw;                       // [2][64][LDD]   (DMA: [2][64][64] swizzled)
+  T* Vs = Ks + 2 * TILE;                      // [2][64][LDD]
+  unsigned long long* ab = (unsigned long long*)(Vs + 2 * TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
@@ -598,7 +661,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) oacc[r][j] = f32x4{0, 0, 0, 0};
   }
-  zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t);
+  if constexpr (!DMA) { zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);   // kv tiles this wave's 16 queries take part in
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
@@ -612,30 +675,48 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 
   TileRegs<T, HD> rk, rv;
   unsigned long long rb = 0ull;
-  auto gload = [&](int kt) {
+  int dv_[2] = {0, 0};   // DMA: wave w fills rows 16 w .. + 15 of a tile with two instructions (8 rows each); per-lane source offsets
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int row = 16 * w + 8 * k + (l >> 3); dv_[k] = (int)((row * p.ld + ((l & 7) ^ (row & 7)) * 8) * sizeof(T)); }
+  }
+  auto gload = [&](int kt, int buf) {   // (DMA: straight into buffer buf; else into registers, lstore(buf) follows after the arithmetic)
     const int so = (int)(kt * 64 * p.ld * sizeof(T));
-    tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
-    tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    if constexpr (DMA) {
+      unsigned char* kd = (unsigned char*)(Ks + buf * TILE) + (16 * w) * 128;
+      unsigned char* vd = (unsigned char*)(Vs + buf * TILE) + (16 * w) * 128;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        rsys_at_buffer_load_lds(k_rs, (LDS_AS unsigned int*)(kd + k * 1024), 16, dv_[k], so, 0, 0);
+        rsys_at_buffer_load_lds(v_rs, (LDS_AS unsigned int*)(vd + k * 1024), 16, dv_[k], so, 0, 0);
+      }
+    } else {
+      tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
+      tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    }
     if (w0) rb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(qb_rs, 8 * l, kt * 512, 0));   // query l's keys of tile kt
   };
   auto lstore = [&](int buf) {
-    tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
-    tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
+    if constexpr (!DMA) {
+      tile_store<T, HD>(rk, Ks + buf * TILE, t);
+      tile_store<T, HD>(rv, Vs + buf * TILE, t);
+    }
     if (w0) ab[buf * 64 + l] = rb;
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA landed (the barrier follows)
   };
 
   int kt = next_bit(bits, 0);
   int cur = 0;
-  if (kt < nt) { gload(kt); lstore(0); }
+  if (kt < nt) { gload(kt, 0); lstore(0); }
   __syncthreads();
   while (kt < nt) {
     const int nxt = next_bit(bits, kt + 1);
-    if (nxt < nt) gload(nxt);
-    const T* Kc = Ks + cur * C::TILE;
-    const T* Vc = Vs + cur * C::TILE;
+    if (nxt < nt) gload(nxt, cur ^ 1);
+    const T* Kc = Ks + cur * TILE;
+    const T* Vc = Vs + cur * TILE;
     if ((wbits >> kt) & 1u) {   // (a wave whose 16 queries have no allowed key in this tile leaves its state untouched)
     f32x4 S[R][4];
-    first_stage_r<T, HD, R>(S, Kc, qf, l);
+    first_stage_r<T, HD, R, DMA>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
       // the lane's query against the tile's 64 keys: one extracted bit per score position, applied to every head (mask_bits_block)
       const unsigned long long wq = ab[cur * 64 + w * 16 + fr] >> (4 * g);
@@ -679,7 +760,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 #pragma unroll
       for (int j = 0; j < HD / 16; ++j) oacc[r][j] *= alpha;
     }
-    acc_second_stage_r<T, HD, R>(oacc, S, Vc, l);
+    acc_second_stage_r<T, HD, R, DMA>(oacc, S, Vc, l);
     }
     if (nxt < nt) lstore(cur ^ 1);
     __syncthreads();
@@ -707,6 +788,10 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 
 // query heads per workgroup of the forward / dQ kernels: the whole group of a kv head when that is 2 (every configuration of
 // H / KV = 2), else 1.  RSYS_ATTN_PAIR=0: one head per workgroup (A/B switch).
+static bool attn_dma_on() {
+  static const bool on = !(getenv("RSYS_ATTN_DMA") && atoi(getenv("RSYS_ATTN_DMA")) == 0);
+  return on;
+}
 static int attn_heads_per_wg(const AttnParams& p) {
   static const int pair = getenv("RSYS_ATTN_PAIR") ? atoi(getenv("RSYS_ATTN_PAIR")) : 1;
   return (pair && p.H / p.KV == 2 && p.hd <= 64) ? 2 : 1;   // (head_dim 128: two heads' accumulators cost a wave per SIMD)
@@ -721,6 +806,15 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd_kernel<T, HD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     set = true;
+  }
+  if constexpr (is_bf16<T>::value && HD == 64) {
+    if (attn_dma_on()) {   // LDS-DMA staging (RSYS_ATTN_DMA=0: the register-staged kernels)
+      const size_t sm_dma = 4 * 64 * 64 * 2 + 384 * 4;
+      if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 2, true>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_dma, s, p);
+      else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 1, true>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_dma, s, p);
+      HIP_CHECK(hipGetLastError());
+      return RSYS_OK;
+    }
   }
   if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 2>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 1>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm, s, p);
@@ -932,56 +1026,6 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 // layout is free of bank conflicts for the natural ds_read_b128 fragments and for both ds_read_b64_tr_b16 reads (as the 160-byte rows
 // are), it is what a DMA instruction can fill (1 KB = 8 consecutive rows, the swizzle applied on the SOURCE side: the lane that fills
 // slot s of row r loads chunk s ^ (r & 7)), and it makes a tile 8 KB: 34 KB per workgroup and ~110 registers -- four workgroups per CU.
-extern "C" __device__ void rsys_at_buffer_load_lds(at_i32x4 rsrc, LDS_AS unsigned int* lds, int size, int voffset, int soffset, int offset,
-                                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
-// store_grad_tile / copy_out_tile on one such 8 KB tile (the epilogue stages through a tile buffer it no longer needs)
-__device__ __forceinline__ void store_grad_tile_sw(f32x4 (&acc)[4], bool rotate, const float* rope_cos, const float* rope_sin, int pos, bf16* Os, int w, int l) {
-  const int g = l >> 4, fr = l & 15, row = w * 16 + fr;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float o[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-    if (rotate) {
-      const int d2 = (16 * j + 4 * g) >> 1;
-      const float2 cc = *(const float2*)(rope_cos + pos * 32 + d2);
-      const float2 ss = *(const float2*)(rope_sin + pos * 32 + d2);
-      const float a0 = o[0] * cc.x + o[1] * ss.x, a1 = -o[0] * ss.x + o[1] * cc.x;
-      const float b0 = o[2] * cc.y + o[3] * ss.y, b1 = -o[2] * ss.y + o[3] * cc.y;
-      o[0] = a0; o[1] = a1; o[2] = b0; o[3] = b1;
-    }
-    const int col = 16 * j + 4 * g;
-    bf16* dst = Os + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dst[r] = (bf16)o[r];
-  }
-}
-__device__ __forceinline__ void copy_out_tile_sw(const bf16* Os, bf16* dst, long long ld, int tile_tok0, int T_len, int t, float* amax = nullptr) {
-  float am = 0.f;
-#pragma unroll
-  for (int c = t; c < 512; c += 256) {
-    const int row = c >> 3, ch = c & 7;
-    if (tile_tok0 + row < T_len) {
-      const uint4 v = *(const uint4*)(Os + row * 64 + ((ch ^ (row & 7)) << 3));
-      *(uint4*)(dst + (long long)row * ld + ch * 8) = v;
-      if (amax != nullptr) am = fmaxf(am, chunk_amax<bf16>(v));
-    }
-  }
-  if (amax != nullptr) {
-    am = wave_max(am);
-    if ((t & 63) == 0) f8_amax_add(amax, am);
-  }
-}
-__device__ __forceinline__ bf16x8 frag_rows_sw(const bf16* tile, int row0, int k0, int l) {
-  const int row = row0 + (l & 15), ch = (k0 >> 3) + (l >> 4);
-  return *(const bf16x8*)(tile + row * 64 + ((ch ^ (row & 7)) << 3));
-}
-__device__ __forceinline__ bf16x8 frag_tr_sw(const bf16* tile, int tok0, int d0, int l) {
-  const int g = l >> 4, i = l & 15;
-  const int row = tok0 + 4 * g + (i >> 2), col = d0 + 4 * (i & 3);
-  const bf16* a = tile + row * 64 + (((col >> 3) ^ (row & 7)) << 3) + (col & 4);
-  bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)a);
-  bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(a + 16 * 64));   // (row + 16: the same slot permutation)
-  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
   constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
   using T = bf16;
@@ -1122,14 +1166,16 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
-template <typename T, int HD, int R>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : 2) : 1) void attn_bwd_q_kernel(AttnParams p) {
+template <typename T, int HD, int R, bool DMA = false>
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : (DMA ? 3 : 2)) : 1) void attn_bwd_q_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
+  static_assert(!DMA || (is_bf16<T>::value && HD == 64), "LDS-DMA staging: bf16, head_dim 64");
+  constexpr int TILE = DMA ? 64 * 64 : C::TILE;   // elements of a staged tile (DMA: unpadded, swizzled; attn_fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Ks = (T*)smem_raw;                  // [2][64 kv][LDD]
-  T* Vs = Ks + 2 * C::TILE;              // [2][64 kv][LDD]
-  unsigned long long* ab = (unsigned long long*)(Vs + 2 * C::TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
+  T* Vs = Ks + 2 * TILE;                 // [2][64 kv][LDD]
+  unsigned long long* ab = (unsigned long long*)(Vs + 2 * TILE);   // [2][64] pair bits of the 64 queries against the staged tile's keys
   const int nt = (p.T + 63) / 64;
   int grp, inner;
   attn_work(p.B * p.KV, (p.H / p.KV / R) * nt, p.order_q, grp, inner);
@@ -1173,7 +1219,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 #pragma unroll
     for (int j = 0; j < HD / 16; ++j) dQ[r][j] = f32x4{0, 0, 0, 0};
   }
-  for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
+  if constexpr (!DMA) for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
   const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
@@ -1186,25 +1232,43 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   const bool w0 = __builtin_amdgcn_readfirstlane(w) == 0;
   TileRegs<T, HD> rk, rv;
   unsigned long long rb = 0ull;
-  auto gload = [&](int kt) {
+  int dv_[2] = {0, 0};   // DMA: per-lane source offsets of the wave's two instructions per tile (attn_fwd_kernel)
+  if constexpr (DMA) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int row = 16 * w + 8 * k + (l >> 3); dv_[k] = (int)((row * p.ld + ((l & 7) ^ (row & 7)) * 8) * sizeof(T)); }
+  }
+  auto gload = [&](int kt, int buf) {
     const int so = (int)(kt * 64 * p.ld * sizeof(T));
-    tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
-    tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    if constexpr (DMA) {
+      unsigned char* kd = (unsigned char*)(Ks + buf * TILE) + (16 * w) * 128;
+      unsigned char* vd = (unsigned char*)(Vs + buf * TILE) + (16 * w) * 128;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        rsys_at_buffer_load_lds(k_rs, (LDS_AS unsigned int*)(kd + k * 1024), 16, dv_[k], so, 0, 0);
+        rsys_at_buffer_load_lds(v_rs, (LDS_AS unsigned int*)(vd + k * 1024), 16, dv_[k], so, 0, 0);
+      }
+    } else {
+      tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
+      tile_load_buf<T, HD>(rv, v_rs, kv_of, so);
+    }
     if (w0) rb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(qb_rs, 8 * l, kt * 512, 0));   // query l's keys of tile kt
   };
   auto lstore = [&](int buf) {
-    tile_store<T, HD>(rk, Ks + buf * C::TILE, t);
-    tile_store<T, HD>(rv, Vs + buf * C::TILE, t);
+    if constexpr (!DMA) {
+      tile_store<T, HD>(rk, Ks + buf * TILE, t);
+      tile_store<T, HD>(rv, Vs + buf * TILE, t);
+    }
     if (w0) ab[buf * 64 + l] = rb;
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   int kt = next_bit(bits, 0), cur = 0;
-  if (kt < nt) { gload(kt); lstore(0); }
+  if (kt < nt) { gload(kt, 0); lstore(0); }
   __syncthreads();
   while (kt < nt) {
     const int nxt = next_bit(bits, kt + 1);
-    if (nxt < nt) gload(nxt);
-    const T* Kc = Ks + cur * C::TILE;
-    const T* Vc = Vs + cur * C::TILE;
+    if (nxt < nt) gload(nxt, cur ^ 1);
+    const T* Kc = Ks + cur * TILE;
+    const T* Vc = Vs + cur * TILE;
     if ((wbits >> kt) & 1u) {
     const bool partial = !((fullbits >> kt) & 1u);
     const unsigned long long wq = ab[cur * 64 + w * 16 + fr] >> (4 * g);   // the lane's query against the tile's 64 keys (mask_bits_block)
@@ -1217,8 +1281,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
         f32x4 S[R], dP[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { S[r] = f32x4{0, 0, 0, 0}; dP[r] = f32x4{-dl[r], -dl[r], -dl[r], -dl[r]}; }
-        first_stage_block_r<T, HD, R>(S, Kc, qf, i, l);      // S^T[kv][q]
-        first_stage_block_r<T, HD, R>(dP, Vc, dof, i, l);    // dP^T[kv][q] - delta[q]
+        first_stage_block_r<T, HD, R, DMA>(S, Kc, qf, i, l);      // S^T[kv][q]
+        first_stage_block_r<T, HD, R, DMA>(dP, Vc, dof, i, l);    // dP^T[kv][q] - delta[q]
         if (partial) mask_bits_block<R>(S, wq, i, -1e30f);   // one extracted bit per score position, applied to every head
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -1228,7 +1292,7 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
             dS[r][ii][rr] = pv * dP[r][rr];   // (the 1/sqrt(hd) factor of dS is applied once to dQ at the end)
           }
       }
-      acc_second_stage_half_r<T, HD, R>(dQ, dS, Kc, t2, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
+      acc_second_stage_half_r<T, HD, R, DMA>(dQ, dS, Kc, t2, l);    // dQ^T[d][q] += K^T[d][kv] dS^T[kv][q]
     }
     }
     if (nxt < nt) lstore(cur ^ 1);
@@ -1262,14 +1326,25 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
     set = true;
   }
   // the dQ kernel also produces delta = rowsum(dO * O), which the dK/dV kernel reads
-  if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 2>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_q, s, p);
-  else hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 1>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
+  bool q_done = false;
+  if constexpr (is_bf16<T>::value && HD == 64) {
+    if (attn_dma_on()) {
+      const size_t sm_dma = 4 * 64 * 64 * 2 + 384 * 4;
+      if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 2, true>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_dma, s, p);
+      else hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 1, true>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_dma, s, p);
+      q_done = true;
+    }
+  }
+  if (!q_done) {
+    if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 2>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_q, s, p);
+    else hipLaunchKernelGGL((attn_bwd_q_kernel<T, HD, 1>), dim3(((p.T + 63) / 64) * p.H * p.B), dim3(256), sm_q, s, p);
+  }
   HIP_CHECK(hipGetLastError());
   // (two adjacent kv tiles per workgroup -- Q / dO staging and every fragment read shared by 32 keys per wave -- measured 6 % slower:
   // 254 registers, two waves per SIMD; profiles/r4_ab_attn_dkv_two_key_tiles.log)
   if constexpr (is_bf16<T>::value && HD == 64) {
-    static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);   // A/B switch
-    if (dma) {
+    static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);   // A/B switch of this kernel alone
+    if (dma && attn_dma_on()) {
       hipLaunchKernelGGL(attn_bwd_kv_dma_kernel, dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), 4 * 64 * 64 * 2 + 512 * 4, s, p);
       HIP_CHECK(hipGetLastError());
       return RSYS_OK;
