@@ -215,7 +215,9 @@ def _attn_ref(q, k, v, uid, tm, dO, H, KV, hd):
 
 @pytest.mark.parametrize("dtype,tol", [(0, 2e-5), (1, 3e-2)])
 @pytest.mark.parametrize("B,T,H,KV,hd,wide_ids", [(2, 128, 2, 1, 64, False), (3, 32, 2, 1, 16, False), (2, 96, 4, 2, 16, False),
-                                                  (1, 200, 2, 2, 32, False), (2, 64, 2, 1, 64, False), (2, 192, 2, 1, 64, True)])
+                                                  (1, 200, 2, 2, 32, False), (2, 64, 2, 1, 64, False), (2, 192, 2, 1, 64, True),
+                                                  # head_dim 64 with a ragged last tile (the LDS-DMA kernels' descriptor bounds), one head per kv head / two
+                                                  (1, 200, 2, 2, 64, False), (2, 136, 4, 2, 64, True), (8, 328, 8, 4, 64, False)])
 def test_attention_fwd_bwd(dtype, tol, B, T, H, KV, hd, wide_ids):
     """Block-sparse masked attention vs numpy: ragged T (not a multiple of the 64-token tile), packed users,
     token-mask ids, GQA, all supported head dims.  Identity RoPE tables so grads compare directly.
