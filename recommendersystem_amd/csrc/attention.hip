@@ -276,19 +276,6 @@ __device__ __forceinline__ void acc_second_stage_half_r(f32x4 (&acc)[R][HD / 16]
 template <typename T, int HD> struct TileRegs { uint4 v[(64 * HD * sizeof(T) / 16 + 255) / 256]; };
 
 template <typename T, int HD>
-__device__ __forceinline__ void tile_load(TileRegs<T, HD>& r, const T* src, long long ld, int t, int nvalid) {
-  using C = ACfg<T, HD>;
-  constexpr int CPR = HD / C::E, N = 64 * CPR;
-#pragma unroll
-  for (int k = 0; k < (N + 255) / 256; ++k) {
-    const int c = t + 256 * k;
-    const int row = c / CPR, ch = c % CPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (c < N && row < nvalid) v = *(const uint4*)(src + row * ld + ch * C::E);
-    r.v[k] = v;
-  }
-}
-template <typename T, int HD>
 __device__ __forceinline__ void tile_store(const TileRegs<T, HD>& r, T* dst, int t) {
   using C = ACfg<T, HD>;
   constexpr int CPR = HD / C::E, N = 64 * CPR;
@@ -1039,7 +1026,17 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? 3 : 1) void 
 // layout is free of bank conflicts for the natural ds_read_b128 fragments and for both ds_read_b64_tr_b16 reads (as the 160-byte rows
 // are), it is what a DMA instruction can fill (1 KB = 8 consecutive rows, the swizzle applied on the SOURCE side: the lane that fills
 // slot s of row r loads chunk s ^ (r & 7)), and it makes a tile 8 KB: 34 KB per workgroup and ~110 registers -- four workgroups per CU.
+// -DATTN_KV_TRACE (tools/trace_attn_kv.sh; never in the product build): wave 0 of every workgroup stamps the wall clock (10 ns) at entry,
+// after the first item is staged, after the item loop and at exit, and sums the item loop's phases -- issue of the next item's DMA and
+// scalar loads, arithmetic, publishing (waits for the DMA), barrier.  rsys_attn_trace_read copies the table out.
+#ifdef ATTN_KV_TRACE
+__device__ unsigned long long rsys_attn_trace[16 * 8192];
+#define KVT_NOW() ((unsigned long long)wall_clock64())
+#else
+#define KVT_NOW() 0ull
+#endif
 __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
+  [[maybe_unused]] unsigned long long tr_[12] = {KVT_NOW(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
   using T = bf16;
   using C = ACfg<T, HD>;
@@ -1124,9 +1121,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
   int it = next_item(0), cur = 0;
   if (it < end) { stage(it, 0); publish(0); }
   __syncthreads();
+  tr_[1] = KVT_NOW();
   while (it < end) {
+    [[maybe_unused]] const unsigned long long ta = KVT_NOW();
     const int nxt = next_item(it + 1);
     if (nxt < end) stage(nxt, cur ^ 1);   // (the other buffer: every wave left it before the barrier that ended the previous item)
+    [[maybe_unused]] const unsigned long long tb = KVT_NOW();
     const T* Qc = Qs + cur * TB;
     const T* dOc = dOs + cur * TB;
     if ((wbits >> (it & 31)) & 1u) {
@@ -1163,11 +1163,21 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
         }
       }
     }
+#ifdef ATTN_KV_TRACE
+    asm volatile("" ::"v"(dK[0][0]), "v"(dV[0][0]));
+    const unsigned long long tc = KVT_NOW();
+#endif
     if (nxt < end) publish(cur ^ 1);
+    [[maybe_unused]] const unsigned long long td = KVT_NOW();
     __syncthreads();
+#ifdef ATTN_KV_TRACE
+    const unsigned long long te = KVT_NOW();
+    tr_[4] += tb - ta; tr_[5] += tc - tb; tr_[6] += td - tc; tr_[7] += te - td; tr_[8] += 1; tr_[9] += (wbits >> (it & 31)) & 1u;
+#endif
     cur ^= 1;
     it = nxt;
   }
+  tr_[2] = KVT_NOW();
   const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) dK[0][j] *= scale;
@@ -1176,6 +1186,10 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
   __syncthreads();
   copy_out_tile_sw(Qs, (T*)p.dk + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 1 : nullptr);
   copy_out_tile_sw(Qs + TB, (T*)p.dv + (tok0 + kvt * 64) * p.ldg + kvh * HD, p.ldg, kvt * 64, p.T, t, p.f8_amax ? p.f8_amax + 2 : nullptr);
+#ifdef ATTN_KV_TRACE
+  tr_[3] = KVT_NOW();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) for (int i = 0; i < 12; ++i) rsys_attn_trace[blockIdx.x * 16 + i] = tr_[i];
+#endif
 }
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
@@ -1387,3 +1401,9 @@ template int launch_attn_bwd<bf16>(const AttnParams&, hipStream_t);
 template int launch_attn_bwd<float>(const AttnParams&, hipStream_t);
 
 }  // namespace rsys
+
+#ifdef ATTN_KV_TRACE
+extern "C" __attribute__((visibility("default"))) int rsys_attn_trace_read(void* dst, unsigned long long n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rsys::rsys_attn_trace), n);
+}
+#endif
