@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--detail", action="store_true", help="per call-site timing table on stderr")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the short legs at other configurations (cfg-2, the reference's production shape in bf16 and fp8) that the default line carries in `other_configs`")
+    ap.add_argument("--zero1", action="store_true",
+                    help="(needs a communicator: --gpus N or --rehearse-comm) ZeRO-1: reduce-scatter of the gradient, AdamW on this rank's 1/N of the "
+                         "parameters, all-gather -- instead of the bucketed all-reduce overlapped with the backward (DESIGN 7)")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
     args = ap.parse_args()
@@ -324,13 +327,19 @@ def main():
     model.upload(d)                            # inputs resident in HBM before the timed region
     tw = ra.make_task_weights()
 
+    zero1 = bool(args.zero1) and comm is not None and not sharded
+    if args.zero1 and not zero1:
+        raise SystemExit("--zero1 needs a communicator (--gpus N or --rehearse-comm) and the replicated table")
+    if zero1:
+        opt.enable_zero1(comm)
+
     def step():
-        if comm is not None:
+        if comm is not None and not zero1:
             comm.begin_grad_sync(model)        # trunk gradient buckets are reduced while the backward runs
         model.forward_resident(False)
-        if comm is not None:
+        if comm is not None and not zero1:
             comm.all_reduce_grads(model)
-        opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=float(world))
+        opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=float(world))   # (zero1: reduce-scatter, partial AdamW and all-gather inside)
         sched.step()
 
     for _ in range(args.warmup):
@@ -477,7 +486,8 @@ def main():
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
                        "parallelism": f"dp{world}" + (f" + item table row-sharded x{world} (vocab-parallel CE, sparse row exchange" +
-                                                                  (f", sampled soft-max {args.sampled_softmax}/rank/medium" if args.sampled_softmax else "") + ")" if sharded else "")},
+                                                                  (f", sampled soft-max {args.sampled_softmax}/rank/medium" if args.sampled_softmax else "") + ")" if sharded else "")
+                                      + (" + ZeRO-1 optimizer" if zero1 else "")},
             "model_flops_per_interaction": fpi,
             "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
             # the same fraction on "useful" FLOPs, attention scaled by the share of same-user (query, key) pairs of this batch

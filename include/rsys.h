@@ -155,6 +155,12 @@ int32_t rsys_adamw_destroy(rsys_optimizer* o);
  * fused_clip_max_norm > 0 fuses clip_grad_norm_ (global norm over the flat gradient buffer) and the
  * data-parallel mean (grads / grad_div) into the update -- one pass over the parameters. */
 int32_t rsys_adamw_step(rsys_optimizer* o, float lr_factor, float fused_clip_max_norm, float grad_div);
+/* (beyond the reference, opt-in) ZeRO-1 for the replicated data-parallel model: rsys_adamw_set_zero1, right after the create, keeps
+ * AdamW moments for this rank's 1/world of the flat parameter range only; rsys_adamw_step_zero1 then replaces rsys_allreduce_grads +
+ * rsys_adamw_step: reduce-scatter of the gradient, global-norm clip from the ranks' partial sums, AdamW on the rank's part,
+ * all-gather of the parameters.  No early gradient buckets in this mode (do not arm rsys_set_grad_sync). */
+int32_t rsys_adamw_set_zero1(rsys_optimizer* o, int32_t rank, int32_t world);
+int32_t rsys_adamw_step_zero1(rsys_optimizer* o, rsys_comm* c, float lr_factor, float fused_clip_max_norm, float grad_div);
 int32_t rsys_adamw_state_get(rsys_optimizer* o, const char* name, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step);
 int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* exp_avg, const float* exp_avg_sq, int64_t n, int32_t step);
 

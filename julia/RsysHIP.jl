@@ -99,6 +99,11 @@ function create_optimizer(m::Model; lr = 1f-4, betas = (0.9f0, 0.95f0), eps = 1f
 end
 step!(o::Optimizer; lr_factor = 1f0, clip = 1f0, grad_div = 1f0) =
     check(ccall((:rsys_adamw_step, LIB), Int32, (Ptr{Cvoid}, Float32, Float32, Float32), o.h, lr_factor, clip, grad_div))
+# (beyond the reference, opt-in) ZeRO-1: moments for this rank's 1/world of the parameters; step_zero1! replaces allreduce_grads! + step!
+set_zero1!(o::Optimizer, rank::Integer, world::Integer) =
+    check(ccall((:rsys_adamw_set_zero1, LIB), Int32, (Ptr{Cvoid}, Int32, Int32), o.h, rank, world))
+step_zero1!(o::Optimizer, c; lr_factor = 1f0, clip = 1f0, grad_div = 1f0) =
+    check(ccall((:rsys_adamw_step_zero1, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Float32, Float32, Float32), o.h, c.h, lr_factor, clip, grad_div))
 
 function unique_id()
     id = Vector{UInt8}(undef, 128)

@@ -78,6 +78,8 @@ _SIGS = [
     ("rsys_adamw_create", C.c_int32, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(_P)]),
     ("rsys_adamw_destroy", C.c_int32, [_P]),
     ("rsys_adamw_step", C.c_int32, [_P, C.c_float, C.c_float, C.c_float]),
+    ("rsys_adamw_set_zero1", C.c_int32, [_P, C.c_int32, C.c_int32]),
+    ("rsys_adamw_step_zero1", C.c_int32, [_P, _P, C.c_float, C.c_float, C.c_float]),
     ("rsys_adamw_state_get", C.c_int32, [_P, C.c_char_p, _P, _P, C.c_int64, C.POINTER(C.c_int32)]),
     ("rsys_adamw_state_set", C.c_int32, [_P, C.c_char_p, _P, _P, C.c_int64, C.c_int32]),
     ("rsys_comm_unique_id", C.c_int32, [C.POINTER(C.c_uint8 * 128)]),

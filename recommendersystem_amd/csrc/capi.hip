@@ -242,10 +242,23 @@ int32_t rsys_adamw_destroy(rsys_optimizer* o) {
   hipSetDevice(o->o.device);
   hipDeviceSynchronize();   // (not the model's stream: the model may already be gone)
   hipFree(o->o.mom); hipFree(o->o.var);
+  if (o->o.z_tailbuf) hipFree(o->o.z_tailbuf);
   delete o;
   return RSYS_OK;
 }
-int32_t rsys_adamw_step(rsys_optimizer* o, float lr_factor, float clip, float grad_div) { CHECK_HANDLE(o); return optimizer_step(&o->o, lr_factor, clip, grad_div); }
+int32_t rsys_adamw_step(rsys_optimizer* o, float lr_factor, float clip, float grad_div) {
+  CHECK_HANDLE(o);
+  ARG_CHECK(!o->o.zero1, "this optimizer is partitioned (rsys_adamw_set_zero1): step it with rsys_adamw_step_zero1");
+  return optimizer_step(&o->o, lr_factor, clip, grad_div);
+}
+int32_t rsys_adamw_set_zero1(rsys_optimizer* o, int32_t rank, int32_t world) { CHECK_HANDLE(o); return optimizer_set_zero1(&o->o, rank, world); }
+int32_t rsys_adamw_step_zero1(rsys_optimizer* o, rsys_comm* c, float lr_factor, float clip, float grad_div) {
+  CHECK_HANDLE(o); CHECK_HANDLE(c);
+  Model* m = o->o.m;
+  m->grad_bucket_hook = nullptr; m->reduced.clear(); m->early_reduced = 0;   // (no early buckets in this mode: the step reduces the whole gradient)
+  m->gemm_flags &= ~2;
+  return optimizer_step_zero1(&o->o, c, lr_factor, clip, grad_div);
+}
 
 static int adam_state_io(rsys_optimizer* o, const char* name, float* m_out, float* v_out, const float* m_in, const float* v_in, int64_t n) {
   Model* m = o->o.m;
@@ -253,6 +266,7 @@ static int adam_state_io(rsys_optimizer* o, const char* name, float* m_out, floa
   if (it == m->by_name.end()) { set_error(std::string("unknown parameter: ") + name); return RSYS_ERR_ARG; }
   const TensorInfo& t = m->tensors[it->second];
   ARG_CHECK(!t.frozen_table, "frozen table has no optimizer state");
+  ARG_CHECK(!o->o.zero1, "partitioned optimizer state (zero1) is not addressable by parameter name");
   ARG_CHECK(n == t.rows * t.cols, "element count");
   HIP_CHECK(hipSetDevice(m->device));
   HIP_CHECK(hipStreamSynchronize(m->stream));

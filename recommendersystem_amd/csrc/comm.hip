@@ -15,6 +15,7 @@ struct RcclApi {
   int (*CommDestroy)(ncclComm_t_) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   int (*Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, ncclComm_t_, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
@@ -35,6 +36,7 @@ int load_rccl() {
   g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(L, "ncclCommDestroy");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(L, "ncclAllReduce");
   g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t_, hipStream_t))dlsym(L, "ncclAllGather");
+  g_rccl.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(L, "ncclReduceScatter");
   g_rccl.Send = (int (*)(const void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(L, "ncclSend");
   g_rccl.Recv = (int (*)(void*, size_t, int, int, ncclComm_t_, hipStream_t))dlsym(L, "ncclRecv");
   g_rccl.GroupStart = (int (*)())dlsym(L, "ncclGroupStart");
@@ -226,6 +228,33 @@ int comm_all_reduce_f64(rsys_comm* c, double* buf, size_t n, hipStream_t s) {
   return RSYS_OK;
 }
 
+int comm_reduce_scatter_f32(rsys_comm* c, float* buf, size_t chunk, hipStream_t s) {
+  if (chunk == 0 || !comm_active(c)) return RSYS_OK;
+  if (c->lg) {
+    LocalGroup* g = c->lg;
+    LocalRankSlot& me = g->slot[c->rank];
+    if (me.tmp_floats < chunk) {
+      if (me.tmp) HIP_CHECK(hipFree(me.tmp));
+      HIP_CHECK(hipMalloc((void**)&me.tmp, chunk * 4));
+      me.tmp_floats = chunk;
+    }
+    int rc = local_begin(c, buf, nullptr, nullptr, s);
+    if (rc) return local_fail(g, rc);
+    if (g->world > 16) { set_error("in-process group: more than 16 ranks"); return local_fail(g, RSYS_ERR_ARG); }
+    PtrList pl; pl.n = g->world;
+    for (int q = 0; q < g->world; ++q) pl.p[q] = (const float*)g->slot[q].send + (size_t)c->rank * chunk;
+    hipLaunchKernelGGL((reduce_ptrs_kernel<float>), dim3((int)std::min<size_t>((chunk + 255) / 256, 4096)), dim3(256), 0, s, pl, (float*)me.tmp, chunk, (int)COMM_SUM);
+    if (hipGetLastError() != hipSuccess) { set_error("reduce-scatter: launch failed"); return local_fail(g, RSYS_ERR_HIP); }
+    rc = local_end(c, s);      // nobody reads a buffer any more: now this rank's chunk may be overwritten with the result
+    if (rc) return local_fail(g, rc);
+    HIP_CHECK(hipMemcpyAsync(buf + (size_t)c->rank * chunk, me.tmp, chunk * 4, hipMemcpyDeviceToDevice, s));
+    return RSYS_OK;
+  }
+  if (!g_rccl.ReduceScatter) { set_error("librccl has no ncclReduceScatter"); return RSYS_ERR_COMM; }
+  NCCL_CHECK(g_rccl.ReduceScatter(buf, buf + (size_t)c->rank * chunk, chunk, NCCL_FLOAT32, COMM_SUM, c->comm, s));
+  return RSYS_OK;
+}
+
 int comm_all_gather(rsys_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
   if (bytes == 0) return RSYS_OK;
   if (!comm_active(c)) {
@@ -237,7 +266,8 @@ int comm_all_gather(rsys_comm* c, const void* send, void* recv, size_t bytes, hi
     int rc = local_begin(c, send, recv, nullptr, s);
     if (rc) return local_fail(g, rc);
     for (int q = 0; q < g->world; ++q)
-      if (hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->slot[q].send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      if ((char*)recv + (size_t)q * bytes != (const char*)g->slot[q].send &&   // (in place: this rank's own chunk is where it belongs)
+          hipMemcpyAsync((char*)recv + (size_t)q * bytes, g->slot[q].send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
         set_error("all-gather: device copy failed");
         return local_fail(g, RSYS_ERR_HIP);    // (the peers must not wait for this rank at the closing barrier)
       }

@@ -64,8 +64,11 @@ inline bool comm_active(const rsys_comm* c) { return c != nullptr && (c->world >
 // in place, float32 (op: COMM_SUM / COMM_MAX) or float64 (sum)
 int comm_all_reduce_f32(rsys_comm* c, float* buf, size_t n, int op, hipStream_t s);
 int comm_all_reduce_f64(rsys_comm* c, double* buf, size_t n, hipStream_t s);
-// recv[r * bytes ..] = rank r's send (bytes per rank)
+// recv[r * bytes ..] = rank r's send (bytes per rank); in place when send == recv + rank * bytes
 int comm_all_gather(rsys_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s);
+// buf holds world * chunk floats on every rank: afterwards this rank's chunk (buf + rank * chunk) is the sum over the ranks (in rank
+// order in the in-process group); the other chunks are undefined
+int comm_reduce_scatter_f32(rsys_comm* c, float* buf, size_t chunk, hipStream_t s);
 // all-to-all with per-pair sizes: rank r sends elements [send_off[q], send_off[q+1]) of `send` to rank q and receives rank
 // q's block for it at recv_off[q]; offsets in elements of elem_bytes, host arrays of world + 1 entries that must stay
 // valid until the call returns

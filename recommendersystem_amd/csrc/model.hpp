@@ -222,7 +222,15 @@ struct Optimizer {
   float lr, b1, b2, eps, wd;
   int step = 0;
   float *mom = nullptr, *var = nullptr;
+  // ZeRO-1 (optimizer_set_zero1): this rank keeps moments for, and updates, only its chunk [z_rank * z_chunk, + z_chunk) of the flat
+  // optimized range (the last rank also the < 64 * world elements behind the last chunk); mom / var hold z_chunk + z_tail floats
+  bool zero1 = false;
+  int z_rank = 0, z_world = 1;
+  long long z_chunk = 0, z_tail = 0;
+  float* z_tailbuf = nullptr;
 };
+int optimizer_set_zero1(Optimizer* o, int rank, int world);
+int optimizer_step_zero1(Optimizer* o, struct rsys_comm* c, float lr_factor, float clip, float grad_div);
 
 int model_create(const rsys_config* cfg, int device, Model** out);
 int model_destroy(Model* m);

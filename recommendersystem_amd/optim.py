@@ -20,8 +20,20 @@ class AdamW:
         self._h = C.c_void_p()
         check(lib().rsys_adamw_create(model._h, lr, betas[0], betas[1], eps, weight_decay, C.byref(self._h)))
 
+        self._zero1 = None
+
+    def enable_zero1(self, comm):
+        """(beyond the reference, opt-in) ZeRO-1: keep AdamW moments for this rank's 1/world of the parameters only.  step() then
+        reduce-scatters the gradient itself (do NOT call comm.all_reduce_grads / begin_grad_sync), updates the rank's part and
+        gathers the parameters.  Call before the first step; replicated pretraining model only."""
+        check(lib().rsys_adamw_set_zero1(self._h, comm.rank, comm.world))
+        self._zero1 = comm
+
     def step(self, lr_factor=1.0, clip_max_norm=0.0, grad_div=1.0):
-        check(lib().rsys_adamw_step(self._h, lr_factor, clip_max_norm, grad_div))
+        if self._zero1 is not None:
+            check(lib().rsys_adamw_step_zero1(self._h, self._zero1._h, lr_factor, clip_max_norm, grad_div))
+        else:
+            check(lib().rsys_adamw_step(self._h, lr_factor, clip_max_norm, grad_div))
 
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad()
