@@ -215,7 +215,8 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     optimizer.zero_grad(set_to_none=True)
     world = 1 if comm is None else comm.world
     for step, data in enumerate(lockstep_batches(model, dataloader, comm)):
-        if comm is not None and (step + 1) % grad_accum_steps == 0:
+        zero1 = getattr(optimizer, "_zero1", None) is not None   # (opt-in ZeRO-1: the optimizer step reduces the gradient itself)
+        if comm is not None and not zero1 and (step + 1) % grad_accum_steps == 0:
             comm.begin_grad_sync(model)        # last micro-step: finished buckets are reduced during the backward
         tloss = model(data, False)
         for i in range(n_tasks):
@@ -224,7 +225,7 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
             training_weights[i] += w
         if (step + 1) % grad_accum_steps != 0:
             continue
-        if comm is not None:
+        if comm is not None and not zero1:
             comm.all_reduce_grads(model)
         optimizer.step(lr_factor=scheduler.factor(), clip_max_norm=max_norm, grad_div=float(world))
         scheduler.step()
