@@ -51,6 +51,7 @@ __device__ __forceinline__ float quad_rows_sum(float v) {
 template <typename T> struct AMma;
 template <> struct AMma<bf16> {
   static constexpr int KS = 32;   // contraction per MFMA
+  // (register-staged kernels; every head size: rows of 96 / 96 / 160 / 288 bytes for head_dim 16 / 32 / 64 / 128 are all free of conflicts)
   // rows of 64 + 16 elements = 160 bytes: by the guide's lane groups the natural ds_read_b128 fragments and both ds_read_b64_tr_b16
   // reads of a transposed fragment are then free of bank conflicts (144-byte rows: 2x the cycles on both; 224-byte rows are free of
   // them too but cost a workgroup per CU).  Measured on one box: dK/dV 311 -> 302 us, forward and dQ unchanged -- the kernels wait on
