@@ -180,13 +180,15 @@ __device__ __forceinline__ void first_stage(f32x4 (&S)[4], const T* X, const typ
 
 // The same two stages for R query heads that share one kv head (grouped-query attention) and the same 16 tokens per wave: the
 // K (V^T, ...) fragment of the staged tile is read from LDS ONCE and feeds R MFMAs.
+// (init != nullptr: the chains of block i start from init[i] instead of zero -- the mask as an additive 0 / -1e30, shared by the heads)
 template <typename T, int HD, int R, bool SW = false>
-__device__ __forceinline__ void first_stage_r(f32x4 (&S)[R][4], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int l) {
+__device__ __forceinline__ void first_stage_r(f32x4 (&S)[R][4], const T* X, const typename AMma<T>::Frag (&f)[R][ACfg<T, HD>::NDS], int l,
+                                              const f32x4* init = nullptr) {
   using C = ACfg<T, HD>;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) S[r][i] = f32x4{0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) S[r][i] = init != nullptr ? init[i] : f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < C::NDS; ++s) {
       const typename AMma<T>::Frag x = frag_rows_x<T, SW>(X, C::LDD, 16 * i, s * C::KS, l);
@@ -517,6 +519,19 @@ __device__ __forceinline__ void mask_bits_block(f32x4 (&S)[R], unsigned long lon
     }
   }
 }
+// The same mask as an ADDEND: 0 where the pair is allowed, -1e30 where not.  A score chain that starts from it ends at exactly the value
+// mask_bits_block would have put there (-1e30 + q.k = -1e30 in fp32), costs no instruction per head, and the addend is the same for every
+// head of the workgroup: extract + insert once per score position instead of extract + one insert per head.
+__device__ __forceinline__ f32x4 mask_bias_block(unsigned long long word, int i) {
+  const int src = (int)(i < 2 ? (unsigned int)word : (unsigned int)(word >> 32));
+  f32x4 b;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int m = __builtin_amdgcn_sbfe(src, 16 * (i & 1) + rr, 1);
+    b[rr] = __builtin_bit_cast(float, __builtin_bit_cast(int, -1e30f) & ~m);
+  }
+  return b;
+}
 // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each); all workgroups of one
 // (row, kv head) group read the same K/V (forward, dQ) or Q/dO (dK/dV) tiles, so a group is kept on ONE XCD: its tiles
 // are fetched from HBM once instead of once per XCD (rocprofv3 FETCH_SIZE: 2.9x the algorithmic bytes before).
@@ -717,23 +732,15 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     const T* Vc = Vs + cur * TILE;
     if ((wbits >> kt) & 1u) {   // (a wave whose 16 queries have no allowed key in this tile leaves its state untouched)
     f32x4 S[R][4];
-    first_stage_r<T, HD, R, DMA>(S, Kc, qf, l);
     if (!((fullbits >> kt) & 1u)) {
-      // the lane's query against the tile's 64 keys: one extracted bit per score position, applied to every head (mask_bits_block)
+      // the lane's query against the tile's 64 keys (pair bits): the mask enters the score chains as their starting value
       const unsigned long long wq = ab[cur * 64 + w * 16 + fr] >> (4 * g);
+      f32x4 bias[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int src = (int)(i < 2 ? (unsigned int)wq : (unsigned int)(wq >> 32));
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int m = __builtin_amdgcn_sbfe(src, 16 * (i & 1) + rr, 1);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const float sv = S[r][i][rr];   // (a copy: see mask_bits_block)
-            S[r][i][rr] = __builtin_bit_cast(float, (__builtin_bit_cast(int, sv) & m) | (__builtin_bit_cast(int, -1e30f) & ~m));
-          }
-        }
-      }
+      for (int i = 0; i < 4; ++i) bias[i] = mask_bias_block(wq, i);
+      first_stage_r<T, HD, R, DMA>(S, Kc, qf, l, bias);
+    } else {
+      first_stage_r<T, HD, R, DMA>(S, Kc, qf, l);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1307,11 +1314,11 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
       for (int ii = 0; ii < 2; ++ii) {
         const int i = 2 * t2 + ii;
         f32x4 S[R], dP[R];
+        const f32x4 s0 = partial ? mask_bias_block(wq, i) : f32x4{0, 0, 0, 0};   // the mask as the chains' starting value, one for every head
 #pragma unroll
-        for (int r = 0; r < R; ++r) { S[r] = f32x4{0, 0, 0, 0}; dP[r] = f32x4{-dl[r], -dl[r], -dl[r], -dl[r]}; }
-        first_stage_block_r<T, HD, R, DMA>(S, Kc, qf, i, l);      // S^T[kv][q]
+        for (int r = 0; r < R; ++r) { S[r] = s0; dP[r] = f32x4{-dl[r], -dl[r], -dl[r], -dl[r]}; }
+        first_stage_block_r<T, HD, R, DMA>(S, Kc, qf, i, l);      // S^T[kv][q] (+ mask)
         first_stage_block_r<T, HD, R, DMA>(dP, Vc, dof, i, l);    // dP^T[kv][q] - delta[q]
-        if (partial) mask_bits_block<R>(S, wq, i, -1e30f);   // one extracted bit per score position, applied to every head
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
