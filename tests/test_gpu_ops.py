@@ -371,3 +371,21 @@ def test_embedding_scatter_is_exact_and_reproducible(case):
     if case == "zipf":
         ref = _run_scatter(gx, ids, m_ids, V, gE0, atomic=1)                               # the float-atomic form agrees to rounding
         assert np.abs(ref - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
+
+
+def test_attention_lds_dma_kernels_equal_the_register_staged_ones_bit_for_bit(tmp_path):
+    """bf16 / head_dim 64 runs the LDS-DMA kernels (swizzled unpadded tiles) by default; RSYS_ATTN_DMA=0 selects the register-staged kernels
+    that every other head size and fp32 use.  Same products in the same order on the same operands: O, the log-sum-exp and dQ / dK / dV
+    must agree bit for bit (two processes: the switch is read once per process).  Ragged last tile, two heads per workgroup."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "recommendersystem_amd", "librsys_hip.so")
+    outs = []
+    for flag in ("0", "1"):
+        f = str(tmp_path / f"attn_{flag}.npz")
+        env = dict(os.environ, RSYS_ATTN_DMA=flag)
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "attn_cmp.py"), "--child", lib, f, "4", "328", "8", "4", "64", "1"], env=env)
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64)).max()))
+    assert np.abs(outs[0]["dqkv"]).max() > 0
