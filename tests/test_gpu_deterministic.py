@@ -54,8 +54,14 @@ def test_three_training_steps_are_bitwise_reproducible(name, rows, dtype):
     c = _three_steps(cfg, P, batches, masks, dtype, False)
     for (la, ga), (lc, gc) in zip(a[0], c[0]):
         assert np.allclose(la, lc, rtol=2e-3 if dtype == "bf16" else 1e-5)
-    worst = max(float(np.abs(a[1][n] - c[1][n]).max() / max(np.abs(c[1][n]).max(), 1e-6)) for n in a[1])
-    assert worst < (5e-2 if dtype == "bf16" else 2e-3), worst
+    # parameters after three Adam steps at lr 1e-2: an element whose gradient is within the summation-order noise of zero may step the other
+    # way (+-lr per step), so two runs -- also two runs of the default mode -- may sit up to 2 * 3 * lr apart in such elements; everything
+    # else agrees to rounding.  (The former bound, 5e-2 of the tensor's maximum, was that same 6e-2 seen through tensors whose maximum is
+    # about one, and a run landed at 0.0505.)
+    worst_abs = max(float(np.abs(a[1][n] - c[1][n]).max()) for n in a[1])
+    assert worst_abs <= (2.2 * 3 * 1e-2 if dtype == "bf16" else 2e-3), worst_abs
+    flipped = max(float((np.abs(a[1][n] - c[1][n]) > 0.5e-2).mean()) for n in a[1] if a[1][n].size >= 1000)
+    assert flipped <= (0.05 if dtype == "bf16" else 0.0), flipped      # ... and only a few elements of a tensor do that
 
 
 def test_default_mode_is_not_bitwise_reproducible_at_this_size():
