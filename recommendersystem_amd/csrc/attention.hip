@@ -340,7 +340,7 @@ __device__ __forceinline__ int next_bit(unsigned int bits, int from) {  // lowes
 // ------------------------------------------------------------------------ tile maps
 // qmap / qmap_full [b][q tile]: bit j = kv tile j has some / only allowed pairs; kmap* is the transposed relation; the
 // *16 maps say the same per group of 16 queries (keys).  One workgroup per (row, q tile); wave w owns the tile's 16
-// queries w*16 .. w*16+15 as SCALARS (v_readlane of the lane that loaded them), the lanes sweep the row's keys 64 at a
+// queries w*16 .. w*16+15 as lane-uniform values (read back from LDS), the lanes sweep the row's keys 64 at a
 // time: allowed(q, kv) <=> key[kv] == key[q] or key[kv] == key[q] without its tm bits (token_key below), so a (query,
 // 64 keys) step is two compares, an OR and a ballot.  Exact: "some" bits may not miss a pair, "only" bits may not claim one.
 __device__ __forceinline__ int token_key(int uid, int tm);
@@ -350,6 +350,8 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   __shared__ int cnt[32];
   __shared__ unsigned short kcols[32][64][4];   // [kv tile][key][query group of 16]: the key's bits against this q tile, written out as words
   __shared__ int keys[2048];                    // the row's token keys (one round of loads instead of a dependent load per kv tile)
+  __shared__ int qkeys[64];                     // the tile's query keys: read back per query as a lane-uniform VECTOR register (as scalars,
+                                                // 16 keys + their tm-less forms + the loop state spilled scalar registers through v_readlane)
   const int qt = blockIdx.x, b = blockIdx.y, t = threadIdx.x, l = t & 63, w = t >> 6;
   const int nt = (p.T + 63) / 64;
   const long long base = (long long)b * p.T;
@@ -360,10 +362,11 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
   // lane i < 16 of wave w holds the key of query qt*64 + w*16 + i
   int myq = KEY_NO_Q;
   if (l < 16) { const int q = qt * 64 + w * 16 + l; if (q < p.T) myq = token_key(p.uid[base + q], p.tm[base + q]); }
-  int aq[16];   // (scalars; the key without its tm bits is one scalar AND away: keeping both arrays spilled scalar registers)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) aq[i] = __builtin_amdgcn_readlane(myq, i);
+  if (l < 16) qkeys[w * 16 + l] = myq;
   __syncthreads();
+  int aq[16], aq0[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { aq[i] = qkeys[w * 16 + i]; aq0[i] = aq[i] & ~4095; }
   unsigned int wany = 0u;
   for (int j = 0; j < nt; ++j) {
     const int ak = keys[j * 64 + l];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
     unsigned int kcol = 0u;           // bit i: this lane's key is seen by query w*16 + i
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const bool hit = ak == aq[i] || ak == (aq[i] & ~4095);
+      const bool hit = ak == aq[i] || ak == aq0[i];
       mine |= hit;
       n += __builtin_popcountll(__ballot(hit));
     }
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
       int qlo = 0, qhi = 0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const bool hit = ak == aq[i] || ak == (aq[i] & ~4095);
+        const bool hit = ak == aq[i] || ak == aq0[i];
         const unsigned long long hb = __ballot(hit);
         qlo = rsys_at_writelane((int)(unsigned int)hb, i, qlo);            // lane i <- query i's row of key bits
         qhi = rsys_at_writelane((int)(unsigned int)(hb >> 32), i, qhi);
