@@ -350,7 +350,7 @@ def main():
     # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first tenth of the timed steps: ~300 event
     # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
     # (at least five instrumented steps once 20 are timed: two samples left the per-kernel entries swinging by 30 %)
-    # (--detail: at most 20 steps -- every call site takes two timing events per step and the runtime's supply is bounded)
+    # (--detail: at most 20 steps)
     n_instr = 0 if args.no_kernel_timing else (min(args.steps, 20) if args.detail else (max(5, args.steps // 10) if args.steps >= 20 else max(1, args.steps // 10)))
     if n_instr:
         model.timing(True, serialize=True)
@@ -361,9 +361,14 @@ def main():
     for i in range(args.steps):
         step()
         model.step_mark()                      # an event on the compute stream per step boundary, no host sync
-        if n_instr and i + 1 == n_instr:
-            rep = model.timing_report()
-            model.timing(False)
+        if n_instr and i < n_instr:
+            # collected after every instrumented step: the event pool is reused, so its size does not depend on the shape
+            # (at the production shape five steps' worth of pending events exceeded what the runtime would record)
+            for k, v in model.timing_report().items():
+                a = rep.setdefault(k, {"ms": 0.0, "count": 0, "flops": 0.0})
+                a["ms"] += v["ms"]; a["count"] += v["count"]; a["flops"] += v["flops"]
+            if i + 1 == n_instr:
+                model.timing(False)
     ra.synchronize()
     hg.barrier()
     elapsed = time.perf_counter() - t0

@@ -38,6 +38,7 @@ static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st =
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
   if (t.used + 2 > t.pool.size()) {
+    if (t.pool.size() >= 8192) { t.enabled = false; return; }   // (a report is taken every few steps; past this the caller forgot to collect)
     for (int i = 0; i < 64; ++i) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) {   // (the runtime hands out a bounded number of timing events: ~10 K; stop measuring, keep running)
@@ -49,7 +50,11 @@ static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st =
     }
   }
   hipEvent_t e = t.pool[t.used++];
-  hipEventRecord(e, st ? st : m->stream);
+  if (hipEventRecord(e, st ? st : m->stream) != hipSuccess) {   // (seen at the production shape with every step instrumented: the record fails once
+    (void)hipGetLastError();                                    //  thousands of events are pending; an unchecked failure surfaced at the next launch check)
+    t.enabled = false;
+    return;
+  }
   t.marks.push_back({std::string(name), e});
   t.acc_ms[std::string("#flops:") + name] += flops;
 }
@@ -57,7 +62,11 @@ static void toc(Model* m, hipStream_t st = nullptr) {
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
   hipEvent_t e = t.pool[t.used++];
-  hipEventRecord(e, st ? st : m->stream);
+  if (hipEventRecord(e, st ? st : m->stream) != hipSuccess) {   // (the span that was open stays unpaired and is dropped by rsys_timing_get)
+    (void)hipGetLastError();
+    t.enabled = false;
+    return;
+  }
   t.marks.push_back({std::string(""), e});
 }
 
