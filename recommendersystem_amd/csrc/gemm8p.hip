@@ -54,6 +54,15 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
   rsys_raw_buffer_load_lds(rsrc, (LDS_AS unsigned int*)lds, 16, (int)voff, 0, 0, 0);
 }
 
+// The same instruction behind asm volatile, for the K-major forms: their fragments are read with ds_read_b64_tr_b16 (an intrinsic),
+// and hipcc's wait-count pass cannot tell such a read apart from a pending LDS-DMA it knows of, so it put s_waitcnt vmcnt(0) in front
+// of the reads of P1, P2 and P3 -- every K tile waited for the half-tile requested one phase earlier (found in the ISA in round 4;
+// the row-major form's plain 16-byte LDS loads are told apart and get no such wait).  Here the compiler does not see the DMA at
+// all: the counted waits of the K loop are the only ones, and the K loop ends with nothing in flight.  lds: wave-uniform LDS byte address.
+__device__ __forceinline__ void dma16_asm(i32x4 rsrc, unsigned int voff, unsigned int lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory");
+}
+
 #define T8_BARRIER()                         \
   do {                                       \
     asm volatile("" ::: "memory");          \
@@ -117,10 +126,20 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     int split;
     if constexpr (GROUP) { tile = g_tile; split = g_split; }
     else {
-      const int ntiles = ((p.M + T8_BM - 1) / T8_BM) * tiles_n;
+      const int tiles_m = (p.M + T8_BM - 1) / T8_BM, ntiles = tiles_m * tiles_n;
       const int xcd = bid & 7, local = bid >> 3;
       tile = local % ntiles;
       split = xcd + 8 * (local / ntiles);
+      // The ~32 workgroups an XCD runs side by side walk their K range in step and share operand columns through its L2: take the
+      // tiles in bands of 8 tile columns (tn fastest inside a band), so that 32 neighbours are 4 x 8 tiles = 12 operand panels rather
+      // than 1.5 rows of a wide product (dW2 at the production shape, 8 x 22 tiles: 24 panels; PMC: 9.3 GB fetched for 2.0 GB of operands)
+      if (tiles_n > 8) {
+        const int full = tiles_n & ~7, band = tiles_m * 8;
+        int tm, tn;
+        if (tile < tiles_m * full) { const int g = tile / band, r = tile - g * band; tm = r >> 3; tn = g * 8 + (r & 7); }
+        else { const int r = tile - tiles_m * full, wd = tiles_n - full; tm = r / wd; tn = full + r - tm * wd; }
+        tile = tm * tiles_n + tn;
+      }
     }
     split_id = split;
     const int ktiles = (p.K + KE - 1) / KE, per = (ktiles + p.splitk - 1) / p.splitk;
@@ -182,17 +201,30 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   };
   unsigned char* const dma_base = smem + w * 2048;   // + buf*65536 + X*32768 + h*16384 + j*1024
   // stage_x(bo, h, d): half-tile h of K tile (current + d) into the buffer at byte offset bo
+  [[maybe_unused]] const unsigned int dma_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)dma_base);
   auto stage_a = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
     const i32x4 rs = window(a_cur, a_rem, stepA, d);
-    dma16(rs, aoff[0][h], dma_base + bo + h * 16384);
-    dma16(rs, aoff[1][h], dma_base + bo + h * 16384 + 1024);
+    if constexpr (KM) {
+      const unsigned int at = (unsigned int)__builtin_amdgcn_readfirstlane((int)(dma_lds + bo + h * 16384));
+      dma16_asm(rs, aoff[0][h], at);
+      dma16_asm(rs, aoff[1][h], at + 1024);
+    } else {
+      dma16(rs, aoff[0][h], dma_base + bo + h * 16384);
+      dma16(rs, aoff[1][h], dma_base + bo + h * 16384 + 1024);
+    }
   };
   auto stage_b = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
     const i32x4 rs = window(b_cur, b_rem, stepB, d);
-    dma16(rs, boff[0][h], dma_base + bo + 32768 + h * 16384);
-    dma16(rs, boff[1][h], dma_base + bo + 32768 + h * 16384 + 1024);
+    if constexpr (KM) {
+      const unsigned int at = (unsigned int)__builtin_amdgcn_readfirstlane((int)(dma_lds + bo + 32768 + h * 16384));
+      dma16_asm(rs, boff[0][h], at);
+      dma16_asm(rs, boff[1][h], at + 1024);
+    } else {
+      dma16(rs, boff[0][h], dma_base + bo + 32768 + h * 16384);
+      dma16(rs, boff[1][h], dma_base + bo + 32768 + h * 16384 + 1024);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -306,7 +338,10 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       if (kt == kseg_next) {   // a K segment with another scale begins: bring the sums so far into its units
         const float r = ((cfloat_p)p.f8_desc)[16 + kseg_idx];
         ++kseg_idx;
-        kseg_next = (kseg_idx < 3 && p.f8_kb[kseg_idx] > 0) ? p.f8_kb[kseg_idx] : -1;
+        // (no run-time index into p: in the grouped kernel p is a local copy, and an indexed member sent the whole struct to scratch
+        //  memory with a scratch load -- and the s_waitcnt vmcnt(0) in front of it -- at the head of every K tile)
+        const int kb = kseg_idx == 1 ? p.f8_kb[1] : (kseg_idx == 2 ? p.f8_kb[2] : 0);
+        kseg_next = kb > 0 ? kb : -1;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -345,6 +380,9 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
     T8_BARRIER();
     a_cur += stepA; b_cur += stepB; a_rem -= stepA; b_rem -= stepB;
   };
+  // (K-major forms, round 4: requesting every half-tile of K tile t+2 as soon as its slot is free for both wave rows -- after the
+  // first barrier of P2 / P3 / P4 -- with each wait one phase before the read it guards: 5.5 phases of lead instead of 3-5.  Equal at
+  // the production shape's products, 10 % slower in the grouped launch of cfg-3; profiles/r4_kmajor_dma_waits.log.  Not kept.)
   // K tile 0 into buffer 0 and (nt > 1) K tile 1 into buffer 1: 16 DMA instructions per wave
   auto prologue = [&]() __attribute__((always_inline)) {
     stage_b(0, I0{}, 0); stage_a(0, I0{}, 0); stage_b(0, I1{}, 0); stage_a(0, I1{}, 0);

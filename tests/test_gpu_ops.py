@@ -171,7 +171,9 @@ def test_gemm_device_side_row_count(monkeypatch, rows, kern):
     assert (raw[started:] == 0x4300).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1408, 8192), (1024, 512, 4160), (520, 264, 1000), (64, 72, 640)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1408, 8192), (1024, 512, 4160), (520, 264, 1000), (64, 72, 640),
+                                   (256, 512, 1216), (264, 256, 1408), (512, 512, 65536),    # (K splits of 3 / 1 K tiles ... and of 128)
+                                   (512, 2568, 2048), (768, 5632, 1024)])                       # (11 / 22 tile columns: banded tile order)
 def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K):
     """K-major operands (weight-gradient shape, K = tokens) on the LDS-DMA pipeline with ds_read_b64_tr_b16 fragments
     and split-K fp32 atomics (gemm8p_kernel<true>), forced: exact on asymmetric integer data, ragged M / N / K (the K tail
