@@ -261,6 +261,9 @@ def main():
     ap.add_argument("--zero1", action="store_true",
                     help="(needs a communicator: --gpus N or --rehearse-comm) ZeRO-1: reduce-scatter of the gradient, AdamW on this rank's 1/N of the "
                          "parameters, all-gather -- instead of the bucketed all-reduce overlapped with the backward (DESIGN 7)")
+    ap.add_argument("--split-table-reduce", action="store_true",
+                    help="(needs a communicator, replicated table, bf16) reduce the item table's gradient in two parts: the heads' part out of place "
+                         "under the trunk backward, the batch's token rows as gathered lists in the tail (DESIGN 7)")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="1 GPU only: issue the RCCL gradient all-reduce at world size 1 (what the data-parallel step enqueues)")
     args = ap.parse_args()
@@ -332,6 +335,11 @@ def main():
         raise SystemExit("--zero1 needs a communicator (--gpus N or --rehearse-comm) and the replicated table")
     if zero1:
         opt.enable_zero1(comm)
+    split_table = bool(args.split_table_reduce) and comm is not None and not sharded and not zero1 and args.dtype == "bf16"
+    if args.split_table_reduce and not split_table:
+        raise SystemExit("--split-table-reduce needs a communicator (--gpus N or --rehearse-comm), the replicated table, bf16, and no --zero1")
+    if split_table:
+        model.set_split_table_reduce(True)
 
     def step():
         if comm is not None and not zero1:
@@ -492,7 +500,7 @@ def main():
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
                        "parallelism": f"dp{world}" + (f" + item table row-sharded x{world} (vocab-parallel CE, sparse row exchange" +
                                                                   (f", sampled soft-max {args.sampled_softmax}/rank/medium" if args.sampled_softmax else "") + ")" if sharded else "")
-                                      + (" + ZeRO-1 optimizer" if zero1 else "")},
+                                      + (" + ZeRO-1 optimizer" if zero1 else "") + (" + split table-gradient reduce" if split_table else "")},
             "model_flops_per_interaction": fpi,
             "step_mfma_frac": round(value / world * fpi / (MFMA_PEAK_TFLOPS * 1e12), 4),
             # the same fraction on "useful" FLOPs, attention scaled by the share of same-user (query, key) pairs of this batch

@@ -175,6 +175,12 @@ int32_t rsys_comm_destroy(rsys_comm* c);
  * of per-layer weight gradients on the communicator's stream while it continues, and rsys_allreduce_grads reduces the
  * rest.  comm == NULL disarms.  (Micro-steps before the last one accumulate locally: DDP no_sync, train.py:268-271.) */
 int32_t rsys_set_grad_sync(rsys_model* m, rsys_comm* c);
+/* (beyond the reference, opt-in; replicated table, bf16) split the reduce of the item table's gradient, 80 % of the flat buffer:
+ * with this on, an armed rsys_set_grad_sync also starts -- as soon as the heads' part of dF is complete, before the trunk backward --
+ * an out-of-place all-reduce of that part; the backward's token scatter is kept as a list of distinct rows, and rsys_allreduce_grads
+ * all-gathers the ranks' lists instead of all-reducing the table: G[E] = sum of the head parts + every rank's token rows, added in
+ * rank order.  Same gradient up to the order of the additions.  Not combined with ZeRO-1. */
+int32_t rsys_model_set_split_table_reduce(rsys_model* m, int32_t on);
 /* row-sharded table mode: the communicator the forward / backward use for the row exchange and the vocabulary-parallel
  * cross entropy (world must equal cfg.table_shard_world; NULL only when that is 1) */
 int32_t rsys_model_set_shard_comm(rsys_model* m, rsys_comm* c);

@@ -117,6 +117,7 @@ end
 self_test(c::Comm) = check(ccall((:rsys_self_test, LIB), Int32, (Ptr{Cvoid},), c.h))
 allreduce_grads!(m::Model, c::Comm) = check(ccall((:rsys_allreduce_grads, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
 # arm the early gradient buckets for the next backward (the last micro-step of an optimizer step)
+set_split_table_reduce!(m::Model, on::Bool=true) = check(ccall((:rsys_model_set_split_table_reduce, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, on ? 1 : 0))
 begin_grad_sync!(m::Model, c::Comm) = check(ccall((:rsys_set_grad_sync, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), m.h, c.h))
 
 # row-sharded item table (rsys_config.table_shard_world >= 1): the communicator of the row exchange and the vocabulary-parallel

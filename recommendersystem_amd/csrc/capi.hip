@@ -349,8 +349,22 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
   Model* m = h->m;
   m->reduced.clear();
   m->grad_bucket_hook = nullptr;
+  m->table_head_hook = nullptr;
   m->gemm_flags &= ~2;
   if (!comm_active(c) || m->cfg.finetune) return RSYS_OK;
+  if (m->split_table && m->bf16_mode && !m->sharded) {
+    // the head part of the item table's gradient, complete when heads() returns: summed over the ranks into tbl_R while the trunk
+    // backward runs (G[E] itself keeps the local gradient: the token scatter and the metadata-projection gradient still need it)
+    m->table_head_hook = [m, c]() -> int {
+      HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
+      HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+      const int64_t n = (int64_t)m->TR * m->D, bucket = 16 * 1024 * 1024;
+      for (int64_t o = 0; o < n; o += bucket)
+        RC(comm_all_reduce_f32_to(c, m->G + m->o_E + o, m->tbl_R + o, (size_t)std::min(bucket, n - o), c->stream));
+      m->split_head_reduced = true;
+      return RSYS_OK;
+    };
+  }
   m->grad_bucket_hook = [m, c](int64_t lo, int64_t hi) -> int {
     hi = std::min(hi, m->n_opt);
     if (lo >= hi) return RSYS_OK;
@@ -362,6 +376,11 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
     return RSYS_OK;
   };
   return RSYS_OK;
+}
+
+int32_t rsys_model_set_split_table_reduce(rsys_model* h, int32_t on) {
+  CHECK_HANDLE(h);
+  return model_split_table_enable(h->m, on);
 }
 
 int32_t rsys_model_set_shard_comm(rsys_model* h, rsys_comm* c) {
@@ -385,6 +404,9 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
   m->grad_bucket_hook = nullptr;   // one backward per arming
+  m->table_head_hook = nullptr;
+  const bool split = m->split_head_reduced && comm_active(c) && model_finalize_splittable(m);   // (else: G[E] holds the whole local gradient, the dense path is right)
+  m->split_head_reduced = false;
   m->gemm_flags &= ~2;             // the optimizer waits for the reduction: nothing after this call overlaps with it
   m->early_reduced = 0;
   for (auto& r : m->reduced) m->early_reduced += r.second - r.first;
@@ -395,6 +417,10 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   // row-sharded table: a rank's table rows already hold the gradient of EVERY rank's loss (vocabulary-parallel head, row
   // exchange of the token gradients): they are not part of the dense all-reduce
   if (m->sharded) done.emplace_back(m->o_E, m->o_E + (int64_t)m->TR * m->D);
+  if (split) {   // split table reduce: tbl_R + the ranks' token rows instead
+    done.emplace_back(m->o_E, m->o_E + (int64_t)m->TR * m->D);
+    m->early_reduced += (int64_t)m->TR * m->D;
+  }
   std::sort(done.begin(), done.end());
   int64_t at = 0;
   for (auto& r : done) { if (r.first > at) rem.emplace_back(at, r.first); at = std::max(at, r.second); }
@@ -415,6 +441,10 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    if (split) {   // nothing reads the local G[E] any more (stage 1 made the operand copy and the bias gradient): it becomes the sum
+      rc = model_split_table_tail(m, c, c->stream);
+      if (rc) return rc;
+    }
     rc = reduce_rest(0, std::min(wo, m->n_opt));
     if (rc) return rc;
     rc = reduce_rest(std::min(wo + wn, m->n_opt), m->n_opt);

@@ -221,6 +221,27 @@ int comm_all_reduce_f32(rsys_comm* c, float* buf, size_t n, int op, hipStream_t 
   NCCL_CHECK(g_rccl.AllReduce(buf, buf, n, NCCL_FLOAT32, op, c->comm, s));
   return RSYS_OK;
 }
+// recv = sum over the ranks of send; send is left as it is (recv != send, no overlap).  The early all-reduce of the item table's
+// head gradient (capi.hip, split table reduce) uses it: the local gradient keeps accumulating while the sum travels.
+int comm_all_reduce_f32_to(rsys_comm* c, const float* send, float* recv, size_t n, hipStream_t s) {
+  if (n == 0) return RSYS_OK;
+  ARG_CHECK(send != recv, "out-of-place all-reduce: send and recv are the same buffer");
+  if (!comm_active(c)) { HIP_CHECK(hipMemcpyAsync(recv, send, n * 4, hipMemcpyDeviceToDevice, s)); return RSYS_OK; }
+  if (c->lg) {
+    LocalGroup* g = c->lg;
+    int rc = local_begin(c, send, recv, nullptr, s);
+    if (rc) return local_fail(g, rc);
+    if (g->world > 16) { set_error("in-process group: more than 16 ranks"); return local_fail(g, RSYS_ERR_ARG); }
+    PtrList pl; pl.n = g->world;
+    for (int q = 0; q < g->world; ++q) pl.p[q] = g->slot[q].send;
+    hipLaunchKernelGGL((reduce_ptrs_kernel<float>), dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, pl, recv, n, (int)COMM_SUM);
+    if (hipGetLastError() != hipSuccess) { set_error("all-reduce: launch failed"); return local_fail(g, RSYS_ERR_HIP); }
+    rc = local_end(c, s);
+    return rc ? local_fail(g, rc) : RSYS_OK;
+  }
+  NCCL_CHECK(g_rccl.AllReduce(send, recv, n, NCCL_FLOAT32, COMM_SUM, c->comm, s));
+  return RSYS_OK;
+}
 int comm_all_reduce_f64(rsys_comm* c, double* buf, size_t n, hipStream_t s) {
   if (n == 0 || !comm_active(c)) return RSYS_OK;
   if (c->lg) { int rc = local_all_reduce<double>(c, buf, n, COMM_SUM, s); return rc ? local_fail(c->lg, rc) : RSYS_OK; }

@@ -63,6 +63,7 @@ inline bool comm_active(const rsys_comm* c) { return c != nullptr && (c->world >
 
 // in place, float32 (op: COMM_SUM / COMM_MAX) or float64 (sum)
 int comm_all_reduce_f32(rsys_comm* c, float* buf, size_t n, int op, hipStream_t s);
+int comm_all_reduce_f32_to(rsys_comm* c, const float* send, float* recv, size_t n, hipStream_t s);   // recv = sum of the ranks' send
 int comm_all_reduce_f64(rsys_comm* c, double* buf, size_t n, hipStream_t s);
 // recv[r * bytes ..] = rank r's send (bytes per rank); in place when send == recv + rank * bytes
 int comm_all_gather(rsys_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s);

@@ -139,6 +139,7 @@ int launch_plan_unique(const int* skey, const int* sidx, int N, int V, int* slot
 int launch_plan_offsets(const int* uniq, const int* plan, const int* bound_dev, int nb, int* off, hipStream_t s);
 int launch_gather_rows_by_id(const float* src, long long ld, const int* ids, int sub, float* dst, int n, int D, hipStream_t s);
 int launch_add_rows_by_id(const float* src, const int* ids, int sub, float* dst, long long ld, int n, int D, hipStream_t s);
+int launch_add_rows_by_id_counted(const float* src, const int* ids, const int* count_dev, float* dst, long long ld, int cap, int D, hipStream_t s);   // rows [0, min(*count_dev, cap))
 int launch_gather_items_remote(const BatchDev& b, const float* Frem, const int* tok2u, const int* plan, int D, float* x0,
                                int* uid_t, int* tm_t, hipStream_t s);
 int launch_vp_meta(const int* idx, const float* label, const float* weight, const int* position, const float* stats,

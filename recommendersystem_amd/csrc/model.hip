@@ -454,6 +454,9 @@ int model_destroy(Model* m) {
   if (m->det_part) hipFree(m->det_part);
   if (m->det_tmp) hipFree(m->det_tmp);
   if (m->req_ids) hipFree(m->req_ids);
+  if (m->tok_Tall) hipFree(m->tok_Tall);
+  if (m->tok_Uall) hipFree(m->tok_Uall);
+  if (m->tok_Pall) hipFree(m->tok_Pall);
   if (m->rows_xchg) hipFree(m->rows_xchg);
   hipEventDestroy(m->ev_fork); hipEventDestroy(m->ev_join); if (m->ev_sel) hipEventDestroy(m->ev_sel); hipStreamDestroy(m->side);
   for (int k = 0; k < 4; ++k) if (m->ev_dw[k]) hipEventDestroy(m->ev_dw[k]);
@@ -748,6 +751,7 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   // the row-sharded table (its exchange plan needs it now), else by the first backward over this batch (an inference or
   // evaluation pass never needs it)
   m->tok_index_valid = false;
+  m->split_plan_valid = false;
   if (m->sharded) { RC(launch_token_index_build(d.matchedid, (int)N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s)); m->tok_index_valid = true; }
   HIP_CHECK(hipStreamSynchronize(s));
   if (m->sharded) RC(build_exchange_plan(m, (int)N));
@@ -1880,6 +1884,22 @@ static int backward_trunk(Model* m) {
         RC(launch_token_index_build(b.matchedid, N, m->V, m->tok_keys, m->tok_skey, m->tok_sidx, s));
         m->tok_index_valid = true;
       }
+      if (m->split_head_reduced) {
+        // split table reduce: one row per distinct id of the batch in tok_T (the sharded path's compact scatter: keys = ranks of the
+        // sorted ids, mask row = slot uV), added to G[E] from there -- the same sums in the same order as the direct scatter
+        if (!m->split_plan_valid) {   // once per resident batch (one host sync: the launcher needs U and uV)
+          RC(launch_plan_unique(m->tok_skey, m->tok_sidx, N, m->V, m->u_slot, m->u_ids, m->u_tok, m->u_plan, s));
+          int plan[2];
+          HIP_CHECK(hipMemcpyAsync(plan, m->u_plan, 8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+          ARG_CHECK(plan[0] >= 1 && plan[0] <= N + 1 && plan[0] <= m->tok_cap && plan[1] >= 0 && plan[1] < plan[0], "split table reduce: inconsistent list of distinct ids");
+          m->U = plan[0]; m->uV = plan[1];
+          m->split_plan_valid = true;
+        }
+        HIP_CHECK(hipMemsetAsync(m->tok_T, 0, (size_t)m->U * D * 4, s));
+        RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->u_slot, m->tok_sidx, N, m->uV, D, m->tok_T, m->scatter_slab, s));
+        RC(launch_add_rows_by_id(m->tok_T, m->u_ids, 0, m->G + m->o_E, D, m->U, D, s));
+      } else
       RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
     }
   }
@@ -1955,6 +1975,44 @@ int model_finalize_grads(Model* m) {
 
 // the two halves separately (gradient all-reduce overlap, capi.hip); only when model_finalize_splittable
 bool model_finalize_splittable(const Model* m) { return m->table_grads_pending && !m->cfg.finetune && m->bf16_mode; }
+
+// ---- split reduce of the replicated item table's gradient (model.hpp; armed per backward by rsys_set_grad_sync)
+int model_split_table_enable(Model* m, int on) {
+  if (!on) { m->split_table = false; m->table_head_hook = nullptr; return RSYS_OK; }
+  ARG_CHECK(!m->sharded, "split table reduce: the item table is row-sharded (its rows are reduced by their owners already)");
+  ARG_CHECK(m->bf16_mode && !m->cfg.finetune, "split table reduce: bf16 training of the full model only (the fp32 mode's metadata-projection gradient reads G[E] itself)");
+  HIP_CHECK(hipSetDevice(m->device));
+  if (!m->tbl_R) {
+    const int64_t N = (int64_t)m->rows_max * m->S;
+    m->tok_cap = N + 1;
+    DALLOC(m->tbl_R, (int64_t)m->TR * m->D * 4);
+    DALLOC(m->tok_T, m->tok_cap * m->D * 4);
+    if (!m->u_slot) { DALLOC(m->u_slot, N * 4); DALLOC(m->u_ids, (N + 1) * 4); DALLOC(m->u_tok, N * 4); DALLOC(m->u_plan, 64); }
+  }
+  m->split_table = true;
+  return RSYS_OK;
+}
+
+int model_split_table_tail(Model* m, rsys_comm* c, hipStream_t cs) {
+  const int W = comm_active(c) ? c->world : 1, D = m->D;
+  const int64_t cap = m->tok_cap;
+  if (m->tok_all_world < W) {
+    for (void* p : {(void*)m->tok_Tall, (void*)m->tok_Uall, (void*)m->tok_Pall}) if (p) HIP_CHECK(hipFree(p));
+    m->tok_Tall = nullptr; m->tok_Uall = nullptr; m->tok_Pall = nullptr;
+    HIP_CHECK(hipMalloc((void**)&m->tok_Tall, (size_t)W * cap * D * 4));
+    HIP_CHECK(hipMalloc((void**)&m->tok_Uall, (size_t)W * cap * 4));
+    HIP_CHECK(hipMalloc((void**)&m->tok_Pall, (size_t)W * 64));
+    m->tok_all_world = W;
+  }
+  RC(comm_all_gather(c, m->tok_T, m->tok_Tall, (size_t)cap * D * 4, cs));
+  RC(comm_all_gather(c, m->u_ids, m->tok_Uall, (size_t)cap * 4, cs));
+  RC(comm_all_gather(c, m->u_plan, m->tok_Pall, 64, cs));
+  HIP_CHECK(hipMemcpyAsync(m->G + m->o_E, m->tbl_R, (size_t)m->TR * D * 4, hipMemcpyDeviceToDevice, cs));
+  for (int q = 0; q < W; ++q)   // rank order: every rank adds the same rows in the same order
+    RC(launch_add_rows_by_id_counted(m->tok_Tall + (size_t)q * cap * D, m->tok_Uall + (size_t)q * cap, m->tok_Pall + (size_t)q * 16,
+                                     m->G + m->o_E, D, (int)cap, D, cs));
+  return RSYS_OK;
+}
 int model_finalize_stage(Model* m, int stage, int64_t* wp_off, int64_t* wp_n) {
   if (wp_off) *wp_off = m->o_Wp;
   if (wp_n) *wp_n = (int64_t)m->D * m->Mp;
@@ -1981,7 +2039,11 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   if (m->sharded) RC(sharded_counts_early<T>(m, !evaluate, tw));
   RC(forward_trunk<T>(m));
   RC(heads<T>(m, evaluate, tw));
-  if (!evaluate) RC(backward_trunk<T>(m));
+  if (!evaluate) {
+    m->split_head_reduced = false;
+    if (m->table_head_hook) RC(m->table_head_hook());   // dF's head part is complete: its all-reduce starts under the trunk backward
+    RC(backward_trunk<T>(m));
+  }
   return RSYS_OK;
 }
 

@@ -58,6 +58,18 @@ struct Model {
   // enqueues its all-reduce on the communicator's stream behind an event and records the range in `reduced`
   std::function<int(int64_t, int64_t)> grad_bucket_hook;
   std::vector<std::pair<int64_t, int64_t>> reduced;
+  // Split reduce of the replicated item table's gradient (opt-in, rsys_model_set_split_table_reduce): the head part of dF
+  // (complete when heads() returns) is all-reduced OUT OF PLACE into tbl_R while the trunk backward runs and G[E] goes on
+  // accumulating the local gradient; the token scatter of that backward goes to a compact list (tok_T rows, u_ids ids, u_plan = {U, uV})
+  // and is added to G[E] from there; in the tail only the ranks' lists travel (all-gather), and G[E] = tbl_R + every rank's rows.
+  bool split_table = false;          // buffers allocated, the hook may be armed
+  bool split_head_reduced = false;   // this backward: the head part is on its way, the token scatter goes through tok_T
+  bool split_plan_valid = false;     // u_slot / u_ids / u_plan describe the resident batch (replicated table)
+  std::function<int()> table_head_hook;
+  float *tbl_R = nullptr, *tok_T = nullptr, *tok_Tall = nullptr;
+  int *tok_Uall = nullptr, *tok_Pall = nullptr;
+  int64_t tok_cap = 0;               // rows of tok_T and ids of u_ids: rows_max * S + 1
+  int tok_all_world = 0;             // ranks tok_Tall / tok_Uall / tok_Pall are sized for
   int gemm_flags = 0;          // OR-ed into GemmParams.flags: 2 while all-reduce kernels may share the CUs with the backward
   int64_t early_reduced = 0;   // elements the last rsys_allreduce_grads found already reduced (tests)
   bool bf16_mode = false;
@@ -247,6 +259,8 @@ int model_item_table(Model* m, float* out, int64_t n);
 int model_materialise_trunk_output(Model* m);   // dense trunk output of the resident forward in m->out (a training pass computes it at the selected tokens only)
 int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);
+int model_split_table_enable(Model* m, int on);
+int model_split_table_tail(Model* m, struct rsys_comm* c, hipStream_t cs);   // on cs: gather the ranks' token rows, G[E] = tbl_R + rows
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);
 int model_clip(Model* m, float max_norm, float* norm_out);
 int model_set_deterministic(Model* m, int on);

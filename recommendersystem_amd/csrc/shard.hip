@@ -101,6 +101,26 @@ int launch_add_rows_by_id(const float* src, const int* ids, int sub, float* dst,
   return RSYS_OK;
 }
 
+// the same with the row count on the device (split table reduce: a peer's list of distinct token rows, its length in plan[0])
+__global__ void add_rows_by_id_counted_kernel(const float* __restrict__ src, const int* __restrict__ ids, const int* __restrict__ count,
+                                              float* dst, long long ld, int cap, int D) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  if (j >= cap || j >= count[0]) return;
+  const float4* s4 = (const float4*)(src + (long long)j * D);
+  float4* d4 = (float4*)(dst + (long long)ids[j] * ld);
+  for (int c = l; c < (D >> 2); c += 64) {
+    float4 a = d4[c]; const float4 b = s4[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[c] = a;
+  }
+}
+int launch_add_rows_by_id_counted(const float* src, const int* ids, const int* count_dev, float* dst, long long ld, int cap, int D, hipStream_t s) {
+  if (cap == 0) return RSYS_OK;
+  hipLaunchKernelGGL(add_rows_by_id_counted_kernel, dim3(div_up(cap, 4)), dim3(256), 0, s, src, ids, count_dev, dst, ld, cap, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 // token gather from the fetched rows: x0[2n] = Frem[masked ? uV : tok2u[n]] (model.py:23-24,139-145) + per-token uid / tm
 __global__ void gather_items_remote_kernel(BatchDev b, const float* __restrict__ Frem, const int* __restrict__ tok2u,
                                            const int* __restrict__ plan, int D, float* x0, int* uid_t, int* tm_t) {

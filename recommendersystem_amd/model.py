@@ -126,6 +126,11 @@ class RecommenderModel:
         """bitwise reproducible training steps (fixed summation order everywhere; a few percent slower); also `config["deterministic"]`"""
         check(lib().rsys_model_set_deterministic(self._h, 1 if on else 0))
 
+    def set_split_table_reduce(self, on=True):
+        """opt-in (replicated table, bf16): reduce the item table's gradient in two parts -- the heads' part early and out of place
+        under the trunk backward, the batch's token rows as a gathered list in the tail (`Comm.begin_grad_sync` arms it per step)"""
+        check(lib().rsys_model_set_split_table_reduce(self._h, 1 if on else 0))
+
     def set_shard_comm(self, comm):
         """row-sharded table mode: the communicator of the row exchange and the vocabulary-parallel cross entropy"""
         check(lib().rsys_model_set_shard_comm(self._h, comm._h if comm is not None else None))
