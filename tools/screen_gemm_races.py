@@ -33,5 +33,14 @@ for _ in range(24):
         n += 1
         if not np.array_equal(out, ref.astype(np.float32)):
             bad += 1; print("MISMATCH 8t", M, N, K, rep, int((out != ref.astype(np.float32)).sum()))
+# the K-major kernel's DMA is issued behind asm volatile since round 4 (the compiler no longer adds its own vmcnt(0) before the transposed
+# LDS reads): the counted waits of the K loop carry it alone.  Long K ranges per split, wide products (banded tile order), odd K tiles.
+for (M, N, K) in [(2048, 5632, 32768), (4096, 2048, 65536), (11264, 2048, 16384), (512, 6208, 131072), (2048, 2048, 131072),
+                  (264, 2568, 12352), (1024, 4104, 9000)]:
+    for rep in range(3):
+        out, ref = T.run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, integer=True, seed=M + N + K + rep)
+        n += 1
+        if not np.array_equal(out, ref.astype(np.float32)):
+            bad += 1; print("MISMATCH 8t long", M, N, K, rep, int((out != ref.astype(np.float32)).sum()))
 print(f"screened {n} GEMMs, {bad} mismatches")
 sys.exit(1 if bad else 0)
