@@ -1205,7 +1205,10 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
 
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
 template <typename T, int HD, int R, bool DMA = false>
-__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : (DMA ? 3 : 2)) : 1) void attn_bwd_q_kernel(AttnParams p) {
+#ifndef ATTN_DQ_WPS
+#define ATTN_DQ_WPS 3   // waves per SIMD the two-head LDS-DMA form is compiled for (4: 128 registers, 13 spilled dwords; A/B in profiles/r4_ab_attn_dq_four_waves.log)
+#endif
+__global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 : (DMA ? ATTN_DQ_WPS : 2)) : 1) void attn_bwd_q_kernel(AttnParams p) {
   using C = ACfg<T, HD>;
   using M = AMma<T>;
   static_assert(!DMA || (is_bf16<T>::value && HD == 64), "LDS-DMA staging: bf16, head_dim 64");
