@@ -350,3 +350,34 @@ def test_library_is_built_without_slp_packing():
     mk = open(os.path.join(os.path.dirname(__file__), "..", "recommendersystem_amd", "csrc", "Makefile")).read()
     flags = [l for l in mk.splitlines() if l.startswith("CXXFLAGS")]
     assert flags and all("-fno-slp-vectorize" in l for l in flags)
+
+
+def test_kmajor_gemm_kernels_do_not_drain_their_dma_before_transposed_lds_reads(tmp_path):
+    """The K-major weight-gradient kernels read their fragments with ds_read_b64_tr_b16 while LDS-DMA for later K tiles is in flight.
+    With the DMA issued through the compiler's intrinsic, hipcc put `s_waitcnt vmcnt(0)` in front of those reads (it cannot tell them
+    from the DMA's target), which drained the pipeline once per phase: 850 instead of 1150 TFLOP/s.  The kernels
+    issue the DMA behind asm volatile for that reason; this test reads the ISA of the built library and fails if such a wait is back."""
+    import os, re, shutil, subprocess
+    lib = os.path.join(os.path.dirname(__file__), "..", "recommendersystem_amd", "librsys_hip.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        pytest.skip("built library or llvm-objdump not present")
+    work = tmp_path / "isa"
+    work.mkdir()
+    shutil.copy(lib, work / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    seen = 0
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        asm = subprocess.run([objdump, "-d", f], cwd=work, check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*gemm8p_(?:group_kernel|kernelILb1ELb0E)\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", asm, re.S | re.M):
+            body = [l.split("//")[0].strip() for l in m.group(2).splitlines() if l.strip()]
+            tr = [i for i, l in enumerate(body) if l.startswith("ds_read_b64_tr_b16")]
+            assert len(tr) >= 48, (m.group(1), len(tr))            # the K loop's fragment reads are there
+            for i in tr:
+                window = body[max(0, i - 12):i]
+                # (between a drain and the reads hipcc only puts address arithmetic; a counted wait, vmcnt(N > 0), is the schedule's own)
+                assert not any(re.match(r"s_waitcnt\s+vmcnt\(0\)", w) for w in window), (m.group(1), window)
+            seen += 1
+    assert seen == 2, seen   # gemm8p_group_kernel and gemm8p_kernel<true, false>
