@@ -85,7 +85,7 @@ long long gemm_slab_need(const GemmParams& p, bool a_f32, bool b_f32, bool a_km,
 // C, EPI_ATOMIC (C must hold zeros or the sum so far).
 struct GemmGroupPlan;
 bool gemm8p_group_eligible(const GemmParams& p);   // (p.f8 set: the fp8 split-K form, else the bf16 K-major form; one form per plan)
-int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out);
+int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out, bool ordered = false);   // ordered: split-K partial tiles to slabs, summed in index order (deterministic mode)
 void gemm8p_group_plan_destroy(GemmGroupPlan* pl);
 double gemm8p_group_flops(const GemmGroupPlan* pl);
 int gemm8p_group_splitk(const GemmGroupPlan* pl);

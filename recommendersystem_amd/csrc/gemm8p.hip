@@ -594,13 +594,33 @@ struct GemmGroupPlan {
   int grid = 0, n = 0, splitk = 1;
   bool f8 = false;
   double flops = 0.0;
+  // ordered (deterministic) form: every product's K splits store their partial tiles into its own slab [split][M][N] (all of them in
+  // one allocation, cleared per launch) and one batched kernel adds the splits in index order into C afterwards
+  float* slab_all = nullptr; size_t slab_bytes = 0; int max_mn4 = 0;
 };
+
+// grid.y = product: C[row][col] += sum over its splits (in index order) of slab[split][row][col]
+__global__ void slab_reduce_group_kernel(const GemmParams* __restrict__ probs) {
+  const GemmParams& p = probs[blockIdx.y];
+  const long long n4 = (long long)p.M * p.N / 4, stride = (long long)p.M * p.N;
+  float* C = (float*)p.C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 acc = *(const float4*)(p.slab + 4 * i);
+    for (int sp = 1; sp < p.splitk; ++sp) {
+      const float4 v = *(const float4*)(p.slab + sp * stride + 4 * i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long long e = 4 * i, row = e / p.N; const int col = (int)(e % p.N);
+    float4* c = (float4*)(C + row * p.ldc + col);
+    float4 o = *c; o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w; *c = o;
+  }
+}
 
 bool gemm8p_group_eligible(const GemmParams& p) { return (p.f8 ? gemm8p_f8_splitk_eligible(p) : gemm8p_tn_eligible(p)) && p.slab == nullptr; }
 
 // Deals `n` (<= 128) K-major products (EPI_ATOMIC, fp32 C, zero or accumulating) to the XCDs and uploads the plan.  The plan
 // holds device pointers of the operands: it stays valid while those buffers do.  Synchronous (one small H2D copy).
-int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out) {
+int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out, bool ordered) {
   ARG_CHECK(n >= 1 && n <= 128, "grouped GEMM: 1..128 products");
   int cus = 256;
   { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
@@ -656,6 +676,20 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   int longest = 0;
   double flops = 0.0;
   for (int i = 0; i < n; ++i) { hp[i].splitk = best_s; if (hp[i].alpha == 0.f) hp[i].alpha = 1.f; flops += 2.0 * hp[i].M * hp[i].N * (double)hp[i].K; }
+  float* slab_all = nullptr; size_t slab_bytes = 0; int max_mn4 = 0;
+  if (ordered) {
+    ARG_CHECK(!f8, "grouped GEMM: the ordered form exists for the bf16 products only");
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+      ARG_CHECK(hp[i].N % 4 == 0 && hp[i].ldc % 4 == 0, "grouped GEMM: the ordered split-K sum needs N % 4 == 0");
+      total += (long long)best_s * hp[i].M * hp[i].N;
+      max_mn4 = std::max(max_mn4, (int)((long long)hp[i].M * hp[i].N / 4));
+    }
+    slab_bytes = (size_t)total * 4;
+    if (hipMalloc((void**)&slab_all, slab_bytes) != hipSuccess) { set_error("grouped GEMM: hipMalloc of the split-K slabs failed"); return RSYS_ERR_HIP; }
+    long long at = 0;
+    for (int i = 0; i < n; ++i) { hp[i].slab = slab_all + at; hp[i].slab_floats = (long long)best_s * hp[i].M * hp[i].N; at += hp[i].slab_floats; }
+  }
   for (int x = 0; x < 8; ++x) {
     off[x] = (int)work.size();
     for (int i : lists[x]) {
@@ -670,24 +704,30 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   off[8] = (int)work.size();
   GemmGroupPlan* pl = new GemmGroupPlan();
   const size_t b_probs = (sizeof(GemmParams) * n + 255) / 256 * 256, b_off = 256, b_work = (work.size() * 4 + 255) / 256 * 256;
-  if (hipMalloc(&pl->dev, b_probs + b_off + b_work) != hipSuccess) { delete pl; set_error("grouped GEMM: hipMalloc failed"); return RSYS_ERR_HIP; }
+  pl->slab_all = slab_all; pl->slab_bytes = slab_bytes; pl->max_mn4 = max_mn4;
+  if (hipMalloc(&pl->dev, b_probs + b_off + b_work) != hipSuccess) { if (slab_all) hipFree(slab_all); delete pl; set_error("grouped GEMM: hipMalloc failed"); return RSYS_ERR_HIP; }
   pl->d_probs = (const GemmParams*)pl->dev; pl->d_off = (const int*)((char*)pl->dev + b_probs); pl->d_work = (const unsigned int*)((char*)pl->dev + b_probs + b_off);
   bool ok = hipMemcpy((void*)pl->d_probs, hp.data(), sizeof(GemmParams) * n, hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy((void*)pl->d_off, off.data(), 9 * 4, hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy((void*)pl->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
-  if (!ok) { hipFree(pl->dev); delete pl; set_error("grouped GEMM: plan upload failed"); return RSYS_ERR_HIP; }
+  if (!ok) { hipFree(pl->dev); if (slab_all) hipFree(slab_all); delete pl; set_error("grouped GEMM: plan upload failed"); return RSYS_ERR_HIP; }
   pl->grid = 8 * longest; pl->n = n; pl->splitk = best_s; pl->flops = flops; pl->f8 = f8;
   *out = pl;
   return RSYS_OK;
 }
-void gemm8p_group_plan_destroy(GemmGroupPlan* pl) { if (pl) { if (pl->dev) hipFree(pl->dev); delete pl; } }
+void gemm8p_group_plan_destroy(GemmGroupPlan* pl) { if (pl) { if (pl->dev) hipFree(pl->dev); if (pl->slab_all) hipFree(pl->slab_all); delete pl; } }
 double gemm8p_group_flops(const GemmGroupPlan* pl) { return pl->flops; }
 int gemm8p_group_splitk(const GemmGroupPlan* pl) { return pl->splitk; }
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s) {
   if (pl->grid <= 0) return RSYS_OK;
+  if (pl->slab_all) HIP_CHECK(hipMemsetAsync(pl->slab_all, 0, pl->slab_bytes, s));   // (K splits without work leave their part untouched)
   if (pl->f8) hipLaunchKernelGGL(gemm8p_group_f8_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
   else hipLaunchKernelGGL(gemm8p_group_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
   HIP_CHECK(hipGetLastError());
+  if (pl->slab_all) {
+    hipLaunchKernelGGL(slab_reduce_group_kernel, dim3((unsigned)std::min(std::max((pl->max_mn4 + 255) / 256, 1), 512), pl->n), dim3(256), 0, s, pl->d_probs);
+    HIP_CHECK(hipGetLastError());
+  }
   return RSYS_OK;
 }
 

@@ -1610,7 +1610,8 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
   const int D = m->D, Ip = m->Ip, NT = 2 * m->cur_rows * m->S;
   const bool top_compact = m->top_is_sparse;   // the last layer's W2 / W13 / Wo products ran on the compact rows already
   const bool f8 = use_f8_dw(m);                 // fp8 trunk: the products read the transposed fp8 copies instead
-  const long long key = ((long long)f8 << 57) | ((long long)top_compact << 56) | ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
+  const bool ordered = m->deterministic;        // the K splits' partial tiles to per-product slabs, added in index order
+  const long long key = ((long long)ordered << 58) | ((long long)f8 << 57) | ((long long)top_compact << 56) | ((long long)l_lo << 40) | ((long long)l_hi << 32) | (unsigned int)m->cur_rows;
   auto it = m->dw_plans.find(key);
   if (it == m->dw_plans.end()) {
     std::vector<GemmParams> ps;
@@ -1636,7 +1637,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
       for (auto& kv : m->dw_plans) gemm8p_group_plan_destroy(kv.second);
       m->dw_plans.clear();
     }
-    RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl));
+    RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl, ordered));
     it = m->dw_plans.emplace(key, pl).first;
   }
   if (m->timer.enabled) tic(m, f8 ? "gemm_dw_group@8gf" : "gemm_dw_group@8g", gemm8p_group_flops(it->second));
@@ -1660,7 +1661,9 @@ static int backward_trunk(Model* m) {
   T* dht = AT<T>(m->dh_t);
   const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
   // deferred weight gradients: the dY operands of layer l live in m->dwb[l] until the grouped launch that consumes them
-  const bool defer = m->defer_dw && !m->deterministic && side_mode() == 0;
+  // (deterministic mode: the grouped launch in its ordered form -- bf16 products only, and the fp8 weight gradients are off in that mode)
+  static const bool det_group = !(getenv("RSYS_DET_DW_GROUP") && atoi(getenv("RSYS_DET_DW_GROUP")) == 0);   // A/B: 0 = the per-layer slab path
+  const bool defer = m->defer_dw && (!m->deterministic || (det_group && m->bf16_mode)) && side_mode() == 0;
   const bool ctop = m->top_is_sparse;
   if (defer && !ctop) gxt = AT<T>(m->dwb[m->L - 1].gxt);
   RC(ensure_transposes(m));
