@@ -9,7 +9,8 @@ import recommendersystem_amd as ra  # noqa: E402
 from oracle import synth  # noqa: E402
 
 out, dtype = sys.argv[1], sys.argv[2]
-cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+import os  # noqa: E402
+cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=os.environ.get("RSYS_TEST_DETERMINISTIC") == "1")
 rows, seed = 4, 31
 P = synth.make_params(cfg, seed, "test")
 d = synth.make_batch(cfg, rows, seed + 1)

@@ -14,7 +14,10 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARMS = {"default": {}, "dense_top": {"RSYS_SPARSE_TOP": "0"}, "token_order": {"RSYS_TOP_ORDER": "0"}, "per_layer_dw": {"RSYS_DW_GROUP": "0"},
-        "all_off": {"RSYS_SPARSE_TOP": "0", "RSYS_DW_GROUP": "0"}}
+        "all_off": {"RSYS_SPARSE_TOP": "0", "RSYS_DW_GROUP": "0"},
+        # deterministic mode (config["deterministic"], set by the worker): the grouped launch in its ordered form (per-product slabs,
+        # one batched in-order sum; round 4) and the per-layer slab path it replaced
+        "det_grouped_dw": {"RSYS_TEST_DETERMINISTIC": "1"}, "det_per_layer_dw": {"RSYS_TEST_DETERMINISTIC": "1", "RSYS_DET_DW_GROUP": "0"}}
 
 
 @pytest.mark.parametrize("dtype,tol_loss,tol", [("fp32", 1e-6, 2e-5), ("bf16", 2e-3, 3e-2)])
