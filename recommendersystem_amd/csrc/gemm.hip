@@ -493,11 +493,11 @@ static bool use_8p_tn(const GemmParams& p) {
   if (e && atoi(e) == 1) return false;
   if (!gemm8p_tn_eligible(p)) return false;
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-  // measured (tools/bench_gemm_tn.py and in the step): the two transposed reads per fragment make this pipeline ~35 %
-  // slower per FLOP than its row-major form, so it wins only where the 128x128 kernel needs many K splits per output
-  // tile AND the output is large (>= 32 tiles of 256 x 256; the per-layer gradients, 4..22 tiles, stay on the 128 x 128 kernel).
-  // (The step's one such product, the metadata-projection gradient, has moved to row-major operand copies: use_8p_nt_splitk.)
-  return (e && atoi(e) == 2) || t256 >= 32;
+  // measured (tools/dbg/dw_small_outputs.py, round 4, after the kernel's LDS-DMA stopped being drained every phase): against the
+  // 128x128 kernel it is 25-40 % faster from 16 output tiles of 256 x 256 on (1024 x 1024: 926 against 744 TFLOP/s; 2048 x 1024: 964
+  // against 688), level at 8-12 tiles and slower at 4 (too few workgroups per K split).  The step's per-layer gradients at cfg-3
+  // (4..22 tiles) go through the grouped launch instead (model.hip); this rule serves the shapes that do not (cfg-4, the production shape).
+  return (e && atoi(e) == 2) || t256 >= 16;
 }
 
 // row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
