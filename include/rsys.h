@@ -192,6 +192,9 @@ int32_t rsys_table_rows(rsys_model* m, int64_t* lo, int64_t* hi);
 int32_t rsys_local_group_create(int32_t world, int32_t device, void** group);
 int32_t rsys_local_group_destroy(void* group);
 int32_t rsys_comm_init_local(void* group, int32_t rank, rsys_comm** out);
+/* tests: occupy the communicator's stream for `microseconds` (<= 2e6) with a spinning kernel -- a collective that starts late; what
+ * the cross-stream ordering test of the split table reduce delays (tests/test_gpu_split_table_reduce.py) */
+int32_t rsys_comm_debug_delay(rsys_comm* c, int32_t microseconds);
 /* sum-all-reduce of (the rest of) the flat gradient buffer in buckets (the mean is folded into rsys_adamw_step's
  * grad_div); *early_floats (optional query): how many gradient elements the last call found already reduced */
 int32_t rsys_allreduce_grads(rsys_model* m, rsys_comm* c);

@@ -85,6 +85,7 @@ _SIGS = [
     ("rsys_comm_unique_id", C.c_int32, [C.POINTER(C.c_uint8 * 128)]),
     ("rsys_comm_init", C.c_int32, [C.POINTER(C.c_uint8 * 128), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("rsys_comm_destroy", C.c_int32, [_P]),
+    ("rsys_comm_debug_delay", C.c_int32, [_P, C.c_int32]),
     ("rsys_set_grad_sync", C.c_int32, [_P, _P]),
     ("rsys_model_set_split_table_reduce", C.c_int32, [_P, C.c_int32]),
     ("rsys_model_set_shard_comm", C.c_int32, [_P, _P]),

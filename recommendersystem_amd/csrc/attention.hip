@@ -595,9 +595,14 @@ extern "C" __device__ void rsys_at_buffer_load_lds(at_i32x4 rsrc, LDS_AS unsigne
 // apart from a pending LDS-DMA behind that DMA, i.e. it would make an item wait for the NEXT item's tiles as soon as it reads LDS.  Here
 // it does not see the DMA; vector memory returns in issue order, so its own counted waits for later loads still cover what they must, and
 // the wave's explicit s_waitcnt vmcnt(0) before the publishing barrier covers the DMA.  lds: wave-uniform LDS byte address.
+// (M0 is written here and listed as clobbered, so that the compiler never takes an M0 value of its own for still valid behind the statement;
+// clang's warning about a reserved register on the clobber list is silenced for this one statement: the clobber is the intent.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16_asm(at_i32x4 rsrc, unsigned int lds, int voffset, int soffset) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 // (Measured per kernel on one box, intrinsic -> asm: dK/dV 193 -> 183 us, dQ 171 -> 177, forward 123 -> 127: the asm form in dK/dV only.)
 template <bool ASM>
 __device__ __forceinline__ void dma16(at_i32x4 rsrc, unsigned char* lds, int voffset, int soffset) {

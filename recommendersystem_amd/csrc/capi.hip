@@ -306,6 +306,7 @@ int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, i
   return comm_init_rccl(id_buf, rank, world, device, out);
 }
 int32_t rsys_comm_destroy(rsys_comm* c) { return comm_destroy(c); }
+int32_t rsys_comm_debug_delay(rsys_comm* c, int32_t microseconds) { CHECK_HANDLE(c); return comm_debug_delay(c, microseconds); }
 
 // in-process rank group (tests of the multi-rank partition arithmetic on one GPU): `world` ranks of THIS process on one
 // device, each driven by its own host thread; rsys_comm_init_local gives rank r its communicator
@@ -361,6 +362,11 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
       const int64_t n = (int64_t)m->TR * m->D, bucket = 16 * 1024 * 1024;
       for (int64_t o = 0; o < n; o += bucket)
         RC(comm_all_reduce_f32_to(c, m->G + m->o_E + o, m->tbl_R + o, (size_t)std::min(bucket, n - o), c->stream));
+      // The collective READS G[E] on the communicator's stream; the trunk backward WRITES G[E] on the model's stream (the token rows,
+      // model.hip backward_trunk).  That write waits for this event: free when the reduce is done by then, and otherwise what keeps a
+      // slow link from folding some ranks' token rows into tbl_R, which the tail would then add a second time.
+      HIP_CHECK(hipEventRecord(c->ev_head, c->stream));
+      m->split_head_event = c->ev_head;
       m->split_head_reduced = true;
       return RSYS_OK;
     };
@@ -407,6 +413,7 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   m->table_head_hook = nullptr;
   const bool split = m->split_head_reduced && comm_active(c) && model_finalize_splittable(m);   // (else: G[E] holds the whole local gradient, the dense path is right)
   m->split_head_reduced = false;
+  m->split_head_event = nullptr;   // (everything below is ordered behind the head reduce on the communicator's stream itself)
   m->gemm_flags &= ~2;             // the optimizer waits for the reduction: nothing after this call overlaps with it
   m->early_reduced = 0;
   for (auto& r : m->reduced) m->early_reduced += r.second - r.first;

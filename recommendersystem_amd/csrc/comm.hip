@@ -70,6 +70,7 @@ static int comm_common_init(rsys_comm* c) {
   HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming));
   HIP_CHECK(hipMalloc((void**)&c->scratch, 64 * sizeof(double)));
   return RSYS_OK;
 }
@@ -150,8 +151,23 @@ int comm_destroy(rsys_comm* c) {
   if (c->scratch) hipFree(c->scratch);
   if (c->ev_ready) hipEventDestroy(c->ev_ready);
   if (c->ev_done) hipEventDestroy(c->ev_done);
+  if (c->ev_head) hipEventDestroy(c->ev_head);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
+  return RSYS_OK;
+}
+
+// tests only: occupy the communicator's stream for a while, as a collective that is late to start would (the in-process group's
+// copies are otherwise too fast to expose a missing cross-stream wait)
+__global__ void comm_spin_kernel(unsigned long long ticks) {   // wall_clock64: 100 MHz
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int comm_debug_delay(rsys_comm* c, int us) {
+  ARG_CHECK(c != nullptr && us >= 0 && us <= 2000000, "delay: 0 .. 2e6 microseconds");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(comm_spin_kernel, dim3(1), dim3(64), 0, c->stream, (unsigned long long)us * 100ull);
+  HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
 
@@ -196,9 +212,10 @@ static int local_all_reduce(rsys_comm* c, T* buf, size_t n, int op, hipStream_t 
   LocalGroup* g = c->lg;
   LocalRankSlot& me = g->slot[c->rank];
   const size_t need = (n * sizeof(T) + 3) / 4;
-  if (me.tmp_floats < need) {
-    if (me.tmp) HIP_CHECK(hipFree(me.tmp));
-    HIP_CHECK(hipMalloc((void**)&me.tmp, need * 4));
+  if (me.tmp_floats < need) {   // (failures return an error code: the callers route it through local_fail, which releases the peers)
+    if (me.tmp) hipFree(me.tmp);
+    me.tmp = nullptr; me.tmp_floats = 0;
+    if (hipMalloc((void**)&me.tmp, need * 4) != hipSuccess) { me.tmp = nullptr; set_error("all-reduce: hipMalloc of the staging buffer failed"); return RSYS_ERR_HIP; }
     me.tmp_floats = need;
   }
   int rc = local_begin(c, buf, nullptr, nullptr, s);
@@ -254,9 +271,10 @@ int comm_reduce_scatter_f32(rsys_comm* c, float* buf, size_t chunk, hipStream_t 
   if (c->lg) {
     LocalGroup* g = c->lg;
     LocalRankSlot& me = g->slot[c->rank];
-    if (me.tmp_floats < chunk) {
-      if (me.tmp) HIP_CHECK(hipFree(me.tmp));
-      HIP_CHECK(hipMalloc((void**)&me.tmp, chunk * 4));
+    if (me.tmp_floats < chunk) {   // (a rank that cannot allocate breaks the group: its peers must not wait for it at the barrier)
+      if (me.tmp) hipFree(me.tmp);
+      me.tmp = nullptr; me.tmp_floats = 0;
+      if (hipMalloc((void**)&me.tmp, chunk * 4) != hipSuccess) { me.tmp = nullptr; set_error("reduce-scatter: hipMalloc of the staging chunk failed"); return local_fail(g, RSYS_ERR_HIP); }
       me.tmp_floats = chunk;
     }
     int rc = local_begin(c, buf, nullptr, nullptr, s);
@@ -268,7 +286,7 @@ int comm_reduce_scatter_f32(rsys_comm* c, float* buf, size_t chunk, hipStream_t 
     if (hipGetLastError() != hipSuccess) { set_error("reduce-scatter: launch failed"); return local_fail(g, RSYS_ERR_HIP); }
     rc = local_end(c, s);      // nobody reads a buffer any more: now this rank's chunk may be overwritten with the result
     if (rc) return local_fail(g, rc);
-    HIP_CHECK(hipMemcpyAsync(buf + (size_t)c->rank * chunk, me.tmp, chunk * 4, hipMemcpyDeviceToDevice, s));
+    if (hipMemcpyAsync(buf + (size_t)c->rank * chunk, me.tmp, chunk * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("reduce-scatter: device copy failed"); return local_fail(g, RSYS_ERR_HIP); }
     return RSYS_OK;
   }
   if (!g_rccl.ReduceScatter) { set_error("librccl has no ncclReduceScatter"); return RSYS_ERR_COMM; }

@@ -44,6 +44,7 @@ struct rsys_comm {
   ncclComm_t_ comm = nullptr;
   hipStream_t stream = nullptr;        // the gradient all-reduce's own stream (overlaps the backward)
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_head = nullptr;        // split table reduce: recorded behind the out-of-place all-reduce that READS G[E] (capi.hip)
   double* scratch = nullptr;
   bool force = false;                  // RSYS_FORCE_RCCL=1: run the collectives even at world == 1 (exercises RCCL on one GPU)
   // in-process group (tests)
@@ -59,6 +60,8 @@ int comm_unique_id(unsigned char id_buf[128]);
 int comm_init_rccl(const unsigned char id_buf[128], int rank, int world, int device, rsys_comm** out);
 int comm_init_local(LocalGroup* g, int rank, rsys_comm** out);
 int comm_destroy(rsys_comm* c);
+// tests: a kernel that spins for `us` microseconds (<= 2 s) on the communicator's stream, i.e. a collective that starts late
+int comm_debug_delay(rsys_comm* c, int us);
 inline bool comm_active(const rsys_comm* c) { return c != nullptr && (c->world > 1 || c->force || c->lg != nullptr); }
 
 // in place, float32 (op: COMM_SUM / COMM_MAX) or float64 (sum)

@@ -59,9 +59,15 @@ __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned int voff, unsigned ch
 // of the reads of P1, P2 and P3 -- every K tile waited for the half-tile requested one phase earlier (found in the ISA in round 4;
 // the row-major form's plain 16-byte LDS loads are told apart and get no such wait).  Here the compiler does not see the DMA at
 // all: the counted waits of the K loop are the only ones, and the K loop ends with nothing in flight.  lds: wave-uniform LDS byte address.
+// The statement writes M0 and lists it as clobbered: the compiler tracks and merges its own M0 initialisations (LDS-DMA intrinsic, movrel,
+// readlane / writelane through M0) and must not take an earlier value of its own for still valid behind this statement.  (clang warns
+// that M0 is a reserved register; the clobber is what the warning's note asks to be aware of, and it is the intent.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16_asm(i32x4 rsrc, unsigned int voff, unsigned int lds) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 #define T8_BARRIER()                         \
   do {                                       \

@@ -1901,6 +1901,9 @@ static int backward_trunk(Model* m) {
         }
         HIP_CHECK(hipMemsetAsync(m->tok_T, 0, (size_t)m->U * D * 4, s));
         RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->u_slot, m->tok_sidx, N, m->uV, D, m->tok_T, m->scatter_slab, s));
+        // G[E] is still the SEND buffer of the head part's out-of-place all-reduce on the communicator's stream (capi.hip
+        // table_head_hook): the first write to it since then waits for that collective to have read it
+        if (m->split_head_event) HIP_CHECK(hipStreamWaitEvent(s, m->split_head_event, 0));
         RC(launch_add_rows_by_id(m->tok_T, m->u_ids, 0, m->G + m->o_E, D, m->U, D, s));
       } else
       RC(launch_embedding_scatter_segmented(gx, 2LL * D, b.m_matchedid, m->tok_skey, m->tok_sidx, N, m->V, D, m->G + m->o_E, m->scatter_slab, s));
@@ -2044,6 +2047,7 @@ static int forward_backward_t(Model* m, int evaluate, const float task_w[4], flo
   RC(heads<T>(m, evaluate, tw));
   if (!evaluate) {
     m->split_head_reduced = false;
+    m->split_head_event = nullptr;
     if (m->table_head_hook) RC(m->table_head_hook());   // dF's head part is complete: its all-reduce starts under the trunk backward
     RC(backward_trunk<T>(m));
   }

@@ -66,6 +66,7 @@ struct Model {
   bool split_head_reduced = false;   // this backward: the head part is on its way, the token scatter goes through tok_T
   bool split_plan_valid = false;     // u_slot / u_ids / u_plan describe the resident batch (replicated table)
   std::function<int()> table_head_hook;
+  hipEvent_t split_head_event = nullptr;   // recorded behind the head part's all-reduce (which reads G[E]); the token-row add into G[E] waits for it
   float *tbl_R = nullptr, *tok_T = nullptr, *tok_Tall = nullptr;
   int *tok_Uall = nullptr, *tok_Pall = nullptr;
   int64_t tok_cap = 0;               // rows of tok_T and ids of u_ids: rows_max * S + 1

@@ -289,6 +289,10 @@ class Comm:
         check(lib().rsys_allreduce_f64(self._h, arr, len(values)))
         return list(arr)
 
+    def debug_delay(self, microseconds):
+        """tests: a kernel that spins this long on the communicator's stream (a collective that starts late)"""
+        check(lib().rsys_comm_debug_delay(self._h, int(microseconds)))
+
     def close(self):
         if self._h:
             lib().rsys_comm_destroy(self._h)

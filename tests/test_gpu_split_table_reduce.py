@@ -30,7 +30,7 @@ def _run_ranks(world, fn):
     return out
 
 
-def _grads(cfg, P, batches, masks, world, split, micro_steps):
+def _grads(cfg, P, batches, masks, world, split, micro_steps, delay_us=0):
     """every rank: `micro_steps` backward passes over its own batches (the last one with the gradient sync armed), then the reduce"""
     import recommendersystem_amd as ra
     from oracle import synth
@@ -50,6 +50,8 @@ def _grads(cfg, P, batches, masks, world, split, micro_steps):
         for i in range(micro_steps):
             if i == micro_steps - 1:
                 comm.begin_grad_sync(model)
+                if delay_us:      # the communicator's stream is busy: the head part's all-reduce starts after the whole backward
+                    comm.debug_delay(delay_us)
             losses.append(model(batches[r][i], False, masks=masks[r][i]))
         comm.all_reduce_grads(model)
         early = comm.early_reduced(model)
@@ -93,6 +95,30 @@ def test_split_table_reduce_equals_the_dense_all_reduce(world, micro_steps):
                 assert d <= 2e-6 * scale, (r, n, d, scale)              # another order of the same fp32 additions
             else:
                 assert np.array_equal(ga[n], gb[n]), (r, n, float(np.abs(ga[n] - gb[n]).max()))
+
+
+def test_token_rows_wait_for_a_late_head_reduce():
+    """The head part's out-of-place all-reduce READS G[E] on the communicator's stream while the trunk backward later ADDS the batch's
+    token rows to G[E] on the model's stream.  With the communicator's stream held back for 0.3 s -- far longer than
+    the backward of this tiny model -- a missing cross-stream wait lets the reduce see the token rows, and the tail adds them a second
+    time: the table's gradient then differs from the dense path by whole token-row gradients, not by float rounding."""
+    from oracle import synth
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=True)
+    world, rows, seed = 2, 2, 91
+    P = synth.make_params(cfg, seed, "test")
+    batches = [[synth.make_batch(cfg, rows, seed + 1 + 10 * r)] for r in range(world)]
+    masks = [[synth.make_masks(cfg, rows, seed + 2 + 10 * r)] for r in range(world)]
+    table = "item_embedding.matchedid_embedding.embedding.weight"
+    ref = _grads(cfg, P, batches, masks, world, False, 1)
+    got = _grads(cfg, P, batches, masks, world, True, 1, delay_us=300000)
+    for r in range(world):
+        ga, gb = ref[r][1], got[r][1]
+        scale = float(np.abs(ga[table]).max())
+        d = float(np.abs(ga[table] - gb[table]).max())
+        assert d <= 2e-6 * scale, (r, d, scale)
+        for n in ga:
+            if n != table:
+                assert np.array_equal(ga[n], gb[n]), (r, n)
 
 
 def test_split_table_reduce_refuses_what_it_does_not_cover():
