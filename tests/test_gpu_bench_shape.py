@@ -28,11 +28,12 @@ def _perturb_scales(model, seed):
             model.set_parameter(n, (1.0 if n.endswith(".scale") else 0.0) + 0.1 * rng.standard_normal(shape).astype(np.float32))
 
 
-def _scale_trunk_to_order_one(model):
+def _scale_trunk_to_order_one(model, frozen_too=False):
     """init weights are N(0, 0.006) (model.py:5-12); bring every trunk / head matrix to N(0, 1 / fan_in) -- attention logits and
-    MLP pre-activations of order one, so that no gradient is a cancellation residue of the rounding noise"""
+    MLP pre-activations of order one, so that no gradient is a cancellation residue of the rounding noise
+    (frozen_too: a finetune model's base matrices are frozen; its LoRA factors keep their own scale)"""
     for n, shape, tr in model.named_parameters():
-        if tr and len(shape) == 2 and (n.startswith("transformers.") or n.startswith("rating_head.") or n.startswith("action_embedding.linear")):
+        if (tr or frozen_too) and "lora_" not in n and len(shape) == 2 and (n.startswith("transformers.") or n.startswith("rating_head.") or n.startswith("action_embedding.linear")):
             model.set_parameter(n, model.get_parameter(n) * np.float32(1.0 / (0.006 * np.sqrt(shape[-1]))))
 
 
@@ -88,14 +89,16 @@ def init_scale_step():
     return _cfg3_step("init", with_exact=True)
 
 
-def _check_losses_norm_and_update(r):
+def _check_losses_norm_and_update(r, tol_loss, tol_norm):
+    """tol_loss / tol_norm: an order of magnitude above what is measured (profiles/r4_bench_shape_tests.log: initialisation-scale weights
+    3.2e-6 / 3.5e-5, order-one weights 1.2e-4 / 2.6e-4), so that a regression of one order fails"""
     names, lr = r["names"], r["lr"]
     e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(r["losses"], r["ref_losses"])]
     norm_gpu = float(np.sqrt(sum(float((r["G"][n].astype(np.float64) ** 2).sum()) for n in names)))
     print("bench-shape parity: losses", r["losses"], "oracle", r["ref_losses"], "rel", e_l)
     print("  grad norm", norm_gpu, "oracle", r["ref_norm"])
-    assert max(e_l) <= 5e-3, (r["losses"], r["ref_losses"])
-    assert abs(norm_gpu - r["ref_norm"]) <= 1e-2 * r["ref_norm"], (norm_gpu, r["ref_norm"])
+    assert max(e_l) <= tol_loss, (r["losses"], r["ref_losses"])
+    assert abs(norm_gpu - r["ref_norm"]) <= tol_norm * r["ref_norm"], (norm_gpu, r["ref_norm"])
     # one fused clip + AdamW step.  The first Adam step moves every element by lr * g / (|g| + eps) ~ +-lr: elements whose two
     # gradients disagree in sign (|g| within the bf16 noise of zero) differ by 2 lr, all the others by ~lr * eps / |g|
     flips, total, worst = 0, 0, 0.0
@@ -115,7 +118,7 @@ def test_bench_shape_step_vs_cpp_oracle(init_scale_step):
     print("  worst gradients: max|hip - oracle_bf16| / max, rel L2, max|hip - exact| / max, max|oracle_bf16 - exact| / max")
     for row in table[:6]:
         print("    %.3e %.3e %.3e %.3e %s" % row)
-    _check_losses_norm_and_update(r)
+    _check_losses_norm_and_update(r, 5e-5, 5e-4)
     # every named gradient within the bf16-rounded-oracle bound (5e-2 of the tensor's max).  The q / k projections of the upper
     # layers are the exception the bound was not made for AT INITIALISATION-SCALE WEIGHTS: rows of dS sum to zero, so the keys'
     # common component cancels in the signal but not in the rounding noise of the bf16 dS operand, and two bf16 evaluations of the
@@ -139,7 +142,7 @@ def test_bench_shape_step_with_order_one_weights_vs_cpp_oracle():
         print("    %.3e %.3e %s" % row)
     qk = [row for row in table if "q_proj" in row[2] or "k_proj" in row[2]]
     print("  worst q / k projection:", "%.3e %.3e %s" % qk[0])
-    _check_losses_norm_and_update(r)
+    _check_losses_norm_and_update(r, 1e-3, 2e-3)
     for e_r, e_l2, n in table:
         assert e_r <= 5e-2, (n, e_r, e_l2)
 
@@ -248,7 +251,7 @@ def test_cfg4_own_size_sharded_step_equals_replicated():
             if e > worst_g[1]:
                 worst_g = (n, e)
     print(f"cfg-4 own size, world {world}: losses {worst_l:.2e}, worst gradient {worst_g}, q / k projections {worst_qk:.2e}, parameters max |diff| {worst_p:.2e} (lr {lr})")
-    assert worst_l <= 2e-3, worst_l                  # measured by tools/rehearse_sharded.py: 3e-5
+    assert worst_l <= 2e-5, worst_l                  # measured 6.7e-7 (profiles/r4_bench_shape_tests.log)
     assert worst_g[1] <= 5e-2, worst_g
     assert worst_qk <= 1e-1, worst_qk
     assert worst_p <= 2.0 * lr * 1.02 + 1e-7, worst_p
@@ -284,7 +287,7 @@ def test_cfg5_lora_finetune_step_at_cfg3_size_vs_numpy_oracle(medium, metric):
     ti = medium * 2 + (0 if metric == "watch" else 1)
     tw = [0.0] * 4; tw[ti] = 1.0
     d = _finetune_batch(cfg, 1, 77, medium, metric)
-    for dtype, tol_loss, tol_grad in (("fp32", 1e-4, 1e-3), ("bf16", 5e-3, 5e-2)):
+    for dtype, tol_loss, tol_grad in (("fp32", 1e-6, 5e-4), ("bf16", 3e-4, 5e-2)):   # (measured: loss 5e-8 / 3.4e-5, fp32 gradients 4.4e-5)
         model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=1)
         model.init_weights(0x1217)
         model.random_pretrained_embeddings(0x3E7A)
@@ -330,6 +333,60 @@ def test_cfg5_lora_finetune_step_at_cfg3_size_vs_numpy_oracle(medium, metric):
         for e_r, n in table:
             e_x, e_rx = mx(G[n], G_x[n]), mx(G_ref[n], G_x[n])
             assert e_r <= tol_grad or ("q_proj" in n and e_x <= 2.0 * e_rx + 1e-3), (n, e_r, e_x, e_rx)
+
+
+def test_cfg5_bf16_lora_gradients_are_signal_with_order_one_weights():
+    """the bf16 leg above exempts the q-path LoRA gradients (one user, one target, initialisation-scale weights: rows of
+    dS sum to zero and only the rounding noise of the bf16 dS operand survives).  The independent check cfg-3 got in round 4, for cfg-5:
+    a finetune batch of EIGHT users with every frozen trunk matrix at N(0, 1 / fan_in) -- attention logits of order one, the q-path
+    gradients are signal -- must put EVERY LoRA tensor, q path included, within the unrelaxed 5e-2 of the bf16-rounded numpy oracle."""
+    import recommendersystem_amd as ra
+    from oracle import model_np, synth
+    medium, metric, rows = 1, "watch", 8
+    cfg = synth.make_config("cfg3", finetune=True, finetune_metric=metric, finetune_medium=medium)
+    cfg["lora_dropout"] = 0.0
+    V = cfg["vocab_sizes"]["0_matchedid"] + cfg["vocab_sizes"]["1_matchedid"]
+    D = cfg["embed_dim"]
+    ti = medium * 2
+    tw = [0.0] * 4; tw[ti] = 1.0
+    d = _finetune_batch(cfg, rows, 311, medium, metric)
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.init_weights(0x1217)
+    model.random_pretrained_embeddings(0x3E7A)
+    _perturb_scales(model, 3)
+    _scale_trunk_to_order_one(model, frozen_too=True)
+    lora = [n for n, _, tr in model.named_parameters() if tr]
+    assert lora and all("lora_" in n for n in lora)
+    rng = np.random.default_rng(8)
+    for n in lora:                                   # lora_B starts at zero (model.py:252-254): its A gradients would vanish
+        if "lora_B" in n:
+            model.set_parameter(n, 0.02 * rng.standard_normal(model._shape(n)[1]).astype(np.float32))
+    model.set_loss_weights(tw, 1)
+    losses = model(d, False)
+    G = {n: model.grad(n) for n in lora}
+    P = {k: v for k, v in model.state_dict(include_frozen=True).items() if not k.startswith("watch_head.")}
+    model.close()
+    meta = P.pop(M_NAME)
+    Wp = model_np.bf16_round(P["item_embedding.projection_layer.weight"]).astype(np.float64)
+    F = np.zeros((V + 1, D), np.float64)
+    for r0 in range(0, V, 8192):
+        F[r0:r0 + 8192] = meta[r0:r0 + 8192].astype(np.float64) @ Wp.T
+    F += P[E_NAME].astype(np.float64) + P["item_embedding.projection_layer.bias"].astype(np.float64)
+    del meta
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    P64["item_embedding.fused_embedding"] = F
+    ref = model_np.OracleModel(cfg, P64, np.float64, operand_round="bf16")
+    dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d))
+    l_ref, G_ref = ref.forward(dm, False, True, tw)
+    e_l = abs(losses[ti] - l_ref[ti]) / max(abs(l_ref[ti]), 1e-6)
+    mx = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    table = sorted(((mx(G[n], G_ref[n]), n) for n in lora), reverse=True)
+    qpath = [row for row in table if "q_proj" in row[1]]
+    print(f"cfg-5 LoRA step, {rows} users, order-one weights, bf16: loss {losses[ti]:.6f} oracle {l_ref[ti]:.6f} rel {e_l:.2e}; worst LoRA gradients {table[:3]}; worst q path {qpath[:2]}")
+    assert e_l <= 2e-3, (losses, l_ref)
+    assert min(np.abs(G_ref[n]).max() for n in lora) > 0
+    for e_r, n in table:
+        assert e_r <= 5e-2, (n, e_r)
 
 
 def test_cfg5_lora_finetune_loop_learns_at_cfg3_size():

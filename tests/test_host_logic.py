@@ -352,6 +352,52 @@ def test_library_is_built_without_slp_packing():
     assert flags and all("-fno-slp-vectorize" in l for l in flags)
 
 
+def _device_isa(tmp_path):
+    """disassembly of every gfx950 code object of the built library, one string per code object (llvm-objdump --offloading, -d)"""
+    import os, shutil, subprocess
+    lib = os.path.join(os.path.dirname(__file__), "..", "recommendersystem_amd", "librsys_hip.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        pytest.skip("built library or llvm-objdump not present")
+    work = tmp_path / "isa_all"
+    work.mkdir()
+    shutil.copy(lib, work / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    out = []
+    for f in sorted(os.listdir(work)):
+        if "gfx950" in f:
+            out.append(subprocess.run([objdump, "-d", f], cwd=work, check=True, capture_output=True, text=True).stdout)
+    assert len(out) >= 10, len(out)     # one code object per .hip source
+    return out
+
+
+def test_built_library_has_no_packed_f32_with_a_crossed_low_half(tmp_path):
+    """The guard of the round-4 attention fault on the ISA itself, not on the Makefile's text: in the shipped code
+    objects no v_pk_{mul,fma,add}_f32 may compute its LOW half from the HIGH dword of a source pair (`op_sel:[..1..]`; the broadcast forms
+    `op_sel_hi:[..]` alone are fine and stay: 1.5 K of them).  That form, produced by the SLP pass from the RoPE rotations of the
+    epilogues, dropped a product on lanes 48-63 about once per 3e5 waves on MI355X (profiles/r4_attn_dq_packed_f32_glitch.log;
+    ISA and hazard-table check: profiles/r5_packed_f32_isa_analysis.md).  Whatever re-creates it -- a flag, a compiler update, an
+    ext-vector expression in a new kernel -- fails here before it reaches a GPU."""
+    import re
+    crossed, packed = [], 0
+    for asm in _device_isa(tmp_path):
+        fn = "?"
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                fn = m.group(1)
+                continue
+            code = line.split("//")[0]
+            if not re.search(r"\bv_pk_(?:mul|fma|add)_f32\b", code):
+                continue
+            packed += 1
+            sel = re.search(r"\bop_sel:\[([01,]+)\]", code)
+            if sel and "1" in sel.group(1):
+                crossed.append((fn, " ".join(code.split())))
+    assert packed >= 100, packed            # the scan saw the library's packed instructions at all
+    assert not crossed, crossed[:8]
+
+
 def test_kmajor_gemm_kernels_do_not_drain_their_dma_before_transposed_lds_reads(tmp_path):
     """The K-major weight-gradient kernels read their fragments with ds_read_b64_tr_b16 while LDS-DMA for later K tiles is in flight.
     With the DMA issued through the compiler's intrinsic, hipcc put `s_waitcnt vmcnt(0)` in front of those reads (it cannot tell them
