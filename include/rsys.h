@@ -199,6 +199,13 @@ int32_t rsys_comm_debug_delay(rsys_comm* c, int32_t microseconds);
  * grad_div); *early_floats (optional query): how many gradient elements the last call found already reduced */
 int32_t rsys_allreduce_grads(rsys_model* m, rsys_comm* c);
 int32_t rsys_grad_sync_early(rsys_model* m, int64_t* early_floats);
+/* what the last optimizer step's gradient reduction enqueued, in enqueue order (the DDP bucket schedule of train.py:678-682 as this
+ * library runs it): up to cap triples {first element, one past the last element, phase} of the flat gradient buffer; phase 0 = early
+ * bucket from inside the backward, 1 = tail beside the metadata-projection gradient GEMM, 2 = that GEMM's output, 3 / 4 = the two parts of
+ * the split table reduce (head part out of place; the ranks' token rows, elements = gathered floats).  *n = entries recorded. */
+int32_t rsys_grad_sync_schedule(rsys_model* m, int64_t* triples, int32_t cap, int32_t* n);
+/* {rank, world, transport (1 = RCCL, 2 = in-process rank group of the tests), RCCL version code (ncclGetVersion) or 0} */
+int32_t rsys_comm_info(rsys_comm* c, int32_t out[4]);
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n);   /* reduce_mean, train.py:199-204 */
 int32_t rsys_self_test(rsys_comm* c);                              /* hardware_check.py:6-12 */
 

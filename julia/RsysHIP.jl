@@ -212,6 +212,17 @@ end
 function grad_sync_early(m::Model)
     n = Ref{Int64}(0); check(ccall((:rsys_grad_sync_early, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), m.h, n)); n[]
 end
+# the gradient reduction's bucket schedule of the last optimizer step: rows (first element, one past the last, phase)
+function grad_sync_schedule(m::Model; cap::Integer = 64)
+    out = zeros(Int64, 3 * cap); n = Ref{Int32}(0)
+    GC.@preserve out check(ccall((:rsys_grad_sync_schedule, LIB), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32, Ref{Int32}), m.h, out, cap, n))
+    permutedims(reshape(out[1:3 * min(Int(n[]), cap)], 3, :))
+end
+# (rank, world, transport, RCCL version code)
+function comm_info(c::Comm)
+    out = zeros(Int32, 4)
+    GC.@preserve out check(ccall((:rsys_comm_info, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), c.h, out)); out
+end
 # in-process rank group (tests on a one-GPU box): `world` ranks as host threads of this process
 function local_group(world::Integer, device::Integer)
     g = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:rsys_local_group_create, LIB), Int32, (Int32, Int32, Ref{Ptr{Cvoid}}), world, device, g)); g[]

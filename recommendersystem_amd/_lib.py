@@ -95,6 +95,8 @@ _SIGS = [
     ("rsys_comm_init_local", C.c_int32, [_P, C.c_int32, C.POINTER(_P)]),
     ("rsys_allreduce_grads", C.c_int32, [_P, _P]),
     ("rsys_grad_sync_early", C.c_int32, [_P, C.POINTER(C.c_int64)]),
+    ("rsys_grad_sync_schedule", C.c_int32, [_P, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]),
+    ("rsys_comm_info", C.c_int32, [_P, C.POINTER(C.c_int32)]),
     ("rsys_allreduce_f64", C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32]),
     ("rsys_self_test", C.c_int32, [_P]),
     ("rsys_grad_buffer", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),

@@ -342,6 +342,7 @@ static int reduce_range(Model* m, rsys_comm* c, int64_t lo, int64_t hi) {
     const int64_t n = std::min(bucket, hi - o);
     RC(comm_all_reduce_f32(c, m->G + o, (size_t)n, COMM_SUM, c->stream));
   }
+  if (hi > lo) m->bucket_log.push_back({lo, hi, m->bucket_phase});
   return RSYS_OK;
 }
 
@@ -349,6 +350,7 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
   CHECK_HANDLE(h);
   Model* m = h->m;
   m->reduced.clear();
+  m->bucket_log.clear(); m->bucket_phase = 0;
   m->grad_bucket_hook = nullptr;
   m->table_head_hook = nullptr;
   m->gemm_flags &= ~2;
@@ -366,6 +368,7 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
       // model.hip backward_trunk).  That write waits for this event: free when the reduce is done by then, and otherwise what keeps a
       // slow link from folding some ranks' token rows into tbl_R, which the tail would then add a second time.
       HIP_CHECK(hipEventRecord(c->ev_head, c->stream));
+      m->bucket_log.push_back({m->o_E, m->o_E + n, 3});
       m->split_head_event = c->ev_head;
       m->split_head_reduced = true;
       return RSYS_OK;
@@ -409,6 +412,7 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   CHECK_HANDLE(h); CHECK_HANDLE(c);
   Model* m = h->m;
   HIP_CHECK(hipSetDevice(m->device));
+  if (m->grad_bucket_hook == nullptr && m->table_head_hook == nullptr) m->bucket_log.clear();   // (not armed: nothing of this step is in the log yet)
   m->grad_bucket_hook = nullptr;   // one backward per arming
   m->table_head_hook = nullptr;
   const bool split = m->split_head_reduced && comm_active(c) && model_finalize_splittable(m);   // (else: G[E] holds the whole local gradient, the dense path is right)
@@ -448,9 +452,11 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    m->bucket_phase = 1;
     if (split) {   // nothing reads the local G[E] any more (stage 1 made the operand copy and the bias gradient): it becomes the sum
       rc = model_split_table_tail(m, c, c->stream);
       if (rc) return rc;
+      m->bucket_log.push_back({0, (int64_t)c->world * m->tok_cap * (m->D + 1), 4});
     }
     rc = reduce_rest(0, std::min(wo, m->n_opt));
     if (rc) return rc;
@@ -460,9 +466,11 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    m->bucket_phase = 2;
     rc = reduce_rest(wo, std::min(wo + wn, m->n_opt));
     if (rc) return rc;
   } else {
+    m->bucket_phase = 1;
     int rc = model_finalize_grads(m);
     if (rc) return rc;
     HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
@@ -475,6 +483,21 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
   return RSYS_OK;
 }
 int32_t rsys_grad_sync_early(rsys_model* h, int64_t* n) { CHECK_HANDLE(h); ARG_CHECK(n, "null"); *n = h->m->early_reduced; return RSYS_OK; }
+int32_t rsys_grad_sync_schedule(rsys_model* h, int64_t* out, int32_t cap, int32_t* n_out) {
+  CHECK_HANDLE(h); ARG_CHECK(out && n_out && cap >= 0, "null");
+  const auto& log = h->m->bucket_log;
+  const int n = (int)std::min<size_t>(log.size(), (size_t)cap);
+  for (int i = 0; i < n; ++i) { out[3 * i] = log[i].lo; out[3 * i + 1] = log[i].hi; out[3 * i + 2] = log[i].phase; }
+  *n_out = (int32_t)log.size();
+  return RSYS_OK;
+}
+int32_t rsys_comm_info(rsys_comm* c, int32_t out[4]) {
+  CHECK_HANDLE(c); ARG_CHECK(out, "null");
+  out[0] = c->rank; out[1] = c->world;
+  out[2] = c->lg ? 2 : (c->comm ? 1 : 0);     // transport: 1 = RCCL, 2 = in-process rank group (tests)
+  out[3] = c->comm ? comm_rccl_version() : 0;
+  return RSYS_OK;
+}
 int32_t rsys_allreduce_f64(rsys_comm* c, double* x, int32_t n) {
   CHECK_HANDLE(c);
   ARG_CHECK(n >= 1 && n <= 64 && x, "n in [1,64]");

@@ -21,6 +21,7 @@ struct RcclApi {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
 };
 static RcclApi g_rccl;
 enum { NCCL_INT8 = 0, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8 };
@@ -42,11 +43,17 @@ int load_rccl() {
   g_rccl.GroupStart = (int (*)())dlsym(L, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(L, "ncclGroupEnd");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(L, "ncclGetErrorString");
+  g_rccl.GetVersion = (int (*)(int*))dlsym(L, "ncclGetVersion");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.AllGather ||
       !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
     set_error("librccl is missing a required symbol"); return RSYS_ERR_COMM;
   }
   return RSYS_OK;
+}
+int comm_rccl_version() {
+  int v = 0;
+  if (g_rccl.lib && g_rccl.GetVersion && g_rccl.GetVersion(&v) == 0) return v;
+  return 0;
 }
 #define NCCL_CHECK(expr)                                                                          \
   do {                                                                                            \

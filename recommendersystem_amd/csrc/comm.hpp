@@ -56,6 +56,7 @@ namespace rsys {
 enum CommOp { COMM_SUM = 0, COMM_MAX = 2 };
 
 int load_rccl();
+int comm_rccl_version();   // ncclGetVersion's code (e.g. 22703), 0 when the library is not loaded or has no such symbol
 int comm_unique_id(unsigned char id_buf[128]);
 int comm_init_rccl(const unsigned char id_buf[128], int rank, int world, int device, rsys_comm** out);
 int comm_init_local(LocalGroup* g, int rank, rsys_comm** out);

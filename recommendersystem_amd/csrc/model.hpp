@@ -73,6 +73,12 @@ struct Model {
   int tok_all_world = 0;             // ranks tok_Tall / tok_Uall / tok_Pall are sized for
   int gemm_flags = 0;          // OR-ed into GemmParams.flags: 2 while all-reduce kernels may share the CUs with the backward
   int64_t early_reduced = 0;   // elements the last rsys_allreduce_grads found already reduced (tests)
+  // what the last optimizer step's gradient reduction enqueued, in order: {first element, one past the last, phase}; phase 0 = early bucket
+  // (from inside the backward), 1 = tail beside the dWp GEMM, 2 = dWp itself, 3 = split table reduce: head part out of place (under the
+  // trunk backward), 4 = split table reduce: the ranks' token rows (all-gather; elements = gathered floats).  rsys_grad_sync_schedule reads it.
+  struct BucketLog { int64_t lo, hi; int phase; };
+  std::vector<BucketLog> bucket_log;
+  int bucket_phase = 0;
   bool bf16_mode = false;
   size_t esz = 4;
   // dims

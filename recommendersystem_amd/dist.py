@@ -289,6 +289,22 @@ class Comm:
         check(lib().rsys_allreduce_f64(self._h, arr, len(values)))
         return list(arr)
 
+    def info(self):
+        """{rank, ranks, transport, rccl_version}: what a SCALE record needs to say which collectives library ran (bench.py `comm`)"""
+        out = (C.c_int32 * 4)()
+        check(lib().rsys_comm_info(self._h, out))
+        v = int(out[3])
+        # ncclGetVersion's code: major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + minor * 100 + patch before)
+        ver = None if not v else (f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v >= 10000 else f"{v // 1000}.{v // 100 % 10}.{v % 100}")
+        return {"rank": int(out[0]), "ranks": int(out[1]), "transport": {0: "none", 1: "rccl", 2: "in-process"}[int(out[2])], "rccl_version": ver}
+
+    def grad_schedule(self, model, cap=64):
+        """the last optimizer step's gradient reduction as enqueued: [(first element, one past the last, phase)] (rsys_grad_sync_schedule)"""
+        out = (C.c_int64 * (3 * cap))(); n = C.c_int32()
+        check(lib().rsys_grad_sync_schedule(model._h, out, cap, C.byref(n)))
+        k = min(int(n.value), cap)
+        return [(int(out[3 * i]), int(out[3 * i + 1]), int(out[3 * i + 2])) for i in range(k)]
+
     def debug_delay(self, microseconds):
         """tests: a kernel that spins this long on the communicator's stream (a collective that starts late)"""
         check(lib().rsys_comm_debug_delay(self._h, int(microseconds)))
