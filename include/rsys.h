@@ -101,6 +101,13 @@ int32_t rsys_zero_grad(rsys_model* m);
 
 /* to_device -- train.py:178-184: copies the batch into device-resident buffers */
 int32_t rsys_batch_upload(rsys_model* m, const rsys_batch* b);
+/* The reference's loader overlap (DataLoader workers + non_blocking to_device, train.py:162-165,178-184): rsys_batch_prefetch checks
+ * and packs the NEXT batch on the calling thread and copies it on a stream of its own while the current step still runs on the
+ * device (a second staging buffer / device blob); rsys_batch_swap then makes it the resident batch -- enqueue the step's forward /
+ * backward / optimizer first, prefetch, read the step's losses, swap.  The host arrays may be freed when prefetch returns.
+ * Replicated item table only (the row-sharded table builds its row-exchange plan inside rsys_batch_upload). */
+int32_t rsys_batch_prefetch(rsys_model* m, const rsys_batch* b);
+int32_t rsys_batch_swap(rsys_model* m);
 /* device-side synthetic batch (bench): fills the resident batch from a counter RNG */
 
 /* model(d, evaluate) + loss.backward() -- model.py:493-529, train.py:259-272.

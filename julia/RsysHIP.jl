@@ -70,6 +70,12 @@ end
 function upload!(m::Model, b::RsysBatch)    # caller wraps this in GC.@preserve of the arrays b points to
     check(ccall((:rsys_batch_upload, LIB), Int32, (Ptr{Cvoid}, Ref{RsysBatch}), m.h, b))
 end
+# the next batch beside the running step (second staging buffer + copy stream), then made the resident one: enqueue the step,
+# prefetch!, read the losses, swap_batch!
+function prefetch!(m::Model, b::RsysBatch)  # caller wraps this in GC.@preserve of the arrays b points to
+    check(ccall((:rsys_batch_prefetch, LIB), Int32, (Ptr{Cvoid}, Ref{RsysBatch}), m.h, b))
+end
+swap_batch!(m::Model) = check(ccall((:rsys_batch_swap, LIB), Int32, (Ptr{Cvoid},), m.h))
 function forward_backward!(m::Model, evaluate::Bool, task_w::NTuple{4,Float32}, grad_scale::Float32, seed::UInt64, step::UInt64)
     tw = Ref(task_w)
     check(ccall((:rsys_forward_backward, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float32}, Float32, UInt64, UInt64),

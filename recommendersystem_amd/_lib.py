@@ -65,6 +65,8 @@ _SIGS = [
     ("rsys_grad_get", C.c_int32, [_P, C.c_char_p, _P, C.c_int64]),
     ("rsys_zero_grad", C.c_int32, [_P]),
     ("rsys_batch_upload", C.c_int32, [_P, C.POINTER(rsys_batch)]),
+    ("rsys_batch_prefetch", C.c_int32, [_P, C.POINTER(rsys_batch)]),
+    ("rsys_batch_swap", C.c_int32, [_P]),
     ("rsys_forward_backward", C.c_int32, [_P, C.c_int32, C.POINTER(C.c_float * 4), C.c_float, C.c_uint64, C.c_uint64]),
     ("rsys_losses_get", C.c_int32, [_P, C.POINTER(C.c_float * 12), C.POINTER(C.c_float * 4)]),
     ("rsys_head_rows_get", C.c_int32, [_P, C.POINTER(C.c_int32 * 4)]),

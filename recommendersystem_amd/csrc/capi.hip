@@ -78,6 +78,8 @@ int32_t rsys_zero_grad(rsys_model* h) {
 }
 
 int32_t rsys_batch_upload(rsys_model* h, const rsys_batch* b) { CHECK_HANDLE(h); return model_batch_upload(h->m, b); }
+int32_t rsys_batch_prefetch(rsys_model* h, const rsys_batch* b) { CHECK_HANDLE(h); return model_batch_prefetch(h->m, b); }
+int32_t rsys_batch_swap(rsys_model* h) { CHECK_HANDLE(h); return model_batch_swap(h->m); }
 
 int32_t rsys_forward_backward(rsys_model* h, int32_t evaluate, const float task_w[4], float grad_scale, uint64_t seed, uint64_t step) {
   CHECK_HANDLE(h);

@@ -266,6 +266,12 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     m->raw_bytes = (size_t)N * (4 * 6 + 8 + 4 * 2 + 18 * 4 + 2 + 8) + 64 * 32;   // raw arrays + the two masks + 2N positions + padding
     DALLOC(m->raw_blob, m->raw_bytes);
     HIP_CHECK(hipHostMalloc((void**)&m->h_stage, m->raw_bytes, hipHostMallocDefault));
+    m->slot_blob[0] = m->raw_blob; m->slot_stage[0] = m->h_stage;
+    DALLOC(m->slot_blob[1], m->raw_bytes);
+    HIP_CHECK(hipHostMalloc((void**)&m->slot_stage[1], m->raw_bytes, hipHostMallocDefault));
+    HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&m->ev_copy_done, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&m->ev_blob_free[i], hipEventDisableTiming));
     m->d_wm = nullptr; m->d_rm = nullptr; m->d_rope_pos = nullptr;   // (placed in raw_blob per upload)
     DALLOC(m->tok_keys, (size_t)token_index_capacity((int)N) * 8); DALLOC(m->tok_skey, N * 4); DALLOC(m->tok_sidx, N * 4);
     DALLOC(m->scatter_slab, seg_scatter_slab_floats((int)N, m->D) * 4);
@@ -447,7 +453,11 @@ int model_destroy(Model* m) {
   hipStreamSynchronize(m->stream);
   hipStreamSynchronize(m->side);
   for (void* p : m->allocs) hipFree(p);
+  if (m->copy_stream) { hipStreamSynchronize(m->copy_stream); hipStreamDestroy(m->copy_stream); }
   if (m->h_stage) hipHostFree(m->h_stage);
+  if (m->slot_stage[1]) hipHostFree(m->slot_stage[1]);
+  if (m->ev_copy_done) hipEventDestroy(m->ev_copy_done);
+  for (int i = 0; i < 2; ++i) if (m->ev_blob_free[i]) hipEventDestroy(m->ev_blob_free[i]);
   if (m->h_counts) hipHostFree(m->h_counts);
   if (m->ev_counts) hipEventDestroy(m->ev_counts);
   if (m->det_slab) hipFree(m->det_slab);
@@ -685,13 +695,13 @@ static int build_exchange_plan(Model* m, int N) {
   return RSYS_OK;
 }
 
-int model_batch_upload(Model* m, const rsys_batch* b) {
+// Checks a host batch and packs it into staging buffer `slot` (pinned); `d` and the flag outputs receive the device addresses the
+// arrays will have in that slot's blob.  Index paths are checked on the host BEFORE anything is written.
+struct StagedBatch { BatchDev bd; bool has_masks = false, has_rope_pos = false; unsigned char *d_wm = nullptr, *d_rm = nullptr; int* d_rope_pos = nullptr; size_t bytes = 0; };
+static int batch_stage(Model* m, const rsys_batch* b, int slot, StagedBatch& out) {
   ARG_CHECK(b != nullptr, "null batch");
   ARG_CHECK(b->rows >= 1 && b->rows <= m->rows_max, "batch rows must be in [1, max_rows]");
-  HIP_CHECK(hipSetDevice(m->device));
   const size_t N = (size_t)b->rows * m->S;
-  BatchDev& d = m->bd;
-  hipStream_t s = m->stream;
   ARG_CHECK(b->userid && b->token_mask_ids && b->gender && b->source && b->matchedid && b->status && b->time && b->rating && b->progress,
             "batch arrays must not be null");
   for (int k = 0; k < 6; ++k) {
@@ -721,14 +731,13 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
     for (size_t i = 0; i < N; ++i) { pos[2 * i] = 2 * b->rope_input_pos[i]; pos[2 * i + 1] = 2 * b->rope_input_pos[i] + 1; }
     for (size_t i = 0; i < 2 * N; ++i) ARG_CHECK(pos[i] >= 0 && pos[i] < m->T, "rope_input_pos out of range");
   }
-  m->cur_rows = 0;   // (a failing copy below must not leave a half-written batch marked as resident)
-  // pack (pinned staging) -> one H2D -> the device arrays sit back to back in raw_blob.  No wait before packing: the previous
-  // upload synchronised after ITS copy, so the staging buffer is free, and the copy below is ordered on the stream behind the
-  // kernels that still read the old batch -- the host packs while the GPU finishes the previous step's optimizer pass.
+  // pack (pinned staging) -> one H2D -> the device arrays sit back to back in the slot's blob
+  unsigned char* blob = m->slot_blob[slot]; unsigned char* stage = m->slot_stage[slot];
+  BatchDev d = m->bd;    // (the mask_tokens outputs and the sizes are the model's own; only the input arrays move)
   size_t off = 0;
   auto place = [&](const void* src, size_t bytes) -> void* {
-    void* dev = m->raw_blob + off;
-    if (src != nullptr) memcpy(m->h_stage + off, src, bytes);
+    void* dev = blob + off;
+    if (src != nullptr) memcpy(stage + off, src, bytes);
     off += (bytes + 63) / 64 * 64;
     return dev;
   };
@@ -741,12 +750,31 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
     d.label[k] = (const float*)place(b->label[k], N * 4); d.weight[k] = (const float*)place(b->weight[k], N * 4);
     d.position[k] = (const int*)place(b->position[k], N * 4);
   }
-  m->has_masks = b->watch_mask != nullptr;
-  m->d_wm = (unsigned char*)place(b->watch_mask, N); m->d_rm = (unsigned char*)place(b->rating_mask, N);
-  m->has_rope_pos = b->rope_input_pos != nullptr;
-  m->d_rope_pos = (int*)place(m->has_rope_pos ? pos.data() : nullptr, 2 * N * 4);
+  out.has_masks = b->watch_mask != nullptr;
+  out.d_wm = (unsigned char*)place(b->watch_mask, N); out.d_rm = (unsigned char*)place(b->rating_mask, N);
+  out.has_rope_pos = b->rope_input_pos != nullptr;
+  out.d_rope_pos = (int*)place(out.has_rope_pos ? pos.data() : nullptr, 2 * N * 4);
   if (off > m->raw_bytes) { set_error("batch upload: staging buffer too small"); return RSYS_ERR_STATE; }
-  HIP_CHECK(hipMemcpyAsync(m->raw_blob, m->h_stage, off, hipMemcpyHostToDevice, s));
+  out.bd = d; out.bytes = off;
+  return RSYS_OK;
+}
+
+int model_batch_upload(Model* m, const rsys_batch* b) {
+  HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  m->pending.valid = false;   // (an explicit upload supersedes a prefetched batch)
+  // No wait before packing: the previous upload synchronised after ITS copy, so the staging buffer is free, and the copy below is
+  // ordered on the stream behind the kernels that still read the old batch -- the host packs while the GPU finishes the previous
+  // step's optimizer pass.  (A prefetch into this slot's staging is complete too: model_batch_swap waited for its copy.)
+  StagedBatch st;
+  RC(batch_stage(m, b, m->cur_slot, st));
+  const size_t N = (size_t)b->rows * m->S;
+  m->cur_rows = 0;   // (a failing copy below must not leave a half-written batch marked as resident)
+  m->bd = st.bd;
+  BatchDev& d = m->bd;
+  m->has_masks = st.has_masks; m->d_wm = st.d_wm; m->d_rm = st.d_rm;
+  m->has_rope_pos = st.has_rope_pos; m->d_rope_pos = st.d_rope_pos;
+  HIP_CHECK(hipMemcpyAsync(m->slot_blob[m->cur_slot], m->slot_stage[m->cur_slot], st.bytes, hipMemcpyHostToDevice, s));
   // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only; built here for
   // the row-sharded table (its exchange plan needs it now), else by the first backward over this batch (an inference or
   // evaluation pass never needs it)
@@ -756,6 +784,47 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   HIP_CHECK(hipStreamSynchronize(s));
   if (m->sharded) RC(build_exchange_plan(m, (int)N));
   m->cur_rows = b->rows;
+  return RSYS_OK;
+}
+
+// The NEXT batch beside the running step: checked and packed into the other slot's staging buffer by the calling thread while the GPU
+// works, copied on a stream of its own.  Nothing of the resident batch changes until model_batch_swap.
+int model_batch_prefetch(Model* m, const rsys_batch* b) {
+  ARG_CHECK(!m->sharded, "batch prefetch: the row-sharded table builds its exchange plan at upload (use rsys_batch_upload)");
+  HIP_CHECK(hipSetDevice(m->device));
+  const int slot = m->cur_slot ^ 1;
+  if (m->pending.valid) HIP_CHECK(hipEventSynchronize(m->ev_copy_done));   // (a prefetch that was never swapped in: its copy still reads the staging buffer)
+  m->pending.valid = false;
+  StagedBatch st;
+  RC(batch_stage(m, b, slot, st));
+  // the slot's blob was the resident batch two swaps ago: the kernels that read it were enqueued before ev_blob_free[slot]
+  if (m->blob_free_valid[slot]) HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->ev_blob_free[slot], 0));
+  HIP_CHECK(hipMemcpyAsync(m->slot_blob[slot], m->slot_stage[slot], st.bytes, hipMemcpyHostToDevice, m->copy_stream));
+  HIP_CHECK(hipEventRecord(m->ev_copy_done, m->copy_stream));
+  m->pending.valid = true; m->pending.bd = st.bd; m->pending.rows = b->rows;
+  m->pending.has_masks = st.has_masks; m->pending.has_rope_pos = st.has_rope_pos;
+  m->pending.d_wm = st.d_wm; m->pending.d_rm = st.d_rm; m->pending.d_rope_pos = st.d_rope_pos;
+  return RSYS_OK;
+}
+
+int model_batch_swap(Model* m) {
+  ARG_CHECK(m->pending.valid, "batch swap: no prefetched batch (rsys_batch_prefetch first)");
+  HIP_CHECK(hipSetDevice(m->device));
+  // everything enqueued so far may still read the resident batch's blob: the next prefetch into it waits for this point
+  HIP_CHECK(hipEventRecord(m->ev_blob_free[m->cur_slot], m->stream));
+  m->blob_free_valid[m->cur_slot] = true;
+  // The copy is waited for on the HOST as well as on the stream: the next prefetch re-packs this slot's staging buffer without a wait
+  // (as uploads always have), and by now -- a whole step after the copy was issued -- the wait returns at once.
+  HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_copy_done, 0));
+  HIP_CHECK(hipEventSynchronize(m->ev_copy_done));
+  m->cur_slot ^= 1;
+  m->bd = m->pending.bd;
+  m->has_masks = m->pending.has_masks; m->d_wm = m->pending.d_wm; m->d_rm = m->pending.d_rm;
+  m->has_rope_pos = m->pending.has_rope_pos; m->d_rope_pos = m->pending.d_rope_pos;
+  m->cur_rows = m->pending.rows;
+  m->tok_index_valid = false;
+  m->split_plan_valid = false;
+  m->pending.valid = false;
   return RSYS_OK;
 }
 

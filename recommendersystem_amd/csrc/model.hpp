@@ -169,6 +169,17 @@ struct Model {
   // one upload = one copy: the batch's arrays are packed back to back (for the rows it has) in a pinned staging buffer and
   // land in `raw_blob` with a single H2D; the BatchDev pointers are re-pointed into it per upload
   unsigned char* raw_blob = nullptr; unsigned char* h_stage = nullptr; size_t raw_bytes = 0;
+  // A second (staging, blob) pair for rsys_batch_prefetch: the NEXT batch is checked, packed and copied on its own stream while the
+  // current step still runs (the reference's DataLoader + non_blocking to_device overlap, train.py:162-165,178-184); rsys_batch_swap
+  // makes it the resident batch.  slot_blob[0] / slot_stage[0] are raw_blob / h_stage.
+  unsigned char* slot_blob[2] = {nullptr, nullptr}; unsigned char* slot_stage[2] = {nullptr, nullptr};
+  int cur_slot = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy_done = nullptr;     // the pending batch's H2D copy (copy_stream)
+  hipEvent_t ev_blob_free[2] = {nullptr, nullptr};   // recorded on `stream` when slot i stops being the resident batch: its kernels are all enqueued before
+  bool blob_free_valid[2] = {false, false};
+  struct PendingBatch { bool valid = false; BatchDev bd; int rows = 0; bool has_masks = false, has_rope_pos = false;
+                        unsigned char *d_wm = nullptr, *d_rm = nullptr; int* d_rope_pos = nullptr; } pending;
   bool tok_index_valid = false;
   // deterministic mode (rsys_model_set_deterministic): every float sum of the step has a fixed order -- split-K partial tiles go
   // to det_slab and are added in split order, the reduction kernels write per-workgroup partials to det_part (kernels.hpp
@@ -266,6 +277,8 @@ int model_item_table(Model* m, float* out, int64_t n);
 int model_materialise_trunk_output(Model* m);   // dense trunk output of the resident forward in m->out (a training pass computes it at the selected tokens only)
 int model_finalize_grads(Model* m);
 bool model_finalize_splittable(const Model* m);
+int model_batch_prefetch(Model* m, const rsys_batch* b);   // stage + copy the NEXT batch beside the running step (replicated table only)
+int model_batch_swap(Model* m);                            // the prefetched batch becomes the resident one
 int model_split_table_enable(Model* m, int on);
 int model_split_table_tail(Model* m, struct rsys_comm* c, hipStream_t cs);   // on cs: gather the ranks' token rows, G[E] = tbl_R + rows
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);

@@ -226,8 +226,8 @@ class RecommenderModel:
         self._task_w = [float(x) for x in task_weights]
         self._grad_scale = 1.0 / float(grad_accum_steps)
 
-    def upload(self, d, masks=None):
-        """to_device, train.py:178-184.  d: the 27 flat arrays (any shape with rows*S elements)."""
+    def _c_batch(self, d, masks=None):
+        """the rsys_batch record of the 27 flat arrays (+ optional masks / RoPE positions) and the arrays it points into"""
         S = self.config["max_sequence_length"]
         n = int(np.asarray(d["userid"]).size)
         assert n % S == 0, "batch must hold whole rows of max_sequence_length"
@@ -256,8 +256,27 @@ class RecommenderModel:
             b.watch_mask = arr(masks[0], np.uint8); b.rating_mask = arr(masks[1], np.uint8)
         if "rope_input_pos" in d:
             b.rope_input_pos = arr(d["rope_input_pos"], np.int32)
+        return b, keep
+
+    def upload(self, d, masks=None):
+        """to_device, train.py:178-184.  d: the 27 flat arrays (any shape with rows*S elements)."""
+        b, keep = self._c_batch(d, masks)
         check(lib().rsys_batch_upload(self._h, C.byref(b)))
         self._keep = keep
+
+    @property
+    def can_prefetch(self):
+        """rsys_batch_prefetch / rsys_batch_swap: the next batch staged and copied beside the running step (replicated table)"""
+        return self.config.get("table_shard") is None and not getattr(self, "_no_prefetch", False)   # (_no_prefetch: A/B switch of the tests)
+
+    def prefetch(self, d, masks=None):
+        """Check, pack and copy the NEXT batch while the step already enqueued still runs on the device (the reference's DataLoader
+        workers + non_blocking to_device, train.py:162-165,178-184); `swap_batch` makes it the resident batch."""
+        b, keep = self._c_batch(d, masks)
+        check(lib().rsys_batch_prefetch(self._h, C.byref(b)))
+
+    def swap_batch(self):
+        check(lib().rsys_batch_swap(self._h))
 
     def forward_resident(self, evaluate, step=None):
         """One pass over the batch already resident on the device (asynchronous)."""

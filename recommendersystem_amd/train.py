@@ -214,21 +214,47 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     model.set_loss_weights(task_weights, grad_accum_steps)
     optimizer.zero_grad(set_to_none=True)
     world = 1 if comm is None else comm.world
-    for step, data in enumerate(lockstep_batches(model, dataloader, comm)):
+    # The loop's one host sync per step is the loss read-back (float(loss), train.py:261-263).  Everything the host does for the NEXT
+    # batch -- taking it from the loader, the index checks, packing and the copy to the device -- is placed between enqueueing this
+    # step's optimizer pass and that read-back (model.prefetch / swap_batch), so it overlaps the step on the device instead of
+    # following it; the arithmetic and the order of the sums are those of the plain loop.  (Row-sharded table: plain uploads.)
+    staged = all(hasattr(model, a) for a in ("upload", "forward_resident", "losses"))   # (a model that is only callable: the plain loop)
+    pipelined = staged and bool(getattr(model, "can_prefetch", False))
+    it = iter(lockstep_batches(model, dataloader, comm))
+    data = next(it, None)
+    if data is not None and staged:
+        model.upload(data)
+    step = 0
+    while data is not None:
         zero1 = getattr(optimizer, "_zero1", None) is not None   # (opt-in ZeRO-1: the optimizer step reduces the gradient itself)
-        if comm is not None and not zero1 and (step + 1) % grad_accum_steps == 0:
+        last_micro = (step + 1) % grad_accum_steps == 0
+        if comm is not None and not zero1 and last_micro:
             comm.begin_grad_sync(model)        # last micro-step: finished buckets are reduced during the backward
-        tloss = model(data, False)
+        if staged:
+            model.forward_resident(False)
+        else:
+            tloss = model(data, False)
+        if last_micro:
+            if comm is not None and not zero1:
+                comm.all_reduce_grads(model)
+            optimizer.step(lr_factor=scheduler.factor(), clip_max_norm=max_norm, grad_div=float(world))
+            scheduler.step()
+        nxt = next(it, None)
+        if nxt is not None and pipelined:
+            model.prefetch(nxt)                # host work of the next batch, beside the step the device is still running
+        if staged:
+            tloss = model.losses(False)        # (synchronises)
         for i in range(n_tasks):
             w = model.last_weight_sums[i]
             training_losses[i] += tloss[i] * w
             training_weights[i] += w
-        if (step + 1) % grad_accum_steps != 0:
-            continue
-        if comm is not None and not zero1:
-            comm.all_reduce_grads(model)
-        optimizer.step(lr_factor=scheduler.factor(), clip_max_norm=max_norm, grad_div=float(world))
-        scheduler.step()
+        if nxt is not None and staged:
+            if pipelined:
+                model.swap_batch()
+            else:
+                model.upload(nxt)
+        data = nxt
+        step += 1
     return reduce_mean(comm, training_losses, training_weights)
 
 
