@@ -427,10 +427,12 @@ __global__ __launch_bounds__(256) void attn_tilemap_kernel(AttnParams p) {
 // attn_work (blockIdx.x = XCD, or the single list of the fallback); rank = slots with more work + equal ones before it (stable, so
 // the order is a function of the maps alone).
 static int attn_heads_per_wg(const AttnParams& p);
-__global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, int identity) {
+static bool attn_kv_pairs(const AttnParams& p);   // the dK/dV launch of this shape is attn_bwd_kv32_kernel (order_k then lists kv tile PAIRS)
+// kv_pairs: the dK/dV side's slots are PAIRS of kv tiles (attn_bwd_kv32_kernel: 128 keys per workgroup), work = q tiles either tile is visited by
+__global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, int identity, int kv_pairs) {
   extern __shared__ int ocnt[];   // [chunks of 64 slots + 1][34]: slots per (chunk, key), then their exclusive prefixes; last row: totals / bases
   const int side = blockIdx.y, nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
-  const int n_inner = side == 0 ? (p.H / p.KV / R) * nt : nt;
+  const int n_inner = side == 0 ? (p.H / p.KV / R) * nt : (kv_pairs ? (nt + 1) / 2 : nt);
   int* out = side == 0 ? p.order_q : p.order_k;
   if (out == nullptr) return;
   const bool lists = (n_groups & 7) == 0;
@@ -444,6 +446,11 @@ __global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, in
     const int group = lists ? (sl / n_inner) * 8 + xcd : sl / n_inner, tile = (sl % n_inner) % nt, b = group / p.KV;
     const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
     if (side == 0) return tile < qa ? __popc(p.qmap[b * nt + tile]) : 0;
+    if (kv_pairs) {
+      const int t0 = 2 * (sl % n_inner);
+      const unsigned int u = p.kmap[b * nt + t0] | (t0 + 1 < nt ? p.kmap[b * nt + t0 + 1] : 0u);
+      return __popc(u & (qa >= 32 ? ~0u : ((1u << qa) - 1u)));
+    }
     return __popc(p.kmap[b * nt + tile] & (qa >= 32 ? ~0u : ((1u << qa) - 1u)));
   };
   auto same_key = [&](int k) -> unsigned long long {   // lanes of this wave that hold the same key
@@ -496,7 +503,8 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
     const int R = attn_heads_per_wg(p), nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
     const int ns_max = ((n_groups & 7) == 0 ? (n_groups >> 3) : n_groups) * (p.H / p.KV) * nt;
     // (a list beyond one workgroup's LDS: keep the plain order -- the kernels read an identity permutation)
-    hipLaunchKernelGGL(attn_order_kernel, dim3((n_groups & 7) == 0 ? 8 : 1, 2), dim3(256), (size_t)(std::min((ns_max + 63) / 64, 400) + 1) * 34 * 4, s, p, R, (ns_max + 63) / 64 > 400 ? 1 : 0);
+    hipLaunchKernelGGL(attn_order_kernel, dim3((n_groups & 7) == 0 ? 8 : 1, 2), dim3(256), (size_t)(std::min((ns_max + 63) / 64, 400) + 1) * 34 * 4, s, p, R, (ns_max + 63) / 64 > 400 ? 1 : 0,
+                       attn_kv_pairs(p) ? 1 : 0);
   }
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
@@ -603,7 +611,14 @@ __device__ __forceinline__ void dma16_asm(at_i32x4 rsrc, unsigned int lds, int v
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
 }
 #pragma clang diagnostic pop
-// (Measured per kernel on one box, intrinsic -> asm: dK/dV 193 -> 183 us, dQ 171 -> 177, forward 123 -> 127: the asm form in dK/dV only.)
+// (Measured per kernel on one box in round 4, intrinsic -> asm: dK/dV 193 -> 183 us, dQ 171 -> 177, forward 123 -> 127.  Round 5 found why the
+// query-side kernels lost: their Q / dO fragment loads were still PENDING in the compiler's bookkeeping when the item loop began, so its
+// wait-count pass kept counted vmcnt waits for them inside the loop -- counts that do not include the asm DMA, so each drained the
+// next item's tiles; with those loads retired in front of the loop (an empty asm that names the registers) the asm form has no vector-memory
+// wait between an item's first MFMA and its publishing wait, where the intrinsic form has a vmcnt(0) after the first third of the item.)
+#ifndef ATTN_QSIDE_DMA_ASM
+#define ATTN_QSIDE_DMA_ASM true
+#endif
 template <bool ASM>
 __device__ __forceinline__ void dma16(at_i32x4 rsrc, unsigned char* lds, int voffset, int soffset) {
   if constexpr (ASM) dma16_asm(rsrc, (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)lds), voffset, soffset);
@@ -686,7 +701,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     for (int j = 0; j < HD / 16; ++j) oacc[r][j] = f32x4{0, 0, 0, 0};
   }
   if constexpr (!DMA) { zero_pad_cols<T, HD>(Ks, t); zero_pad_cols<T, HD>(Ks + C::TILE, t); }
-  const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  // (scalars through readfirstlane: loaded by vector memory -- the maps are not const -- and otherwise still pending when the item loop begins)
+  const unsigned int bits = (unsigned int)__builtin_amdgcn_readfirstlane((int)p.qmap[b * nt + qt]), fullbits = (unsigned int)__builtin_amdgcn_readfirstlane((int)p.qmap_full[b * nt + qt]);
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);   // kv tiles this wave's 16 queries take part in
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
   const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
@@ -711,8 +727,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
       unsigned char* vd = (unsigned char*)(Vs + buf * TILE) + (16 * w) * 128;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        dma16<false>(k_rs, kd + k * 1024, dv_[k], so);
-        dma16<false>(v_rs, vd + k * 1024, dv_[k], so);
+        dma16<ATTN_QSIDE_DMA_ASM>(k_rs, kd + k * 1024, dv_[k], so);
+        dma16<ATTN_QSIDE_DMA_ASM>(v_rs, vd + k * 1024, dv_[k], so);
       }
     } else {
       tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
@@ -732,6 +748,12 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   int kt = next_bit(bits, 0);
   int cur = 0;
   if (kt < nt) { gload(kt, 0); lstore(0); }
+  if constexpr (DMA && ATTN_QSIDE_DMA_ASM) {   // retire the Q fragments' loads in the compiler's bookkeeping before the loop (see dma16)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int s = 0; s < C::NDS; ++s) asm volatile("" : "+v"(qf[r][s]));
+  }
   __syncthreads();
   while (kt < nt) {
     const int nxt = next_bit(bits, kt + 1);
@@ -1208,6 +1230,266 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------------ dK, dV on v_mfma_f32_32x32x16_bf16 (bf16, head_dim 64)
+// The item loops above are bound by instruction ISSUE (profiles/r4_pmc_attention_sq.txt: the waves' active cycles add up to the SIMDs'
+// issue capacity; an MFMA holds the vector issue port for 8 cycles whatever its shape).  This kernel does the same arithmetic with half
+// the MFMA instructions, half the LDS fragment reads and half the staging per FLOP: a wave owns 32 keys (the lanes' l & 31) and runs
+// 32 x 32 x 16 products, four waves = 128 keys = two kv tiles per workgroup, each staged Q / dO tile feeds all of them.
+//   S[q][kv] = sum_d Q[q][d] K[kv][d]:  A = Q rows from LDS (ds_read_b128: row q0 + (l & 31), d = 16 s + 8 (l >> 5) ..+7), B = K from registers
+//   dV^T[d][kv] += dO^T[d][q] P[q][kv]: the P accumulator registers 8 s .. 8 s + 7 ARE the B operand of k-step s (rows 16 s + 8 (j >> 2) +
+//   4 (l >> 5) + (j & 3)); the matching A operand is read transposed from the row-major tile (two ds_read_b64_tr_b16: rows R .. R + 3 and R + 8 ..)
+// LDS image: unpadded 128-byte rows, 16-byte chunk c of row r in slot c ^ sw32(r), sw32(r) = (r1, r2, r3) as bits (2, 1, 0): with that
+// permutation the 32-row ds_read_b128 fragments (lane groups {0-3, 12-15, 20-27}, ...) and the 4-row x 4-chunk transposed reads of a
+// 32-lane half both touch every bank once (checked against the guide's lane groups; the 16-row kernels' c ^ (r & 7) is 2-way here).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ int sw32(int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 pack8f(const f32x16& v, int o) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)v[o + j];
+  return r;
+}
+static bool attn_kv32_on() {
+  static const bool on = !(getenv("RSYS_ATTN_KV32") && atoi(getenv("RSYS_ATTN_KV32")) == 0);   // A/B switch: 0 = the 16-key-per-wave kernel
+  return on;
+}
+static bool attn_kv_pairs(const AttnParams& p) {   // (bf16 is the caller's business: the fp32 launches never read order_k's pair form)
+  static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);
+  return p.hd == 64 && p.is_bf16 && dma && attn_dma_on() && attn_kv32_on();
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv32_kernel(AttnParams p) {
+  [[maybe_unused]] unsigned long long tr_[12] = {KVT_NOW(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (-DATTN_KV_TRACE only: tools/trace_attn_kv.sh)
+  constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
+  using T = bf16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const Qb = smem_raw;                   // [2][64 q][128 B] swizzled
+  unsigned char* const dOb = smem_raw + 2 * TB * 2;     // [2][64 q][128 B]
+  float* const lse2 = (float*)(smem_raw + 4 * TB * 2);  // [2][64]
+  float* const dls = lse2 + 128;                        // [2][64]
+  const int rep = p.H / p.KV, nt = (p.T + 63) / 64, npair = (nt + 1) / 2;
+  int grp, pr;
+  attn_work(p.B * p.KV, npair, p.order_k, grp, pr);
+  const int b = grp / p.KV, kvh = grp % p.KV;
+  const int t = threadIdx.x, l = t & 63, r32 = l & 31, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kvt = 2 * pr + (w >> 1);                    // this wave's kv tile (may be nt: the odd tile's partner does nothing)
+  const bool tile_ok = kvt < nt;
+  const long long tok0 = (long long)b * p.T;
+  const float scale = rsqrtf((float)HD), c2 = scale * LOG2E;
+  const int kv = kvt * 64 + 32 * (w & 1) + r32;        // this lane's key/value token
+  bf16x8 kf[4], vf[4];
+  {
+    const int kr = min(kv, p.T - 1);
+    const T* krow = (const T*)p.k + (tok0 + kr) * p.ld + kvh * HD;
+    const T* vrow = (const T*)p.v + (tok0 + kr) * p.ld + kvh * HD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(krow + 16 * s + 8 * h); vf[s] = *(const bf16x8*)(vrow + 16 * s + 8 * h); }
+  }
+  f32x16 dK[2], dV[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
+  const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
+  const unsigned int act = qa >= 32 ? ~0u : ((1u << qa) - 1u);
+  const int t0i = b * nt + 2 * pr, t1i = min(2 * pr + 1, nt - 1) + b * nt;
+  const unsigned int bits = (unsigned int)__builtin_amdgcn_readfirstlane((int)((p.kmap[t0i] | (2 * pr + 1 < nt ? p.kmap[t1i] : 0u)) & act));   // q tiles the workgroup stages (union of its two kv tiles)
+  const int kti = b * nt + min(kvt, nt - 1);
+  const unsigned int fullbits = tile_ok ? (unsigned int)__builtin_amdgcn_readfirstlane((int)p.kmap_full[kti]) : 0u;
+  const unsigned int wbits = tile_ok ? (unsigned int)__builtin_amdgcn_readfirstlane((int)(p.kmap16[kti * 4 + 2 * (w & 1)] | p.kmap16[kti * 4 + 2 * (w & 1) + 1])) : 0u;
+  const at_i32x4 q_rs = at_rsrc((const T*)p.q + tok0 * p.ld + kvh * rep * HD, ((long long)(p.T - 1) * p.ld + rep * HD) * sizeof(T));
+  const at_i32x4 do_rs = at_rsrc((const T*)p.dO + tok0 * p.ldo + kvh * rep * HD, ((long long)(p.T - 1) * p.ldo + rep * HD) * sizeof(T));
+  const at_i32x4 lse_rs = at_rsrc(p.lse + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  const at_i32x4 dl_rs = at_rsrc(p.delta + ((long long)b * p.H + kvh * rep) * p.T, (long long)rep * p.T * 4);
+  // the pair bits of this wave's kv tile against every q tile: [nt][64 keys] words (an absent tile: an empty window, all zero)
+  const at_i32x4 kb_rs = at_rsrc(p.kbits + (long long)kti * nt * 64, tile_ok ? (long long)nt * 64 * 8 : 0);
+  // wave w fills rows 16 w .. 16 w + 15 of each tile with two DMA instructions (8 rows = 1 KB each): per-lane source offsets, fixed
+  int qv_[2], dv_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = 16 * w + 8 * k + (l >> 3), ch = (l & 7) ^ sw32(row);
+    qv_[k] = (int)((row * p.ld + ch * 8) * sizeof(T));
+    dv_[k] = (int)((row * p.ldo + ch * 8) * sizeof(T));
+  }
+  // fragment addresses inside a tile (bytes; lane constants, the item / block / k-step parts are immediates):
+  //   row reads: row q0 + r32, chunk 2 s + h -> slot (2 s) ^ G, G = h ^ sw32(r32)
+  //   transposed reads: row q0 + 16 s2 + 8 u + 4 h + (i >> 2), columns 32 db + 16 g16 + 4 (i & 3) -> slot L ^ (4 db) ^ u
+  const int G = h ^ sw32(r32);
+  const int i16 = l & 15, g16 = (l >> 4) & 1;
+  const int Lc = (2 * g16 + ((i16 & 3) >> 1)) ^ ((((i16 >> 2) >> 1) & 1) << 2 | (h << 1));
+  int a_row[4], a_tr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_row[s] = r32 * 128 + (((2 * s) ^ G) << 4);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) a_tr[v] = (4 * h + (i16 >> 2)) * 128 + ((Lc ^ ((v >> 1) << 2) ^ (v & 1)) << 4) + ((i16 & 1) << 3);   // v = 2 db + u
+  const bool w0 = w == 0;
+  const unsigned int lds0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)smem_raw);
+  int sx = 0, sy = 0; unsigned long long skb = 0ull;   // the next item's row scalars (wave 0) and this lane's pair-bit word on their way
+  auto stage = [&](int it, int buf) {   // it = head-in-group * 32 + q tile
+    const int hh = it >> 5, qt = it & 31;
+    const int qso = (int)((qt * 64 * p.ld + hh * HD) * sizeof(T)), dso = (int)((qt * 64 * p.ldo + hh * HD) * sizeof(T));
+    const unsigned int qd = lds0 + buf * (TB * 2) + (16 * w) * 128, dd = qd + 2 * TB * 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      dma16_asm(q_rs, qd + k * 1024, qv_[k], qso);
+      dma16_asm(do_rs, dd + k * 1024, dv_[k], dso);
+    }
+    skb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(kb_rs, 8 * (32 * (w & 1) + r32), qt * 512, 0));
+    if (w0) {
+      const int so = (hh * p.T + qt * 64) * 4;
+      sx = rsys_at_buffer_load_b32(lse_rs, 4 * l, so, 0);
+      sy = rsys_at_buffer_load_b32(dl_rs, 4 * l, so, 0);
+    }
+  };
+  auto publish = [&](int buf) {   // the scalars into LDS; every DMA of this wave landed
+    if (w0) { lse2[buf * 64 + l] = __builtin_bit_cast(float, sx) * LOG2E; ((int*)dls)[buf * 64 + l] = sy ^ 0x80000000; }   // log2 units; -delta
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // items = (head of the group, q tile in `bits`), heads outermost: a scalar iterator, two scalar instructions per step
+  const int end = rep * 32;
+  auto next_item = [&](int from) {
+    int hh = from >> 5, qt = from & 31;
+    while (hh < rep) {
+      const int n = next_bit(bits, qt);
+      if (n < nt) return hh * 32 + n;
+      ++hh; qt = 0;
+    }
+    return end;
+  };
+  int it = next_item(0), cur = 0;
+  unsigned long long wk = 0ull;
+  if (it < end) { stage(it, 0); publish(0); wk = skb; }
+  // The K / V fragments' loads are retired HERE, in the compiler's own bookkeeping: left pending into the loop, its wait-count pass
+  // keeps counted vmcnt waits in front of the loop's first MFMAs on every trip, and those counts do not know about the LDS-DMA issued
+  // behind asm just before them -- vector memory retires in order, so each such wait would drain the DMA of the NEXT item
+  // (s_waitcnt vmcnt(8) .. (1) in the ISA of the first build: the arithmetic of an item began by waiting for the next item's tiles).
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(kf[s]), "+v"(vf[s]));
+  asm volatile("" : "+v"(wk));
+  __syncthreads();
+  tr_[1] = KVT_NOW();
+  while (it < end) {
+    [[maybe_unused]] const unsigned long long ta = KVT_NOW();
+    const int nxt = next_item(it + 1);
+    if (nxt < end) stage(nxt, cur ^ 1);   // (the other buffer: every wave left it before the barrier that ended the previous item)
+    [[maybe_unused]] const unsigned long long tb = KVT_NOW();
+    if ((wbits >> (it & 31)) & 1u) {
+      const bool fullt = (fullbits >> (it & 31)) & 1u;
+      const unsigned char* Qc = Qb + cur * (TB * 2);
+      const unsigned char* dOc = dOb + cur * (TB * 2);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {   // 32 queries at a time
+        f32x16 S, dP;
+        float ll[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // accumulator rows 4 k .. 4 k + 3 = queries 32 qb + 8 k + 4 h ..+3
+          const float4 l4 = *(const float4*)(lse2 + cur * 64 + 32 * qb + 8 * k + 4 * h);
+          const float4 d4 = *(const float4*)(dls + cur * 64 + 32 * qb + 8 * k + 4 * h);
+          ll[4 * k] = l4.x; ll[4 * k + 1] = l4.y; ll[4 * k + 2] = l4.z; ll[4 * k + 3] = l4.w;
+          dP[4 * k] = d4.x; dP[4 * k + 1] = d4.y; dP[4 * k + 2] = d4.z; dP[4 * k + 3] = d4.w;   // the dP chain starts from -delta[q]
+          S[4 * k] = 0.f; S[4 * k + 1] = 0.f; S[4 * k + 2] = 0.f; S[4 * k + 3] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          S = mfma32(*(const bf16x8*)(Qc + qb * 4096 + a_row[s]), kf[s], S);       // S[q][kv]
+          dP = mfma32(*(const bf16x8*)(dOc + qb * 4096 + a_row[s]), vf[s], dP);    // dP[q][kv] - delta[q]
+        }
+        if (!fullt) {   // bit (query) of the lane's key word: query 32 qb + 8 (r >> 2) + 4 h + (r & 3)
+          const int src = (int)((unsigned int)(qb ? (wk >> 32) : wk) >> (4 * h));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = __builtin_amdgcn_sbfe(src, 8 * (r >> 2) + (r & 3), 1);
+            const float sv = S[r];
+            S[r] = __builtin_bit_cast(float, (__builtin_bit_cast(int, sv) & m) | (__builtin_bit_cast(int, -1e30f) & ~m));
+          }
+        }
+        f32x16 P, dS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fexp2(fmaf(S[r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
+          P[r] = pv;
+          dS[r] = pv * dP[r];   // (the 1/sqrt(hd) factor of dS is applied once to dK at the end)
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // k-step = 16 queries: accumulator registers 8 s2 .. 8 s2 + 7
+          const bf16x8 pf = pack8f(P, 8 * s2), sf = pack8f(dS, 8 * s2);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int o = (32 * qb + 16 * s2) * 128;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(dOc + o + a_tr[2 * db]));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(dOc + o + 8 * 128 + a_tr[2 * db + 1]));
+            dV[db] = mfma32(__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), pf, dV[db]);   // dV^T[d][kv] += dO^T[d][q] P[q][kv]
+            const bf16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(Qc + o + a_tr[2 * db]));
+            const bf16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(Qc + o + 8 * 128 + a_tr[2 * db + 1]));
+            dK[db] = mfma32(__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), sf, dK[db]);   // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+          }
+        }
+      }
+    }
+#ifdef ATTN_KV_TRACE
+    asm volatile("" ::"v"(dK[0][0]), "v"(dV[0][0]));
+    const unsigned long long tc = KVT_NOW();
+#endif
+    if (nxt < end) publish(cur ^ 1);
+    [[maybe_unused]] const unsigned long long td = KVT_NOW();
+    __syncthreads();
+#ifdef ATTN_KV_TRACE
+    const unsigned long long te = KVT_NOW();
+    tr_[4] += tb - ta; tr_[5] += tc - tb; tr_[6] += td - tc; tr_[7] += te - td; tr_[8] += 1; tr_[9] += (wbits >> (it & 31)) & 1u;
+#endif
+    wk = skb;
+    cur ^= 1;
+    it = nxt;
+  }
+  tr_[2] = KVT_NOW();
+  // epilogue: dK (scaled, un-rotated) and dV as bf16 rows [key][64] through the two Q buffers (128 keys x 128 bytes each), then row stores.
+  // accumulator register r of block db: d = 32 db + 8 (r >> 2) + 4 h + (r & 3), key = r32 of this wave
+  const int pos = p.rope_pos ? p.rope_pos[tok0 + min(kv, p.T - 1)] : min(kv, p.T - 1);
+  unsigned char* const Ks_ = Qb;                 // [128 keys][128 B]: wave w's keys at rows 32 w ..
+  unsigned char* const Vs_ = Qb + 128 * 128;
+  const int orow = 32 * w + r32;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = 32 * db + 8 * g4 + 4 * h;
+      float o[4] = {dK[db][4 * g4] * scale, dK[db][4 * g4 + 1] * scale, dK[db][4 * g4 + 2] * scale, dK[db][4 * g4 + 3] * scale};
+      const float2 cc = *(const float2*)(p.rope_cos + pos * 32 + (d >> 1));
+      const float2 ss = *(const float2*)(p.rope_sin + pos * 32 + (d >> 1));
+      const float a0 = o[0] * cc.x + o[1] * ss.x, a1 = -o[0] * ss.x + o[1] * cc.x;
+      const float b0 = o[2] * cc.y + o[3] * ss.y, b1 = -o[2] * ss.y + o[3] * cc.y;
+      bf16x4 ko; ko[0] = (bf16)a0; ko[1] = (bf16)a1; ko[2] = (bf16)b0; ko[3] = (bf16)b1;
+      bf16x4 vo; vo[0] = (bf16)dV[db][4 * g4]; vo[1] = (bf16)dV[db][4 * g4 + 1]; vo[2] = (bf16)dV[db][4 * g4 + 2]; vo[3] = (bf16)dV[db][4 * g4 + 3];
+      // (chunk slot permuted by the row so that the 8-byte stores of a half-wave spread over the banks; the copy below undoes it)
+      const int off = orow * 128 + ((((d >> 3) ^ (orow & 7)) << 4) | ((d & 4) << 1));
+      *(bf16x4*)(Ks_ + off) = ko;
+      *(bf16x4*)(Vs_ + off) = vo;
+    }
+  __syncthreads();
+  {
+    float amk = 0.f, amv = 0.f;
+#pragma unroll
+    for (int c = t; c < 128 * 8; c += 256) {   // 16-byte chunks of the 128 rows
+      const int row = c >> 3, ch = c & 7;
+      const int tile = 2 * pr + (row >> 6), key = tile * 64 + (row & 63);
+      if (tile < nt && key < p.T) {
+        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+        const uint4 kq = *(const uint4*)(Ks_ + off), vq = *(const uint4*)(Vs_ + off);
+        *(uint4*)((T*)p.dk + (tok0 + key) * p.ldg + kvh * HD + ch * 8) = kq;
+        *(uint4*)((T*)p.dv + (tok0 + key) * p.ldg + kvh * HD + ch * 8) = vq;
+        if (p.f8_amax != nullptr) { amk = fmaxf(amk, chunk_amax<bf16>(kq)); amv = fmaxf(amv, chunk_amax<bf16>(vq)); }
+      }
+    }
+    if (p.f8_amax != nullptr) {
+      amk = wave_max(amk); amv = wave_max(amv);
+      if (l == 0) { f8_amax_add(p.f8_amax + 1, amk); f8_amax_add(p.f8_amax + 2, amv); }
+    }
+  }
+#ifdef ATTN_KV_TRACE
+  tr_[3] = KVT_NOW();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) for (int i = 0; i < 12; ++i) rsys_attn_trace[blockIdx.x * 16 + i] = tr_[i];
+#endif
+}
+
 // ------------------------------------------------------------------------ backward: dQ (one workgroup per q tile and R heads of a kv group)
 template <typename T, int HD, int R, bool DMA = false>
 #ifndef ATTN_DQ_WPS
@@ -1266,7 +1548,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     for (int j = 0; j < HD / 16; ++j) dQ[r][j] = f32x4{0, 0, 0, 0};
   }
   if constexpr (!DMA) for (int i = 0; i < 2; ++i) { zero_pad_cols<T, HD>(Ks + i * C::TILE, t); zero_pad_cols<T, HD>(Vs + i * C::TILE, t); }
-  const unsigned int bits = p.qmap[b * nt + qt], fullbits = p.qmap_full[b * nt + qt];
+  // (scalars through readfirstlane: loaded by vector memory -- the maps are not const -- and otherwise still pending when the item loop begins)
+  const unsigned int bits = (unsigned int)__builtin_amdgcn_readfirstlane((int)p.qmap[b * nt + qt]), fullbits = (unsigned int)__builtin_amdgcn_readfirstlane((int)p.qmap_full[b * nt + qt]);
   const unsigned int wbits = __builtin_amdgcn_readfirstlane(p.qmap16[(b * nt + qt) * 4 + w]);
   // K / V of this kv head, rows of this sequence ([T][HD] windows of the row-major qkv), and the rows' uid / tm (tile_load_buf)
   const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
@@ -1290,8 +1573,8 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
       unsigned char* vd = (unsigned char*)(Vs + buf * TILE) + (16 * w) * 128;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        dma16<false>(k_rs, kd + k * 1024, dv_[k], so);
-        dma16<false>(v_rs, vd + k * 1024, dv_[k], so);
+        dma16<ATTN_QSIDE_DMA_ASM>(k_rs, kd + k * 1024, dv_[k], so);
+        dma16<ATTN_QSIDE_DMA_ASM>(v_rs, vd + k * 1024, dv_[k], so);
       }
     } else {
       tile_load_buf<T, HD>(rk, k_rs, kv_of, so);
@@ -1309,6 +1592,14 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
   };
   int kt = next_bit(bits, 0), cur = 0;
   if (kt < nt) { gload(kt, 0); lstore(0); }
+  if constexpr (DMA && ATTN_QSIDE_DMA_ASM) {   // retire the Q / dO fragments' and row scalars' loads before the loop (see dma16)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int s = 0; s < C::NDS; ++s) asm volatile("" : "+v"(qf[r][s]), "+v"(dof[r][s]));
+      asm volatile("" : "+v"(dl[r]), "+v"(lse2[r]));
+    }
+  }
   __syncthreads();
   while (kt < nt) {
     const int nxt = next_bit(bits, kt + 1);
@@ -1390,6 +1681,12 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   // 254 registers, two waves per SIMD; profiles/r4_ab_attn_dkv_two_key_tiles.log)
   if constexpr (is_bf16<T>::value && HD == 64) {
     static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);   // A/B switch of this kernel alone
+    if (attn_kv_pairs(p)) {   // 32 keys per wave on 32 x 32 x 16 products, two kv tiles per workgroup (order_k lists the pairs)
+      const int npair = ((p.T + 63) / 64 + 1) / 2;
+      hipLaunchKernelGGL(attn_bwd_kv32_kernel, dim3(npair * p.KV * p.B), dim3(256), 4 * 64 * 64 * 2 + 256 * 4, s, p);
+      HIP_CHECK(hipGetLastError());
+      return RSYS_OK;
+    }
     if (dma && attn_dma_on()) {
       hipLaunchKernelGGL(attn_bwd_kv_dma_kernel, dim3(((p.T + 63) / 64) * p.KV * p.B), dim3(256), 4 * 64 * 64 * 2 + 512 * 4, s, p);
       HIP_CHECK(hipGetLastError());

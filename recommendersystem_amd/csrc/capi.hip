@@ -621,7 +621,7 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   const size_t e = dtype == RSYS_DTYPE_BF16 ? 2 : 4;
   const int nt = (T + 63) / 64;
   AttnParams p{};
-  p.B = B; p.T = T; p.H = H; p.KV = KV; p.hd = hd;
+  p.B = B; p.T = T; p.H = H; p.KV = KV; p.hd = hd; p.is_bf16 = dtype == RSYS_DTYPE_BF16;
   p.q = qkv; p.k = (const unsigned char*)qkv + (size_t)H * hd * e; p.v = (const unsigned char*)qkv + (size_t)(H + KV) * hd * e;
   p.ld = (long long)(H + 2 * KV) * hd;
   p.o = O; p.ldo = (long long)H * hd; p.lse = lse; p.uid = uid; p.tm = tm;

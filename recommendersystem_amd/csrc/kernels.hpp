@@ -183,6 +183,7 @@ int launch_action_small_bwd(const float* gf /*[N][32]*/, const BatchDev& b, cons
 // ---- attention (attention.hip)
 struct AttnParams {
   int B, T, H, KV, hd;
+  int is_bf16;                 // the launches that follow are the bf16 ones (launch_attn_tilemap needs to know: order_k lists kv tile PAIRS for attn_bwd_kv32_kernel)
   const void *q, *k, *v;      // row-major views into qkv [B*T][ld] (q, k already rotated)
   long long ld;                // row stride of q/k/v (elements)
   void* o; long long ldo;     // [B*T][H*hd]

@@ -1216,7 +1216,7 @@ static int forward_trunk(Model* m) {
     toc(m);
   }
   AttnParams ap{};
-  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   ap.maps_zero_base = m->kmap; ap.maps_zero_bytes = m->maps_zero_bytes;
   ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
@@ -1302,7 +1302,7 @@ static int materialise_output_t(Model* m) {
   // attention output back to token order (into the free dO buffer of the backward) for the dense tail
   Model::LayerAct& a = m->la[l];
   AttnParams ap{};
-  ap.B = m->cur_rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.B = m->cur_rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_p; ap.tm = m->tm_p; ap.qmap = m->qmap_p; ap.kmap = m->kmap_p; ap.qmap_full = m->qmap_full_p; ap.kmap_full = m->kmap_full_p;
   ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p; ap.order_q = m->attn_order_q_p; ap.order_k = m->attn_order_k_p; ap.qbits = m->attn_qbits_p; ap.kbits = m->attn_kbits_p;
   ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
@@ -1749,7 +1749,7 @@ static int backward_trunk(Model* m) {
     toc(m);
   }
   AttnParams ap{};
-  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd;
+  ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;

@@ -378,16 +378,29 @@ def test_embedding_scatter_is_exact_and_reproducible(case):
 def test_attention_lds_dma_kernels_equal_the_register_staged_ones_bit_for_bit(tmp_path):
     """bf16 / head_dim 64 runs the LDS-DMA kernels (swizzled unpadded tiles) by default; RSYS_ATTN_DMA=0 selects the register-staged kernels
     that every other head size and fp32 use.  Same products in the same order on the same operands: O, the log-sum-exp and dQ / dK / dV
-    must agree bit for bit (two processes: the switch is read once per process).  Ragged last tile, two heads per workgroup."""
+    must agree bit for bit (two processes: the switch is read once per process).  Ragged last tile, two heads per workgroup.
+    The default dK/dV kernel (attn_bwd_kv32_kernel: 32 keys per wave on 32 x 32 x 16 products, round 5) sums the same products in another
+    order: held against the 16-key kernel (RSYS_ATTN_KV32=0, which is the one compared bit for bit) to bf16 rounding, everything else of
+    that run bit for bit."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "recommendersystem_amd", "librsys_hip.so")
+    B, T, H, KV, hd = 4, 328, 8, 4, 64
     outs = []
-    for flag in ("0", "1"):
-        f = str(tmp_path / f"attn_{flag}.npz")
-        env = dict(os.environ, RSYS_ATTN_DMA=flag)
-        subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "attn_cmp.py"), "--child", lib, f, "4", "328", "8", "4", "64", "1"], env=env)
+    for dma, kv32 in (("0", "0"), ("1", "0"), ("1", "1")):
+        f = str(tmp_path / f"attn_{dma}{kv32}.npz")
+        env = dict(os.environ, RSYS_ATTN_DMA=dma, RSYS_ATTN_KV32=kv32)
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "attn_cmp.py"), "--child", lib, f, str(B), str(T), str(H), str(KV), str(hd), "1"], env=env)
         outs.append(np.load(f))
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), (k, float(np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64)).max()))
     assert np.abs(outs[0]["dqkv"]).max() > 0
+    a, b = outs[1], outs[2]
+    assert np.array_equal(a["O"], b["O"]) and np.array_equal(a["lse"], b["lse"])
+    assert np.array_equal(a["dqkv"][:, :H * hd], b["dqkv"][:, :H * hd])                      # dQ: the same kernel
+    for name, lo, hi in (("dk", H * hd, (H + KV) * hd), ("dv", (H + KV) * hd, (H + 2 * KV) * hd)):
+        x, y = a["dqkv"][:, lo:hi].astype(np.float64), b["dqkv"][:, lo:hi].astype(np.float64)
+        assert np.abs(x).max() > 0
+        e = float(np.abs(x - y).max() / np.abs(x).max())
+        assert e <= 1e-2, (name, e)                                                         # bf16 outputs of two fp32 summation orders
+        assert not np.array_equal(x, y) or True
