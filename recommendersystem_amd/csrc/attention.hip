@@ -1258,7 +1258,10 @@ static bool attn_kv_pairs(const AttnParams& p) {   // (bf16 is the caller's busi
   static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);
   return p.hd == 64 && p.is_bf16 && dma && attn_dma_on() && attn_kv32_on();
 }
-__global__ __launch_bounds__(256, 2) void attn_bwd_kv32_kernel(AttnParams p) {
+#ifndef ATTN_KV32_WPS
+#define ATTN_KV32_WPS 3   // waves per SIMD the kernel is compiled for: 168 registers, 5 dwords spilled OUTSIDE the item loop; 2 (189 registers) is 9 % slower (profiles/r5_ab_attn_kv32.log)
+#endif
+__global__ __launch_bounds__(256, ATTN_KV32_WPS) void attn_bwd_kv32_kernel(AttnParams p) {
   [[maybe_unused]] unsigned long long tr_[12] = {KVT_NOW(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (-DATTN_KV_TRACE only: tools/trace_attn_kv.sh)
   constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
   using T = bf16;
@@ -1341,7 +1344,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv32_kernel(AttnParams p) {
     }
   };
   auto publish = [&](int buf) {   // the scalars into LDS; every DMA of this wave landed
-    if (w0) { lse2[buf * 64 + l] = __builtin_bit_cast(float, sx) * LOG2E; ((int*)dls)[buf * 64 + l] = sy ^ 0x80000000; }   // log2 units; -delta
+    // -lse / scale: what the S chains start from, so that p = exp2(c2 * S') needs no subtraction (1 / scale = 8 is exact); -delta likewise for dP
+    if (w0) { lse2[buf * 64 + l] = __builtin_bit_cast(float, sx) * -8.0f; ((int*)dls)[buf * 64 + l] = sy ^ 0x80000000; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   // items = (head of the group, q tile in `bits`), heads outermost: a scalar iterator, two scalar instructions per step
@@ -1379,22 +1383,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv32_kernel(AttnParams p) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {   // 32 queries at a time
         f32x16 S, dP;
-        float ll[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {   // accumulator rows 4 k .. 4 k + 3 = queries 32 qb + 8 k + 4 h ..+3
           const float4 l4 = *(const float4*)(lse2 + cur * 64 + 32 * qb + 8 * k + 4 * h);
           const float4 d4 = *(const float4*)(dls + cur * 64 + 32 * qb + 8 * k + 4 * h);
-          ll[4 * k] = l4.x; ll[4 * k + 1] = l4.y; ll[4 * k + 2] = l4.z; ll[4 * k + 3] = l4.w;
+          S[4 * k] = l4.x; S[4 * k + 1] = l4.y; S[4 * k + 2] = l4.z; S[4 * k + 3] = l4.w;       // the S chain starts from -lse[q] / scale
           dP[4 * k] = d4.x; dP[4 * k + 1] = d4.y; dP[4 * k + 2] = d4.z; dP[4 * k + 3] = d4.w;   // the dP chain starts from -delta[q]
-          S[4 * k] = 0.f; S[4 * k + 1] = 0.f; S[4 * k + 2] = 0.f; S[4 * k + 3] = 0.f;
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           S = mfma32(*(const bf16x8*)(Qc + qb * 4096 + a_row[s]), kf[s], S);       // S[q][kv]
           dP = mfma32(*(const bf16x8*)(dOc + qb * 4096 + a_row[s]), vf[s], dP);    // dP[q][kv] - delta[q]
         }
-        if (!fullt) {   // bit (query) of the lane's key word: query 32 qb + 8 (r >> 2) + 4 h + (r & 3)
-          const int src = (int)((unsigned int)(qb ? (wk >> 32) : wk) >> (4 * h));
+        // bit (query) of the lane's key word: query 32 qb + 8 (r >> 2) + 4 h + (r & 3).  A 32 x 32 block of which every pair is allowed
+        // needs no mask (wave-uniform: one compare and a ballot): with ~5 % of the events carrying a token-mask id a 64 x 64 tile is
+        // rarely full, a block of 32 keys often is
+        const unsigned int w32 = (unsigned int)(qb ? (wk >> 32) : wk);
+        if (!fullt && __builtin_amdgcn_ballot_w64(w32 != 0xFFFFFFFFu) != 0ull) {
+          const int src = (int)(w32 >> (4 * h));
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = __builtin_amdgcn_sbfe(src, 8 * (r >> 2) + (r & 3), 1);
@@ -1405,7 +1411,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv32_kernel(AttnParams p) {
         f32x16 P, dS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = fexp2(fmaf(S[r], c2, -ll[r]));   // masked: exp2(-1.8e29 - lse) = 0
+          const float pv = fexp2(S[r] * c2);   // = exp(q.k / sqrt(hd) - lse); masked: exp2(-1.8e29) = 0
           P[r] = pv;
           dS[r] = pv * dP[r];   // (the 1/sqrt(hd) factor of dS is applied once to dK at the end)
         }
