@@ -29,6 +29,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8p": "gemm8p_kernel<false, false>",                  # its predecessor: operand requests stop at the end of every output tile (gemm8p.hip; classes without an 8c kernel, RSYS_GEMM8C=0)
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
     "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
+    "8ts": "gemm8p_kernel<true, false>",                  # the same kernel, one K split, fp32 output stored / accumulated (the tied head's table gradient)
     "8g": "gemm8p_group_kernel",                          # the K-major pipeline, all layers' weight gradients in one grouped launch
     "8f": "gemm8p_f8_kernel",                             # --dtype fp8: the persistent pipeline on e4m3 / e5m2 operands (K tiles of 128)
     "8fs": "gemm8p_f8sk_kernel",                          # --dtype fp8: split-K weight gradients on transposed fp8 copies, one product per launch
@@ -40,6 +41,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
 KERNEL_LABEL = {"8c": "gemm8c_kernel<epilogue class> (256x256 LDS-DMA, persistent, one operand stream per workgroup, row-major bf16)",
                 "8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
+                "8ts": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, one K split, plain fp32 store / accumulate)",
                 "8g": "gemm8p_group_kernel (256x256 LDS-DMA, K-major bf16, split-K, grouped weight gradients of all layers)",
                 "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
                 "8fs": "gemm8p_f8sk_kernel (256x256 LDS-DMA, fp8 e5m2 x e4m3 on K-contiguous copies, split-K weight gradient)",

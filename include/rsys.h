@@ -236,6 +236,11 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
  * (rows up to the end of the last started tile may be written); row-major A, c_f32 / b_km as above */
 int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev);
+/* K-major operands (A [K][lda >= M], B [K][ldb >= N]), f32 C stored (accumulate = 0) or added to (1), the reduction limited to the first
+ * *k_dev rows of the operands (device memory): the tied head's table gradient dF (+)= dlogits^T Ew over the live selected rows
+ * (model.py:153-170 backward); rows >= *k_dev may hold anything */
+int32_t rsys_op_gemm_klimit(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
+                            int64_t lda, int64_t ldb, int64_t ldc, int32_t accumulate, const int32_t* k_dev);
 /* attention fwd+bwd on caller-provided device buffers (T-typed): qkv [B*T][(H+2KV)*hd] post-RoPE, dO [B*T][H*hd],
  * uid/tm [B*T] int32 with 0 <= uid < 2^19 and 0 <= tm < 4096, rope tables [T][hd/2] f32; outputs O [B*T][H*hd], lse [B][H][T] f32,
  * dqkv [B*T][(H+2KV)*hd] (gradients w.r.t. the un-rotated q, k and v) */

@@ -118,6 +118,7 @@ _SIGS = [
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("rsys_op_gemm_rows", C.c_int32, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_int32, C.c_int32, _P]),
+    ("rsys_op_gemm_klimit", C.c_int32, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _P]),
     ("rsys_op_attention", C.c_int32, [C.c_int32] + [C.c_int32] * 5 + [_P] * 9),
     ("rsys_op_embedding_scatter", C.c_int32, [_P, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     ("rsys_step_mark", C.c_int32, [_P]),

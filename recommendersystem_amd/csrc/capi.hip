@@ -564,6 +564,19 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
   return RSYS_OK;
 }
 
+int32_t rsys_op_gemm_klimit(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                            int64_t ldb, int64_t ldc, int32_t accumulate, const int32_t* k_dev) {
+  ARG_CHECK(k_dev != nullptr, "rsys_op_gemm_klimit: k_dev is null");
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.c_f32 = 1; p.splitk = 1; p.alpha = 1.f; p.epi = accumulate ? EPI_ACCUM : EPI_STORE; p.k_dev = k_dev;
+  int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, false, false, true, true, nullptr)
+                                    : launch_gemm<float>(p, false, false, true, true, nullptr);
+  if (rc) return rc;
+  HIP_CHECK(hipDeviceSynchronize());
+  return RSYS_OK;
+}
+
 int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32_t cols, int32_t fmt, int32_t layout, int32_t seg_cols,
                             int32_t seg_rep, void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev,
                             int32_t n_w, int32_t w_rep, int32_t desc_mode) {

@@ -500,6 +500,15 @@ static bool use_8p_tn(const GemmParams& p) {
   return (e && atoi(e) == 2) || t256 >= 16;
 }
 
+// K-major bf16 operands, fp32 output stored or accumulated (no split-K): the tied head's table gradient (10^5 x D outputs, K = the live
+// selected rows).  On the LDS-DMA pipeline when the output fills the chip; RSYS_GEMM_KERNEL_TN=1 keeps the 128x128 kernel (A/B).
+static bool use_8p_tn_store(const GemmParams& p) {
+  const char* e = getenv("RSYS_GEMM_KERNEL_TN");   // (read per call, as use_8p_tn: the tests switch it)
+  if (e && atoi(e) == 1) return false;
+  if (!gemm8p_tn_store_eligible(p)) return false;
+  return (e && atoi(e) == 2) || (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 128;
+}
+
 // row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
 static bool use_8p_nt_splitk(const GemmParams& p) {
   if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
@@ -516,6 +525,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
     if (k == 2) return gemm8p_forwards_to_8c(p) ? "8c" : "8p";
   }
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
+  if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return "8ts";
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return "8s";
   return a_km ? "tn" : (b_km ? "nn" : "nt");
 }
@@ -552,6 +562,7 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
       if (k == 2) return launch_gemm8p(p, s);
     }
     if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return launch_gemm8p_tn(p, s);
+    if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return launch_gemm8p_tn_store(p, s);
   }
   if (!a_km && !b_km) {
     if (!a_f32 && !b_f32) return launch_one<CT, false, false, false, false>(p, s);

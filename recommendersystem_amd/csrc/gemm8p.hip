@@ -114,6 +114,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   // tiles (tn fastest) and its workgroups walk that run side by side, so neighbouring tiles share A rows / B rows
   // through the XCD's private L2
   const int tiles_n = (p.N + T8_BN - 1) / T8_BN;
+  // K-major store / accumulate form: a device-side K limit (rows of the operands that are live: the head GEMMs over the selected positions)
+  [[maybe_unused]] const int keff = (KM && p.k_dev != nullptr) ? __builtin_amdgcn_readfirstlane(max(min(*p.k_dev, p.K), 0)) : p.K;
   int tile, tile_first = 0, tile_end = 0, tile_step = 1, kt0 = 0, nt, split_id = 0;
   if constexpr (PERSIST) {
     const int rows = p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M;
@@ -136,6 +138,15 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       const int xcd = bid & 7, local = bid >> 3;
       tile = local % ntiles;
       split = xcd + 8 * (local / ntiles);
+      if constexpr (KM) {
+        if (p.epi != EPI_ATOMIC) {   // store / accumulate form (one K split, launch_gemm8p_tn_store): XCD x owns a contiguous run of tiles
+          const int q = ntiles >> 3, r = ntiles & 7;
+          const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+          if (local >= cnt) return;
+          tile = first + local;
+          split = 0;
+        }
+      }
       // The ~32 workgroups an XCD runs side by side walk their K range in step and share operand columns through its L2: take the
       // tiles in bands of 8 tile columns (tn fastest inside a band), so that 32 neighbours are 4 x 8 tiles = 12 operand panels rather
       // than 1.5 rows of a wide product (dW2 at the production shape, 8 x 22 tiles: 24 panels; PMC: 9.3 GB fetched for 2.0 GB of operands)
@@ -148,9 +159,10 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       }
     }
     split_id = split;
-    const int ktiles = (p.K + KE - 1) / KE, per = (ktiles + p.splitk - 1) / p.splitk;
+    const int ktiles = (keff + KE - 1) / KE, per = (ktiles + p.splitk - 1) / p.splitk;
     kt0 = split * per;
     nt = min(ktiles, kt0 + per) - kt0;
+    if (KM && p.epi != EPI_ATOMIC) nt = max(nt, 1);   // (no live K row: the window below is empty, the tile is stored as zeros)
     if (nt <= 0) return;
   }
   int m0 = (tile / tiles_n) * T8_BM, n0 = (tile % tiles_n) * T8_BN;
@@ -195,8 +207,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   const long long stepB = KM ? (long long)T8_BK * p.ldb * 2 : (long long)T8_BK * 2;
   const char* a_cur = (const char*)p.A + (long long)kt0 * stepA;
   const char* b_cur = (const char*)p.B + (long long)kt0 * stepB;
-  long long a_rem = KM ? (long long)p.K * p.lda * 2 - (long long)kt0 * stepA : 0;
-  long long b_rem = KM ? (long long)p.K * p.ldb * 2 - (long long)kt0 * stepB : 0;
+  long long a_rem = KM ? (long long)keff * p.lda * 2 - (long long)kt0 * stepA : 0;
+  long long b_rem = KM ? (long long)keff * p.ldb * 2 - (long long)kt0 * stepB : 0;
   auto window = [&](const char* cur, long long rem, long long step, int d) __attribute__((always_inline)) -> i32x4 {
     i32x4 r = make_rsrc(cur + d * step);
     if constexpr (KM) {
@@ -523,6 +535,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
               if (p.f8_rowmode == 1) { const int half = p.M >> 1, isb = row >= half ? 1 : 0, i = row - isb * half; orow = ((i >> 4) << 5) + (isb << 4) + (i & 15); }
             }
             if (p.slab != nullptr) p.slab[((long long)split_id * p.M + row) * p.N + col] = v;   // deterministic mode (gemm.hpp)
+            else if (KM && p.epi == EPI_STORE) C[(long long)orow * p.ldc + col] = v;        // (one K split: 256 contiguous bytes per wave instruction)
+            else if (KM && p.epi == EPI_ACCUM) C[(long long)orow * p.ldc + col] += v;
             else atomicAdd(C + (long long)orow * p.ldc + col, v);
           }
         }
@@ -778,6 +792,25 @@ int gemm8p_splits(const GemmParams& p, bool k_major) {
   }
   static const int force = getenv("RSYS_DEBUG_8T_SPLITK") ? atoi(getenv("RSYS_DEBUG_8T_SPLITK")) : 0;   // scans (tools/)
   return (k_major && force > 0) ? (force + 7) / 8 * 8 : best;
+}
+
+// K-major operands, ONE K split, fp32 output stored or accumulated with plain memory operations (the tied head's table gradient
+// dF[v][:] (+)= sum_rows dlogits[row][v] Ew[row][:]: few hundred live rows -- a device-side K limit -- against 10^5 output rows)
+bool gemm8p_tn_store_eligible(const GemmParams& p) {
+  if ((p.epi != EPI_STORE && p.epi != EPI_ACCUM) || !p.c_f32 || p.m_dev != nullptr || p.splitk > 1 || p.alpha != 1.f || p.f8 != 0) return false;
+  if (p.M % 8 != 0 || p.N % 8 != 0 || p.M < 8 || p.N < 8 || p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
+  if ((unsigned long long)64 * p.lda * 2 + (unsigned long long)p.M * 2 >= (1ull << 31)) return false;
+  if ((unsigned long long)64 * p.ldb * 2 + (unsigned long long)p.N * 2 >= (1ull << 31)) return false;
+  if ((unsigned long long)p.K * p.lda * 2 >= (1ull << 40) || (unsigned long long)p.K * p.ldb * 2 >= (1ull << 40)) return false;
+  return true;
+}
+int launch_gemm8p_tn_store(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.splitk = 1; p.slab = nullptr;
+  const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(8 * ((tiles + 7) / 8)), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
 }
 
 int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {

@@ -148,6 +148,8 @@ bool gemm8p_forwards_to_8c(const GemmParams& p);   // what launch_gemm8p will do
 // the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
 bool gemm8p_tn_eligible(const GemmParams& p);
 int launch_gemm8p_tn(const GemmParams& p, hipStream_t s);
+bool gemm8p_tn_store_eligible(const GemmParams& p);   // K-major operands, one K split, fp32 C stored / accumulated (device-side K limit allowed)
+int launch_gemm8p_tn_store(const GemmParams& p, hipStream_t s);
 // the row-major pipeline with the same split-K mapping and atomic epilogue (long K, few output tiles, K-contiguous operands)
 bool gemm8p_nt_splitk_eligible(const GemmParams& p);
 int launch_gemm8p_nt_splitk(const GemmParams& p, hipStream_t s);

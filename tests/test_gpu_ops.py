@@ -188,6 +188,43 @@ def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,live", [(768, 512, 704, 333), (1024, 256, 192, 64), (520, 264, 320, 1), (512, 512, 256, 0), (2048, 512, 4096, 4096)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_gemm_kmajor_store_form_with_device_side_k_limit(monkeypatch, M, N, K, live, accumulate):
+    """K-major operands on the LDS-DMA pipeline with ONE K split and a plain fp32 store / accumulate epilogue, the reduction bounded by a
+    row count in device memory (gemm8p_kernel<true>, launch_gemm8p_tn_store: the tied head's table gradient dF (+)= dlogits^T Ew over
+    the live selected rows).  Rows of the operands at and beyond the limit hold poison (1e30): the buffer descriptor must stop there,
+    not at the next K tile.  Exact on integer data; ragged M / N; zero live rows store zeros (or leave C alone when accumulating)."""
+    from recommendersystem_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(M + N + K + live)
+    A = rng.integers(-3, 4, (K, M)).astype(np.float32); B = rng.integers(-3, 4, (K, N)).astype(np.float32)
+    A[:, 0] = np.arange(K) % 5 - 2; B[0, :] = np.arange(N) % 7 - 3
+    ref = A[:live].astype(np.float64).T @ B[:live].astype(np.float64)
+    Ap, Bp = A.copy(), B.copy()
+    Ap[live:] = 1e30; Bp[live:] = -1e30       # poison: a row read past the limit shows as 1e60-scale sums or NaN
+    pad = lambda n: (n + 7) // 8 * 8
+    lda, ldb, ldc = pad(M), pad(N), pad(N)
+    As = np.zeros((K, lda), np.float32); As[:, :M] = Ap
+    Bs = np.zeros((K, ldb), np.float32); Bs[:, :N] = Bp
+    C0 = rng.integers(-5, 6, (M, ldc)).astype(np.float32)
+    for kern in ("2", "1") if live > 0 else ("2",):   # the LDS-DMA store form, then the 128x128 kernel on the same data (which needs zeros up to the next K tile)
+        monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", kern)
+        if kern == "1":
+            As[live:] = 0; Bs[live:] = 0
+        dA = _to_dev(lib, _pack(As, True)); dB = _to_dev(lib, _pack(Bs, True)); dC = _to_dev(lib, C0)
+        dK = _to_dev(lib, np.array([live], np.int32))
+        rc = lib.rsys_op_gemm_klimit(1, dA, dB, dC, M, N, K, lda, ldb, ldc, accumulate, dK)
+        assert rc == 0, _lib.last_error()
+        out = np.empty((M, ldc), np.float32)
+        assert lib.rsys_dev_d2h(out.ctypes.data, dC, out.nbytes) == 0
+        for ptr in (dA, dB, dC, dK):
+            lib.rsys_dev_free(ptr)
+        want = ref + (C0[:, :N] if accumulate else 0.0)
+        np.testing.assert_array_equal(out[:, :N], want.astype(np.float32))
+        np.testing.assert_array_equal(out[:, N:], C0[:, N:])          # padding columns untouched
+
+
 def test_gemm_bf16_output():
     out, ref = run_gemm(1, 128, 256, 128, False, False, c_f32=False, seed=3)
     err = np.abs(out - ref).max() / np.abs(ref).max()

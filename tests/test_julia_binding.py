@@ -12,7 +12,7 @@ JULIA = os.path.join(ROOT, "julia", "RsysHIP.jl")
 # entry points a Julia host has no use for: raw per-kernel access of the unit tests (device pointers from rsys_dev_alloc)
 NOT_BOUND = {"rsys_dev_alloc", "rsys_dev_free", "rsys_dev_h2d", "rsys_dev_d2h", "rsys_dev_memset", "rsys_op_gemm", "rsys_op_gemm_rows",
              "rsys_op_attention", "rsys_op_embedding_scatter", "rsys_op_f8_quantize", "rsys_op_f8_weights", "rsys_op_gemm_f8",
-             "rsys_comm_debug_delay"}
+             "rsys_comm_debug_delay", "rsys_op_gemm_klimit"}
 
 SCALAR = {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint8_t": "UInt8", "float": "Float32", "double": "Float64",
           "size_t": "Csize_t", "int": "Int32", "char": "UInt8", "void": "Cvoid"}
