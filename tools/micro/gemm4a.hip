@@ -1,0 +1,216 @@
+// Experiment for VERDICT r4 item 2 (long-K loop at vendor parity): the vendor's wave shape -- FOUR waves of 128 x 128 on a 256 x 256 x 64
+// macro tile, one wave per SIMD, 0.25 LDS fragment reads per MFMA -- with the two things round 3's HIP attempt (653 TFLOP/s) did not have:
+//   * every fragment is read ONE PHASE AHEAD of the MFMAs that use it (four named register sets A_x, A_y, B_x, B_y: no MFMA waits on LDS),
+//   * every 16 KB half-tile region is re-requested right after its last read, SEVEN phases before its next one (one barrier per phase,
+//     a constant counted vmcnt(24); requests behind the last K tile go through an empty descriptor, so the count never changes).
+// Phases of K tile t (LDS stage s = t & 1; regions A h0 | A h1 | B h0 | B h1 of 16 KB; h = 64-row halves of a wave's 128 rows / columns):
+//   P1: MFMA A_x(h0) x B_x(h0)   read B_y <- B h1 (t)        request (s, B h0) <- K tile t + 2
+//   P2: MFMA A_x     x B_y       read A_y <- A h1 (t)        request (s, B h1) <- t + 2
+//   P3: MFMA A_y     x B_y       read A_x <- A h0 (t + 1)    request (s, A h1) <- t + 2
+//   P4: MFMA A_y     x B_x       read B_y <- B h0 (t + 1)    request (s ^ 1, A h0) <- t + 3
+// (the B sets swap roles every K tile: the loop is unrolled by two).  Same LDS image, swizzle and MFMA order per accumulator as gemm8c:
+// results are compared bit for bit with launch_gemm8c.  K loop only + a plain bf16 store; one output tile per workgroup.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude tools/micro/gemm4a.hip -o tools/micro/bin/gemm4a && tools/micro/bin/gemm4a
+#include "../../recommendersystem_amd/csrc/gemm8p.hip"
+#include "../../recommendersystem_amd/csrc/gemm8c.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rsys {
+void set_error(const std::string& msg) { fprintf(stderr, "error: %s\n", msg.c_str()); }
+int gemm_slab_begin(const GemmParams&, hipStream_t) { return 0; }
+int gemm_slab_end(const GemmParams&, hipStream_t) { return 0; }
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void g4_dma(c8_i32x4 rsrc, unsigned int voff, unsigned int soff, unsigned int lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#define G4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#ifndef G4_LEAD_WAIT
+#define G4_LEAD_WAIT 24
+#endif
+
+__global__ __launch_bounds__(256) void gemm4a_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [stage][A h0 | A h1 | B h0 | B h1] x 16 KB
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int tiles_n = p.N / 256;
+  // XCD-aware tile order (as gemm8c: an XCD owns a contiguous run of tiles)
+  const int ntiles = (p.M / 256) * tiles_n, bid = blockIdx.x;
+  const int xcd = bid & 7, q = ntiles >> 3;
+  const int tile = xcd * q + (bid >> 3);
+  if (tile >= ntiles) return;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int nt = p.K / 64;
+  const int fq = l >> 4, fr = l & 15;
+  // DMA: a region = 16 pieces of 1 KB (8 local rows x 128 B); wave w issues pieces 4 w .. 4 w + 3: local rows lr = 32 w + 8 j + (l >> 3),
+  // tile row (lr >> 6) * 128 + h * 64 + (lr & 63); lane slot l & 7 holds chunk (l & 7) ^ ((lr >> 1) & 7) = (l & 7) ^ ((4 j + (l >> 4)) & 7)
+  unsigned int va[2], vb[2];   // per-lane source offsets for even / odd j (the j * 8 rows and the half go into the scalar offset)
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const int lr0 = 32 * w + (l >> 3);
+    const int ch = (l & 7) ^ ((4 * jp + (l >> 4)) & 7);
+    const int row = (lr0 >> 6) * 128 + (lr0 & 63);
+    va[jp] = (unsigned int)(row * p.lda * 2 + ch * 16);
+    vb[jp] = (unsigned int)(row * p.ldb * 2 + ch * 16);
+  }
+  const unsigned int lds0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)smem);
+  const unsigned int dma_lds = lds0 + w * 4096;   // + stage * 65536 + region * 16384 + j * 1024
+  const char* a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
+  const char* b_base = (const char*)p.B + (long long)n0 * p.ldb * 2;
+  const unsigned int rec_a = (unsigned int)(255 * p.lda * 2 + 128), rec_b = (unsigned int)(255 * p.ldb * 2 + 128);
+  auto rsrc_of = [&](const char* base, unsigned int rec) __attribute__((always_inline)) -> c8_i32x4 {
+    const unsigned long long a = (unsigned long long)base;
+    c8_i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)((a >> 32) & 0xFFFFu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)rec);
+    r[3] = 0x00020000;
+    return r;
+  };
+  // request half-tile (is_b, h) of K tile kt into stage st (kt >= nt: an empty window, the request still counts in vmcnt)
+  auto request = [&](int kt, int st, bool is_b, int h) __attribute__((always_inline)) {
+    const bool live = kt < nt;
+    const c8_i32x4 rs = is_b ? rsrc_of(b_base + (long long)kt * 128, live ? rec_b : 0u) : rsrc_of(a_base + (long long)kt * 128, live ? rec_a : 0u);
+    const unsigned int ld = (unsigned int)((is_b ? p.ldb : p.lda) * 2);
+    const unsigned int at = dma_lds + st * 65536 + ((is_b ? 2 : 0) + h) * 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g4_dma(rs, is_b ? vb[j & 1] : va[j & 1], (unsigned int)(h * 64 + j * 8) * ld, at + j * 1024);
+  };
+  // fragment reads: row block i of half h of the wave's rows (columns), k half kk: local row wr * 64 + 16 i + fr, chunk 4 kk + fq
+  const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
+  const int a_rd0 = (wr * 64 + fr) * 128 + sw0, a_rd1 = (wr * 64 + fr) * 128 + sw1;
+  const int b_rd0 = 32768 + (wc * 64 + fr) * 128 + sw0, b_rd1 = 32768 + (wc * 64 + fr) * 128 + sw1;
+  bf16x8 Ax[4][2], Ay[4][2], Bx[4][2], By[4][2];
+  auto read_a = [&](bf16x8(&f)[4][2], int st, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[i][0] = *(const bf16x8*)(smem + st * 65536 + h * 16384 + i * 2048 + a_rd0);
+      f[i][1] = *(const bf16x8*)(smem + st * 65536 + h * 16384 + i * 2048 + a_rd1);
+    }
+  };
+  auto read_b = [&](bf16x8(&f)[4][2], int st, int h) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j][0] = *(const bf16x8*)(smem + st * 65536 + h * 16384 + j * 2048 + b_rd0);
+      f[j][1] = *(const bf16x8*)(smem + st * 65536 + h * 16384 + j * 2048 + b_rd1);
+    }
+  };
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma_q = [&](auto IH, auto JH, const bf16x8(&af)[4][2], const bf16x8(&bf)[4][2]) __attribute__((always_inline)) {
+    constexpr int ih = decltype(IH)::value, jh = decltype(JH)::value;
+    static_for<4>([&](auto i) {
+      static_for<4>([&](auto j) {
+        acc[ih * 4 + i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[i][0], acc[ih * 4 + i][jh * 4 + j], 0, 0, 0);
+        acc[ih * 4 + i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[i][1], acc[ih * 4 + i][jh * 4 + j], 0, 0, 0);
+      });
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // phase opening: this wave's fragment reads of the previous phase have returned (their region may be overwritten once every wave is
+  // here), the region read in this phase has landed for every wave
+  auto open = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G4_LEAD_WAIT) : "memory");
+    G4_BARRIER();
+  };
+  // ---- prologue: K tiles 0 and 1 in the order their regions are first read; then the first two fragment sets
+  request(0, 0, false, 0); request(0, 0, true, 0); request(0, 0, true, 1); request(0, 0, false, 1);
+  request(1, 1, false, 0); request(1, 1, true, 0); request(1, 1, true, 1); request(1, 1, false, 1);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // A h0, B h0 of K tile 0
+  G4_BARRIER();
+  read_a(Ax, 0, 0); read_b(Bx, 0, 0);
+  // the request the fourth phase of "K tile -1" would have made (A h0 of K tile 2 into the region just read), so that the request stream
+  // is in its steady state -- nine groups, in the order the phases consume them -- when the loop's constant vmcnt begins
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  G4_BARRIER();
+  request(2, 0, false, 0);
+  auto ktile = [&](int kt, int st, bf16x8(&Bc)[4][2], bf16x8(&Bn)[4][2]) __attribute__((always_inline)) {   // Bc = B h0 of this K tile
+    open(); request(kt + 2, st, true, 0);      read_b(Bn, st, 1);          mma_q(I0{}, I0{}, Ax, Bc);
+    open(); request(kt + 2, st, true, 1);      read_a(Ay, st, 1);          mma_q(I0{}, I1{}, Ax, Bn);
+    open(); request(kt + 2, st, false, 1);     read_a(Ax, st ^ 1, 0);      mma_q(I1{}, I1{}, Ay, Bn);
+    open(); request(kt + 3, st ^ 1, false, 0); read_b(Bn, st ^ 1, 0);      mma_q(I1{}, I0{}, Ay, Bc);
+  };
+#pragma unroll 1
+  for (int kt = 0; kt < nt; kt += 2) {
+    ktile(kt, 0, Bx, By);
+    ktile(kt + 1, 1, By, Bx);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- plain bf16 store: acc[i][j][r] = C[m0 + wr * 128 + 16 i + fr][n0 + wc * 128 + 16 j + 4 fq + r]
+  bf16* C = (bf16*)p.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16x4 o; o[0] = (bf16)acc[i][j][0]; o[1] = (bf16)acc[i][j][1]; o[2] = (bf16)acc[i][j][2]; o[3] = (bf16)acc[i][j][3];
+      *(bf16x4*)(C + (long long)(m0 + wr * 128 + 16 * i + fr) * p.ldc + n0 + wc * 128 + 16 * j + 4 * fq) = o;
+    }
+}
+}  // namespace rsys
+
+static unsigned int g_seed = 0x1234567u;
+static void fill_bf16(void* d, size_t n) {
+  std::vector<unsigned short> h(n);
+  for (auto& v : h) { g_seed = g_seed * 1664525u + 1013904223u; const float f = ((float)(g_seed >> 8) * (2.0f / 16777216.0f) - 1.0f); unsigned int u; memcpy(&u, &f, 4); v = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1)) >> 16); }
+  hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
+}
+
+static void run(int M, int N, int K, int reps) {
+  using namespace rsys;
+  void *A, *B, *C0, *C1;
+  hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C0, (size_t)M * N * 2); hipMalloc(&C1, (size_t)M * N * 2);
+  fill_bf16(A, (size_t)M * K); fill_bf16(B, (size_t)N * K);
+  hipMemset(C0, 0xEE, (size_t)M * N * 2); hipMemset(C1, 0xEE, (size_t)M * N * 2);
+  GemmParams p{};
+  p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.epi = EPI_STORE; p.c_f32 = 0; p.alpha = 1.f; p.splitk = 1;
+  const int tiles = (M / 256) * (N / 256);
+  auto launch4 = [&]() { GemmParams q = p; q.C = C1; hipLaunchKernelGGL(gemm4a_kernel, dim3(tiles), dim3(256), 0, nullptr, q); };
+  auto launch8 = [&]() { GemmParams q = p; q.C = C0; launch_gemm8c(q, nullptr); };
+  launch8(); launch4();
+  if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); exit(2); }
+  std::vector<unsigned short> h0((size_t)M * N), h1((size_t)M * N);
+  hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost);
+  size_t bad = 0, first = 0;
+  for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { if (!bad) first = i; ++bad; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms[2] = {1e30f, 1e30f};
+  for (int round = 0; round < 6; ++round)
+    for (int wi = 0; wi < 2; ++wi) {
+      const int which = (round & 1) ? 1 - wi : wi;
+      for (int i = 0; i < 2; ++i) { if (which) launch4(); else launch8(); }
+      hipEventRecord(e0, nullptr);
+      for (int i = 0; i < reps; ++i) { if (which) launch4(); else launch8(); }
+      hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
+      float tms = 0; hipEventElapsedTime(&tms, e0, e1);
+      if (round >= 2 && tms < ms[which]) ms[which] = tms;
+    }
+  const double fl = 2.0 * M * N * (double)K;
+  printf("M=%6d N=%6d K=%5d : gemm8c %8.1f us %7.1f TF/s | gemm4a %8.1f us %7.1f TF/s | x%.3f | %s (%zu mismatching elements, first %zu)\n", M, N, K,
+         ms[0] * 1000 / reps, fl / (ms[0] / reps) * 1e-9, ms[1] * 1000 / reps, fl / (ms[1] / reps) * 1e-9, ms[0] / ms[1], bad ? "MISMATCH" : "bit-identical", bad, first);
+  fflush(stdout);
+  hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
+}
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 5;
+  setenv("RSYS_GEMM8C", "1", 1);
+  run(512, 512, 256, 1);
+  run(2048, 2048, 1024, 2);
+  run(8192, 8192, 8192, reps);
+  run(65536, 512, 2816, reps);
+  run(65536, 512, 1408, reps);
+  run(65536, 1024, 512, reps);
+  return 0;
+}
