@@ -88,6 +88,19 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     tile_step = (nblk + 7 - xcd) >> 3;
   }
   if (tile_first >= tile_end) return;
+  // flags bits 3-6 = R > 0 (the launcher sets 4): the tile sequence runs band by band of R tile rows, down the band's columns (4 x 1 pieces) instead of row by row, so
+  // the 32 workgroups an XCD runs side by side cover 4 row blocks x 8 column blocks and share 12 operand blocks per K step through the
+  // XCD's L2 where a row-major run of a wide output shares 1 + 32 (launcher: outputs more than eight tiles wide)
+  const int band_rows = (p.flags >> 3) & 15;
+  const bool patch = band_rows != 0;
+  const int tiles_m_all = ntiles / tiles_n;
+  auto tile_pos = [&](C8Tile& x) __attribute__((always_inline)) {
+    if (x.t >= ntiles) return;   // (past the end: never dereferenced)
+    const int per_band = band_rows * tiles_n, band = x.t / per_band, rem = x.t - band * per_band;
+    const int rows_here = min(band_rows, tiles_m_all - band * band_rows);
+    const int c = rem / rows_here;
+    x.tm = band * band_rows + (rem - c * rows_here); x.tn = c;
+  };
   const int nt = p.K / C8_BK;   // launcher: K % 64 == 0, nt >= 2
   const int step_m = tile_step / tiles_n, step_n = tile_step % tiles_n;
 
@@ -223,7 +236,9 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       return x.tm * C8_BM + C8_BM <= p.M && x.tn * C8_BN + C8_BN <= p.N;
     };
     auto tile_inc = [&](C8Tile& x) __attribute__((always_inline)) {
-      x.t += tile_step; x.tm += step_m; x.tn += step_n;
+      x.t += tile_step;
+      if (patch) { tile_pos(x); return; }
+      x.tm += step_m; x.tn += step_n;
       if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
     };
     auto next_tile = [&](C8Tile x) __attribute__((always_inline)) -> C8Tile {   // the next tile of this pass (t >= tile_end: none)
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       } else { c.a = (const char*)p.A; c.b = (const char*)p.B; c.ra = 0; c.rb = 0; }
     };
     C8Tile tile{tile_first, tile_first / tiles_n, tile_first % tiles_n};
+    if (patch) tile_pos(tile);
     while (tile.t < tile_end && tile_full(tile) != WANT) tile_inc(tile);
     if (tile.t >= tile_end) return;
     // The request stream runs two K tiles ahead of the MFMAs.  cs = window of K tile g + 2, cn = of g + 1; nx = the first K tile
@@ -328,6 +344,15 @@ int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   { static int n = 0; if (n == 0) { int dev = 0, v = 0; n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; } cus = n; }
   const int tiles = ((p.M + C8_BM - 1) / C8_BM) * ((p.N + C8_BN - 1) / C8_BN);
   const dim3 grid((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cus)), blk(512);
+  {
+    // RSYS_GEMM_PATCH=0: row-major tile order everywhere (A/B), 2: band order everywhere (read per call, as RSYS_GEMM8C: the GEMM tests
+    // compare the orders inside one process)
+    const char* e = getenv("RSYS_GEMM_PATCH");
+    const int mode = e ? atoi(e) : 1, rows = 4;
+    const int tiles_n = (p.N + C8_BN - 1) / C8_BN;
+    // wide AND tall outputs only: 4096 x 120000 (16 tile rows: every XCD already holds all of A) measured 6 % slower in band order
+    if (mode == 2 || (mode == 1 && tiles_n > 8 && tiles >= 32 * tiles_n)) p.flags |= rows << 3;
+  }
   switch (p.epi) {
     case EPI_STORE:
       if (p.c_f32) hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, true>), grid, blk, 0, s, p);

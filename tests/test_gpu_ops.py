@@ -89,6 +89,25 @@ def test_gemm_exact_integer_asymmetric(dtype, a_km, b_km):
         np.testing.assert_array_equal(out, ref.astype(np.float32), err_msg=f"{dtype} {a_km} {b_km} {M} {N} {K}")
 
 
+def test_gemm_band_order_of_the_output_tiles_changes_no_bit(monkeypatch):
+    """gemm8c walks outputs more than eight tiles wide (and at least 32 tile rows tall) band by band of four tile rows so that the
+    workgroups an XCD runs together share operand blocks through its L2 (launch_gemm8c, round 5).  The order assigns tiles to workgroups
+    and nothing else: forced everywhere (RSYS_GEMM_PATCH=2) and switched off (=0), outputs agree bit for bit, on shapes whose last band
+    has fewer than four tile rows and whose edge tiles are ragged; exact on integer operands either way."""
+    for (M, N, K) in [(1100, 2400, 192), (2304, 2816, 128), (300, 520, 128), (8448, 2816, 128)]:
+        outs = []
+        for mode in ("0", "2", None):
+            if mode is None: monkeypatch.delenv("RSYS_GEMM_PATCH", raising=False)
+            else: monkeypatch.setenv("RSYS_GEMM_PATCH", mode)
+            out, ref = run_gemm(1, M, N, K, False, False, c_f32=False, integer=False, seed=M + K)
+            outs.append(out)
+            outi, refi = run_gemm(1, M, N, K, False, False, integer=True, seed=N)
+            np.testing.assert_array_equal(outi, refi.astype(np.float32), err_msg=f"{mode} {M} {N} {K}")
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (M, N, K)
+        assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32)), (M, N, K)
+    monkeypatch.delenv("RSYS_GEMM_PATCH", raising=False)
+
+
 @pytest.mark.parametrize("dtype,tol", [(0, 2e-5), (1, 2e-2)])
 @pytest.mark.parametrize("a_km,b_km", LAYOUTS)
 def test_gemm_random(dtype, tol, a_km, b_km):

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <cmath>
 
 namespace rsys {
 void set_error(const std::string& msg) { fprintf(stderr, "error: %s\n", msg.c_str()); }
@@ -158,12 +159,97 @@ __global__ __launch_bounds__(256) void gemm4a_kernel(GemmParams p) {
       *(bf16x4*)(C + (long long)(m0 + wr * 128 + 16 * i + fr) * p.ldc + n0 + wc * 128 + 16 * j + 4 * fq) = o;
     }
 }
+
+// ---- the same schedule with every register named (tools/micro/gen_gemm4a_asm.py): accumulators a[0:255], fragment sets v[128:255]
+__global__ __launch_bounds__(256) void gemm4b_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int tiles_n = p.N / 256;
+  const int ntiles = (p.M / 256) * tiles_n, bid = blockIdx.x;
+  const int xcd = bid & 7, q = ntiles >> 3;
+  int tile = xcd * q + (bid >> 3);
+  if (tile >= ntiles) return;
+  const int tiles_m = p.M / 256;
+  if ((tiles_m & 31) == 0) {
+    // an XCD owns a band of tiles_m / 8 tile rows and walks it in patches of 4 rows, column by column: the 32 workgroups resident on the XCD at a
+    // time share 4 A row blocks and 8 B column blocks per K step instead of 1 and 32 (one L2 per XCD)
+    const int rows_per = tiles_m >> 3, i = bid >> 3, per_patch = 4 * tiles_n;
+    const int pi = i / per_patch, r = (i % per_patch) & 3, c = (i % per_patch) >> 2;
+    tile = (xcd * rows_per + pi * 4 + r) * tiles_n + c;
+  }
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int fq = l >> 4, fr = l & 15;
+  unsigned int va0, va1, vb0, vb1;
+  {
+    const int lr0 = 32 * w + (l >> 3), row = (lr0 >> 6) * 128 + (lr0 & 63);
+    const int ch0 = (l & 7) ^ ((l >> 4) & 7), ch1 = (l & 7) ^ ((4 + (l >> 4)) & 7);
+    va0 = (unsigned int)(row * p.lda * 2 + ch0 * 16); va1 = (unsigned int)(row * p.lda * 2 + ch1 * 16);
+    vb0 = (unsigned int)(row * p.ldb * 2 + ch0 * 16); vb1 = (unsigned int)(row * p.ldb * 2 + ch1 * 16);
+  }
+  const unsigned int lds0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)smem);
+  const unsigned int dmalds = lds0 + w * 4096;
+  const unsigned long long a_base = (unsigned long long)((const char*)p.A + (long long)m0 * p.lda * 2);
+  const unsigned long long b_base = (unsigned long long)((const char*)p.B + (long long)n0 * p.ldb * 2);
+  unsigned int alo = __builtin_amdgcn_readfirstlane((int)(unsigned int)a_base), ahi = __builtin_amdgcn_readfirstlane((int)(unsigned int)(a_base >> 32));
+  unsigned int blo = __builtin_amdgcn_readfirstlane((int)(unsigned int)b_base), bhi = __builtin_amdgcn_readfirstlane((int)(unsigned int)(b_base >> 32));
+  const unsigned int reca = (unsigned int)(255 * p.lda * 2 + 128), recb = (unsigned int)(255 * p.ldb * 2 + 128);
+  const unsigned int unita = (unsigned int)(8 * p.lda * 2), unitb = (unsigned int)(8 * p.ldb * 2), unitc = (unsigned int)(16 * p.ldc * 2);
+  const int nt = p.K / 64;
+  const int sw0 = ((fq ^ (fr >> 1)) << 4), sw1 = (((4 + fq) ^ (fr >> 1)) << 4);
+  const unsigned int ra0 = lds0 + (wr * 64 + fr) * 128 + sw0, ra1 = lds0 + (wr * 64 + fr) * 128 + sw1;
+  const unsigned int rb0 = lds0 + 32768 + (wc * 64 + fr) * 128 + sw0, rb1 = lds0 + 32768 + (wc * 64 + fr) * 128 + sw1;
+  const unsigned long long c_base = (unsigned long long)((const char*)p.C + ((long long)m0 * p.ldc + n0) * 2);
+  c8_i32x4 cdesc;
+  cdesc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)c_base);
+  cdesc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned int)((c_base >> 32) & 0xFFFFu));
+  cdesc[2] = __builtin_amdgcn_readfirstlane((int)(unsigned int)(255 * p.ldc * 2 + 512));
+  cdesc[3] = 0x00020000;
+#ifdef G4_MFMA32
+  // 32x32x16 fragments: lane (r = l & 31, hh = l >> 5) reads row r's 16-byte chunk 2 ks + hh of k step ks; the image's swizzle XORs the chunk
+  // index with (row >> 1) & 7, so each k step has its own address
+  const int r32 = l & 31, hh = l >> 5;
+  unsigned int ra[4], rb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = (((2 * ks + hh) ^ ((r32 >> 1) & 7)) << 4);
+    ra[ks] = lds0 + (wr * 64 + r32) * 128 + sw;
+    rb[ks] = lds0 + 32768 + (wc * 64 + r32) * 128 + sw;
+  }
+  const unsigned int vc = (unsigned int)(((wr * 128 + r32) * p.ldc + wc * 128 + 4 * hh) * 2);
+#else
+  const unsigned int vc = (unsigned int)(((wr * 128 + fr) * p.ldc + wc * 128 + 4 * fq) * 2);
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile(
+#ifndef G4_ASM_INC
+#define G4_ASM_INC "gemm4a_asm.inc"
+#endif
+#include G4_ASM_INC
+      : [alo] "+s"(alo), [ahi] "+s"(ahi), [blo] "+s"(blo), [bhi] "+s"(bhi)
+      : [reca] "s"(reca), [recb] "s"(recb), [unita] "s"(unita), [unitb] "s"(unitb), [unitc] "s"(unitc), [dmalds] "s"(dmalds), [nt] "s"(nt),
+        [cdesc] "s"(cdesc),
+#ifdef G4_MFMA32
+        [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [ra3] "v"(ra[3]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [rb2] "v"(rb[2]), [rb3] "v"(rb[3]),
+#else
+        [ra0] "v"(ra0), [ra1] "v"(ra1), [rb0] "v"(rb0), [rb1] "v"(rb1),
+#endif
+        [va0] "v"(va0), [va1] "v"(va1), [vb0] "v"(vb0), [vb1] "v"(vb1), [vc] "v"(vc)
+      : "memory", "m0", "scc",
+#include "gemm4a_clobbers.inc"
+  );
+#pragma clang diagnostic pop
+}
 }  // namespace rsys
 
 static unsigned int g_seed = 0x1234567u;
 static void fill_bf16(void* d, size_t n) {
   std::vector<unsigned short> h(n);
-  for (auto& v : h) { g_seed = g_seed * 1664525u + 1013904223u; const float f = ((float)(g_seed >> 8) * (2.0f / 16777216.0f) - 1.0f); unsigned int u; memcpy(&u, &f, 4); v = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1)) >> 16); }
+  static const bool normal = getenv("G4_NORMAL") != nullptr;   // standard-normal operands (what tools/bench_gemm.py and torch.randn feed) instead of uniform(-1, 1)
+  for (auto& v : h) { g_seed = g_seed * 1664525u + 1013904223u; float f = ((float)(g_seed >> 8) * (2.0f / 16777216.0f) - 1.0f);
+    if (normal) { const float u1 = 0.5f * (f + 1.0f) + 1e-7f; g_seed = g_seed * 1664525u + 1013904223u; const float u2 = (float)(g_seed >> 8) * (1.0f / 16777216.0f); f = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2); } unsigned int u; memcpy(&u, &f, 4); v = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1)) >> 16); }
   hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
 }
 
@@ -176,14 +262,23 @@ static void run(int M, int N, int K, int reps) {
   GemmParams p{};
   p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.epi = EPI_STORE; p.c_f32 = 0; p.alpha = 1.f; p.splitk = 1;
   const int tiles = (M / 256) * (N / 256);
-  auto launch4 = [&]() { GemmParams q = p; q.C = C1; hipLaunchKernelGGL(gemm4a_kernel, dim3(tiles), dim3(256), 0, nullptr, q); };
+  auto launch4_ = [&]() { GemmParams q = p; q.C = C1; hipLaunchKernelGGL(gemm4b_kernel, dim3(tiles), dim3(256), 0, nullptr, q); };
   auto launch8 = [&]() { GemmParams q = p; q.C = C0; launch_gemm8c(q, nullptr); };
+  const bool asm_ok = M % 256 == 0 && N % 256 == 0 && tiles % 8 == 0;   // (the experiment kernel has no edge handling)
+  auto launch4 = [&]() { if (asm_ok) launch4_(); };
   launch8(); launch4();
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); exit(2); }
   std::vector<unsigned short> h0((size_t)M * N), h1((size_t)M * N);
   hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost);
   size_t bad = 0, first = 0;
-  for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { if (!bad) first = i; ++bad; }
+  double maxd = 0, maxv = 0;
+  auto tof = [](unsigned short v) { unsigned int u = (unsigned int)v << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+  for (size_t i = 0; asm_ok && i < h0.size(); ++i) {
+    if (h0[i] != h1[i]) { if (!bad) first = i; ++bad; }
+    const double a = tof(h0[i]), b = tof(h1[i]);
+    if (fabs(a - b) > maxd || !(fabs(a - b) <= 1e30)) maxd = fabs(a - b);
+    if (fabs(a) > maxv) maxv = fabs(a);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms[2] = {1e30f, 1e30f};
   for (int round = 0; round < 6; ++round)
@@ -197,8 +292,9 @@ static void run(int M, int N, int K, int reps) {
       if (round >= 2 && tms < ms[which]) ms[which] = tms;
     }
   const double fl = 2.0 * M * N * (double)K;
-  printf("M=%6d N=%6d K=%5d : gemm8c %8.1f us %7.1f TF/s | gemm4a %8.1f us %7.1f TF/s | x%.3f | %s (%zu mismatching elements, first %zu)\n", M, N, K,
-         ms[0] * 1000 / reps, fl / (ms[0] / reps) * 1e-9, ms[1] * 1000 / reps, fl / (ms[1] / reps) * 1e-9, ms[0] / ms[1], bad ? "MISMATCH" : "bit-identical", bad, first);
+  printf("M=%6d N=%6d K=%5d : gemm8c %8.1f us %7.1f TF/s | gemm4b(asm) %8.1f us %7.1f TF/s | x%.3f | %s (%zu mismatching elements, first %zu)\n", M, N, K,
+         ms[0] * 1000 / reps, fl / (ms[0] / reps) * 1e-9, ms[1] * 1000 / reps, fl / (ms[1] / reps) * 1e-9, ms[0] / ms[1], !asm_ok ? "(asm kernel: shape not a multiple of its tile)" : bad ? "MISMATCH" : "bit-identical", bad, first);
+  if (bad) printf("    max |difference| %.4g at max |value| %.4g\n", maxd, maxv);
   fflush(stdout);
   hipFree(A); hipFree(B); hipFree(C0); hipFree(C1);
 }
@@ -206,8 +302,16 @@ static void run(int M, int N, int K, int reps) {
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 5;
   setenv("RSYS_GEMM8C", "1", 1);
-  run(512, 512, 256, 1);
+  if (argc > 4) { run(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), reps); return 0; }   // one shape (counter passes)
+  if (getenv("G4_STEP_SHAPES")) {   // the trunk's row-major shapes + 8192^3 (the rows of tools/bench_vendor_gemm.py), HIP-event timed back to back
+    const int NT = 65536;
+    run(NT, 1024, 512, reps); run(NT, 512, 512, reps); run(NT, 2816, 512, reps); run(NT, 512, 1408, reps); run(NT, 1408, 512, reps);
+    run(NT, 512, 2816, reps); run(NT, 512, 1024, reps); run(8192, 8192, 8192, reps);
+    return 0;
+  }
   run(2048, 2048, 1024, 2);
+  run(4096, 4096, 8192, reps);     // one tile per CU: (K = 16384) - (K = 8192) = 128 K tiles of the loop alone
+  run(4096, 4096, 16384, reps);
   run(8192, 8192, 8192, reps);
   run(65536, 512, 2816, reps);
   run(65536, 512, 1408, reps);
