@@ -181,6 +181,12 @@ def hdf5_loop_leg(ra, synth, rows, files=6, per_file=262144):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _lib_switches():
+    """RSYS_* environment switches in effect that differ from the library's defaults (csrc/switches.hpp)"""
+    from recommendersystem_amd import _lib
+    return _lib.switches()
+
+
 def git_blob_id(path):
     """the id `git hash-object` gives the file (the GPU box has no .git): which committed PMC summary a line quotes"""
     import hashlib
@@ -560,6 +566,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "comm": comm_info,
+            "switches": _lib_switches(),     # RSYS_* switches that differ from the library's defaults ({} = the shipped path)
             "config": {"workload": f"{args.config}: train step fwd+bwd+{'allreduce+' if comm is not None else ''}clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,

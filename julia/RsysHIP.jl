@@ -244,6 +244,13 @@ function step_marks(m::Model, cap::Integer = 65536)
     ms = Vector{Float32}(undef, cap); n = Ref{Int32}(0)
     GC.@preserve ms check(ccall((:rsys_step_marks_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int32, Ref{Int32}), m.h, ms, cap, n)); ms[1:n[]]
 end
+# RSYS_* environment switches (csrc/switches.hpp): parsed at model / communicator creation; reload_switches!() parses on demand
+reload_switches!() = check(ccall((:rsys_switches_reload, LIB), Int32, ()))
+function switches_set()
+    buf = Vector{UInt8}(undef, 4096)
+    GC.@preserve buf ccall((:rsys_switches_describe, LIB), Int32, (Ptr{UInt8}, Int32), buf, length(buf))
+    unsafe_string(pointer(buf))
+end
 op_timing!(m::Model, mode::Integer) = check(ccall((:rsys_op_timing, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, mode))
 function timing_report(m::Model)
     buf = Vector{UInt8}(undef, 1 << 16)

@@ -125,6 +125,8 @@ _SIGS = [
     ("rsys_step_marks_get", C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("rsys_op_timing", C.c_int32, [_P, C.c_int32]),
     ("rsys_timing_get", C.c_int32, [_P, C.c_char_p, C.c_size_t]),
+    ("rsys_switches_reload", C.c_int32, []),
+    ("rsys_switches_describe", C.c_int32, [C.c_char_p, C.c_int32]),
 ]
 EXPORTED = [s[0] for s in _SIGS]
 
@@ -162,3 +164,16 @@ def device_count():
     n = C.c_int32(0)
     check(lib().rsys_device_count(C.byref(n)))
     return n.value
+
+
+def switches():
+    """The RSYS_* environment switches that differ from their defaults, as {name: value} (csrc/switches.hpp; parsed now)."""
+    L = lib()
+    L.rsys_switches_reload()
+    buf = C.create_string_buffer(4096)
+    L.rsys_switches_describe(buf, len(buf))
+    out = {}
+    for item in buf.value.decode().split():
+        k, v = item.split("=")
+        out[k] = int(v)
+    return out

@@ -825,14 +825,10 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
 }
 
 // query heads per workgroup of the forward / dQ kernels: the whole group of a kv head when that is 2 (every configuration of
-// H / KV = 2), else 1.  RSYS_ATTN_PAIR=0: one head per workgroup (A/B switch).
-static bool attn_dma_on() {
-  static const bool on = !(getenv("RSYS_ATTN_DMA") && atoi(getenv("RSYS_ATTN_DMA")) == 0);
-  return on;
-}
+// H / KV = 2), else 1.
+static bool attn_dma_on() { return sw().attn_dma != 0; }
 static int attn_heads_per_wg(const AttnParams& p) {
-  static const int pair = getenv("RSYS_ATTN_PAIR") ? atoi(getenv("RSYS_ATTN_PAIR")) : 1;
-  return (pair && p.H / p.KV == 2 && p.hd <= 64) ? 2 : 1;   // (head_dim 128: two heads' accumulators cost a wave per SIMD)
+  return (p.H / p.KV == 2 && p.hd <= 64) ? 2 : 1;   // (head_dim 128: two heads' accumulators cost a wave per SIMD)
 }
 
 template <typename T, int HD>
@@ -868,16 +864,8 @@ static int check_attn(const AttnParams& p, size_t esz) {
   return RSYS_OK;
 }
 
-// RSYS_ATTN_ORDER=0: plain launch order (A/B switch of the heaviest-first orders)
-static AttnParams attn_order_switch(const AttnParams& p0) {
-  static const bool on = !(getenv("RSYS_ATTN_ORDER") && atoi(getenv("RSYS_ATTN_ORDER")) == 0);
-  AttnParams p = p0;
-  if (!on) p.order_q = p.order_k = nullptr;
-  return p;
-}
 template <typename T>
-int launch_attn_fwd(const AttnParams& p0, hipStream_t s) {
-  const AttnParams p = attn_order_switch(p0);
+int launch_attn_fwd(const AttnParams& p, hipStream_t s) {
   int rc = check_attn(p, sizeof(T));
   if (rc) return rc;
   switch (p.hd) {
@@ -1250,13 +1238,9 @@ __device__ __forceinline__ bf16x8 pack8f(const f32x16& v, int o) {
   for (int j = 0; j < 8; ++j) r[j] = (bf16)v[o + j];
   return r;
 }
-static bool attn_kv32_on() {
-  static const bool on = !(getenv("RSYS_ATTN_KV32") && atoi(getenv("RSYS_ATTN_KV32")) == 0);   // A/B switch: 0 = the 16-key-per-wave kernel
-  return on;
-}
+static bool attn_kv32_on() { return sw().attn_kv32 != 0; }   // 0 = the 16-key-per-wave kernel
 static bool attn_kv_pairs(const AttnParams& p) {   // (bf16 is the caller's business: the fp32 launches never read order_k's pair form)
-  static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);
-  return p.hd == 64 && p.is_bf16 && dma && attn_dma_on() && attn_kv32_on();
+  return p.hd == 64 && p.is_bf16 && sw().attn_kv_dma != 0 && attn_dma_on() && attn_kv32_on();
 }
 #ifndef ATTN_KV32_WPS
 #define ATTN_KV32_WPS 3   // waves per SIMD the kernel is compiled for: 168 registers, 5 dwords spilled OUTSIDE the item loop; 2 (189 registers) is 9 % slower (profiles/r5_ab_attn_kv32.log)
@@ -1686,7 +1670,7 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
   // (two adjacent kv tiles per workgroup -- Q / dO staging and every fragment read shared by 32 keys per wave -- measured 6 % slower:
   // 254 registers, two waves per SIMD; profiles/r4_ab_attn_dkv_two_key_tiles.log)
   if constexpr (is_bf16<T>::value && HD == 64) {
-    static const bool dma = !(getenv("RSYS_ATTN_KV_DMA") && atoi(getenv("RSYS_ATTN_KV_DMA")) == 0);   // A/B switch of this kernel alone
+    const bool dma = sw().attn_kv_dma != 0;   // A/B switch of this kernel alone
     if (attn_kv_pairs(p)) {   // 32 keys per wave on 32 x 32 x 16 products, two kv tiles per workgroup (order_k lists the pairs)
       const int npair = ((p.T + 63) / 64 + 1) / 2;
       hipLaunchKernelGGL(attn_bwd_kv32_kernel, dim3(npair * p.KV * p.B), dim3(256), 4 * 64 * 64 * 2 + 256 * 4, s, p);
@@ -1705,8 +1689,7 @@ static int attn_bwd_hd(const AttnParams& p, hipStream_t s) {
 }
 
 template <typename T>
-int launch_attn_bwd(const AttnParams& p0, hipStream_t s) {
-  const AttnParams p = attn_order_switch(p0);
+int launch_attn_bwd(const AttnParams& p, hipStream_t s) {
   int rc = check_attn(p, sizeof(T));
   if (rc) return rc;
   ARG_CHECK(p.H / p.KV <= 8, "attention: at most 8 query heads per kv head");

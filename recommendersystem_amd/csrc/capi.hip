@@ -42,6 +42,7 @@ int32_t rsys_device_count(int32_t* n) {
 int32_t rsys_device_synchronize(void) { HIP_CHECK(hipDeviceSynchronize()); return RSYS_OK; }
 
 int32_t rsys_model_create(const rsys_config* cfg, int32_t device, rsys_model** out) {
+  switches_parse();
   Model* m = nullptr;
   int rc = model_create(cfg, device, &m);
   if (rc) return rc;
@@ -304,6 +305,7 @@ int32_t rsys_adamw_state_set(rsys_optimizer* o, const char* name, const float* m
 // ---------------------------------------------------------------- communicator
 int32_t rsys_comm_unique_id(uint8_t id_buf[128]) { return comm_unique_id(id_buf); }
 int32_t rsys_comm_init(const uint8_t id_buf[128], int32_t rank, int32_t world, int32_t device, rsys_comm** out) {
+  switches_parse();
   ARG_CHECK(id_buf && out, "null");
   return comm_init_rccl(id_buf, rank, world, device, out);
 }
@@ -327,6 +329,7 @@ int32_t rsys_local_group_destroy(void* group) {
   return RSYS_OK;
 }
 int32_t rsys_comm_init_local(void* group, int32_t rank, rsys_comm** out) {
+  switches_parse();
   ARG_CHECK(group && out, "null");
   return comm_init_local((LocalGroup*)group, rank, out);
 }
@@ -539,11 +542,12 @@ int32_t rsys_dev_memset(void* d, int v, size_t n) { HIP_CHECK(hipMemset(d, v, n)
 
 int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                      int64_t ldb, int64_t ldc, int32_t a_km, int32_t b_km, int32_t a_f32, int32_t c_f32, int32_t splitk) {
+  switches_parse();
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.c_f32 = c_f32; p.splitk = splitk < 1 ? 1 : splitk; p.alpha = 1.f;
   p.epi = p.splitk > 1 ? EPI_ATOMIC : EPI_STORE;
-  if (getenv("RSYS_DEBUG_EPI")) p.epi = atoi(getenv("RSYS_DEBUG_EPI"));   // timing experiments only (e.g. 99 = no epilogue)
+  if (sw().debug_epi >= 0) p.epi = sw().debug_epi;   // timing experiments only (e.g. 99 = no epilogue)
   int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, a_f32 != 0, false, a_km != 0, b_km != 0, nullptr)
                                     : launch_gemm<float>(p, false, false, a_km != 0, b_km != 0, nullptr);
   if (rc) return rc;
@@ -553,6 +557,7 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
 
 int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                           int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev) {
+  switches_parse();
   ARG_CHECK(rows_dev != nullptr, "rsys_op_gemm_rows: rows_dev is null");
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -566,6 +571,7 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
 
 int32_t rsys_op_gemm_klimit(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int32_t accumulate, const int32_t* k_dev) {
+  switches_parse();
   ARG_CHECK(k_dev != nullptr, "rsys_op_gemm_klimit: k_dev is null");
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -580,6 +586,7 @@ int32_t rsys_op_gemm_klimit(int32_t dtype, const void* A, const void* B, void* C
 int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32_t cols, int32_t fmt, int32_t layout, int32_t seg_cols,
                             int32_t seg_rep, void* dst, int64_t ld_dst, float* amax_dev, float* desc_dev, const float* wamax_dev,
                             int32_t n_w, int32_t w_rep, int32_t desc_mode) {
+  switches_parse();
   ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_quantize: null buffer");
   F8Cast c{};
   c.src = src; c.ld_src = ld_src; c.rows = rows; c.cols = cols; c.fmt = fmt; c.layout = layout; c.seg_cols = seg_cols; c.seg_rep = seg_rep < 1 ? 1 : seg_rep;
@@ -595,6 +602,7 @@ int32_t rsys_op_f8_quantize(const void* src, int64_t ld_src, int32_t rows, int32
 
 int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t cols, int32_t layout, int32_t seg_rows, int32_t seg_rep,
                            float* amax_dev, void* dst, void* dst_t, int64_t ld_t) {
+  switches_parse();
   ARG_CHECK(src && dst && amax_dev, "rsys_op_f8_weights: null buffer");
   ARG_CHECK(cols % 4 == 0 && rows % 16 == 0, "rsys_op_f8_weights: rows % 16, cols % 4");
   F8WeightJob j{};
@@ -618,6 +626,7 @@ int32_t rsys_op_f8_weights(const float* src, int64_t ld, int32_t rows, int32_t c
 int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                         int32_t a_fmt, int32_t c_f32, const float* desc_dev, int32_t seg_cols, int32_t alt, int32_t kb0, int32_t kb1,
                         int32_t kb2) {
+  switches_parse();
   GemmParams p{};
   p.A = A8; p.B = B8; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.c_f32 = c_f32; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE;
@@ -631,6 +640,7 @@ int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int3
 int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t KV, int32_t hd, const void* qkv,
                           const int32_t* uid, const int32_t* tm, void* O, float* lse, const void* dO, void* dqkv,
                           const float* rope_cos, const float* rope_sin) {
+  switches_parse();
   const size_t e = dtype == RSYS_DTYPE_BF16 ? 2 : 4;
   const int nt = (T + 63) / 64;
   AttnParams p{};
@@ -667,6 +677,7 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
 // atomic != 0 runs the float-atomic form instead (A/B reference).
 int32_t rsys_op_embedding_scatter(const float* gx0, int64_t ldx, const int32_t* matchedid, const int32_t* m_matchedid, int32_t N,
                                   int32_t V, int32_t D, float* gE, int32_t atomic) {
+  switches_parse();
   ARG_CHECK(gx0 && matchedid && m_matchedid && gE && N >= 1 && ldx >= D, "rsys_op_embedding_scatter: arguments");
   if (atomic) {
     ARG_CHECK(ldx == 2LL * D, "the atomic form reads the interleaved layout (row stride 2 D)");
@@ -718,6 +729,10 @@ int32_t rsys_step_marks_get(rsys_model* h, float* ms_out, int32_t cap, int32_t* 
   if (n_out) *n_out = n;
   return RSYS_OK;
 }
+
+int32_t rsys_switches_reload(void) { switches_parse(); return RSYS_OK; }
+
+int32_t rsys_switches_describe(char* buf, int32_t cap) { return switches_describe(buf, cap); }
 
 int32_t rsys_op_timing(rsys_model* h, int32_t enable) {
   CHECK_HANDLE(h);

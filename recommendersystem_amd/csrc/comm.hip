@@ -101,7 +101,7 @@ int comm_init_rccl(const unsigned char id_buf[128], int rank, int world, int dev
   }
   rc = comm_common_init(c);
   if (rc) { comm_destroy(c); return rc; }   // (frees whatever the failed step had created: communicator, stream, events)
-  { const char* f = getenv("RSYS_FORCE_RCCL"); c->force = f && f[0] == '1'; }
+  c->force = sw().force_rccl == 1;
   *out = c;
   return RSYS_OK;
 }

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string>
 
+#include "switches.hpp"
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -192,7 +192,7 @@ int launch_token_union(const int* const* idx, const int* const* npos, int ntask,
 int launch_selected_first(const unsigned int* bits, const int* pre, int* slot, int* sel, const int* uid, const int* tm, const int* rope_pos, int B, int T,
                           int* perm, int* uid_p, int* tm_p, int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s) {
   ARG_CHECK(T >= 1 && T <= 2048, "selected-first order: at most 2048 tokens per row");
-  static const int identity = getenv("RSYS_TOP_ORDER") && atoi(getenv("RSYS_TOP_ORDER")) == 0 ? 1 : 0;   // RSYS_TOP_ORDER=0: keep the token order
+  const int identity = sw().top_order == 0 ? 1 : 0;   // RSYS_TOP_ORDER=0: keep the token order
   hipLaunchKernelGGL(selected_first_kernel, dim3(B), dim3(1024), 0, s, bits, pre, slot, sel, uid, tm, rope_pos, T, perm, uid_p, tm_p, pos_p, slot_p, sel_p, q_active, identity);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;

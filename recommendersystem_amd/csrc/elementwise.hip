@@ -357,7 +357,7 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
                            const int* resid_slot, const int* io_rows = nullptr, float* f8_amax = nullptr) {
   float* const amax = f8_amax;
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
-  static const int grid_cap = getenv("RSYS_DEBUG_NORM_BWD_GRID") ? atoi(getenv("RSYS_DEBUG_NORM_BWD_GRID")) : 1024;   // (every workgroup ends with D atomics onto the same D scale gradients: 512-1024 workgroups 1.39-1.45 ms per step at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37)
+  const int grid_cap = sw().debug_norm_bwd_grid;   // (every workgroup ends with D atomics onto the same D scale gradients: 512-1024 workgroups 1.39-1.45 ms per step at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37)
   const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, grid_cap)), block(256);
   float* part = det_part((long long)grid.x * D);
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \

@@ -363,7 +363,7 @@ int launch_f8_cast(const F8Cast& c, hipStream_t s) {
   if (c.dst_t != nullptr) {
     ARG_CHECK(c.rows % 128 == 0 && c.cols % 64 == 0 && c.rows_dev == nullptr && c.ld_dst_t % 16 == 0 && c.ld_dst_t >= c.rows, "fp8 cast with a transposed copy: rows % 128, cols % 64");
     ARG_CHECK(c.desc_dw == nullptr || (c.xamax != nullptr && c.dw_units >= 1 && c.dw_units <= 16), "fp8 cast: weight-gradient descale job");
-    static const int wpb = std::min(4, std::max(1, getenv("RSYS_DEBUG_F8_CAST_WAVES") ? atoi(getenv("RSYS_DEBUG_F8_CAST_WAVES")) : 4));   // waves (tiles) per workgroup: A/B; 1..4 (__launch_bounds__(256))
+    const int wpb = std::min(4, std::max(1, sw().debug_f8_cast_waves));   // waves (tiles) per workgroup: A/B; 1..4 (__launch_bounds__(256))
     const int ntile_t = (c.rows / 128) * ((c.cols + 127) / 128);
     const int grid_t = (ntile_t + wpb - 1) / wpb;
     if (c.src_f32) { if (e5) hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E5M2>), dim3(grid_t), dim3(64 * wpb), 0, s, c); else hipLaunchKernelGGL((f8_cast_t_kernel<float, F8_E4M3>), dim3(grid_t), dim3(64 * wpb), 0, s, c); }

@@ -476,8 +476,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
 // A/B timing).  (The 256x128 two-per-CU sibling of rounds 1-3 left the library: slower than gemm8c on every shape of the step,
 // profiles/r4_gemm4w_two_per_cu_stagger.log; its source is kept under tools/micro/ for measurements.)
 static int pick_rowmajor_kernel(const GemmParams& p) {
-  const char* e = getenv("RSYS_GEMM_KERNEL");
-  const int hint = e ? atoi(e) : 0;
+  const int hint = sw().gemm_kernel;
   if (hint == 1) return 0;
   const bool e8 = gemm8p_eligible(p);
   if (hint == 2) return e8 ? 2 : 0;
@@ -489,31 +488,30 @@ static int pick_rowmajor_kernel(const GemmParams& p) {
 
 // K-major bf16 operands with the atomic epilogue (weight gradients): the LDS-DMA pipeline unless RSYS_GEMM_KERNEL_TN=1
 static bool use_8p_tn(const GemmParams& p) {
-  const char* e = getenv("RSYS_GEMM_KERNEL_TN");
-  if (e && atoi(e) == 1) return false;
+  const int e = sw().gemm_kernel_tn;
+  if (e == 1) return false;
   if (!gemm8p_tn_eligible(p)) return false;
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   // measured (tools/dbg/dw_small_outputs.py, round 4, after the kernel's LDS-DMA stopped being drained every phase): against the
   // 128x128 kernel it is 25-40 % faster from 16 output tiles of 256 x 256 on (1024 x 1024: 926 against 744 TFLOP/s; 2048 x 1024: 964
   // against 688), level at 8-12 tiles and slower at 4 (too few workgroups per K split).  The step's per-layer gradients at cfg-3
   // (4..22 tiles) go through the grouped launch instead (model.hip); this rule serves the shapes that do not (cfg-4, the production shape).
-  return (e && atoi(e) == 2) || t256 >= 16;
+  return e == 2 || t256 >= 16;
 }
 
 // K-major bf16 operands, fp32 output stored or accumulated (no split-K): the tied head's table gradient (10^5 x D outputs, K = the live
 // selected rows).  On the LDS-DMA pipeline when the output fills the chip; RSYS_GEMM_KERNEL_TN=1 keeps the 128x128 kernel (A/B).
 static bool use_8p_tn_store(const GemmParams& p) {
-  const char* e = getenv("RSYS_GEMM_KERNEL_TN");   // (read per call, as use_8p_tn: the tests switch it)
-  if (e && atoi(e) == 1) return false;
+  const int e = sw().gemm_kernel_tn;
+  if (e == 1) return false;
   if (!gemm8p_tn_store_eligible(p)) return false;
-  return (e && atoi(e) == 2) || (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 128;
+  return e == 2 || (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 128;
 }
 
 // row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
 static bool use_8p_nt_splitk(const GemmParams& p) {
   if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
-  static const char* e = getenv("RSYS_GEMM_KERNEL_NT_SPLITK");   // 2: force (tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
-  if (e && atoi(e) == 2) return true;
+  if (sw().gemm_kernel_nt_splitk == 2) return true;   // 2: force (tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
   return (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 32;
 }
 

@@ -345,10 +345,8 @@ int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   const int tiles = ((p.M + C8_BM - 1) / C8_BM) * ((p.N + C8_BN - 1) / C8_BN);
   const dim3 grid((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cus)), blk(512);
   {
-    // RSYS_GEMM_PATCH=0: row-major tile order everywhere (A/B), 2: band order everywhere (read per call, as RSYS_GEMM8C: the GEMM tests
-    // compare the orders inside one process)
-    const char* e = getenv("RSYS_GEMM_PATCH");
-    const int mode = e ? atoi(e) : 1, rows = 4;
+    // RSYS_GEMM_PATCH=0: row-major tile order everywhere (A/B), 2: band order everywhere (the GEMM tests compare the orders)
+    const int mode = sw().gemm_patch, rows = 4;
     const int tiles_n = (p.N + C8_BN - 1) / C8_BN;
     // wide AND tall outputs only: 4096 x 120000 (16 tile rows: every XCD already holds all of A) measured 6 % slower in band order
     if (mode == 2 || (mode == 1 && tiles_n > 8 && tiles >= 32 * tiles_n)) p.flags |= rows << 3;

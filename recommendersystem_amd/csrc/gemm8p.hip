@@ -669,7 +669,7 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   }
   // one K-split count for the whole group: the one whose slowest XCD finishes first (a workgroup costs its K tiles plus
   // ~24 K-tile times of prologue and 256 KB of atomics; a list runs in rounds of one workgroup per CU)
-  static const int force = getenv("RSYS_DEBUG_8G_SPLITK") ? atoi(getenv("RSYS_DEBUG_8G_SPLITK")) : 0;
+  const int force = sw().debug_8g_splitk;
   int best_s = 1; double best_t = 1e300;
   for (int s = 1; s <= 16; ++s) {
     if (s > 1 && (ktmax + s - 1) / s < 8) break;
@@ -790,7 +790,7 @@ int gemm8p_splits(const GemmParams& p, bool k_major) {
     const double score = eff * per / (per + 16.0);   // (tools/scan_splitk_8t.py: 24 splits 694 TFLOP/s, 40 splits 660 on the dWp shape)
     if (score > best_score) { best_score = score; best = sk; }
   }
-  static const int force = getenv("RSYS_DEBUG_8T_SPLITK") ? atoi(getenv("RSYS_DEBUG_8T_SPLITK")) : 0;   // scans (tools/)
+  const int force = sw().debug_8t_splitk;   // scans (tools/)
   return (k_major && force > 0) ? (force + 7) / 8 * 8 : best;
 }
 
@@ -924,15 +924,14 @@ int launch_gemm8p_f8_splitk(const GemmParams& p0, hipStream_t s) {
 
 // the one-stream form of this pipeline (gemm8c.hip) takes the epilogue classes it has kernels for; RSYS_GEMM8C=0: A/B switch
 bool gemm8p_forwards_to_8c(const GemmParams& p) {
-  static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
-  const char* e = getenv("RSYS_GEMM8C");   // (read per call: the GEMM tests switch between the two kernels inside one process)
-  const int use_8c = e ? atoi(e) : 1;
+  const int dbg = sw().debug_8p;
+  const int use_8c = sw().gemm8c;
   return use_8c && dbg == 0 && p.epi != 99 && gemm8c_eligible(p);
 }
 
 int launch_gemm8p(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
-  static const int dbg = getenv("RSYS_DEBUG_8P") ? atoi(getenv("RSYS_DEBUG_8P")) : 0;
+  const int dbg = sw().debug_8p;
   p.flags |= dbg;
   if (gemm8p_forwards_to_8c(p0)) return launch_gemm8c(p0, s);
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);

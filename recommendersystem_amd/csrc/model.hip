@@ -352,10 +352,10 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   {
     // grouped weight gradients where one layer's products are too small for the 256x256 K-major kernel on their own (the
     // dispatcher's threshold: >= 32 output tiles, gemm.hip use_8p_tn): cfg-3 has 22 / 12 / 8 / 4 tiles per product
-    static const int grp = getenv("RSYS_DW_GROUP") ? atoi(getenv("RSYS_DW_GROUP")) : 1;
+    const int grp = sw().dw_group;
     const long long t13 = (long long)((2 * m->Ip + 255) / 256) * ((m->D + 255) / 256);
     m->defer_dw = grp != 0 && m->bf16_mode && !cfg->finetune && t13 < 32 && m->D % 8 == 0 && m->Ip % 8 == 0 && m->Nqkv % 8 == 0 && m->L <= 30;
-    static const int sp = getenv("RSYS_SPARSE_TOP") ? atoi(getenv("RSYS_SPARSE_TOP")) : 1;
+    const int sp = sw().sparse_top;
     // (fp8 trunk: a tensor-wise scale is the amax over ALL tokens of the last layer's activations, so that layer stays dense)
     m->sparse_top = sp != 0 && NT <= (1 << 19) && !m->fp8;   // (also the LoRA finetune: one target per row -- the last layer's tail shrinks to `rows` tokens)
     if (m->defer_dw) {
@@ -415,7 +415,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       add(l, m->lo[l].w2, (int)D, Ip, F8_LAYOUT_PLAIN, 0, 6);
     }
     if (!aligned) { set_error("fp8 trunk: weight offsets are not 16-byte aligned in the fp8 copies"); return RSYS_ERR_ARG; }
-    static const int f8dw = getenv("RSYS_F8_DW") ? atoi(getenv("RSYS_F8_DW")) : 1;
+    const int f8dw = sw().f8_dw;
     m->f8_dw = f8dw != 0 && (2 * m->S) % 128 == 0;   // (K = tokens in tiles of 128)
     if (m->f8_dw) {
       m->f8_ldt = NT;
@@ -426,14 +426,14 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
         DALLOC(t.gxt, D * NT); DALLOC(t.dab, (int64_t)2 * Ip * NT); DALLOC(t.dht, D * NT); DALLOC(t.dqkv, (int64_t)m->Nqkv * NT);
       }
       DALLOC(m->f8_desc_dw, L * 4 * 32 * 4);
-      if (getenv("RSYS_F8_DW_ROUND_BF16") && atoi(getenv("RSYS_F8_DW_ROUND_BF16")) != 0) {
+      if (sw().f8_dw_round_bf16 != 0) {
         m->f8_dw_stage_base = m->lo[0].wqkv;
         const int64_t n = m->lo[L - 1].w2 + pad8((int64_t)D * Ip) - m->f8_dw_stage_base;
         DALLOC(m->f8_dw_stage, n * 4);
         HIP_CHECK(hipMemset(m->f8_dw_stage, 0, n * 4));
       }
     }
-    if (getenv("RSYS_F8_DEBUG_KEEP") && atoi(getenv("RSYS_F8_DEBUG_KEEP")) != 0) {   // stage-wise parity tests of the backward products
+    if (sw().f8_debug_keep != 0) {   // stage-wise parity tests of the backward products
       m->f8_keep.assign((size_t)L * 3, nullptr);
       for (size_t i = 0; i < m->f8_keep.size(); ++i) DALLOC(m->f8_keep[i], NT * D * 2);
     }
@@ -900,7 +900,7 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
 // (bench.py --detail) runs everything in line instead, so that every kernel's time is measured without a neighbour.
 enum { DW_W2 = 0, DW_W13 = 1, DW_O = 2, DW_QKV = 3 };
 static int side_mode() {
-  static const int mode = [] { const char* e = getenv("RSYS_SIDE_STREAM"); return e ? atoi(e) : 0; }();
+  const int mode = sw().side_stream;
   return mode;
 }
 template <typename T>
@@ -1596,11 +1596,11 @@ static int select_positions_all(Model* m) {
   for (int ti = 0; ti < 4; ++ti) { ws[ti] = m->bd.m_weight[ti]; is[ti] = m->idx[ti]; sts[ti] = m->stats + 2 * ti; nps[ti] = m->npos + ti; }
   // (RSYS_SELECT_ASIDE=1: measured on one box, alternating, 30 steps each: 24.27 / 24.41 / 24.36 ms in line against 24.44 / 24.61 / 24.38 ms
   // aside -- a 1024-thread workgroup landing on a CU stalls that CU's share of the persistent GEMM's tiles: off by default)
-  static const bool aside_on = getenv("RSYS_SELECT_ASIDE") && atoi(getenv("RSYS_SELECT_ASIDE")) == 1;
+  const bool aside_on = sw().select_aside == 1;
   const bool aside = aside_on && !m->sharded && !(m->timer.enabled && m->timer.serialize);   // (sharded: the early counts need them at once)
   hipStream_t s = aside ? m->side : m->stream;
   if (aside) { HIP_CHECK(hipEventRecord(m->ev_fork, m->stream)); HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
-  static const bool chunked_on = !(getenv("RSYS_SELECT_CHUNKED") && atoi(getenv("RSYS_SELECT_CHUNKED")) == 0);   // (A/B)
+  const bool chunked_on = sw().select_chunked != 0;   // (A/B)
   if (chunked_on && N >= 4096) RC(launch_select_positions_chunked(4, ws, N, KB, is, sts, nps, m->sel_scratch, s));
   else RC(launch_select_positions_batch(4, ws, N, KB, is, sts, nps, s));
   if (m->top_is_sparse) RC(launch_token_union(is, nps, 4, 2 * N, m->c_bits, m->c_pre, m->c_n, s));
@@ -1731,7 +1731,7 @@ static int backward_trunk(Model* m) {
   const bool cp = m->bf16_mode;  // fp32 mode: the operand IS the fp32 buffer, no copy
   // deferred weight gradients: the dY operands of layer l live in m->dwb[l] until the grouped launch that consumes them
   // (deterministic mode: the grouped launch in its ordered form -- bf16 products only, and the fp8 weight gradients are off in that mode)
-  static const bool det_group = !(getenv("RSYS_DET_DW_GROUP") && atoi(getenv("RSYS_DET_DW_GROUP")) == 0);   // A/B: 0 = the per-layer slab path
+  const bool det_group = sw().det_dw_group != 0;   // A/B: 0 = the per-layer slab path
   const bool defer = m->defer_dw && (!m->deterministic || (det_group && m->bf16_mode)) && side_mode() == 0;
   const bool ctop = m->top_is_sparse;
   if (defer && !ctop) gxt = AT<T>(m->dwb[m->L - 1].gxt);
@@ -1926,8 +1926,7 @@ static int backward_trunk(Model* m) {
         // From here on all-reduce kernels share the CUs with the backward.  A persistent grid (one workgroup pinned per
         // CU, a fixed share of the tiles each) would stall on every CU a communication kernel holds, so the 256x256
         // GEMMs go back to one workgroup per tile until the reduction is over: the tiles flow to whatever CUs are free.
-        static const bool keep_persistent = getenv("RSYS_DEBUG_KEEP_PERSISTENT") != nullptr;   // (measurement of what the switch costs)
-        if (!keep_persistent) m->gemm_flags |= 2;
+        m->gemm_flags |= 2;
       }
     }
   }
@@ -1939,7 +1938,7 @@ static int backward_trunk(Model* m) {
   BatchDev b = m->bd; b.N = N; b.rows = rows; b.S = m->S;
   tic(m, "hbm_scatter", 12.0 * D * N);   // bytes: one gradient row read + one table-gradient row read-modify-written per interaction
   {
-    static const bool atomic_ab = getenv("RSYS_SCATTER_ATOMIC") != nullptr;   // A/B measurement against the float-atomic form only
+    const bool atomic_ab = sw().scatter_atomic != 0;   // A/B measurement against the float-atomic form only
     if (m->sharded) {
       // one gradient row per distinct id of the batch (keys = the ids' slots in the exchange plan, mask row = slot uV), sent
       // to the rows' owners; an owner adds what it receives requester by requester (the ids of one requester are distinct)

@@ -165,6 +165,32 @@ def test_fp8_trunk_vs_fp8_oracle():
     model.close()
 
 
+def test_fp8_trunk_with_bf16_weight_gradients(monkeypatch):
+    """RSYS_F8_DW=0 (Switches::f8_dw): the fp8 trunk takes its weight gradients from the bf16 operands instead of the transposed fp8
+    copies (the path deterministic mode uses).  The forward pass is untouched -- the same losses -- and every gradient stays within
+    the fp8 quantisation of the default arm."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("f8t", mask_rate=0.2, mask_topk=16)
+    rows, seed = 3, 41
+    P = synth.make_params(cfg, seed, "test")
+    d = synth.make_batch(cfg, rows, seed + 1); mk = synth.make_masks(cfg, rows, seed + 2)
+    names = synth.trainable_names(cfg)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RSYS_F8_DW", flag)
+        model = ra.RecommenderModel(cfg, dtype="fp8", max_rows=rows)
+        model.load_state_dict(P)
+        model.set_loss_weights(TASK_W, 1)
+        losses = model(d, False, masks=mk)
+        res[flag] = (np.array(losses), {n: model.grad(n).copy() for n in names})
+        model.close()
+    assert np.allclose(res["0"][0], res["1"][0], rtol=1e-6, atol=0), (res["0"][0], res["1"][0])   # (the loss sums use float atomics)
+    worst = max((_rms(res["0"][1][n], res["1"][1][n]), n) for n in names)
+    assert worst[0] < 8e-2, worst
+    assert any(not np.array_equal(res["0"][1][n], res["1"][1][n]) for n in names)      # the switch did select another path
+
+
 def test_fp8_is_refused_where_the_reference_does_not_use_it():
     import recommendersystem_amd as ra
     from oracle import synth

@@ -17,7 +17,11 @@ ARMS = {"default": {}, "dense_top": {"RSYS_SPARSE_TOP": "0"}, "token_order": {"R
         "all_off": {"RSYS_SPARSE_TOP": "0", "RSYS_DW_GROUP": "0"},
         # deterministic mode (config["deterministic"], set by the worker): the grouped launch in its ordered form (per-product slabs,
         # one batched in-order sum; round 4) and the per-layer slab path it replaced
-        "det_grouped_dw": {"RSYS_TEST_DETERMINISTIC": "1"}, "det_per_layer_dw": {"RSYS_TEST_DETERMINISTIC": "1", "RSYS_DET_DW_GROUP": "0"}}
+        "det_grouped_dw": {"RSYS_TEST_DETERMINISTIC": "1"}, "det_per_layer_dw": {"RSYS_TEST_DETERMINISTIC": "1", "RSYS_DET_DW_GROUP": "0"},
+        # round 5 (csrc/switches.hpp): every kernel-choice switch whose other arm is live code has an arm here or a test of its own
+        "select_one_pass": {"RSYS_SELECT_CHUNKED": "0"}, "select_aside": {"RSYS_SELECT_ASIDE": "1"},
+        "scatter_atomic": {"RSYS_SCATTER_ATOMIC": "1"}, "dkdv_register_staged": {"RSYS_ATTN_KV_DMA": "0"},
+        "side_stream_joined": {"RSYS_SIDE_STREAM": "1"}, "side_stream_deferred": {"RSYS_SIDE_STREAM": "2"}}
 
 
 @pytest.mark.parametrize("dtype,tol_loss,tol", [("fp32", 1e-6, 2e-5), ("bf16", 2e-3, 3e-2)])

@@ -427,3 +427,26 @@ def test_kmajor_gemm_kernels_do_not_drain_their_dma_before_transposed_lds_reads(
                 assert not any(re.match(r"s_waitcnt\s+vmcnt\(0\)", w) for w in window), (m.group(1), window)
             seen += 1
     assert seen == 2, seen   # gemm8p_group_kernel and gemm8p_kernel<true, false>
+
+
+def test_environment_is_read_in_one_place():
+    """every RSYS_* switch of the library is a field of csrc/switches.hpp's struct, parsed by switches.hip and by
+    nothing else; DESIGN.md's table names each of them."""
+    import glob, re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(ROOT, "recommendersystem_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
+        if os.path.basename(f) in ("switches.hip",):
+            continue
+        text = open(f).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        assert "getenv(" not in code, f
+    names = re.findall(r'\{"(RSYS_[A-Z0-9_]+)", &Switches::(\w+), (-?\d+)\}', open(os.path.join(csrc, "switches.hip")).read())
+    assert len(names) >= 20
+    header = open(os.path.join(csrc, "switches.hpp")).read()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for env, field, _ in names:
+        assert re.search(r"\bint " + field + r";", header), field
+        assert env in design, env
+    for gone in ("RSYS_ATTN_PAIR", "RSYS_ATTN_ORDER", "RSYS_DEBUG_KEEP_PERSISTENT"):
+        assert gone not in open(os.path.join(csrc, "switches.hip")).read()
