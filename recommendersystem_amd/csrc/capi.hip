@@ -269,16 +269,49 @@ static int adam_state_io(rsys_optimizer* o, const char* name, float* m_out, floa
   if (it == m->by_name.end()) { set_error(std::string("unknown parameter: ") + name); return RSYS_ERR_ARG; }
   const TensorInfo& t = m->tensors[it->second];
   ARG_CHECK(!t.frozen_table, "frozen table has no optimizer state");
-  ARG_CHECK(!o->o.zero1, "partitioned optimizer state (zero1) is not addressable by parameter name");
   ARG_CHECK(n == t.rows * t.cols, "element count");
   HIP_CHECK(hipSetDevice(m->device));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   const int64_t int_rows = (t.map == MAP_DIRECT) ? t.rows : 2 * m->Ip;
   std::vector<float> host((size_t)int_rows * t.ld);
+  // ZeRO-1 (optimizer_set_zero1): this rank holds the moments of flat elements [rank * chunk, (rank + 1) * chunk) at local offset 0 and --
+  // the last rank -- of the tail [chunk * world, n_opt) behind them.  A read returns the rank's part of the tensor and zeros elsewhere
+  // (the parts of all ranks are disjoint: AdamW.state_dict sums them over the ranks' HostGroup); a write keeps the rank's part.
+  struct Piece { int64_t g_lo, g_hi, local; };
+  std::vector<Piece> pieces;
+  const int64_t t_lo = t.off, t_hi = t.off + (int64_t)host.size();
+  if (o->o.zero1) {
+    const int64_t chunk = o->o.z_chunk, own = o->o.z_rank * chunk, tail_lo = chunk * o->o.z_world;
+    pieces.push_back({own, own + chunk, 0});
+    if (o->o.z_rank == o->o.z_world - 1 && o->o.z_tail > 0) pieces.push_back({tail_lo, tail_lo + o->o.z_tail, chunk});
+  }
   for (int which = 0; which < 2; ++which) {
-    float* base = (which == 0 ? o->o.mom : o->o.var) + t.off;
+    float* zbase = which == 0 ? o->o.mom : o->o.var;
+    float* base = zbase + t.off;
     float* out = which == 0 ? m_out : v_out;
     const float* in = which == 0 ? m_in : v_in;
+    if (o->o.zero1) {
+      std::fill(host.begin(), host.end(), 0.f);
+      auto irow = [&](int64_t r) { return t.map == MAP_W1 ? (r / 16) * 32 + r % 16 : t.map == MAP_W3 ? (r / 16) * 32 + 16 + r % 16 : r; };
+      if (in) for (int64_t r = 0; r < t.rows; ++r) memcpy(host.data() + irow(r) * t.ld, in + r * t.cols, t.cols * 4);
+      for (const Piece& pc : pieces) {
+        const int64_t a = std::max(pc.g_lo, t_lo), b = std::min(pc.g_hi, t_hi);
+        if (a >= b) continue;
+        if (in) {
+          // (a W1 / W3 tensor shares its interleaved rows with its partner: write this tensor's rows only)
+          if (t.map == MAP_DIRECT) HIP_CHECK(hipMemcpy(zbase + pc.local + (a - pc.g_lo), host.data() + (a - t_lo), (size_t)(b - a) * 4, hipMemcpyHostToDevice));
+          else
+            for (int64_t r = 0; r < t.rows; ++r) {
+              const int64_t ra = std::max(a, t_lo + irow(r) * t.ld), rb = std::min(b, t_lo + irow(r) * t.ld + t.cols);
+              if (ra < rb) HIP_CHECK(hipMemcpy(zbase + pc.local + (ra - pc.g_lo), host.data() + (ra - t_lo), (size_t)(rb - ra) * 4, hipMemcpyHostToDevice));
+            }
+        } else {
+          HIP_CHECK(hipMemcpy(host.data() + (a - t_lo), zbase + pc.local + (a - pc.g_lo), (size_t)(b - a) * 4, hipMemcpyDeviceToHost));
+        }
+      }
+      if (out) for (int64_t r = 0; r < t.rows; ++r) memcpy(out + r * t.cols, host.data() + irow(r) * t.ld, t.cols * 4);
+      continue;
+    }
     HIP_CHECK(hipMemcpy(host.data(), base, host.size() * 4, hipMemcpyDeviceToHost));
     auto irow = [&](int64_t r) { return t.map == MAP_W1 ? (r / 16) * 32 + r % 16 : t.map == MAP_W3 ? (r / 16) * 32 + 16 + r % 16 : r; };
     if (out) for (int64_t r = 0; r < t.rows; ++r) memcpy(out + r * t.cols, host.data() + irow(r) * t.ld, t.cols * 4);

@@ -39,8 +39,14 @@ class AdamW:
         self.model.zero_grad()
 
     def state_dict(self, gather=None):
-        """AdamW moments by parameter name.  `gather` (the ranks' HostGroup): moments of a row-sharded table whole."""
+        """AdamW moments by parameter name.  `gather` (the ranks' HostGroup): moments of a row-sharded table whole, and -- ZeRO-1 --
+        the moments every rank keeps for its 1/world of the flat parameter range summed into whole tensors (every rank calls this;
+        the result is the replicated optimizer's state_dict, so a checkpoint does not depend on the world size it was written at)."""
         from .model import gather_rows
+        zero1_parts = self._zero1 is not None and self._zero1.world > 1
+        if zero1_parts and gather is None:
+            raise ValueError("ZeRO-1 optimizer state is partitioned over the ranks: call state_dict(gather=<the ranks' dist.HostGroup>) on "
+                             "every rank (train.train passes its `gather` argument through)")
         st = C.c_int32()
         check(lib().rsys_adamw_state_get(self._h, None, None, None, 0, C.byref(st)))
         state = {}
@@ -50,12 +56,18 @@ class AdamW:
                 continue
             m = np.empty(shape, np.float32); v = np.empty(shape, np.float32)
             check(lib().rsys_adamw_state_get(self._h, n.encode(), m.ctypes.data, v.ctypes.data, m.size, None))
+            if zero1_parts:      # the ranks' parts are disjoint (zeros elsewhere): their sum is the tensor
+                mv = np.stack([m, v])
+                parts = gather.all_gather_bytes(mv.tobytes())
+                mv = np.sum([np.frombuffer(p, np.float32).reshape(mv.shape) for p in parts], axis=0, dtype=np.float32)
+                m, v = np.ascontiguousarray(mv[0]), np.ascontiguousarray(mv[1])
             if gather is not None and sharded and n in self.model.TABLE_KEYS:
                 m, v = gather_rows(gather, m), gather_rows(gather, v)
             state[n] = {"exp_avg": m, "exp_avg_sq": v}
         return {"step": st.value, "lr": self.lr, "state": state}
 
     def load_state_dict(self, sd):
+        """Whole tensors in; a ZeRO-1 optimizer keeps the part of each that falls into this rank's range (enable_zero1 first)."""
         check(lib().rsys_adamw_state_set(self._h, None, None, None, 0, int(sd["step"])))
         lo, hi = self.model.table_rows()
         for n, s in sd["state"].items():

@@ -108,11 +108,88 @@ def test_zero1_refuses_what_it_does_not_cover():
     model.init_weights(3)
     opt = AdamW(model, lr=1e-3)
     opt.enable_zero1(comm)
-    with pytest.raises(ra.RsysError):      # partitioned moments have no per-parameter view
-        opt.state_dict()
+    sd = opt.state_dict()                  # world 1: the rank's part is everything
+    assert set(sd["state"]) == {n for n, _, tr in model.named_parameters() if tr}
     opt.close(); model.close()
     ft = ra.RecommenderModel(synth.make_config("hd64", finetune=True, finetune_metric="rating"), dtype="bf16", max_rows=2)
     o2 = AdamW(ft, lr=1e-3)
     with pytest.raises(ra.RsysError):      # finetune (LoRA segment only) keeps the plain optimizer
         o2.enable_zero1(comm)
     o2.close(); ft.close(); comm.close(); group.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_zero1_state_dict_is_the_replicated_optimizers_and_restores(dtype):
+    """a ZeRO-1 optimizer could not be checkpointed.  Two steps on two concurrent ranks, then `state_dict(gather=HostGroup)`:
+    every rank gets WHOLE moment tensors, bitwise those of the all-reduce run's replicated optimizer (same arithmetic per element,
+    deterministic mode).  Loaded into fresh ZeRO-1 optimizers (each keeps its part) and into a fresh replicated one, a third step
+    lands on bitwise the same parameters as the uninterrupted runs.  Without `gather` a partitioned optimizer refuses with a clear error."""
+    import os, socket
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.optim import AdamW
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=True)
+    rows, seed, world = 2, 47, 2
+    P = synth.make_params(cfg, seed, "test")
+    names = synth.trainable_names(cfg)
+    batches = [[synth.make_batch(cfg, rows, seed + 1 + 10 * r + i) for i in range(3)] for r in range(world)]
+    masks = [[synth.make_masks(cfg, rows, seed + 2 + 10 * r + i) for i in range(3)] for r in range(world)]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["RSYS_RDZV_PORT"] = str(port)
+
+    def run(zero1, resume_from=None, steps=(0, 1, 2), want_state_after=None):
+        group = rdist.LocalGroup(world)
+
+        def rank_fn(r):
+            hg = rdist.HostGroup(r, world)
+            comm = rdist.LocalComm(group, r)
+            model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
+            model.load_state_dict(P if resume_from is None else resume_from[0])
+            model.set_loss_weights(TASK_W, 1)
+            opt = AdamW(model, lr=1e-2)
+            if zero1:
+                opt.enable_zero1(comm)
+                if resume_from is None and r == 0:
+                    with pytest.raises(ValueError, match="partitioned"):
+                        opt.state_dict()
+            if resume_from is not None:
+                opt.load_state_dict(resume_from[1])
+            sd = None
+            for i in steps:
+                model(batches[r][i], False, masks=masks[r][i])
+                if not zero1:
+                    comm.all_reduce_grads(model)
+                opt.step(clip_max_norm=0.0, grad_div=float(world))
+                if i == want_state_after:
+                    sd = (model.state_dict(), opt.state_dict(gather=hg))
+            Pn = {n: model.get_parameter(n).copy() for n in names}
+            opt.close(); model.close(); comm.close(); hg.close()
+            return Pn, sd
+
+        out = _run_ranks(world, rank_fn)
+        group.close()
+        return out
+
+    try:
+        full_ref = run(False)                                   # three steps, replicated optimizer
+        full_z = run(True)
+        for n in names:
+            assert np.array_equal(full_ref[0][0][n], full_z[0][0][n]), n
+        two_ref = run(False, steps=(0, 1), want_state_after=1)
+        two_z = run(True, steps=(0, 1), want_state_after=1)
+        for r in range(world):
+            sa, sb = two_ref[r][1][1], two_z[r][1][1]
+            assert sa["step"] == sb["step"] == 2
+            for n in names:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    assert sb["state"][n][k].shape == sa["state"][n][k].shape
+                    assert np.array_equal(sa["state"][n][k], sb["state"][n][k]), (r, n, k)
+            assert any(np.abs(sb["state"][n]["exp_avg"]).max() > 0 for n in names)
+        for zero1 in (True, False):                             # the ZeRO-1 checkpoint resumes either kind of optimizer
+            res = run(zero1, resume_from=two_z[0][1], steps=(2,))
+            for r in range(world):
+                for n in names:
+                    assert np.array_equal(res[r][0][n], full_ref[0][0][n]), (zero1, r, n, float(np.abs(res[r][0][n] - full_ref[0][0][n]).max()))
+    finally:
+        os.environ.pop("RSYS_RDZV_PORT", None)
