@@ -408,31 +408,55 @@ def main():
         opt.step(lr_factor=sched.factor(), clip_max_norm=1.0, grad_div=float(world))   # (zero1: reduce-scatter, partial AdamW and all-gather inside)
         sched.step()
 
-    for _ in range(args.warmup):
+    # The per-call-site breakdown (every kernel of a step between two HIP events on its own stream: ms_per_step_by_phase, gemm_variants,
+    # hbm_kernels, executed FLOPs) is taken on the LAST warm-up steps, outside the timed region: ~240 event records cost a step 7 %.  Inside
+    # the timed region only the dominant kernel family's call sites are timed (the roofline object's launch duration; ~0.4 ms per
+    # instrumented step).  Fewer than three warm-up steps, or --detail: everything is timed inside the region, as before round 5.
+    pre = (not args.no_kernel_timing) and (not args.detail) and args.warmup >= 3
+    n_pre = min(3, args.warmup - 2) if pre else 0
+    rep = {}
+
+    def collect(into):
+        # collected after every instrumented step: the event pool is reused, so its size does not depend on the shape
+        # (at the production shape five steps' worth of pending events exceeded what the runtime would record)
+        for k, v in model.timing_report().items():
+            a = into.setdefault(k, {"ms": 0.0, "count": 0, "flops": 0.0})
+            a["ms"] += v["ms"]; a["count"] += v["count"]; a["flops"] += v["flops"]
+
+    for w in range(args.warmup):
+        if pre and w == args.warmup - n_pre:
+            model.timing(True, serialize=True)
         step()
+        if pre and w >= args.warmup - n_pre:
+            collect(rep)
+    if pre:
+        model.timing(False)
     ra.synchronize()
     first_losses = model.losses(False)
     hg.barrier()
-    # Per-kernel HIP events (on the stream each kernel runs on) are taken on the first tenth of the timed steps: ~300 event
-    # records per step cost about 3 % of the step.  The remaining steps run without events.  --detail instruments every step.
-    # (at least five instrumented steps once 20 are timed: two samples left the per-kernel entries swinging by 30 %)
-    # (--detail: at most 20 steps)
+    # (at least five instrumented steps once 20 are timed: two samples left the per-kernel entries swinging by 30 %; --detail: at most 20)
     n_instr = 0 if args.no_kernel_timing else (min(args.steps, 20) if args.detail else (max(5, args.steps // 10) if args.steps >= 20 else max(1, args.steps // 10)))
+    dom_pre = None
+    if pre and rep:
+        fam = {}
+        for tag, r in rep.items():
+            if tag.startswith("gemm_") and "@" in tag:
+                fam[tag.split("@")[1]] = fam.get(tag.split("@")[1], 0.0) + r["ms"]
+        dom_pre = max(fam, key=fam.get) if fam else None
     if n_instr:
         model.timing(True, serialize=True)
+        if dom_pre is not None:
+            model.timing_filter("@" + dom_pre)
     ra.synchronize()
     t0 = time.perf_counter()
-    rep = {}
+    rep_t = {} if pre else rep          # what the timed region's events measured (pre: the dominant family's sites only)
+    n_rep = n_pre if pre else n_instr   # steps `rep` (the full breakdown) covers
     model.step_mark()
     for i in range(args.steps):
         step()
         model.step_mark()                      # an event on the compute stream per step boundary, no host sync
         if n_instr and i < n_instr:
-            # collected after every instrumented step: the event pool is reused, so its size does not depend on the shape
-            # (at the production shape five steps' worth of pending events exceeded what the runtime would record)
-            for k, v in model.timing_report().items():
-                a = rep.setdefault(k, {"ms": 0.0, "count": 0, "flops": 0.0})
-                a["ms"] += v["ms"]; a["count"] += v["count"]; a["flops"] += v["flops"]
+            collect(rep_t)
             if i + 1 == n_instr:
                 model.timing(False)
     ra.synchronize()
@@ -477,9 +501,9 @@ def main():
         npos = model.head_rows()
         D = cfg["embed_dim"]; V0 = cfg["vocab_sizes"]["0_matchedid"]; V1 = cfg["vocab_sizes"]["1_matchedid"]
         up = lambda n, q: (n + q - 1) // q * q
-        fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
-        fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
-        fl_rows256 = sum(2.0 * up(npos[2 * m_], 256) * v * D for m_, v in ((0, V0), (1, V1))) * n_instr
+        fl_rows = sum(2.0 * up(npos[2 * m_], 128) * v * D for m_, v in ((0, V0), (1, V1))) * n_rep
+        fl_k = sum(2.0 * up(npos[2 * m_], 64) * v * D for m_, v in ((0, V0), (1, V1))) * n_rep
+        fl_rows256 = sum(2.0 * up(npos[2 * m_], 256) * v * D for m_, v in ((0, V0), (1, V1))) * n_rep
         for tag, fl in (("gemm_logits", fl_rows), ("gemm_head_dx", fl_rows), ("gemm_head_dw", fl_k)):
             for full in [k for k in rep if k.split("@")[0] == tag]:
                 rep[full]["flops"] = fl_rows256 if (tag != "gemm_head_dw" and full.endswith(("@8p", "@8c"))) else fl   # 256-row tiles
@@ -528,7 +552,7 @@ def main():
             hd = cfg["embed_dim"] // cfg["num_heads"]
             tdens = attention_tile_density(d["userid"], S)
             attn_fl = cfg["num_layers"] * cfg["num_heads"] * rows * (2 * S) ** 2 * tdens * (2 + 7) * 2.0 * hd
-            gemm_fl = sum(r["flops"] for tag, r in rep.items() if tag.startswith("gemm_")) / n_instr
+            gemm_fl = sum(r["flops"] for tag, r in rep.items() if tag.startswith("gemm_")) / n_rep
             executed = {"gemm_flops_per_step": gemm_fl, "attention_flops_per_step": attn_fl, "attention_tile_density": round(tdens, 4)}
         # dominant kernel: the MFMA GEMM family, per instantiation
         var = {}
@@ -549,7 +573,14 @@ def main():
             pass
         if var:
             dom = max(var, key=lambda k: var[k]["ms"])
-            a = var[dom]
+            a = dict(var[dom])
+            if pre:
+                # duration from the TIMED region's events (the family's call sites only); FLOPs per step from the full breakdown of the
+                # warm-up steps (the same resident batch every step: the same launches and device-side limits)
+                t_ms = sum(r["ms"] for tag, r in rep_t.items() if tag.endswith("@" + dom))
+                t_n = sum(r["count"] for tag, r in rep_t.items() if tag.endswith("@" + dom))
+                if t_ms > 0 and t_n > 0 and n_instr:
+                    a = {"ms": t_ms, "launches": t_n, "flops": a["flops"] / n_rep * n_instr}
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS_FP8 if dom in ("8f", "8fs", "8gf") else MFMA_PEAK_TFLOPS
             roofline = {"bound": "mfma", "kernel": KERNEL_LABEL.get(dom, dom), "achieved": round(ach, 1),
@@ -559,7 +590,9 @@ def main():
                                                                         "note": "separate rocprofv3 --pmc passes of this workload (tools/prof_round.sh), read from the committed summary, not measured in this run"}),
                         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],
-                        "share_of_step": round(a["ms"] / n_instr / ms, 3), "instrumented_steps": n_instr}
+                        "share_of_step": round(a["ms"] / max(n_instr, 1) / ms, 3), "instrumented_steps": n_instr,
+                        "timed_with": ("HIP events around this family's call sites only, first %d of the %d timed steps; the other per-kernel fields of this line come from %d fully "
+                                       "instrumented warm-up steps" % (n_instr, args.steps, n_rep)) if pre else "HIP events around every call site, first %d of the timed steps" % n_instr}
         out = {
             "metric": "interactions/sec", "value": round(value, 1), "unit": "interactions/sec",
             "user_seqs_per_sec": round(value / S, 2),
@@ -605,8 +638,8 @@ def main():
         hbm = {}
         for tag, r in rep.items():                                # HBM-bound row kernels: algorithmic bytes / HIP-event time
             if (tag.startswith("hbm_") or tag in ("adamw", "sumsq")) and r["ms"] > 0:
-                e = {"GBps": round(r["flops"] / (r["ms"] * 1e-3) / 1e9, 1), "ms_per_step": round(r["ms"] / n_instr, 4),
-                     "launches_per_step": r["count"] // n_instr, "algorithmic_MB_per_launch": round(r["flops"] / r["count"] / 1e6, 2)}
+                e = {"GBps": round(r["flops"] / (r["ms"] * 1e-3) / 1e9, 1), "ms_per_step": round(r["ms"] / n_rep, 4),
+                     "launches_per_step": r["count"] // n_rep, "algorithmic_MB_per_launch": round(r["flops"] / r["count"] / 1e6, 2)}
                 e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 3)
                 pm = traffic_of_name(traffic_db, HBM_KERNEL_SYMBOL.get(tag))
                 if pm:
@@ -615,13 +648,15 @@ def main():
         if hbm:
             out["hbm_kernels"] = hbm
         if rep:
-            phases = {k: round(v["ms"] / n_instr, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
+            out["per_kernel_fields_measured_on"] = (f"the last {n_rep} warm-up steps, every call site between HIP events (outside the timed region)" if pre
+                                                    else f"the first {n_rep} timed steps, every call site between HIP events")
+            phases = {k: round(v["ms"] / n_rep, 3) for k, v in rep.items() if k.startswith("phase_") or k in ("adamw", "sumsq", "attn_fwd", "attn_bwd", "ce")}
             out["ms_per_step_by_phase"] = phases
-            out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / n_instr, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
+            out["gemm_variants"] = {k: {"ms_per_step": round(v["ms"] / n_rep, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in var.items()}
         if args.detail:
             for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
-                print(f"  {k:22s} {v['ms'] / n_instr:8.3f} ms/step  {v['count'] // n_instr:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
+                print(f"  {k:22s} {v['ms'] / n_rep:8.3f} ms/step  {v['count'] // n_rep:4d} launches/step  {tf:7.1f} TFLOP/s", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, 1, args.cpu_rows)
         # the numbers README / DESIGN quote for other configurations, under the same clock as `value`: short

@@ -278,6 +278,8 @@ int32_t rsys_step_mark(rsys_model* m);
 int32_t rsys_step_marks_get(rsys_model* m, float* ms_out, int32_t cap, int32_t* n_out);
 int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-call-site HIP-event timings; 2: also run the side-stream GEMMs in line */
 int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
+/* time only the call sites whose name contains `substr` (NULL or "": all); cleared by rsys_op_timing(m, 0).  Call after rsys_op_timing(m, 1|2). */
+int32_t rsys_op_timing_filter(rsys_model* m, const char* substr);
 /* Environment switches (RSYS_*; the table is in DESIGN.md "Environment switches", the fields in csrc/switches.hpp).  The library parses the
  * environment when a model or communicator is created and at the entry of every rsys_op_* operator, never inside a training step;
  * rsys_switches_reload parses it on demand.  rsys_switches_describe writes "NAME=value" of the switches that differ from their defaults

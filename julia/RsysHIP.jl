@@ -252,6 +252,7 @@ function switches_set()
     unsafe_string(pointer(buf))
 end
 op_timing!(m::Model, mode::Integer) = check(ccall((:rsys_op_timing, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, mode))
+op_timing_filter!(m::Model, substr::AbstractString) = check(ccall((:rsys_op_timing_filter, LIB), Int32, (Ptr{Cvoid}, Cstring), m.h, substr))
 function timing_report(m::Model)
     buf = Vector{UInt8}(undef, 1 << 16)
     GC.@preserve buf check(ccall((:rsys_timing_get, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), m.h, buf, length(buf)))

@@ -125,6 +125,7 @@ _SIGS = [
     ("rsys_step_marks_get", C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("rsys_op_timing", C.c_int32, [_P, C.c_int32]),
     ("rsys_timing_get", C.c_int32, [_P, C.c_char_p, C.c_size_t]),
+    ("rsys_op_timing_filter", C.c_int32, [_P, C.c_char_p]),
     ("rsys_switches_reload", C.c_int32, []),
     ("rsys_switches_describe", C.c_int32, [C.c_char_p, C.c_int32]),
 ]

@@ -775,7 +775,14 @@ int32_t rsys_op_timing(rsys_model* h, int32_t enable) {
   m->timer.enabled = enable != 0;
   m->timer.serialize = enable == 2;
   HIP_CHECK(hipStreamSynchronize(m->side));
-  m->timer.marks.clear(); m->timer.acc_ms.clear(); m->timer.used = 0;
+  m->timer.marks.clear(); m->timer.acc_ms.clear(); m->timer.used = 0; m->timer.open.clear();
+  if (!enable) m->timer.filter.clear();
+  return RSYS_OK;
+}
+
+int32_t rsys_op_timing_filter(rsys_model* h, const char* substr) {
+  CHECK_HANDLE(h);
+  h->m->timer.filter = substr ? substr : "";
   return RSYS_OK;
 }
 
@@ -807,7 +814,7 @@ int32_t rsys_timing_get(rsys_model* h, char* buf, size_t cap) {
   }
   std::string s = os.str();
   if (buf && cap) { strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
-  t.marks.clear(); t.acc_ms.clear(); t.used = 0;
+  t.marks.clear(); t.acc_ms.clear(); t.used = 0; t.open.clear();
   return (int32_t)RSYS_OK;
 }
 

@@ -37,6 +37,10 @@ struct PhaseTimer {
   std::map<std::string, double> acc_ms;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
+  // only call sites whose name contains `filter` are timed ("" = all): bench.py times the dominant kernel family alone inside its timed
+  // region (two event records per site cost the step ~4 us each; all ~120 sites of a step: +7 %)
+  std::string filter;
+  std::vector<char> open;   // per open tic: 1 = recorded, 0 = filtered out (its toc records nothing)
 };
 
 struct Model {

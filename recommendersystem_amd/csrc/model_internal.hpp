@@ -33,6 +33,8 @@ static int dalloc(Model* m, void** p, size_t bytes) {
 static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st = nullptr) {
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
+  if (!t.filter.empty() && strstr(name, t.filter.c_str()) == nullptr) { t.open.push_back(0); return; }
+  t.open.push_back(1);
   if (t.used + 2 > t.pool.size()) {
     if (t.pool.size() >= 8192) { t.enabled = false; return; }   // (a report is taken every few steps; past this the caller forgot to collect)
     for (int i = 0; i < 64; ++i) {
@@ -57,6 +59,7 @@ static void tic(Model* m, const char* name, double flops = 0.0, hipStream_t st =
 static void toc(Model* m, hipStream_t st = nullptr) {
   PhaseTimer& t = m->timer;
   if (!t.enabled) return;
+  if (!t.open.empty()) { const char rec = t.open.back(); t.open.pop_back(); if (!rec) return; }
   hipEvent_t e = t.pool[t.used++];
   if (hipEventRecord(e, st ? st : m->stream) != hipSuccess) {   // (the span that was open stays unpaired and is dropped by rsys_timing_get)
     (void)hipGetLastError();

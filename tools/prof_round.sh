@@ -16,3 +16,4 @@ find $R/gpurun_out/prof_$T -name "*kernel_stats.csv" | head -2
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_mfma_$T --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-train-loop > /dev/null 2> $R/gpurun_out/pmc_mfma_$T.err; echo "pmc mfma rc=$?"
 cd $R && python tools/pmc_mfma_util.py gpurun_out/pmc_mfma_$T > gpurun_out/${T}_pmc_mfma_util.txt; head -12 gpurun_out/${T}_pmc_mfma_util.txt | cut -c1-150
 cd $R && python tools/trace_steady.py gpurun_out/prof_$T > gpurun_out/${T}_steady_state_per_step.txt; head -14 gpurun_out/${T}_steady_state_per_step.txt | cut -c1-150
+cd /tmp && python3 $R/bench.py --steps 20 --warmup 5 --detail --no-cpu-baseline --no-train-loop > /dev/null 2> $R/gpurun_out/${T}_bench_detail.txt; echo "detail rc=$?"; head -12 $R/gpurun_out/${T}_bench_detail.txt | cut -c1-120
