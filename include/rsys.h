@@ -120,6 +120,12 @@ int32_t rsys_forward_backward(rsys_model* m, int32_t evaluate, const float task_
 /* losses_out[12]: per task 3 slots (train: [loss,0,0]; evaluate rating tasks: 3 moments of model.py:395-401);
  * weight_sums_out[4]: d[name.weight].sum() after masking (train.py:261).  Synchronises. */
 int32_t rsys_losses_get(rsys_model* m, float losses_out[12], float weight_sums_out[4]);
+/* The same without a host wait per step (transformer.py:245-262 adds the losses into device tensors and reads them at the end of the
+ * epoch, :279-283): rsys_losses_push parks the finished step's sums on the device (stream-ordered, at most 1024 steps),
+ * rsys_losses_drain synchronises once and writes every parked step in order: losses_out[n][12], weight_sums_out[n][4] as
+ * rsys_losses_get would have returned them; *n_out = n <= cap. */
+int32_t rsys_losses_push(rsys_model* m);
+int32_t rsys_losses_drain(rsys_model* m, float* losses_out, float* weight_sums_out, int32_t cap, int32_t* n_out);
 /* number of positive-weight positions selected per task in the last forward (they bound the head GEMMs) */
 int32_t rsys_head_rows_get(rsys_model* m, int32_t out[4]);
 /* ItemEmbedding.forward over all items (model.py:139-145), the table Finetune/register.py:27-33 exports as the watch-head

@@ -87,6 +87,14 @@ function losses(m::Model)
     lo, ws
 end
 
+# losses without a host wait per step (transformer.py:245-262 accumulates on the device): park, then read every parked step at once
+push_losses!(m::Model) = check(ccall((:rsys_losses_push, LIB), Int32, (Ptr{Cvoid},), m.h))
+function drain_losses(m::Model, cap::Integer = 1024)
+    lo = Matrix{Float32}(undef, 12, cap); ws = Matrix{Float32}(undef, 4, cap); n = Ref{Int32}(0)
+    GC.@preserve lo ws check(ccall((:rsys_losses_drain, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Ref{Int32}), m.h, lo, ws, cap, n))
+    lo[:, 1:n[]], ws[:, 1:n[]]
+end
+
 set_deterministic!(m::Model, on::Bool = true) = check(ccall((:rsys_model_set_deterministic, LIB), Int32, (Ptr{Cvoid}, Int32), m.h, on ? 1 : 0))
 
 # inference forward (model.py:531-538): task 0 = retrieval, 1 = ranking; `tokens` = flat token indices (0-based) to report

@@ -69,6 +69,8 @@ _SIGS = [
     ("rsys_batch_swap", C.c_int32, [_P]),
     ("rsys_forward_backward", C.c_int32, [_P, C.c_int32, C.POINTER(C.c_float * 4), C.c_float, C.c_uint64, C.c_uint64]),
     ("rsys_losses_get", C.c_int32, [_P, C.POINTER(C.c_float * 12), C.POINTER(C.c_float * 4)]),
+    ("rsys_losses_push", C.c_int32, [_P]),
+    ("rsys_losses_drain", C.c_int32, [_P, _P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("rsys_head_rows_get", C.c_int32, [_P, C.POINTER(C.c_int32 * 4)]),
     ("rsys_item_table", C.c_int32, [_P, _P, C.c_int64]),
     ("rsys_model_set_deterministic", C.c_int32, [_P, C.c_int32]),

@@ -103,6 +103,46 @@ int32_t rsys_losses_get(rsys_model* h, float losses_out[12], float wsum_out[4]) 
   return RSYS_OK;
 }
 
+// The reference's loop adds each step's losses into device tensors and reads them once per epoch (transformer.py:245-262, 279-283):
+// push parks the finished step's loss sums and weight sums in a device ring (a 96-byte copy on the model's stream, no host wait),
+// drain reads every parked step back in order with the arithmetic of rsys_losses_get.
+int32_t rsys_losses_push(rsys_model* h) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  if (m->loss_ring == nullptr) HIP_CHECK(hipMalloc((void**)&m->loss_ring, (size_t)Model::loss_ring_cap * 24 * 4));
+  if (m->loss_ring_n >= Model::loss_ring_cap) { set_error("rsys_losses_push: ring full (rsys_losses_drain first)"); return RSYS_ERR_STATE; }
+  float* slot = m->loss_ring + (size_t)m->loss_ring_n * 24;
+  HIP_CHECK(hipMemcpyAsync(slot, m->loss_acc, 16 * 4, hipMemcpyDeviceToDevice, m->stream));
+  HIP_CHECK(hipMemcpyAsync(slot + 16, m->stats, 8 * 4, hipMemcpyDeviceToDevice, m->stream));
+  m->loss_ring_n += 1;
+  return RSYS_OK;
+}
+
+int32_t rsys_losses_drain(rsys_model* h, float* losses_out, float* wsum_out, int32_t cap, int32_t* n_out) {
+  CHECK_HANDLE(h);
+  Model* m = h->m;
+  ARG_CHECK(losses_out && wsum_out && n_out, "rsys_losses_drain: null output");
+  ARG_CHECK(cap >= m->loss_ring_n, "rsys_losses_drain: output holds fewer steps than are parked");
+  HIP_CHECK(hipSetDevice(m->device));
+  const int n = m->loss_ring_n;
+  *n_out = n;
+  if (n == 0) return RSYS_OK;
+  std::vector<float> host((size_t)n * 24);
+  HIP_CHECK(hipMemcpyAsync(host.data(), m->loss_ring, host.size() * 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+  for (int s = 0; s < n; ++s) {
+    const float* acc = host.data() + (size_t)s * 24; const float* st = acc + 16;
+    for (int ti = 0; ti < 4; ++ti) {
+      const float ws = fmaxf(st[2 * ti], 1e-8f);
+      for (int k = 0; k < 3; ++k) losses_out[(size_t)s * 12 + 3 * ti + k] = acc[3 * ti + k] / ws;
+      wsum_out[(size_t)s * 4 + ti] = st[2 * ti + 1];
+    }
+  }
+  m->loss_ring_n = 0;
+  return RSYS_OK;
+}
+
 int32_t rsys_head_rows_get(rsys_model* h, int32_t out[4]) {
   CHECK_HANDLE(h);
   HIP_CHECK(hipSetDevice(h->m->device));

@@ -383,6 +383,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
 }
 
 int model_destroy(Model* m) {
+  if (m->loss_ring) { hipFree(m->loss_ring); m->loss_ring = nullptr; }
   if (!m) return RSYS_OK;
   hipSetDevice(m->device);
   hipStreamSynchronize(m->stream);

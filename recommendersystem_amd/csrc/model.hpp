@@ -205,6 +205,9 @@ struct Model {
   std::vector<LayerAct> la;
   float* xL; float* rstdf; void* out;
   // heads
+  // losses of finished steps parked on the device (rsys_losses_push / _drain): the loop's per-step read-back -- its only host
+  // synchronisation -- becomes one read every `loss_ring_cap` steps; slot = [16 loss sums | 8 stats] of a step
+  float* loss_ring = nullptr; int loss_ring_n = 0; static constexpr int loss_ring_cap = 1024;
   int* idx[4]; int* npos; float* stats; void* Ew; void* logits; int64_t ldl; float* dE; void* z; void* hact; float* loss_acc;
   // backward workspaces
   float *gy, *gxa, *gxb, *dh; void *gxa_t, *gxb_t, *dh_t;   // *_t: T-typed operand copies (bf16 mode)

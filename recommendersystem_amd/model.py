@@ -303,6 +303,22 @@ class RecommenderModel:
         self.last_weight_sums = [float(x) for x in ws]
         return out
 
+    LOSS_RING = 1024
+
+    def push_losses(self):
+        """park the enqueued step's losses and weight sums on the device (no host wait); read them with drain_losses()"""
+        check(lib().rsys_losses_push(self._h))
+
+    def drain_losses(self):
+        """Synchronises once; [(losses, weight_sums)] of every step parked since the last drain, in order, as losses(False) /
+        last_weight_sums would have given them step by step."""
+        lo = np.empty((self.LOSS_RING, 12), np.float32); ws = np.empty((self.LOSS_RING, 4), np.float32); n = C.c_int32()
+        check(lib().rsys_losses_drain(self._h, lo.ctypes.data, ws.ctypes.data, self.LOSS_RING, C.byref(n)))
+        out = [([float(lo[s, 3 * ti]) for ti in range(4)], [float(x) for x in ws[s]]) for s in range(n.value)]
+        if out:
+            self.last_weight_sums = out[-1][1]
+        return out
+
     def __call__(self, d, evaluate_or_task, masks=None):
         if isinstance(evaluate_or_task, str):
             return self.inference_forward(d, evaluate_or_task)

@@ -220,6 +220,11 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     # following it; the arithmetic and the order of the sums are those of the plain loop.  (Row-sharded table: plain uploads.)
     staged = all(hasattr(model, a) for a in ("upload", "forward_resident", "losses"))   # (a model that is only callable: the plain loop)
     pipelined = staged and bool(getattr(model, "can_prefetch", False))
+    # ... and the read-back itself is deferred the way the reference defers it (its losses are device tensors summed on the device and
+    # read at the end of the epoch, transformer.py:245-262, 279-283): each step's sums are parked in a device ring and read every
+    # LOSS_RING steps, in order, with the same host arithmetic -- the same floats as the step-by-step read, without a host wait per step.
+    deferred = pipelined and hasattr(model, "push_losses")
+    parked = 0
     it = iter(lockstep_batches(model, dataloader, comm))
     data = next(it, None)
     if data is not None and staged:
@@ -239,15 +244,26 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
                 comm.all_reduce_grads(model)
             optimizer.step(lr_factor=scheduler.factor(), clip_max_norm=max_norm, grad_div=float(world))
             scheduler.step()
+        if deferred:
+            model.push_losses()                # the step's sums stay on the device (no host wait)
+            parked += 1
         nxt = next(it, None)
         if nxt is not None and pipelined:
             model.prefetch(nxt)                # host work of the next batch, beside the step the device is still running
-        if staged:
-            tloss = model.losses(False)        # (synchronises)
-        for i in range(n_tasks):
-            w = model.last_weight_sums[i]
-            training_losses[i] += tloss[i] * w
-            training_weights[i] += w
+        if deferred:
+            if parked == model.LOSS_RING or nxt is None:
+                for tloss, ws in model.drain_losses():      # (synchronises: once per LOSS_RING steps and at the end of the epoch)
+                    for i in range(n_tasks):
+                        training_losses[i] += tloss[i] * ws[i]
+                        training_weights[i] += ws[i]
+                parked = 0
+        else:
+            if staged:
+                tloss = model.losses(False)        # (synchronises)
+            for i in range(n_tasks):
+                w = model.last_weight_sums[i]
+                training_losses[i] += tloss[i] * w
+                training_weights[i] += w
         if nxt is not None and staged:
             if pipelined:
                 model.swap_batch()

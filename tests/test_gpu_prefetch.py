@@ -66,3 +66,41 @@ def test_rejected_prefetch_leaves_the_resident_batch_and_swap_needs_a_prefetch()
     with pytest.raises(ra.RsysError):
         model.swap_batch()
     model.close()
+
+
+def test_parked_losses_are_the_step_by_step_ones():
+    """rsys_losses_push / _drain (the reference adds its losses into device tensors and reads them at the end of the epoch,
+    transformer.py:245-262): three steps parked and read once give exactly what rsys_losses_get gave after each step; an empty drain is
+    an empty list."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=True)
+    batches = [synth.make_batch(cfg, 2, 300 + i) for i in range(3)]
+
+    def run(parked):
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=2)
+        model.load_state_dict(synth.make_params(cfg, 6, "test"))
+        model.set_loss_weights([0.05, 0.2, 0.3, 0.25], 1)
+        model.mask_seed = 13
+        opt = ra.create_optimizer(model, cfg)
+        out = []
+        assert model.drain_losses() == []
+        for i, b in enumerate(batches):
+            model.upload(b)
+            model.forward_resident(False, step=i)
+            opt.step(clip_max_norm=1.0)
+            if parked:
+                model.push_losses()
+            else:
+                lo = model.losses(False)
+                out.append((lo, list(model.last_weight_sums)))
+        if parked:
+            out = model.drain_losses()
+            assert model.drain_losses() == []
+        model.close()
+        return out
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == 3
+    for (la, wa), (lb, wb) in zip(a, b):
+        assert la == lb and wa == wb, (la, lb, wa, wb)
+    assert a[0][0] != a[1][0]
