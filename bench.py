@@ -82,6 +82,44 @@ def traffic_of_name(db, syms):
     return total or None
 
 
+def live_pmc_traffic(timeout_s=200):
+    """HBM bytes per launch of every kernel of the default workload, measured NOW: two child `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE: separate runs, no trace domains beside the counters -- MI355X_MICROARCH.md, HBM section) of this script on 4 steps, summarised with
+    the guide's corrections by tools/pmc_traffic.py.  Children of this process, started after its timed region; returns (db, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="rsys_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            cmd = [exe, "--pmc", counter, "-d", os.path.join(tmp, sub), "--output-format", "csv", "--", "python3", os.path.join(ROOT, "bench.py"),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-train-loop"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-160:]}"
+        fetch = pmc_traffic.collect(os.path.join(tmp, "fetch"), "FETCH_SIZE")
+        write = pmc_traffic.collect(os.path.join(tmp, "write"), "WRITE_SIZE")
+        db = {}
+        for k in set(fetch) | set(write):
+            fs, fn = fetch.get(k, (0.0, 0)); ws, wn = write.get(k, (0.0, 0))
+            db[k] = {"launches": max(fn, wn, 1), "hbm_bytes_per_launch": (2 * fs / max(fn, 1) + ws / max(wn, 1)) * 1024}
+        if not db:
+            return None, "the counter passes produced no rows"
+        return db, ("measured in this run: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of `bench.py --steps 3 --warmup 1` after the timed "
+                    f"region ({time.perf_counter() - t0:.0f} s), bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (tools/pmc_traffic.py)")
+    except Exception as e:   # noqa: BLE001  (a profiler problem must not lose the headline line)
+        return None, f"live PMC passes failed: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def flops_per_interaction(cfg, B, attention_density=1.0):
     """fwd+bwd, metadata projection once per step; attention dense (the upper bound the roofline fraction is
     quoted on) or scaled by the share of (query, key) pairs the packed users' mask allows (the "useful" figure)."""
@@ -333,6 +371,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two child rocprofv3 --pmc passes (roofline.traffic then comes from the committed summary)")
     ap.add_argument("--no-train-loop", action="store_true", help="skip the train_epoch (upload + loss read-back per step) measurement")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline step (oracle/cpu_step.cpp); 0 = 64 if a GEMM probe predicts <= 30 s, else 16")
     ap.add_argument("--table-shard", action="store_true",
@@ -595,8 +634,15 @@ def main():
         # PMC passes are separate runs (rocprofv3 --pmc) of the default workload; their per-launch summary is committed under
         # profiles/ and only describes that workload
         pmc_applies = args.config == "cfg3" and rows == 64 and args.layers is None and args.dtype == "bf16" and not sharded and not args.deterministic
+        traffic_note = None
+        live_ok = (pmc_applies and world == 1 and rows == 64 and not args.no_live_pmc and not args.detail and not args.no_kernel_timing
+                   and not zero1 and not split_table and comm is None)
+        if live_ok:
+            traffic_db, traffic_note = live_pmc_traffic()
+            traffic_db = traffic_db or {}
+        traffic_live = bool(traffic_db)
         try:
-            if pmc_applies:
+            if pmc_applies and not traffic_db:
                 traffic_db = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels"]
         except Exception:
             pass
@@ -615,7 +661,8 @@ def main():
             roofline = {"bound": "mfma", "kernel": KERNEL_LABEL.get(dom, dom), "achieved": round(ach, 1),
                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": traffic_of(traffic_db, dom),
-                        "traffic_source": (None if not traffic_db else {"file": "profiles/" + TRAFFIC_FILE, "git_blob": git_blob_id(os.path.join(ROOT, "profiles", TRAFFIC_FILE)),
+                        "traffic_source": (None if not traffic_db else {"note": traffic_note} if traffic_live else
+                                           {"file": "profiles/" + TRAFFIC_FILE, "git_blob": git_blob_id(os.path.join(ROOT, "profiles", TRAFFIC_FILE)), "live_attempt": traffic_note,
                                                                         "note": "separate rocprofv3 --pmc passes of this workload (tools/prof_round.sh), read from the committed summary, not measured in this run"}),
                         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                         "launches": a["launches"],

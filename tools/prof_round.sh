@@ -11,7 +11,7 @@ cd $R && python tools/pmc_traffic.py gpurun_out/pmc_fetch_$T gpurun_out/pmc_writ
 cp gpurun_out/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json
 cd /tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/${T}_bench_cfg3.json 2> $R/gpurun_out/${T}_bench_cfg3.err; echo "bench rc=$?"
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train-loop --no-extra-legs > $R/gpurun_out/prof_$T.json 2> $R/gpurun_out/prof_$T.err; echo "prof rc=$?"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train-loop --no-extra-legs --no-live-pmc > $R/gpurun_out/prof_$T.json 2> $R/gpurun_out/prof_$T.err; echo "prof rc=$?"
 find $R/gpurun_out/prof_$T -name "*kernel_stats.csv" | head -2
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_mfma_$T --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-train-loop > /dev/null 2> $R/gpurun_out/pmc_mfma_$T.err; echo "pmc mfma rc=$?"
 cd $R && python tools/pmc_mfma_util.py gpurun_out/pmc_mfma_$T > gpurun_out/${T}_pmc_mfma_util.txt; head -12 gpurun_out/${T}_pmc_mfma_util.txt | cut -c1-150
