@@ -191,8 +191,11 @@ def test_committed_bench_line_follows_the_contract():
         assert abs(d["step_mfma_frac_executed"] - total / (d["ms_per_step"] * 1e-3) / 2.5e15) < 2e-4
         assert r["instrumented_steps"] >= 5
         src = r["traffic_source"]
-        blob = __import__("bench").git_blob_id(os.path.join(root, src["file"]))
-        assert src["git_blob"] == blob, (src, blob)                                  # the committed file IS the one the line quotes
+        if "file" in src:                                                             # (round 5 on: measured live by two child rocprofv3 passes; the
+            blob = __import__("bench").git_blob_id(os.path.join(root, src["file"]))  #  committed summary is only the fallback)
+            assert src["git_blob"] == blob, (src, blob)                              # the committed file IS the one the line quotes
+        else:
+            assert "measured in this run" in src["note"] and r["traffic"] > 0
 
 
 def test_cli_training_config(tmp_path):
