@@ -282,7 +282,8 @@ int32_t rsys_op_gemm_f8(const void* A8, const void* B8, void* C, int32_t M, int3
  * boundary; rsys_step_marks_get writes the milliseconds between consecutive marks (at most cap) and clears the marks */
 int32_t rsys_step_mark(rsys_model* m);
 int32_t rsys_step_marks_get(rsys_model* m, float* ms_out, int32_t cap, int32_t* n_out);
-int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-call-site HIP-event timings; 2: also run the side-stream GEMMs in line */
+int32_t rsys_op_timing(rsys_model* m, int32_t enable);  /* collect per-call-site HIP-event timings; 2: also run the side-stream GEMMs in line;
+                                                          * 3: pause -- stop recording without a host wait and keep the recorded spans for rsys_timing_get */
 int32_t rsys_timing_get(rsys_model* m, char* buf, size_t cap);
 /* time only the call sites whose name contains `substr` (NULL or "": all); cleared by rsys_op_timing(m, 0).  Call after rsys_op_timing(m, 1|2). */
 int32_t rsys_op_timing_filter(rsys_model* m, const char* substr);

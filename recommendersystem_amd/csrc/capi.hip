@@ -810,6 +810,7 @@ int32_t rsys_switches_describe(char* buf, int32_t cap) { return switches_describ
 int32_t rsys_op_timing(rsys_model* h, int32_t enable) {
   CHECK_HANDLE(h);
   Model* m = h->m;
+  if (enable == 3) { m->timer.enabled = false; return RSYS_OK; }   // pause: stop recording, keep what was recorded, no host wait (read it later with rsys_timing_get)
   HIP_CHECK(hipSetDevice(m->device));
   HIP_CHECK(hipStreamSynchronize(m->stream));
   m->timer.enabled = enable != 0;

@@ -426,6 +426,10 @@ class RecommenderModel:
         line, so that each kernel is measured without a concurrent neighbour (bench.py --detail)."""
         check(lib().rsys_op_timing(self._h, (2 if serialize else 1) if enable else 0))
 
+    def timing_pause(self):
+        """stop recording call-site events without waiting for the device; timing_report() later returns what was recorded"""
+        check(lib().rsys_op_timing(self._h, 3))
+
     def timing_filter(self, substr):
         """time only the call sites whose name contains `substr` ("" = all); call after timing(True); cleared by timing(False)"""
         check(lib().rsys_op_timing_filter(self._h, (substr or "").encode()))
