@@ -1,3 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_prefetch.py tests/test_gpu_training_curve.py -x -q -m gpu 2>&1 | tail -5
+bash tools/prof_round.sh r5z
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python tools/soak.py 3000 > gpurun_out/r5z_soak.log 2>&1; echo "soak rc=$?"; tail -4 gpurun_out/r5z_soak.log
