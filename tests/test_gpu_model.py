@@ -1046,3 +1046,41 @@ def test_call_site_timer_gives_up_quietly_when_nobody_collects():
     assert rep2["phase_trunk_fwd"]["count"] == 1
     model.timing(False)
     model.close()
+
+
+def test_call_site_timer_filter_and_pause():
+    """bench.py times only the dominant kernel family's call sites inside its timed region (`timing_filter`: sites whose name contains
+    the substring; nested phase spans that do not match record nothing) and reads them after the region (`timing_pause`: recording stops
+    without a host wait, what was recorded stays readable).  Same losses with and without the timer."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    name, over, rows, seed = CASES[1]
+    cfg, P, d = _setup(name, over, rows, seed)
+    wm, rm = synth.make_masks(cfg, rows, 5)
+    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model.load_state_dict(P)
+    model.set_loss_weights(TASK_W, 1)
+    plain = np.array(model(d, False, masks=(wm, rm)))
+    model.zero_grad()
+    model.timing(True)
+    full = None
+    np.testing.assert_array_equal(np.array(model(d, False, masks=(wm, rm))), plain)
+    full = model.timing_report()
+    model.zero_grad()
+    assert any(k.startswith("phase_") for k in full) and any(k.startswith("gemm_") for k in full)
+    fam = sorted({k.split("@")[1] for k in full if k.startswith("gemm_") and "@" in k})[0]
+    model.timing_filter("@" + fam)
+    model(d, False, masks=(wm, rm)); model.zero_grad()
+    model(d, False, masks=(wm, rm)); model.zero_grad()
+    model.timing_pause()
+    model(d, False, masks=(wm, rm)); model.zero_grad()          # not recorded
+    rep = model.timing_report()
+    assert rep and all(k.endswith("@" + fam) for k in rep), sorted(rep)
+    for k, v in rep.items():
+        assert v["count"] == 2 * full[k]["count"], (k, v, full[k])
+    model.timing(False)                                          # clears the filter
+    model.timing(True)
+    model(d, False, masks=(wm, rm))
+    assert any(k.startswith("phase_") for k in model.timing_report())
+    model.timing(False)
+    model.close()
