@@ -1064,7 +1064,7 @@ def test_call_site_timer_filter_and_pause():
     model.zero_grad()
     model.timing(True)
     full = None
-    np.testing.assert_array_equal(np.array(model(d, False, masks=(wm, rm))), plain)
+    np.testing.assert_allclose(np.array(model(d, False, masks=(wm, rm))), plain, rtol=1e-6)   # (loss sums use float atomics)
     full = model.timing_report()
     model.zero_grad()
     assert any(k.startswith("phase_") for k in full) and any(k.startswith("gemm_") for k in full)
