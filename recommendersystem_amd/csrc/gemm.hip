@@ -511,7 +511,8 @@ static bool use_8p_tn_store(const GemmParams& p) {
 // row-major bf16 operands with the atomic epilogue: the LDS-DMA split-K form when the output is large enough for it
 static bool use_8p_nt_splitk(const GemmParams& p) {
   if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
-  if (sw().gemm_kernel_nt_splitk == 2) return true;   // 2: force (tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
+  if (sw().gemm_kernel_nt_splitk == 2 || (p.flags & 128)) return true;   // 2: force; flags bit 7: the caller wants the 256x256 split-K form for a few tiles (table_forward's tail)
+  // (RSYS_GEMM_KERNEL_NT_SPLITK=2: tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
   return (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 32;
 }
 

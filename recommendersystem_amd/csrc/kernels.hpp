@@ -229,6 +229,7 @@ int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_
                  float lr, float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div,
                  float max_norm, int zero_grad, hipStream_t s, long long sh_skip_lo = 0, long long sh_skip_hi = 0 /* elements [lo, hi) get no shadow copy */);
 template <typename T> int launch_cast(const float* src, T* dst, long long n, hipStream_t s);
+int launch_add_bias_rows(const float* a, const float* bias, float* dst, long long rows, int D, hipStream_t s);   // dst = a + bias (row-wise)
 template <typename T> int launch_widen(const T* src, float* dst, long long n, hipStream_t s);
 template <typename T> int launch_rowdot(const T* h, const float* w, const float* b, float* out, int n, int D, hipStream_t s);
 // batched 2-D transposes of bf16 matrices (the weight shadows the dx GEMMs read as row-major [in][out] operands)

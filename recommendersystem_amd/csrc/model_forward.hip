@@ -5,15 +5,45 @@
 namespace rsys {
 
 // Fused item table F = E + Meta Wp^T + bp over all V + 1 rows (model.py:120-133): f32 copy for the token gather, T copy as the
-// tied watch-head operand.  (At cfg-3 this is 782 x 2 tiles of 256 x 256 = 6.1 per CU; sending the rows beyond whole rounds
-// to the 128 x 128 kernel in a second launch was measured: 1.32 -> 1.18 + 0.12 ms, not worth the second code path.)
+// tied watch-head operand.  At cfg-3 this is 782 x 2 tiles of 256 x 256 = 6.1 per CU: a persistent grid runs SEVEN rounds, the last
+// one on 28 of 256 CUs (13 % of the launch).  Round 5: the rows beyond the whole rounds (3 393 of 200 001) go to the row-major
+// split-K form of the same pipeline instead -- their slice of F starts as E + bp (one row kernel), 28 tiles x 8 K splits add their
+// products with fp32 atomics, a cast writes the T copy: three small launches (~35 us) for one round of the main launch (~180 us).
+// (Sending those rows to the 128 x 128 kernel was measured in round 3: 1.32 -> 1.18 + 0.12 ms, no gain.)  Deterministic mode and
+// fp32 keep the single launch (the atomics' order is free).
 template <typename T>
 int table_forward(Model* m) {
   GemmParams p{};
   p.A = m->Meta; p.lda = m->Mp; p.B = W<T>(m, m->o_Wp); p.ldb = m->Mp; p.C = m->F32; p.ldc = m->D; p.c_f32 = 1;
   p.M = m->TR; p.N = m->D; p.K = m->Mp; p.epi = EPI_TABLE; p.E = m->P + m->o_E; p.bias = m->P + m->o_bp;
   p.C2 = m->FT; p.ldc2 = m->D;
-  return gemm<T>(m, "gemm_table_fwd", p, false, false, false);
+  int rows_main = m->TR;
+  if constexpr (is_bf16<T>::value) {
+    static int cus = 0;
+    if (cus == 0) { int dev = 0, v = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+    const int tiles_n = (m->D + 255) / 256, tiles = ((m->TR + 255) / 256) * tiles_n;
+    const int rounds = tiles / cus, rem = tiles % cus;
+    if (sw().table_tail != 0 && !m->deterministic && rounds >= 3 && rem > 0 && rem * 4 <= cus && (rounds * cus) % tiles_n == 0 && m->D % 256 == 0 &&
+        m->Mp % 64 == 0 && m->Mp >= 1024)
+      rows_main = (rounds * cus / tiles_n) * 256;
+  }
+  p.M = rows_main;
+  RC(gemm<T>(m, "gemm_table_fwd", p, false, false, false));
+  if (rows_main < m->TR) {
+    const int64_t r0 = rows_main, nr = m->TR - rows_main;
+    float* Ft = (float*)m->F32 + r0 * m->D;
+    tic(m, "table_tail_rows");
+    RC(launch_add_bias_rows(m->P + m->o_E + r0 * m->D, m->P + m->o_bp, Ft, nr, (int)m->D, m->stream));
+    toc(m);
+    GemmParams q{};
+    q.A = (const T*)m->Meta + r0 * m->Mp; q.lda = m->Mp; q.B = W<T>(m, m->o_Wp); q.ldb = m->Mp; q.C = Ft; q.ldc = m->D; q.c_f32 = 1;
+    q.M = (int)nr; q.N = m->D; q.K = m->Mp; q.epi = EPI_ATOMIC; q.flags = 128;
+    RC(gemm<T>(m, "gemm_table_fwd_tail", q, false, false, false));
+    tic(m, "table_tail_rows");
+    RC(launch_cast<T>(Ft, (T*)m->FT + r0 * m->D, nr * m->D, m->stream));
+    toc(m);
+  }
+  return RSYS_OK;
 }
 
 // ------------------------------------------------------------------ fp8 trunk (f8.hip)

@@ -103,6 +103,22 @@ int launch_cast(const float* src, T* dst, long long n, hipStream_t s) {
 template int launch_cast<bf16>(const float*, bf16*, long long, hipStream_t);
 template int launch_cast<float>(const float*, float*, long long, hipStream_t);
 
+// dst[r][c] = a[r][c] + bias[c]: the start value of the split-K tail of the fused item table (model_forward.hip table_forward)
+__global__ void add_bias_rows_kernel(const float* __restrict__ a, const float* __restrict__ bias, float* __restrict__ dst, long long n, int D) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 x = *(const float4*)(a + i), b = *(const float4*)(bias + (int)(i % D));
+    *(float4*)(dst + i) = make_float4(x.x + b.x, x.y + b.y, x.z + b.z, x.w + b.w);
+  }
+}
+int launch_add_bias_rows(const float* a, const float* bias, float* dst, long long rows, int D, hipStream_t s) {
+  ARG_CHECK(D % 4 == 0, "add_bias_rows: D % 4");
+  const long long n = rows * D;
+  int grid = (int)std::min<long long>((n / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(add_bias_rows_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, a, bias, dst, n, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+
 __global__ void scale_kernel(float* g, long long n, const float* sumsq, float grad_div, float max_norm) {
   const float coef = grad_coef(sumsq, grad_div, max_norm);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) g[i] *= coef;

@@ -19,6 +19,7 @@ const Entry kEntries[] = {
     {"RSYS_GEMM_KERNEL_NT_SPLITK", &Switches::gemm_kernel_nt_splitk, -1},
     {"RSYS_GEMM8C", &Switches::gemm8c, 1},
     {"RSYS_GEMM_PATCH", &Switches::gemm_patch, 1},
+    {"RSYS_TABLE_TAIL", &Switches::table_tail, 1},
     {"RSYS_DW_GROUP", &Switches::dw_group, 1},
     {"RSYS_DET_DW_GROUP", &Switches::det_dw_group, 1},
     {"RSYS_SPARSE_TOP", &Switches::sparse_top, 1},

@@ -17,6 +17,7 @@ struct Switches {
   int gemm_kernel_nt_splitk;  // RSYS_GEMM_KERNEL_NT_SPLITK: -1 unset (shape rule); 0 off; 2 force
   int gemm8c;                 // RSYS_GEMM8C=0: row-major 256x256 products on gemm8p.hip (per-tile operand requests) instead of gemm8c.hip
   int gemm_patch;             // RSYS_GEMM_PATCH: 1 = band order of the output tiles for wide and tall outputs; 0 = row-major everywhere; 2 = bands everywhere
+  int table_tail;             // RSYS_TABLE_TAIL=0: the fused item table in ONE launch (its last persistent round on a fraction of the CUs) instead of main launch + split-K tail
   int dw_group;               // RSYS_DW_GROUP=0: one weight-gradient launch per product instead of the grouped launch
   int det_dw_group;           // RSYS_DET_DW_GROUP=0: deterministic mode on the per-layer slab path instead of the ordered grouped launch
   int sparse_top;             // RSYS_SPARSE_TOP=0: dense last layer and final norm
