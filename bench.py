@@ -446,6 +446,9 @@ def main():
         comm = rdist.Comm(hg, device)
     if sharded and comm is not None:
         model.set_shard_comm(comm)             # row exchange + vocabulary-parallel head run on this communicator
+    # DDP broadcasts rank 0's parameters when it wraps the model (transformer.py:678-682); here every rank initialised from the same seed
+    # and the ranks compare device-side checksums of their parameter buffers: now, and again behind the timed steps
+    replicas = {"after_init": rdist.assert_replicas_equal(model, comm, "after init") is not None} if comm is not None else None
     sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
     for _ in range(2000):
         sched.step()                           # bench at the stable learning rate
@@ -540,6 +543,8 @@ def main():
         collect(rep_t)
         model.timing(False)
     sched_log = comm.grad_schedule(model) if (comm is not None and hasattr(comm, "grad_schedule") and not zero1) else None
+    if replicas is not None:   # (outside the timed region: every rank still holds the same parameters after the timed steps' all-reduces)
+        replicas["after_timed_steps"] = rdist.assert_replicas_equal(model, comm, f"after {args.warmup + args.steps} data-parallel steps") is not None
     per_step = model.step_times_ms()
     plain = per_step[n_instr:] if len(per_step) > n_instr else per_step     # steps without per-kernel events
     # the reference's real loop (train.py:238-283) beside the resident-batch number: every step uploads its batch from an
@@ -684,6 +689,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "comm": comm_info,
+            "replicas_consistent": replicas,   # per-rank parameter checksums equal on every rank (None: one rank, nothing to compare)
             "switches": _lib_switches(),     # RSYS_* switches that differ from the library's defaults ({} = the shipped path)
             "config": {"workload": f"{args.config}: train step fwd+bwd+{'allreduce+' if comm is not None else ''}clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "

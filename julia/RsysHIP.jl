@@ -1,6 +1,6 @@
 # Julia binding of librsys_hip.so (C ABI: include/rsys.h) -- thin `ccall` wrappers, 1:1 with the header: every entry point of
-# the header is bound here except the per-kernel unit-test access (rsys_dev_*, rsys_op_gemm*, rsys_op_attention,
-# rsys_op_embedding_scatter).  tests/test_julia_binding.py parses the `ccall` tuples and the two struct mirrors below and checks
+# the header is bound here; the test and parity hooks of include/rsys_debug.h (index-path read-back, in-process rank group, per-kernel
+# access) are not part of the boundary and are not bound.  tests/test_julia_binding.py parses the `ccall` tuples and the two struct mirrors below and checks
 # names, arity and C types against include/rsys.h (Julia itself cannot run in the build image).
 #
 # NOT EXECUTED in the build container (Julia is absent from the image, SURVEY.md 8(c)); it is the stub a
@@ -203,9 +203,6 @@ function trunk_output(m::Model, rows::Integer, S::Integer, D::Integer)
     out = Array{Float32}(undef, D, 2S, rows)
     GC.@preserve out check(ccall((:rsys_trunk_output_get, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int64), m.h, out, length(out))); out
 end
-function debug_get!(m::Model, key::String, out::Array)
-    GC.@preserve out check(ccall((:rsys_debug_get, LIB), Int32, (Ptr{Cvoid}, Cstring, Ptr{Cvoid}, Int64), m.h, key, out, sizeof(out))); out
-end
 
 # ---- optimizer state (checkpoint / resume, transformer.py:456-466,690-695)
 function adamw_state(o::Optimizer, name::String, n::Integer)
@@ -237,13 +234,16 @@ function comm_info(c::Comm)
     out = zeros(Int32, 4)
     GC.@preserve out check(ccall((:rsys_comm_info, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), c.h, out)); out
 end
-# in-process rank group (tests on a one-GPU box): `world` ranks as host threads of this process
-function local_group(world::Integer, device::Integer)
-    g = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:rsys_local_group_create, LIB), Int32, (Int32, Int32, Ref{Ptr{Cvoid}}), world, device, g)); g[]
+# replica consistency (DDP's parameter broadcast, transformer.py:678-682, replaced by same-seed init + comparison): this rank's four
+# checksum words travel in one slot per rank of a SUM all-reduce (the other slots zero: exact), then every rank compares all slots
+function param_checksum(m::Model)
+    out = zeros(Float64, 4)
+    GC.@preserve out check(ccall((:rsys_param_checksum, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), m.h, out)); out
 end
-local_group_destroy(g::Ptr{Cvoid}) = check(ccall((:rsys_local_group_destroy, LIB), Int32, (Ptr{Cvoid},), g))
-function local_comm(g::Ptr{Cvoid}, rank::Integer, world::Integer)
-    h = Ref{Ptr{Cvoid}}(C_NULL); check(ccall((:rsys_comm_init_local, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), g, rank, h)); Comm(h[], world)
+function assert_replicas_equal(m::Model, c::Comm, rank::Integer, what::String = "")
+    w = param_checksum(m); slots = zeros(Float64, 4 * c.world); slots[4rank + 1:4rank + 4] = w
+    allreduce_f64!(c, slots)
+    all(slots[4r + 1:4r + 4] == w for r in 0:c.world - 1) || error("replicas differ $what: $(reshape(slots, 4, :))")
 end
 
 # ---- instrumentation

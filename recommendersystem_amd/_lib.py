@@ -1,4 +1,4 @@
-"""ctypes binding of librsys_hip.so (C ABI: include/rsys.h).
+"""ctypes binding of librsys_hip.so (C ABI: include/rsys.h; test and parity hooks: include/rsys_debug.h).
 
 The HIP library is the product path: there is no CPU fallback.  Importing this
 module without the built library raises; calling compute entry points without a
@@ -45,7 +45,7 @@ class rsys_batch(C.Structure):
     ]
 
 
-# every symbol include/rsys.h declares: (name, restype, argtypes)
+# every symbol include/rsys.h and include/rsys_debug.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 _SIGS = [
     ("rsys_version", C.c_char_p, []),
@@ -103,6 +103,7 @@ _SIGS = [
     ("rsys_comm_info", C.c_int32, [_P, C.POINTER(C.c_int32)]),
     ("rsys_allreduce_f64", C.c_int32, [_P, C.POINTER(C.c_double), C.c_int32]),
     ("rsys_self_test", C.c_int32, [_P]),
+    ("rsys_param_checksum", C.c_int32, [_P, C.POINTER(C.c_double * 4)]),
     ("rsys_grad_buffer", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     ("rsys_param_buffer", C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     ("rsys_refresh_shadow", C.c_int32, [_P]),

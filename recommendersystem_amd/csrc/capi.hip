@@ -267,6 +267,32 @@ int32_t rsys_debug_get(rsys_model* h, const char* key, void* out, int64_t bytes)
 
 int32_t rsys_clip_grad_norm(rsys_model* h, float max_norm, float* norm_out) { CHECK_HANDLE(h); return model_clip(h->m, max_norm, norm_out); }
 
+// Replica-consistency words of this rank's parameters (transformer.py:678-682): the flat fp32 parameter buffer -- of a
+// row-sharded model everything but its table rows, which differ between the ranks by construction -- as {fp64 sum, fp64 sum of
+// squares, low and high 32 bits of a position-weighted integer sum of the bit patterns}.  Synchronises.
+int32_t rsys_param_checksum(rsys_model* h, double out[4]) {
+  CHECK_HANDLE(h);
+  ARG_CHECK(out != nullptr, "rsys_param_checksum: out is NULL");
+  Model* m = h->m;
+  HIP_CHECK(hipSetDevice(m->device));
+  double* scratch = nullptr;
+  HIP_CHECK(hipMalloc((void**)&scratch, (size_t)checksum_scratch_doubles() * 8));
+  long long ranges[4] = {0, m->n_total, 0, 0};
+  int nr = 1;
+  if (m->sharded && m->sh_world > 1) {
+    ranges[1] = m->o_E; ranges[2] = m->o_E + ((int64_t)m->TR * m->D + 7) / 8 * 8; ranges[3] = m->n_total; nr = 2;
+  }
+  double* out_dev = scratch + checksum_scratch_doubles() - 4;
+  int rc = launch_checksum(m->P, ranges, nr, scratch, out_dev, m->stream);
+  if (rc == RSYS_OK) {
+    hipError_t e = hipMemcpyAsync(out, out_dev, 32, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) { set_error(std::string("rsys_param_checksum: ") + hipGetErrorString(e)); rc = RSYS_ERR_HIP; }
+  }
+  (void)hipFree(scratch);
+  return rc;
+}
+
 int32_t rsys_adamw_create(rsys_model* h, float lr, float b1, float b2, float eps, float wd, rsys_optimizer** out) {
   CHECK_HANDLE(h);
   Model* m = h->m;

@@ -513,7 +513,10 @@ static bool use_8p_nt_splitk(const GemmParams& p) {
   if (p.epi != EPI_ATOMIC || !gemm8p_nt_splitk_eligible(p)) return false;
   if (sw().gemm_kernel_nt_splitk == 2 || (p.flags & 128)) return true;   // 2: force; flags bit 7: the caller wants the 256x256 split-K form for a few tiles (table_forward's tail)
   // (RSYS_GEMM_KERNEL_NT_SPLITK=2: tools/ab_dw_rowmajor.py: the trunk's weight-gradient shapes on K-contiguous copies)
-  return (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 32;
+  // from 32 output tiles on; from 8 when K is long enough that the K splits fill the chip by themselves (cfg-2's metadata-projection
+  // gradient: 256 x 6148 outputs = 25 tiles, K = 100 K: 0.59 -> 0.33 ms against the 128x128 kernel, profiles/r6b_*)
+  const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  return t256 >= 32 || (t256 >= 8 && (long long)p.K * t256 >= 32LL * 16384);
 }
 
 const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km) {

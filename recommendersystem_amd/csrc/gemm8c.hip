@@ -20,6 +20,11 @@
 //    memory retires in issue order per wave, so a wave that waits for its LDS-DMA also waits for every older store, and stores to
 //    HBM need longer than the two K tiles of prefetch the LDS allows.  Starting the workgroups of an XCD staggered in time changed
 //    nothing either: the output stream is bound per CU (bytes in flight / store latency), not by the CUs storing together.
+//  * HALF form (round 6, template parameter): 128 x 256 output tiles for outputs with fewer 256 x 256 tiles than CUs (cfg-2's N = 256
+//    products: 128 tiles, half the chip idle while the other half streams its output).  Same LDS image, same barriers and the same
+//    request stream minus the second row half of A: the A image holds 128 rows, wave row wr owns rows [64 wr, 64 wr + 64) as 4 x 4
+//    accumulator blocks, phases P1 / P2 carry the tile's 2 x 16 MFMAs per wave and P3 / P4 only issue requests; one counted wait
+//    per K tile (P4: B1 of the next K tile has landed).  Bit-identical to the full form (same K order per accumulator).
 #include <algorithm>
 
 #include "gemm.hpp"
@@ -56,10 +61,10 @@ struct C8Cur {
 struct C8Tile { int t, tm, tn; };
 
 // lower bound on the stores a register epilogue issues after its last load (see gemm8p.hip `pend`)
-template <int EC, bool CF32>
+template <int EC, bool CF32, bool HALF = false>
 constexpr int c8_pend() {
-  if (EC == EPI_STORE) return CF32 ? 32 : 16;   // (no loads: all stores)
-  if (EC == EPI_SWIGLU) return 24;
+  if (EC == EPI_STORE) return (CF32 ? 32 : 16) / (HALF ? 2 : 1);   // (no loads: all stores)
+  if (EC == EPI_SWIGLU) return HALF ? 12 : 24;
   if (EC == EPI_ACCUM || EC == EPI_RESIDUAL || EC == EPI_SWIGLU_BWD) return 8;   // (the stores of the last two row blocks)
   if (EC == EPI_TABLE) return 12;
   if (EC == EPI_QKV_ROPE) return CF32 ? 8 : 4;
@@ -68,8 +73,10 @@ constexpr int c8_pend() {
 
 template <int N> __device__ __forceinline__ void c8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EC, bool CF32>
+template <int EC, bool CF32, bool HALF = false>
 __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
+  constexpr int BMT = HALF ? 128 : C8_BM;   // rows of an output tile
+  constexpr int WROWS = BMT / 2;            // rows of a wave row's block
   __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];   // [buf][A h0 | A h1 | B h0 | B h1] x 16 KB
   const int t = threadIdx.x, l0 = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
   // ---- the workgroup's run of output tiles (XCD-aware, as gemm8p.hip)
   const int tiles_n = (p.N + C8_BN - 1) / C8_BN;
   const int rows = __builtin_amdgcn_readfirstlane(p.m_dev != nullptr ? min(*p.m_dev, p.M) : p.M);   // (a vector load: make it scalar again)
-  const int ntiles = ((rows + C8_BM - 1) / C8_BM) * tiles_n;
+  const int ntiles = ((rows + BMT - 1) / BMT) * tiles_n;
   int tile_first, tile_end, tile_step;
   {
     const int xcd = bid & 7, q = ntiles >> 3, r = ntiles & 7;
@@ -119,7 +126,8 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       const int c = (l & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        aoff[j][h] = (unsigned int)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned int)(p.lda * 2) + (unsigned int)(c * 16);
+        // (HALF: the A image's first half holds the tile's 128 rows in order, the second half is never requested)
+        aoff[j][h] = (unsigned int)(HALF ? lr : (lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned int)(p.lda * 2) + (unsigned int)(c * 16);
         boff[j][h] = (unsigned int)((lr >> 5) * 64 + h * 32 + (lr & 31)) * (unsigned int)(p.ldb * 2) + (unsigned int)(c * 16);
       }
     }
@@ -209,31 +217,33 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     C8_BARRIER();
     // P2
     read_b(bf1, bo, 1);
-    if constexpr (dma12) stage_a(cn, I1{}, bn);
-    c8_wait_vm<8 + x2>();
+    if constexpr (!HALF) {
+      if constexpr (dma12) stage_a(cn, I1{}, bn);
+      c8_wait_vm<8 + x2>();
+    }
     C8_BARRIER();
     mma_q(I0{}, I1{}, C0, bf1);
     C8_BARRIER();
     // P3
-    read_a(bo, 1);
+    if constexpr (!HALF) read_a(bo, 1);
     stage_b(cs, I0{}, bo);
     C8_BARRIER();
-    mma_q(I1{}, I1{}, C0, bf1);
+    if constexpr (!HALF) mma_q(I1{}, I1{}, C0, bf1);
     C8_BARRIER();
-    // P4
+    // P4 (HALF: the two half-tiles requested after B1 of the next K tile stay in flight)
     stage_a(cs, I0{}, bo);
-    c8_wait_vm<6 + x4>();
+    c8_wait_vm<(HALF ? 4 : 6) + x4>();
     C8_BARRIER();
-    mma_q(I1{}, I0{}, C0, bf0);
+    if constexpr (!HALF) mma_q(I1{}, I0{}, C0, bf0);
     C8_BARRIER();
     bo = bn;
   };
   using T_ = std::true_type; using F_ = std::false_type;
   auto run_pass = [&](auto FULLC) __attribute__((always_inline)) {
     constexpr bool WANT = decltype(FULLC)::value;
-    constexpr int PEND = WANT ? c8_pend<EC, CF32>() : 0;
+    constexpr int PEND = WANT ? c8_pend<EC, CF32, HALF>() : 0;
     auto tile_full = [&](const C8Tile& x) __attribute__((always_inline)) -> bool {
-      return x.tm * C8_BM + C8_BM <= p.M && x.tn * C8_BN + C8_BN <= p.N;
+      return x.tm * BMT + BMT <= p.M && x.tn * C8_BN + C8_BN <= p.N;
     };
     auto tile_inc = [&](C8Tile& x) __attribute__((always_inline)) {
       x.t += tile_step;
@@ -248,11 +258,11 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     auto set_tile = [&](C8Cur& c, const C8Tile& x) __attribute__((always_inline)) {
       c.kt = 0;
       if (x.t < tile_end) {
-        const int m0 = x.tm * C8_BM, n0 = x.tn * C8_BN;
+        const int m0 = x.tm * BMT, n0 = x.tn * C8_BN;
         c.a = (const char*)p.A + (long long)m0 * p.lda * 2;
         c.b = (const char*)p.B + (long long)n0 * p.ldb * 2;
         // (launcher: 256 rows of either operand span < 4 GB)
-        c.ra = (unsigned int)min(p.M - 1 - m0, 255) * (unsigned int)(p.lda * 2) + 128u;
+        c.ra = (unsigned int)min(p.M - 1 - m0, BMT - 1) * (unsigned int)(p.lda * 2) + 128u;
         c.rb = (unsigned int)min(p.N - 1 - n0, 255) * (unsigned int)(p.ldb * 2) + 128u;
       } else { c.a = (const char*)p.A; c.b = (const char*)p.B; c.ra = 0; c.rb = 0; }
     };
@@ -273,17 +283,18 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       if (nx_stale) { ts = next_tile(ts); nx_stale = false; }
       set_tile(nx, next_tile(ts));
     };
-    // K tile 0 (all four half-tiles) and the first halves of K tile 1: 12 DMA instructions per wave
+    // K tile 0 (all four half-tiles; HALF: three) and the first halves of K tile 1: 12 (10) DMA instructions per wave
     C8Cur c0;
     set_tile(c0, tile);
     set_tile(nx, next_tile(ts));
     bo = 0;
-    stage_b(c0, I0{}, 0); stage_a(c0, I0{}, 0); stage_b(c0, I1{}, 0); stage_a(c0, I1{}, 0);
+    stage_b(c0, I0{}, 0); stage_a(c0, I0{}, 0); stage_b(c0, I1{}, 0);
+    if constexpr (!HALF) stage_a(c0, I1{}, 0);
     cn = c0; advance(cn);
     stage_b(cn, I0{}, 65536); stage_a(cn, I0{}, 65536);
     cs = cn; advance(cs);
     if (nx_stale) refresh_nx();   // (nt == 2: the stream is already in the second output tile)
-    c8_wait_vm<6>();   // B0, A0, B1 of K tile 0 have landed
+    c8_wait_vm<(HALF ? 4 : 6)>();   // B0, A0, B1 of K tile 0 have landed
     C8_BARRIER();
     if (wr == 1) C8_BARRIER();   // the second wave row runs one barrier behind the first
     auto step = [&]() __attribute__((always_inline)) { cn = cs; advance(cs); };
@@ -295,12 +306,13 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     C8Tile tnext = next_tile(tile);
 #pragma unroll 1
     while (tnext.t < tile_end) {
-      const int em0 = tile.tm * C8_BM, en0 = tile.tn * C8_BN;
+      const int em0 = tile.tm * BMT, en0 = tile.tn * C8_BN;
       refresh_nx();
       // run-ahead: second halves of the next K tile but one (their LDS slots were last read a phase ago), then the register epilogue
-      stage_b(cn, I1{}, bo ^ 65536); stage_a(cn, I1{}, bo ^ 65536);
+      stage_b(cn, I1{}, bo ^ 65536);
+      if constexpr (!HALF) stage_a(cn, I1{}, bo ^ 65536);
       if constexpr (C8_DEBUG == 1) keep_acc(); else
-      epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+      epilogue_regs<WANT ? 1 : 0, EC, HALF ? 4 : 8>(p, acc, em0 + wr * WROWS, en0 + wc * 64, WANT, fq, fr);
       if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): edge epilogues leave masked loads "pending" for hipcc
       lane_setup();
       body(T_{}, F_{}, PD{}, PD{}); step();
@@ -311,10 +323,10 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
       tnext = next_tile(tile);
     }
     {   // last tile of the pass: nothing left to overlap with
-      const int em0 = tile.tm * C8_BM, en0 = tile.tn * C8_BN;
+      const int em0 = tile.tm * BMT, en0 = tile.tn * C8_BN;
       if (wr == 0) C8_BARRIER();   // rejoin (equal barrier counts)
       if constexpr (C8_DEBUG == 1) keep_acc(); else
-      epilogue_regs<WANT ? 1 : 0, EC>(p, acc, em0 + wr * 128, en0 + wc * 64, WANT, fq, fr);
+      epilogue_regs<WANT ? 1 : 0, EC, HALF ? 4 : 8>(p, acc, em0 + wr * WROWS, en0 + wc * 64, WANT, fq, fr);
       if constexpr (!WANT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
   };
@@ -338,11 +350,31 @@ bool gemm8c_eligible(const GemmParams& p) {
   }
 }
 
+// The HALF form (128 x 256 tiles) has kernels for the classes that meet narrow outputs in a training step (plain bf16 store, fp32
+// residual, QKV + RoPE, SwiGLU forward / backward).  RSYS_GEMM8C_HALF: 1 (default) = when the output has fewer 256 x 256 tiles than the chip
+// has CUs, 0 = never, 2 = wherever a kernel exists (tests: both forms on every shape).
+static bool c8_half_class(const GemmParams& p) {
+  switch (p.epi) {
+    case EPI_STORE: return !p.c_f32;
+    case EPI_RESIDUAL: case EPI_QKV_ROPE: case EPI_SWIGLU: case EPI_SWIGLU_BWD: return true;
+    default: return false;
+  }
+}
+bool gemm8c_uses_half(const GemmParams& p, int cus) {
+  const int mode = sw().gemm8c_half;
+  if (mode == 0 || !c8_half_class(p)) return false;
+  if (mode == 2) return true;
+  const long long t256 = (long long)((p.M + C8_BM - 1) / C8_BM) * ((p.N + C8_BN - 1) / C8_BN);
+  return t256 < cus;
+}
+
 int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   int cus = 256;
   { static int n = 0; if (n == 0) { int dev = 0, v = 0; n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; } cus = n; }
-  const int tiles = ((p.M + C8_BM - 1) / C8_BM) * ((p.N + C8_BN - 1) / C8_BN);
+  const bool half = gemm8c_uses_half(p, cus);
+  const int bmt = half ? 128 : C8_BM;
+  const int tiles = ((p.M + bmt - 1) / bmt) * ((p.N + C8_BN - 1) / C8_BN);
   const dim3 grid((p.flags & 2) && p.m_dev == nullptr ? tiles : std::min(tiles, cus)), blk(512);
   {
     // RSYS_GEMM_PATCH=0: row-major tile order everywhere (A/B), 2: band order everywhere (the GEMM tests compare the orders)
@@ -354,14 +386,27 @@ int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   switch (p.epi) {
     case EPI_STORE:
       if (p.c_f32) hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, true>), grid, blk, 0, s, p);
+      else if (half) hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, false, true>), grid, blk, 0, s, p);
       else hipLaunchKernelGGL((gemm8c_kernel<EPI_STORE, false>), grid, blk, 0, s, p);
       break;
-    case EPI_SWIGLU: hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false>), grid, blk, 0, s, p); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm8c_kernel<EPI_RESIDUAL, true>), grid, blk, 0, s, p); break;
+    case EPI_SWIGLU:
+      if (half) hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false, true>), grid, blk, 0, s, p);
+      else hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU, false>), grid, blk, 0, s, p);
+      break;
+    case EPI_RESIDUAL:
+      if (half) hipLaunchKernelGGL((gemm8c_kernel<EPI_RESIDUAL, true, true>), grid, blk, 0, s, p);
+      else hipLaunchKernelGGL((gemm8c_kernel<EPI_RESIDUAL, true>), grid, blk, 0, s, p);
+      break;
     case EPI_ACCUM: hipLaunchKernelGGL((gemm8c_kernel<EPI_ACCUM, true>), grid, blk, 0, s, p); break;
-    case EPI_SWIGLU_BWD: hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU_BWD, false>), grid, blk, 0, s, p); break;
+    case EPI_SWIGLU_BWD:
+      if (half) hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU_BWD, false, true>), grid, blk, 0, s, p);
+      else hipLaunchKernelGGL((gemm8c_kernel<EPI_SWIGLU_BWD, false>), grid, blk, 0, s, p);
+      break;
     case EPI_TABLE: hipLaunchKernelGGL((gemm8c_kernel<EPI_TABLE, true>), grid, blk, 0, s, p); break;
-    case EPI_QKV_ROPE: hipLaunchKernelGGL((gemm8c_kernel<EPI_QKV_ROPE, false>), grid, blk, 0, s, p); break;
+    case EPI_QKV_ROPE:
+      if (half) hipLaunchKernelGGL((gemm8c_kernel<EPI_QKV_ROPE, false, true>), grid, blk, 0, s, p);
+      else hipLaunchKernelGGL((gemm8c_kernel<EPI_QKV_ROPE, false>), grid, blk, 0, s, p);
+      break;
     default: set_error("gemm8c: epilogue class without a kernel"); return RSYS_ERR_ARG;
   }
   HIP_CHECK(hipGetLastError());

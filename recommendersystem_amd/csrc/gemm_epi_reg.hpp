@@ -18,7 +18,8 @@ namespace rsys {
 // full tiles and its edge tiles in two separate loops); -1: decided by `full` at run time.
 // ECF >= 0: the epilogue class is known at compile time (gemm8c.hip: one kernel per class; EPI_QKV_ROPE there means the
 // implicit positions row % T), else it is p.epi.
-template <int MODE = -1, int ECF = -1>
+// NRB: row blocks of 16 the wave owns (8; 4 in the 128-row tiles of gemm8c's HALF form, which leave acc[4..7] unused).
+template <int MODE = -1, int ECF = -1, int NRB = 8>
 __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (&acc)[8][4], int wm0, int wn0, bool full,
                                               int fq, int fr) {
   auto pk2 = [](float a, float b) __attribute__((always_inline)) -> unsigned int {
@@ -262,19 +263,19 @@ __device__ __forceinline__ void epilogue_regs(const GemmParams& p, const f32x4 (
         }
       }
     };
-    // software pipeline over the 8 row blocks: the operands of block i+1 are in flight while block i is finished.  (Two
+    // software pipeline over the 8 (NRB) row blocks: the operands of block i+1 are in flight while block i is finished.  (Two
     // blocks of lookahead measured the same -- 31 K vs 33 K cycles per tile for the residual epilogue,
     // tools/micro/gemm8p_trace.hip: with every CU in its epilogue at once these loads are bandwidth-, not latency-bound
     // -- and cost 16 more registers.)  The memory clobbers keep each request ahead of the stores that follow it in
     // program order: the persistent kernel counts on "the stores of the last row block follow the last load".
     Pre pa, pb;
     request(std::integral_constant<int, 0>{}, pa);
-    static_for<4>([&](auto H) __attribute__((always_inline))  {
+    static_for<NRB / 2>([&](auto H) __attribute__((always_inline))  {
       constexpr int i = decltype(H)::value * 2;
       request(std::integral_constant<int, i + 1>{}, pb);
       asm volatile("" ::: "memory");
       finish(std::integral_constant<int, i>{}, pa);
-      if constexpr (i + 2 < 8) { request(std::integral_constant<int, i + 2>{}, pa); asm volatile("" ::: "memory"); }
+      if constexpr (i + 2 < NRB) { request(std::integral_constant<int, i + 2>{}, pa); asm volatile("" ::: "memory"); }
       finish(std::integral_constant<int, i + 1>{}, pb);
     });
     if constexpr (ec == EPI_SWIGLU || ec == EPI_SWIGLU_BWD) {

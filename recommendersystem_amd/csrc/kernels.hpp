@@ -223,7 +223,14 @@ template <typename T> int launch_attn_fwd(const AttnParams& p, hipStream_t s);
 template <typename T> int launch_attn_bwd(const AttnParams& p, hipStream_t s);
 
 // ---- optimizer (optim.hip)
-int launch_sumsq(const float* g, long long n, float* out /*device scalar, accumulated*/, hipStream_t s);
+// *out += sum of g[i]^2 in a fixed order (bitwise the same on every rank for the same gradient); part: sumsq_parts() floats of device scratch,
+// reused by consecutive calls on one stream
+int launch_sumsq(const float* g, long long n, float* out /*device scalar, accumulated*/, float* part, hipStream_t s);
+int sumsq_parts();
+// replica-consistency checksum of the ranges [ranges[2r], ranges[2r+1]) of a flat fp32 buffer: out (device) = {fp64 sum, fp64 sum of squares,
+// low / high 32 bits of a position-weighted wrapping sum of the bit patterns}; part = checksum_scratch_doubles() doubles of device scratch
+int launch_checksum(const float* p, const long long* ranges, int n_ranges, double* part, double* out, hipStream_t s);
+int checksum_scratch_doubles();
 template <typename T>
 int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_decay, long long n_total,
                  float lr, float b1, float b2, float eps, float wd, int step, const float* sumsq, float grad_div,

@@ -280,7 +280,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
   DALLOC(m->dab, NT * 2 * m->Ip * e); DALLOC(m->dhn, NT * D * e);
   DALLOC(m->dO, NT * D * e); DALLOC(m->dqkv, NT * m->Nqkv * e);
   DALLOC(m->delta, (int64_t)m->rows_max * m->H * m->T * 4); DALLOC(m->gf, N * 32 * 4);
-  DALLOC(m->sumsq, 64);
+  DALLOC(m->sumsq, 64); DALLOC(m->sumsq_part, (size_t)sumsq_parts() * 4);
   DALLOC(m->sel_scratch, 12 * 32 * 4);
   m->dLa = nullptr; m->dxl = nullptr;
   if (cfg->finetune) { DALLOC(m->dLa, NT * 16 * e); DALLOC(m->dxl, NT * D * e); }

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/rsys.h"
+#include "../../include/rsys_debug.h"
 #include "comm.hpp"
 #include "gemm.hpp"
 #include "kernels.hpp"
@@ -213,7 +214,7 @@ struct Model {
   float *gy, *gxa, *gxb, *dh; void *gxa_t, *gxb_t, *dh_t;   // *_t: T-typed operand copies (bf16 mode)
   void *dab, *dhn, *dO, *dqkv; float* delta; float* gf;
   void *dLa, *dxl;   // finetune workspaces
-  float* sumsq;
+  float* sumsq; float* sumsq_part;   // the gradient norm's scalar and the per-workgroup partial sums of its fixed-order reduction
   // Deferred, grouped weight gradients (bf16 pretraining, products too small for the chip one at a time): the backward keeps
   // every layer's dY operands (gradient of the layer's output, of the SwiGLU pre-activations, of the attention residual, of
   // q/k/v) in per-layer buffers and ONE grouped launch (per gradient bucket when buckets are reduced early) computes the four

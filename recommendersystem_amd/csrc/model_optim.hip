@@ -7,12 +7,12 @@ namespace rsys {
 // (after the all-reduce), the table rows differ: their sum of squares is all-reduced and added.
 static int grad_sumsq(Model* m) {
   HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
-  if (!m->sharded || !comm_active(m->shard_comm)) return launch_sumsq(m->G, m->n_opt, m->sumsq, m->stream);
+  if (!m->sharded || !comm_active(m->shard_comm)) return launch_sumsq(m->G, m->n_opt, m->sumsq, m->sumsq_part, m->stream);
   const int64_t e0 = m->o_E, e1 = m->o_E + (int64_t)m->TR * m->D;
-  RC(launch_sumsq(m->G, e0, m->sumsq, m->stream));
-  RC(launch_sumsq(m->G + e1, m->n_opt - e1, m->sumsq, m->stream));
+  RC(launch_sumsq(m->G, e0, m->sumsq, m->sumsq_part, m->stream));
+  RC(launch_sumsq(m->G + e1, m->n_opt - e1, m->sumsq, m->sumsq_part, m->stream));
   HIP_CHECK(hipMemsetAsync(m->sumsq_E, 0, 4, m->stream));
-  RC(launch_sumsq(m->G + e0, e1 - e0, m->sumsq_E, m->stream));
+  RC(launch_sumsq(m->G + e0, e1 - e0, m->sumsq_E, m->sumsq_part, m->stream));
   RC(comm_all_reduce_f32(m->shard_comm, m->sumsq_E, 1, COMM_SUM, m->stream));
   return launch_add_scalar(m->sumsq, m->sumsq_E, m->stream);
 }
@@ -106,8 +106,8 @@ int optimizer_step_zero1(Optimizer* o, rsys_comm* c, float lr_factor, float clip
   const float* ss = nullptr;
   if (clip > 0.f) {
     HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, s));
-    RC(launch_sumsq(m->G + lo, chunk, m->sumsq, s));
-    if (last && tail > 0) RC(launch_sumsq(m->G + tail_lo, tail, m->sumsq, s));
+    RC(launch_sumsq(m->G + lo, chunk, m->sumsq, m->sumsq_part, s));
+    if (last && tail > 0) RC(launch_sumsq(m->G + tail_lo, tail, m->sumsq, m->sumsq_part, s));
     RC(comm_all_reduce_f32(c, m->sumsq, 1, COMM_SUM, s));
     ss = m->sumsq;
   }

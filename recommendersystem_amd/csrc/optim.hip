@@ -5,31 +5,101 @@
 
 namespace rsys {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* out, float* part) {
+// Sum of squares of a flat fp32 range, ALWAYS in a fixed order (round 6): per-workgroup partial sums (fixed grid for a given n, fixed
+// in-block tree) and one small workgroup that adds them in index order into `out`.  The float-atomic form it replaces gave every rank of
+// a data-parallel job its own rounding of the SAME all-reduced gradient's norm, hence its own clip coefficient, and the replicas drifted
+// apart by an ulp per step -- found by the replica-consistency check (dist.assert_replicas_equal) on three in-process ranks.  Four
+// independent 16-byte loads per thread per trip (the one-load loop ran at 0.33 of the HBM peak on cfg-2's 133 MB).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
   __shared__ float red[16];
-  float acc = 0.f;
-  const long long n4 = n >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 v = ((const float4*)g)[i];
-    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float4* g4 = (const float4*)g;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    a0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+    a1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    a2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+    a3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = g4[i];
+    a0 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   if (blockIdx.x == 0)
-    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += g[i] * g[i];
-  acc = block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    if (part != nullptr) part[blockIdx.x] = acc;   // deterministic mode: added in workgroup order afterwards
-    else atomicAdd(out, acc);
-  }
+    for (long long k = (n4 << 2) + threadIdx.x; k < n; k += blockDim.x) a1 += g[k] * g[k];
+  const float acc = block_sum((a0 + a1) + (a2 + a3), red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) *out += a;
 }
 
-int launch_sumsq(const float* g, long long n, float* out, hipStream_t s) {
-  int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
-  float* part = (g_det.part != nullptr && grid <= g_det.cap) ? g_det.part : nullptr;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, out, part);
+int sumsq_parts() { return 2048; }
+int launch_sumsq(const float* g, long long n, float* out, float* part, hipStream_t s) {
+  ARG_CHECK(part != nullptr, "sumsq: no partial-sum buffer");
+  if (n <= 0) return RSYS_OK;
+  ARG_CHECK(((uintptr_t)g % 16) == 0, "sumsq: the range must start on a 16-byte boundary");
+  const int grid = (int)std::min<long long>(((n >> 2) + 1023) / 1024 + 1, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, part);
   HIP_CHECK(hipGetLastError());
-  if (part != nullptr) return launch_reduce_parts(part, grid, 1, 1, out, s);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, part, grid, out);
+  HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
+
+// Replica-consistency checksum of a flat fp32 range (DDP's constructor broadcasts rank 0's parameters,
+// transformer.py:678-682; here every rank initialises from the same seed and the ranks COMPARE): fp64 sum, fp64 sum of squares and the
+// wrapping 64-bit sum of the floats' bit patterns.  Fixed grid, fixed in-block tree, partials added in workgroup order by one
+// workgroup: the same values give the same three words on every rank, and the integer word notices any differing bit that the two
+// float sums could round away.  acc[3 * gridDim.x] holds the partials; out = {sum, sumsq, bits low 32, bits high 32} (exact in doubles).
+static constexpr int CHECKSUM_GRID = 1024;
+__global__ __launch_bounds__(256) void checksum_part_kernel(const float* __restrict__ p, long long n, double* part, int add) {
+  __shared__ double s0[256], s1[256];
+  __shared__ unsigned long long s2[256];
+  double a = 0.0, b = 0.0;
+  unsigned long long c = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    a += (double)v; b += (double)v * (double)v; c += (unsigned long long)__float_as_uint(v) * (unsigned long long)((i & 1023) + 1);
+  }
+  s0[threadIdx.x] = a; s1[threadIdx.x] = b; s2[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; s2[threadIdx.x] += s2[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double* q = part + 3 * blockIdx.x;
+    unsigned long long prev = add ? (unsigned long long)__double_as_longlong(q[2]) : 0ull;
+    q[0] = (add ? q[0] : 0.0) + s0[0]; q[1] = (add ? q[1] : 0.0) + s1[0];
+    q[2] = __longlong_as_double((long long)(prev + s2[0]));   // (the integer word travels in a double-sized slot)
+  }
+}
+__global__ __launch_bounds__(64) void checksum_final_kernel(const double* part, int nparts, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0; unsigned long long c = 0;
+  for (int i = 0; i < nparts; ++i) { a += part[3 * i]; b += part[3 * i + 1]; c += (unsigned long long)__double_as_longlong(part[3 * i + 2]); }
+  out[0] = a; out[1] = b; out[2] = (double)(unsigned int)(c & 0xffffffffull); out[3] = (double)(unsigned int)(c >> 32);
+}
+// ranges: n_ranges pairs {first element, one past the last}; part: 3 * CHECKSUM_GRID doubles; out: 4 doubles (device)
+int launch_checksum(const float* p, const long long* ranges, int n_ranges, double* part, double* out, hipStream_t s) {
+  for (int r = 0; r < n_ranges; ++r) {
+    const long long lo = ranges[2 * r], hi = ranges[2 * r + 1];
+    ARG_CHECK(hi >= lo, "checksum: empty or reversed range");
+    hipLaunchKernelGGL(checksum_part_kernel, dim3(CHECKSUM_GRID), dim3(256), 0, s, p + lo, hi - lo, part, r > 0 ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(checksum_final_kernel, dim3(1), dim3(64), 0, s, part, CHECKSUM_GRID, out);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+int checksum_scratch_doubles() { return 3 * CHECKSUM_GRID + 4; }
 
 // clip coefficient of torch.nn.utils.clip_grad_norm_: min(1, max_norm / (norm + 1e-6)); grads are first
 // divided by grad_div (data-parallel mean, folded in here instead of a separate pass)

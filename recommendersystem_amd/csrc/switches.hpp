@@ -12,9 +12,10 @@ struct Switches {
   int attn_dma;               // RSYS_ATTN_DMA=0: bf16 / head_dim 64 on the register-staged attention kernels (every other head size's kernels)
   int attn_kv_dma;            // RSYS_ATTN_KV_DMA=0: dK/dV alone on the register-staged kernel
   int attn_kv32;              // RSYS_ATTN_KV32=0: dK/dV on the 16-key-per-wave LDS-DMA kernel (the bitwise partner of the register-staged one)
-  int gemm_kernel;            // RSYS_GEMM_KERNEL: -1 unset (shape rule); 0 = 64x64 kernel, 1 = 128x128, 2 = 256x256 LDS-DMA wherever eligible
-  int gemm_kernel_tn;         // RSYS_GEMM_KERNEL_TN: -1 unset (shape rule); 0 = never the K-major LDS-DMA kernels, 1 = split-K form, 2 = store form too
+  int gemm_kernel;            // RSYS_GEMM_KERNEL: -1 unset / 0 (shape rule); 1 = the 128x128 register-staged kernel everywhere, 2 = 256x256 LDS-DMA wherever eligible
+  int gemm_kernel_tn;         // RSYS_GEMM_KERNEL_TN: -1 unset / 0 (shape rule); 1 = never the K-major LDS-DMA kernels, 2 = both their forms (split-K, store) wherever eligible
   int gemm_kernel_nt_splitk;  // RSYS_GEMM_KERNEL_NT_SPLITK: -1 unset (shape rule); 0 off; 2 force
+  int gemm8c_half;            // RSYS_GEMM8C_HALF: 1 = 128x256 output tiles for outputs with fewer 256x256 tiles than CUs; 0 = never; 2 = wherever the class has the kernel
   int gemm8c;                 // RSYS_GEMM8C=0: row-major 256x256 products on gemm8p.hip (per-tile operand requests) instead of gemm8c.hip
   int gemm_patch;             // RSYS_GEMM_PATCH: 1 = band order of the output tiles for wide and tall outputs; 0 = row-major everywhere; 2 = bands everywhere
   int table_tail;             // RSYS_TABLE_TAIL=0: the fused item table in ONE launch (its last persistent round on a fraction of the CUs) instead of main launch + split-K tail

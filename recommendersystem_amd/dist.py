@@ -410,6 +410,35 @@ def make_comm(host_group, device):
     return _no_rccl(host_group, err or "another rank failed")
 
 
+class ReplicaMismatch(RuntimeError):
+    pass
+
+
+def assert_replicas_equal(model, comm, what=""):
+    """The reference's DDP constructor broadcasts rank 0's parameters to every rank (transformer.py:678-682).  Here every rank builds
+    the same parameters itself (same seed, same checkpoint file) and the ranks VERIFY it: each rank's checksum words
+    (`model.param_checksum()`: fp64 sum, fp64 sum of squares and an integer sum of the bit patterns, computed in a fixed order on the
+    device -- or the words themselves, for a caller that has no device model) travel in one slot per rank of a SUM all-reduce (the other
+    slots are zero, so the sums are exact), every rank then holds every rank's words and checks minimum == maximum.  A mismatch raises
+    `ReplicaMismatch` on EVERY rank, with the differing ranks named: nobody trains on.  Called after init, after a resume and at the end
+    of every epoch (train.train).  comm = a `Comm` / `LocalComm` / `HostComm` (all_reduce_sum) or a `HostGroup`; None or a world of one: nothing to do."""
+    world = 1 if comm is None else comm.world
+    if world <= 1:
+        return None
+    words = model.param_checksum() if hasattr(model, "param_checksum") else [float(w) for w in model]
+    k = len(words)
+    slots = [0.0] * (k * world)
+    slots[k * comm.rank:k * comm.rank + k] = words
+    reduce = comm.all_reduce_sum if hasattr(comm, "all_reduce_sum") else (lambda v: comm.all_reduce(v, "sum"))
+    got = np.asarray(reduce(slots), np.float64).reshape(world, k)
+    if not (got.min(axis=0) == got.max(axis=0)).all():     # (NaN parameters fail this too: NaN != NaN)
+        ref = got[0]
+        odd = [r for r in range(world) if not (got[r] == ref).all()]
+        raise ReplicaMismatch(f"replicas differ{' ' + what if what else ''}: ranks {odd} do not hold rank 0's parameters "
+                              f"(checksum words by rank: {got.tolist()})")
+    return got[0].tolist()
+
+
 def shard_for_rank(shards, local_rank, local_world_size):
     """train.py:46-51: shard directory i goes to rank i % world; the count must divide evenly."""
     assert len(shards) % local_world_size == 0

@@ -414,6 +414,14 @@ class RecommenderModel:
         check(lib().rsys_debug_get(self._h, key.encode(), out.ctypes.data, out.nbytes))
         return out
 
+    def param_checksum(self):
+        """[fp64 sum, fp64 sum of squares, low / high 32 bits of a position-weighted integer sum of the bit patterns] of this rank's flat
+        parameter buffer (a row-sharded model: without its own table rows), computed on the device in a fixed order: what the ranks
+        compare instead of DDP's parameter broadcast (transformer.py:678-682; dist.assert_replicas_equal)"""
+        out = (C.c_double * 4)()
+        check(lib().rsys_param_checksum(self._h, C.byref(out)))
+        return [float(x) for x in out]
+
     def head_rows(self):
         """positive-weight positions per task in the last forward (the head GEMMs stop there)."""
         out = (C.c_int32 * 4)()

@@ -360,6 +360,11 @@ def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weight
     when the stopper runs out of patience.  Returns the list of (epoch, training_loss, test_loss)."""
     stopper = make_early_stopper(config)
     get_loss = lambda: evaluate_metrics(model, dataloaders["test"], comm)
+    # DDP broadcasts rank 0's parameters when it wraps the model (train.py:678-682); every rank here built its own from the same seed or
+    # the same checkpoint, and the ranks check that they agree: now (after init / resume) and at the end of every epoch
+    from .dist import assert_replicas_equal
+    consistent = lambda when: assert_replicas_equal(model, comm, when) if hasattr(model, "param_checksum") else None
+    consistent(f"before epoch {starting_epoch}")
     initial_loss = get_loss()
     log(f"Initial Loss: {wsum(initial_loss, task_weights)}, {initial_loss}")
     stopper(wsum(initial_loss, task_weights))
@@ -370,6 +375,7 @@ def train(model, optimizer, scheduler, dataloaders, config, datadir, task_weight
     for epoch in range(starting_epoch, num_epochs):
         training_loss = train_epoch(model, dataloaders["training"], optimizer, scheduler, task_weights, grad_accum_steps, comm)
         log(f"Epoch: {epoch}, Training Loss: {wsum(training_loss, task_weights)} {training_loss}, LR factor: {scheduler.factor()}")
+        consistent(f"after epoch {epoch}")
         test_loss = get_loss()
         log(f"Epoch: {epoch}, Test Loss: {wsum(test_loss, task_weights)} {test_loss}")
         stopper(wsum(test_loss, task_weights))

@@ -1,5 +1,8 @@
 """Worker of tests/test_gpu_bench_shape.py: the benchmarked step (cfg-3, 64 rows, bf16, initialisation-scale weights) under whatever
-RSYS_* switches the parent set (they are read once per process); losses and the last layer's gradients to an .npz."""
+RSYS_* switches the parent set (they are read once per process); losses and the last layer's gradients to an .npz.
+RSYS_TEST_CFG names another configuration, RSYS_TEST_DETERMINISTIC=1 runs the bitwise reproducible mode, RSYS_TEST_ALL_GRADS=1 keeps
+every named gradient and the dense trunk output."""
+import os
 import sys
 
 import numpy as np
@@ -8,7 +11,7 @@ sys.path.insert(0, sys.argv[2])
 import recommendersystem_amd as ra  # noqa: E402
 from oracle import synth, train_np  # noqa: E402
 
-cfg = synth.make_config("cfg3")
+cfg = synth.make_config(os.environ.get("RSYS_TEST_CFG", "cfg3"), deterministic=os.environ.get("RSYS_TEST_DETERMINISTIC") == "1")
 rows = 64
 d = synth.make_batch(cfg, rows, 0xD47A, mu=4.6, sigma=1.0)
 wm, rm = synth.make_masks(cfg, rows, 0x3A5C)
@@ -23,8 +26,11 @@ model.set_loss_weights(train_np.make_task_weights(), 1)
 losses = model(d, False, masks=(wm, rm))
 L = cfg["num_layers"] - 1
 res = {"losses": np.array(losses, np.float64)}
+every = os.environ.get("RSYS_TEST_ALL_GRADS") == "1"
 for n in synth.trainable_names(cfg):
-    if n.startswith(f"transformers.layers.{L}.") or n.startswith(f"transformers.layers.{L - 1}.attn."):
+    if every or n.startswith(f"transformers.layers.{L}.") or n.startswith(f"transformers.layers.{L - 1}.attn."):
         res["g/" + n] = model.grad(n)
+if every:
+    res["trunk"] = model.trunk_output(rows)
 np.savez(sys.argv[1], **res)
 model.close()

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library builds, loads, and exports every symbol include/rsys.h declares;
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/rsys.h (the boundary) and include/rsys_debug.h (test hooks) declare;
 compute entry points fail loudly without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
@@ -19,13 +19,18 @@ def built():
 
 
 def test_header_symbols_exported(built):
-    hdr = open(os.path.join(ROOT, "include", "rsys.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(rsys_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(declared) > 30
+    declared = []
+    for name in ("rsys.h", "rsys_debug.h"):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        here = sorted(set(re.findall(r"\b(rsys_[a-z0-9_]+)\s*\(", hdr)))
+        assert len(here) > 15, name
+        declared += here
+    assert len(declared) == len(set(declared))
+    declared = sorted(declared)
     L = built.lib()
     for name in declared:
-        assert hasattr(L, name), f"{name} declared in rsys.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
     assert sorted(built.EXPORTED) == declared
 
 

@@ -93,6 +93,50 @@ def test_collective_fails_on_every_rank_when_a_peer_dies():
     assert [p.wait(timeout=120) for p in procs] == [5, 7, 5]
 
 
+def test_replica_consistency_check_fails_on_every_rank_when_one_rank_differs(tmp_path):
+    """SURVEY 2.4 C1 / transformer.py:678-682: DDP broadcasts rank 0's parameters; this package initialises every rank from the same
+    seed and CHECKS (dist.assert_replicas_equal: one slot per rank of a SUM all-reduce, min == max on every rank).  World of three over
+    the TCP control plane, checksum words of a host buffer standing in for the device model's (`model.param_checksum`, GPU test in
+    tests/test_gpu_shard.py): equal buffers pass and every rank returns the same words; with ONE element of rank 1's buffer off by one
+    ulp every rank -- not only rank 1 -- raises ReplicaMismatch naming rank 1."""
+    import textwrap
+    port = _free_port()
+    code = textwrap.dedent("""
+        import json, os, sys
+        import numpy as np
+        sys.modules["torch"] = None
+        sys.path.insert(0, %r)
+        from recommendersystem_amd import dist
+        hg = dist.HostGroup()
+        P = np.random.default_rng(7).standard_normal(100003).astype(np.float32)
+        def words(p):
+            bits = int((p.view(np.uint32).astype(np.uint64) * (np.arange(p.size, dtype=np.uint64) %% 1024 + 1)).sum(dtype=np.uint64))
+            return [float(p.astype(np.float64).sum()), float((p.astype(np.float64) ** 2).sum()), float(bits & 0xffffffff), float(bits >> 32)]
+        res = {"ok": dist.assert_replicas_equal(words(P), hg, "after init")}
+        if hg.rank == 1:
+            P[54321] = np.nextafter(P[54321], np.float32(10.0))
+        try:
+            dist.assert_replicas_equal(words(P), hg, "after epoch 0")
+            res["second"] = "passed"
+        except dist.ReplicaMismatch as e:
+            res["second"] = str(e)
+        res["single"] = dist.assert_replicas_equal(words(P), None)
+        json.dump(res, open(%r + ".%%d" %% hg.rank, "w"))
+        hg.close()
+    """ % (ROOT, str(tmp_path / "rc")))
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RSYS_RDZV_PORT=str(port), RSYS_RDZV_TIMEOUT="60")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
+    assert [p.wait(timeout=120) for p in procs] == [0, 0, 0]
+    res = [json.load(open(str(tmp_path / "rc") + f".{r}")) for r in range(3)]
+    assert res[0]["ok"] == res[1]["ok"] == res[2]["ok"] and len(res[0]["ok"]) == 4
+    for r in res:
+        assert r["second"].startswith("replicas differ after epoch 0: ranks [1] do not hold rank 0's parameters"), r["second"]
+        assert r["single"] is None
+
+
 def test_launch_local_relays_and_stops_everyone_on_failure(tmp_path):
     from recommendersystem_amd.dist import launch_local
     ok = tmp_path / "ok.py"

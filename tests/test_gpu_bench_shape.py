@@ -37,17 +37,19 @@ def _scale_trunk_to_order_one(model, frozen_too=False):
             model.set_parameter(n, model.get_parameter(n) * np.float32(1.0 / (0.006 * np.sqrt(shape[-1]))))
 
 
-def _cfg3_step(weights, with_exact):
+def _cfg3_step(weights, with_exact, cfg_name="cfg3", dtype="bf16", with_rounded=True):
     """the step bench.py times (cfg-3, 64 rows, bf16) on the HIP path and on the oracle's C++ step with the same storage roundings
-    (and, with_exact, on the unrounded C++ step: how far bf16 arithmetic itself is from fp32 on each tensor)"""
+    (and, with_exact, on the unrounded C++ step: how far bf16 arithmetic itself is from fp32 on each tensor).
+    cfg_name / dtype: the same step at another BASELINE configuration (cfg-2 = configs[1]) or in the fp32 parity mode;
+    with_rounded=False: only the unrounded C++ step is run and stands as the reference (fp32 mode has no storage roundings)"""
     import recommendersystem_amd as ra
     from oracle import cpu_step, model_np, synth, train_np
-    cfg = synth.make_config("cfg3")
+    cfg = synth.make_config(cfg_name)
     rows, lr = 64, 1e-4
     d = synth.make_batch(cfg, rows, 0xD47A, mu=4.6, sigma=1.0)
     wm, rm = synth.make_masks(cfg, rows, 0x3A5C)
     tw = train_np.make_task_weights()
-    model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+    model = ra.RecommenderModel(cfg, dtype=dtype, max_rows=rows)
     model.init_weights(0x1217)
     model.random_pretrained_embeddings(0x3E7A)
     _perturb_scales(model, 3)
@@ -65,12 +67,12 @@ def _cfg3_step(weights, with_exact):
 
     dm = model_np.mask_tokens(cfg, model_np.reshape_batch(cfg, d), wm, rm)
     ex_G = None
-    if with_exact:
+    if with_exact and with_rounded:
         ex = cpu_step.CpuStep(cfg, P, lr=lr)
         _, ex_G = ex.forward_backward(dm, tw)
         ex_G = {n: ex_G[n].copy() for n in names}
         del ex
-    cs = cpu_step.CpuStep(cfg, P, lr=lr, operand_round="bf16")
+    cs = cpu_step.CpuStep(cfg, P, lr=lr, operand_round="bf16") if with_rounded else cpu_step.CpuStep(cfg, P, lr=lr)
     ref_losses, ref_G = cs.forward_backward(dm, tw)
     ref_G = {n: ref_G[n].copy() for n in names}
     ref_norm = cs.clip_adamw()
@@ -145,6 +147,77 @@ def test_bench_shape_step_with_order_one_weights_vs_cpp_oracle():
     _check_losses_norm_and_update(r, 1e-3, 2e-3)
     for e_r, e_l2, n in table:
         assert e_r <= 5e-2, (n, e_r, e_l2)
+
+
+def test_cfg2_bench_shape_step_vs_cpp_oracle():
+    """BASELINE configs[1] -- the one configuration stated for a single MI355X in bf16 (D = 256, S = 256, 100 K items, H = 4 / KV = 2,
+    K = 32) -- at the 64 rows bench.py's `other_configs.cfg2_bf16` times: the K = 256 dispatch arms of the trunk GEMMs, the grouped
+    weight gradients of 256-wide outputs, the row kernels at D = 256 and the attention kernels at two query heads per kv head, against
+    the C++ oracle with the same storage roundings; cfg-3's bounds (transformer.model.py:193-213,256-286,493-529; transformer.py:535-560)."""
+    r = _cfg3_step("init", with_exact=True, cfg_name="cfg2")
+    names, G, ref_G, ex_G = r["names"], r["G"], r["ref_G"], r["ex_G"]
+    table = sorted(((_mx(G[n], ref_G[n]), _l2(G[n], ref_G[n]), _mx(G[n], ex_G[n]), _mx(ref_G[n], ex_G[n]), n) for n in names), reverse=True)
+    print("  cfg-2 worst gradients: max|hip - oracle_bf16| / max, rel L2, max|hip - exact| / max, max|oracle_bf16 - exact| / max")
+    for row in table[:6]:
+        print("    %.3e %.3e %.3e %.3e %s" % row)
+    _check_losses_norm_and_update(r, 5e-5, 5e-4)
+    for e_r, e_l2, e_x, e_rx, n in table:   # (the q / k clause: see test_bench_shape_step_vs_cpp_oracle)
+        assert e_r <= 5e-2 or (e_r <= 1e-1 and e_x <= 2.0 * e_rx and ("q_proj" in n or "k_proj" in n)), (n, e_r, e_l2, e_x, e_rx)
+
+
+def test_gemm8c_half_tiles_change_no_bit_of_a_cfg2_step(tmp_path):
+    """gemm8c's 128 x 256 output tiles (round 6: the outputs of cfg-2's N = 256 products have 128 tiles of 256 x 256, half the chip)
+    change which workgroup computes which rows and nothing else: every accumulator sees the same K order and the same epilogue
+    arithmetic.  cfg-2, 64 rows, bf16, deterministic mode (so that a step is reproducible at all), the HALF form switched off
+    (RSYS_GEMM8C_HALF=0) against forced for every class that has it (=2: plain store, residual, QKV + RoPE, SwiGLU forward and
+    backward), each arm its own process: losses, dense trunk output and every named gradient agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = {}
+    for arm in ("0", "2"):
+        out = str(tmp_path / f"half{arm}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tests", "_bench_shape_worker.py"), out, root], check=True, cwd=root, timeout=600,
+                       env=dict(os.environ, RSYS_GEMM8C_HALF=arm, RSYS_TEST_CFG="cfg2", RSYS_TEST_DETERMINISTIC="1", RSYS_TEST_ALL_GRADS="1"))
+        z[arm] = np.load(out)
+    assert sorted(z["0"].files) == sorted(z["2"].files) and len(z["0"].files) > 80
+    assert np.isfinite(z["0"]["losses"]).all()
+    for k in z["0"].files:
+        a, b = z["0"][k], z["2"][k]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), k
+
+
+def test_cfg3_fp32_full_step_vs_exact_cpp_oracle():
+    """north_star's tolerance on the step that is benchmarked: cfg-3, 64 rows, the fp32 parity mode (`dtype="fp32"`: fp32 storage,
+    v_mfma_f32_16x16x4_f32 products) with the batch / masks / seeds of the bf16 bench-shape test, against the UNROUNDED C++ step
+    (`cpu_step.CpuStep(cfg, P)`): the 200 K-class tied head with its cross entropy, the segmented scatter, every weight gradient, the
+    global norm and the parameters after one clip + AdamW step (transformer.model.py:493-529, transformer.py:259-276).
+    Bounds: losses and gradient norm 1e-4 relative, every named gradient 5e-4 of its tensor's maximum."""
+    r = _cfg3_step("init", with_exact=False, dtype="fp32", with_rounded=False)
+    names, lr = r["names"], r["lr"]
+    e_l = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(r["losses"], r["ref_losses"])]
+    norm_gpu = float(np.sqrt(sum(float((r["G"][n].astype(np.float64) ** 2).sum()) for n in names)))
+    table = sorted(((_mx(r["G"][n], r["ref_G"][n]), _l2(r["G"][n], r["ref_G"][n]), n) for n in names), reverse=True)
+    print("cfg-3 fp32 full step vs exact C++ oracle: losses", r["losses"], "oracle", r["ref_losses"], "rel", e_l)
+    print("  grad norm", norm_gpu, "oracle", r["ref_norm"], "rel", abs(norm_gpu - r["ref_norm"]) / r["ref_norm"])
+    print("  worst gradients: max|hip - oracle| / max, rel L2")
+    for row in table[:8]:
+        print("    %.3e %.3e %s" % row)
+    assert max(e_l) <= 1e-4, (r["losses"], r["ref_losses"])
+    assert abs(norm_gpu - r["ref_norm"]) <= 1e-4 * r["ref_norm"], (norm_gpu, r["ref_norm"])
+    for e_r, e_l2, n in table:
+        assert e_r <= 5e-4, (n, e_r, e_l2)
+    # one clip + AdamW step: m / (sqrt(v) + eps) = g / (|g| + eps) on the first step, so two fp32 evaluations of g that agree to 5e-4 of the
+    # tensor's maximum move an element by the same lr unless |g| is within that noise of zero (then by up to 2 lr)
+    flips, total, worst = 0, 0, 0.0
+    for n in names:
+        diff = np.abs(r["Pn"][n] - r["ref_P"][n])
+        worst = max(worst, float(diff.max()))
+        flips += int((diff > 0.5 * lr).sum()); total += diff.size
+    print(f"  parameters after clip + AdamW: max |diff| {worst:.3e} (lr {lr}), {flips} of {total} elements moved the other way")
+    assert worst <= 2.0 * lr * 1.02 + 1e-7, worst
+    assert flips <= 1e-2 * total, (flips, total)
 
 
 def test_last_layer_token_orders_agree_on_qk_gradients(init_scale_step, tmp_path):

@@ -238,6 +238,62 @@ def test_data_parallel_step_with_early_buckets_on_concurrent_ranks(world):
             assert np.abs(Pn[n] - P_ref[n]).mean() <= 2e-3, (r, n)
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_replica_consistency_check_on_concurrent_ranks(sharded):
+    """SURVEY 2.4 C1 (transformer.py:678-682: DDP broadcasts rank 0's parameters; here: same-seed init + comparison): three concurrent
+    ranks of one GPU, device-side checksum words (`rsys_param_checksum`) gathered through the communicator's fp64 all-reduce.  Equal after
+    the same-seed init and after one data-parallel optimizer step on different batches (the all-reduce keeps replicas equal); the lowest
+    mantissa bit of ONE norm scale changed on rank 2 fails the check on EVERY rank.  Row-sharded table: the ranks' own table rows differ
+    by construction and stay out of the words; everything replicated is still compared."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd import dist as rdist
+    from recommendersystem_amd.optim import AdamW
+    world, rows = 3, 2
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16)
+    batches = [synth.make_batch(cfg, rows, 71 + 10 * r) for r in range(world)]
+    masks = [synth.make_masks(cfg, rows, 72 + 10 * r) for r in range(world)]
+    group = rdist.LocalGroup(world)
+
+    def rank_fn(r):
+        comm = rdist.LocalComm(group, r)
+        c = dict(cfg)
+        if sharded:
+            c["table_shard"] = (r, world)
+        model = ra.RecommenderModel(c, dtype="bf16", max_rows=rows)
+        model.init_weights(0x1217); model.random_pretrained_embeddings(0x3E7A)
+        if sharded:
+            model.set_shard_comm(comm)
+        w0 = rdist.assert_replicas_equal(model, comm, "after init")
+        assert w0 == model.param_checksum() and np.isfinite(w0).all() and w0[1] > 0
+        model.set_loss_weights(TASK_W, 1)
+        if not sharded:
+            comm.begin_grad_sync(model)
+        model(batches[r], False, masks=masks[r])
+        comm.all_reduce_grads(model)
+        AdamW(model, lr=1e-2).step(clip_max_norm=1.0, grad_div=float(world))
+        w1 = rdist.assert_replicas_equal(model, comm, "after one step")
+        assert w1 != w0
+        name = "transformers.layers.1.mlp_norm.scale"
+        if r == 2:
+            v = model.get_parameter(name)
+            v.view(np.uint32)[5] ^= 1
+            model.set_parameter(name, v)
+        try:
+            rdist.assert_replicas_equal(model, comm, "after the bit flip")
+            err = None
+        except rdist.ReplicaMismatch as e:
+            err = str(e)
+        model.close(); comm.close()
+        return w0, w1, err
+
+    res = _run_ranks(world, rank_fn)
+    group.close()
+    assert res[0][0] == res[1][0] == res[2][0] and res[0][1] == res[1][1] == res[2][1]
+    for w0, w1, err in res:
+        assert err is not None and "ranks [2] do not hold rank 0's parameters" in err, err
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_sampled_softmax_with_every_class_sampled_is_the_full_softmax(world):
     """cfg-4's sampled soft-max has no reference counterpart; its machinery (sampled-class gather, target logit by the

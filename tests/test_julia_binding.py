@@ -1,6 +1,6 @@
 """julia/RsysHIP.jl against include/rsys.h without Julia (absent from the image): every `ccall` tuple of the binding is parsed and
 its symbol, return type, arity and argument types are checked against the header's prototype; the two struct mirrors are checked
-field by field; every entry point of the header must be bound except the per-kernel unit-test access.  What this cannot check is
+field by field; every entry point of the header must be bound, and none of the test hooks of include/rsys_debug.h.  What this cannot check is
 behaviour -- the .jl file has never executed -- only that what it declares is the ABI the library exports."""
 import os
 import re
@@ -9,10 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "rsys.h")
 JULIA = os.path.join(ROOT, "julia", "RsysHIP.jl")
 
-# entry points a Julia host has no use for: raw per-kernel access of the unit tests (device pointers from rsys_dev_alloc)
-NOT_BOUND = {"rsys_dev_alloc", "rsys_dev_free", "rsys_dev_h2d", "rsys_dev_d2h", "rsys_dev_memset", "rsys_op_gemm", "rsys_op_gemm_rows",
-             "rsys_op_attention", "rsys_op_embedding_scatter", "rsys_op_f8_quantize", "rsys_op_f8_weights", "rsys_op_gemm_f8",
-             "rsys_comm_debug_delay", "rsys_op_gemm_klimit"}
+DEBUG_HEADER = os.path.join(ROOT, "include", "rsys_debug.h")   # test / parity hooks: not part of the boundary, not bound
 
 SCALAR = {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint8_t": "UInt8", "float": "Float32", "double": "Float64",
           "size_t": "Csize_t", "int": "Int32", "char": "UInt8", "void": "Cvoid"}
@@ -40,8 +37,8 @@ def c_type_to_julia(ctype):
     return jt
 
 
-def header_prototypes():
-    text = strip_comments(open(HEADER).read())
+def header_prototypes(path=HEADER):
+    text = strip_comments(open(path).read())
     protos = {}
     for m in re.finditer(r"(const\s+char\s*\*|int32_t|size_t)\s+(rsys_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
@@ -100,7 +97,7 @@ def julia_ccalls():
 
 def test_every_ccall_matches_its_prototype():
     protos = header_prototypes()
-    assert len(protos) >= 55, len(protos)
+    assert len(protos) >= 50, len(protos)
     calls = julia_ccalls()
     assert len(calls) >= 45
     for name, ret, args in calls:
@@ -115,9 +112,11 @@ def test_every_ccall_matches_its_prototype():
 def test_every_entry_point_is_bound_or_listed_as_test_only():
     protos = header_prototypes()
     bound = {c[0] for c in julia_ccalls()}
-    missing = sorted(set(protos) - bound - NOT_BOUND)
+    missing = sorted(set(protos) - bound)
     assert not missing, missing
-    assert not (bound & NOT_BOUND)
+    debug_only = set(header_prototypes(DEBUG_HEADER))
+    assert len(debug_only) >= 15 and not (debug_only & set(protos))
+    assert not (bound & debug_only)
 
 
 def _c_struct_fields(name):
