@@ -257,15 +257,19 @@ template int launch_rmsnorm_fwd<bf16>(const float*, const float*, bf16*, float*,
 template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float*, long long, int, hipStream_t, const int*, const int*, float*);
 
 // backward: dx = r*g*s - x*r^3*sum(g*s*x)/D (+ residual gradient) ; dscale += g*x*r
+// Workgroups of 16 waves (round 6).  Every workgroup ends with D float atomics onto the same D scale gradients, and the workgroups of a
+// launch all finish together: with 1024 workgroups of 4 waves that tail was a fixed ~29 us per launch at cfg-2 AND cfg-3 (two-point fit of
+// 45 us for 134 MB and 93 us for 537 MB: the streaming part alone runs at 8.4 TB/s; the grid scan in rmsnorm_bwd_any prices an atomic
+// tail at ~23 ns per workgroup).  The same 16 waves per CU as one workgroup: a quarter of the atomics, same bytes in flight.
 template <typename TG, typename TO, int NJ, bool EXACT>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
                                                           float* part, long long rows, int D, const int* __restrict__ rows_dev,
                                                           const int* __restrict__ resid_slot, const int* __restrict__ io_rows, float* amax) {
-  extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (4 * D in deterministic mode: `part` set)
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long wave0 = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
+  extern __shared__ __attribute__((aligned(16))) float sds[];  // D floats (waves per workgroup * D in deterministic mode: `part` set)
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const long long wave0 = (long long)blockIdx.x * nw + w, nwaves = (long long)gridDim.x * nw;
   float4 acc[NJ], sc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
     acc[j] = make_float4(0, 0, 0, 0);
     sc[j] = (EXACT || c < D) ? *(const float4*)(scale + c) : make_float4(0, 0, 0, 0);
   }
-  for (int c = threadIdx.x; c < D; c += 256) sds[c] = 0.f;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) sds[c] = 0.f;
   __syncthreads();
   // compact row set (compact.hip): rows [0, n) live, rows [n, n rounded up to 256) get zero outputs
   const long long n_live = rows_dev != nullptr ? (long long)*rows_dev : rows;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
     if (l == 0) f8_amax_add(amax, (float)from_f32<TO>(am));
   }
   if (part != nullptr) {
-    // deterministic: the four waves' sums side by side in LDS ([4][D], launcher), added in wave order, one partial row per workgroup
+    // deterministic: the waves' sums side by side in LDS ([waves][D], launcher), added in wave order, one partial row per workgroup
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -335,7 +339,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
       if (EXACT || c < D) *(float4*)&sds[w * D + c] = acc[j];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) part[(long long)blockIdx.x * D + c] = ((sds[c] + sds[D + c]) + sds[2 * D + c]) + sds[3 * D + c];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+      float t = sds[c];
+      for (int k = 1; k < nw; ++k) t += sds[k * D + c];
+      part[(long long)blockIdx.x * D + c] = t;
+    }
     return;
   }
 #pragma unroll
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const TG* __restrict__
   }
   __syncthreads();
   if (wave0 - w >= n_live) return;   // (a compact row set: workgroups without a live row have nothing to add -- uniform: wave0 - w = first row of the workgroup)
-  for (int c = threadIdx.x; c < D; c += 256) atomicAdd(&dscale[c], sds[c]);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(&dscale[c], sds[c]);
 }
 
 template <typename TG, typename TO>
@@ -357,10 +365,13 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
                            const int* resid_slot, const int* io_rows = nullptr, float* f8_amax = nullptr) {
   float* const amax = f8_amax;
   ARG_CHECK(D % 4 == 0 && D <= 64 * 4 * NORM_MAXJ, "rmsnorm_bwd: D must be a multiple of 4 and <= 2048");
-  const int grid_cap = sw().debug_norm_bwd_grid;   // (every workgroup ends with D atomics onto the same D scale gradients: 512-1024 workgroups 1.39-1.45 ms per step at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37)
-  const dim3 grid((unsigned)std::min<long long>((rows + 3) / 4, grid_cap)), block(256);
+  // (every workgroup ends with D atomics onto the same D scale gradients: with 4 waves per workgroup, 512-1024 workgroups 1.39-1.45 ms per step
+  // at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37.)  RSYS_DEBUG_NORM_BWD_GRID caps the number of WAVES / 4 (the unit of those scans).
+  const int grid_cap = sw().debug_norm_bwd_grid;
+  const int wpb = sw().debug_norm_bwd_waves > 0 ? sw().debug_norm_bwd_waves : (D <= 1024 ? 16 : 4);   // waves per workgroup (deterministic mode keeps wpb * D floats in LDS)
+  const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((rows + wpb - 1) / wpb, (long long)grid_cap * 4 / wpb))), block(64 * wpb);
   float* part = det_part((long long)grid.x * D);
-#define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? 4 : 1) * D * sizeof(float), s, g, x, scale, \
+#define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? wpb : 1) * D * sizeof(float), s, g, x, scale, \
                                                  rstd, resid, dx_out, dx_out_t, dscale, part, rows, D, rows_dev, resid_slot, io_rows, amax)
   if (D == 256) RSYS_NORM_BWD(1, true);
   else if (D == 512) RSYS_NORM_BWD(2, true);

@@ -365,7 +365,10 @@ bool gemm8c_uses_half(const GemmParams& p, int cus) {
   if (mode == 0 || !c8_half_class(p)) return false;
   if (mode == 2) return true;
   const long long t256 = (long long)((p.M + C8_BM - 1) / C8_BM) * ((p.N + C8_BN - 1) / C8_BN);
-  return t256 < cus;
+  // ... and the SwiGLU backward at K <= 256 whatever its tile count: four K tiles of MFMAs against an epilogue that reads and writes 256 KB per
+  // tile -- half tiles interleave the two finer across the chip (cfg-2's w2_dx 0.475 -> 0.418 ms per step; at K = 512 every class LOSES
+  // 8 - 25 % in the HALF form, profiles/r6k_*)
+  return t256 < cus || (p.epi == EPI_SWIGLU_BWD && p.K <= 256);
 }
 
 int launch_gemm8c(const GemmParams& p0, hipStream_t s) {

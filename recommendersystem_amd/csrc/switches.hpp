@@ -37,7 +37,8 @@ struct Switches {
   int debug_8t_splitk;        // RSYS_DEBUG_8T_SPLITK: force the K-major kernel's K-split count
   int debug_epi;              // RSYS_DEBUG_EPI: rsys_op_gemm only: epilogue class override (99 = none)
   int debug_f8_cast_waves;    // RSYS_DEBUG_F8_CAST_WAVES: waves per workgroup of the fp8 cast kernel (1..4)
-  int debug_norm_bwd_grid;    // RSYS_DEBUG_NORM_BWD_GRID: workgroup cap of rmsnorm_bwd
+  int debug_norm_bwd_grid;    // RSYS_DEBUG_NORM_BWD_GRID: cap of rmsnorm_bwd's waves / 4
+  int debug_norm_bwd_waves;   // RSYS_DEBUG_NORM_BWD_WAVES: waves per workgroup of rmsnorm_bwd (0 = 16 up to D = 1024, else 4)
 };
 
 const Switches& sw();        // the parsed switches (parses at first use)
