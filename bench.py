@@ -101,9 +101,21 @@ def live_pmc_traffic(timeout_s=200):
         for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             cmd = [exe, "--pmc", counter, "-d", os.path.join(tmp, sub), "--output-format", "csv", "--", "python3", os.path.join(ROOT, "bench.py"),
                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-train-loop"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-160:]}"
+            # (a session of its own: a pass that overruns is killed as a GROUP -- rocprofv3 AND the bench.py child it started, which
+            # would otherwise go on using the GPU beside the legs measured next)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except BaseException:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            if proc.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {proc.returncode}): {err.decode(errors='replace')[-160:]}"
         fetch = pmc_traffic.collect(os.path.join(tmp, "fetch"), "FETCH_SIZE")
         write = pmc_traffic.collect(os.path.join(tmp, "write"), "WRITE_SIZE")
         db = {}
@@ -448,7 +460,7 @@ def main():
         model.set_shard_comm(comm)             # row exchange + vocabulary-parallel head run on this communicator
     # DDP broadcasts rank 0's parameters when it wraps the model (transformer.py:678-682); here every rank initialised from the same seed
     # and the ranks compare device-side checksums of their parameter buffers: now, and again behind the timed steps
-    replicas = {"after_init": rdist.assert_replicas_equal(model, comm, "after init") is not None} if comm is not None else None
+    replicas = {"after_init": rdist.assert_replicas_equal(model, comm, "after init") is not None} if (comm is not None and world > 1) else None
     sched = LambdaLR(WSDScheduler(warmup_steps=2000, total_steps=250000, decay_ratio=0.1, final_ratio=0.1))
     for _ in range(2000):
         sched.step()                           # bench at the stable learning rate
@@ -468,6 +480,7 @@ def main():
         raise SystemExit("--split-table-reduce needs a communicator (--gpus N or --rehearse-comm), the replicated table, bf16, and no --zero1")
     if split_table:
         model.set_split_table_reduce(True)
+        model.upload(d)                        # (staged again: the host counts the batch's distinct item ids only while the split reduce is on)
 
     def step():
         if comm is not None and not zero1:

@@ -463,6 +463,9 @@ int32_t rsys_set_grad_sync(rsys_model* h, rsys_comm* c) {
     // the head part of the item table's gradient, complete when heads() returns: summed over the ranks into tbl_R while the trunk
     // backward runs (G[E] itself keeps the local gradient: the token scatter and the metadata-projection gradient still need it)
     m->table_head_hook = [m, c]() -> int {
+      // first on the communicator's stream, a whole trunk backward before the tail needs it on the host: the ranks' maximum of the
+      // distinct ids of their resident batches = the rows per rank the tail's gathers will carry
+      RC(model_split_table_arm(m, c));
       HIP_CHECK(hipEventRecord(c->ev_ready, m->stream));
       HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
       const int64_t n = (int64_t)m->TR * m->D, bucket = 16 * 1024 * 1024;
@@ -558,9 +561,10 @@ int32_t rsys_allreduce_grads(rsys_model* h, rsys_comm* c) {
     HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
     m->bucket_phase = 1;
     if (split) {   // nothing reads the local G[E] any more (stage 1 made the operand copy and the bias gradient): it becomes the sum
-      rc = model_split_table_tail(m, c, c->stream);
+      int64_t tail_rows = 0;
+      rc = model_split_table_tail(m, c, c->stream, &tail_rows);
       if (rc) return rc;
-      m->bucket_log.push_back({0, (int64_t)c->world * m->tok_cap * (m->D + 1), 4});
+      m->bucket_log.push_back({0, (int64_t)c->world * tail_rows * (m->D + 1), 4});
     }
     rc = reduce_rest(0, std::min(wo, m->n_opt));
     if (rc) return rc;

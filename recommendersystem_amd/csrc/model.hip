@@ -401,6 +401,9 @@ int model_destroy(Model* m) {
   if (m->det_tmp) hipFree(m->det_tmp);
   if (m->req_ids) hipFree(m->req_ids);
   if (m->tok_Tall) hipFree(m->tok_Tall);
+  if (m->h_umax) hipHostFree(m->h_umax);
+  if (m->d_umax) hipFree(m->d_umax);
+  if (m->ev_umax) hipEventDestroy(m->ev_umax);
   if (m->tok_Uall) hipFree(m->tok_Uall);
   if (m->tok_Pall) hipFree(m->tok_Pall);
   if (m->rows_xchg) hipFree(m->rows_xchg);
@@ -633,7 +636,8 @@ static int build_exchange_plan(Model* m, int N) {
 
 // Checks a host batch and packs it into staging buffer `slot` (pinned); `d` and the flag outputs receive the device addresses the
 // arrays will have in that slot's blob.  Index paths are checked on the host BEFORE anything is written.
-struct StagedBatch { BatchDev bd; bool has_masks = false, has_rope_pos = false; unsigned char *d_wm = nullptr, *d_rm = nullptr; int* d_rope_pos = nullptr; size_t bytes = 0; };
+struct StagedBatch { BatchDev bd; bool has_masks = false, has_rope_pos = false; unsigned char *d_wm = nullptr, *d_rm = nullptr; int* d_rope_pos = nullptr; size_t bytes = 0;
+                     int distinct_ids = 0; };   // split table reduce: distinct matchedid values of the batch + 1 (the mask row): an upper bound of its token-row list
 static int batch_stage(Model* m, const rsys_batch* b, int slot, StagedBatch& out) {
   ARG_CHECK(b != nullptr, "null batch");
   ARG_CHECK(b->rows >= 1 && b->rows <= m->rows_max, "batch rows must be in [1, max_rows]");
@@ -659,6 +663,17 @@ static int batch_stage(Model* m, const rsys_batch* b, int slot, StagedBatch& out
               "manga target position out of range");
     ARG_CHECK(b->position[3][i] >= 0 && b->position[3][i] < m->V1 && b->position[4][i] >= 0 && b->position[4][i] < m->V1,
               "anime target position out of range");
+  }
+  if (m->split_table) {   // (one pass over the ids with a bitmap of the table's rows: ~30 us for 32 K ids, on the thread that packs the batch anyway)
+    m->id_seen.assign(((size_t)m->V + 64) / 64, 0ull);
+    int distinct = 1;       // the mask row V: mask_tokens sends the masked events there (model.py:451)
+    for (size_t i = 0; i < N; ++i) {
+      const int id = b->matchedid[i] < 0 ? m->V : b->matchedid[i];
+      unsigned long long& wd = m->id_seen[(size_t)id >> 6];
+      const unsigned long long bit = 1ull << (id & 63);
+      if (!(wd & bit)) { wd |= bit; if (id != m->V) ++distinct; }
+    }
+    out.distinct_ids = distinct;
   }
   std::vector<int> pos;
   if (b->rope_input_pos != nullptr) {
@@ -698,7 +713,10 @@ static int batch_stage(Model* m, const rsys_batch* b, int slot, StagedBatch& out
 int model_batch_upload(Model* m, const rsys_batch* b) {
   HIP_CHECK(hipSetDevice(m->device));
   hipStream_t s = m->stream;
-  m->pending.valid = false;   // (an explicit upload supersedes a prefetched batch)
+  // an explicit upload supersedes a prefetched batch.  Its copy may still be reading the OTHER slot's staging buffer on the copy stream:
+  // wait for it here, so that the next prefetch (which skips its own wait when nothing is pending) never re-packs a buffer under a copy
+  if (m->pending.valid) HIP_CHECK(hipEventSynchronize(m->ev_copy_done));
+  m->pending.valid = false;
   // No wait before packing: the previous upload synchronised after ITS copy, so the staging buffer is free, and the copy below is
   // ordered on the stream behind the kernels that still read the old batch -- the host packs while the GPU finishes the previous
   // step's optimizer pass.  (A prefetch into this slot's staging is complete too: model_batch_swap waited for its copy.)
@@ -710,6 +728,7 @@ int model_batch_upload(Model* m, const rsys_batch* b) {
   BatchDev& d = m->bd;
   m->has_masks = st.has_masks; m->d_wm = st.d_wm; m->d_rm = st.d_rm;
   m->has_rope_pos = st.has_rope_pos; m->d_rope_pos = st.d_rope_pos;
+  m->u_bound_host = st.distinct_ids;
   HIP_CHECK(hipMemcpyAsync(m->slot_blob[m->cur_slot], m->slot_stage[m->cur_slot], st.bytes, hipMemcpyHostToDevice, s));
   // inverted index "table row -> its tokens" for the backward's segmented scatter: depends on the batch only; built here for
   // the row-sharded table (its exchange plan needs it now), else by the first backward over this batch (an inference or
@@ -740,6 +759,7 @@ int model_batch_prefetch(Model* m, const rsys_batch* b) {
   m->pending.valid = true; m->pending.bd = st.bd; m->pending.rows = b->rows;
   m->pending.has_masks = st.has_masks; m->pending.has_rope_pos = st.has_rope_pos;
   m->pending.d_wm = st.d_wm; m->pending.d_rm = st.d_rm; m->pending.d_rope_pos = st.d_rope_pos;
+  m->pending.distinct_ids = st.distinct_ids;
   return RSYS_OK;
 }
 
@@ -758,6 +778,7 @@ int model_batch_swap(Model* m) {
   m->has_masks = m->pending.has_masks; m->d_wm = m->pending.d_wm; m->d_rm = m->pending.d_rm;
   m->has_rope_pos = m->pending.has_rope_pos; m->d_rope_pos = m->pending.d_rope_pos;
   m->cur_rows = m->pending.rows;
+  m->u_bound_host = m->pending.distinct_ids;
   m->tok_index_valid = false;
   m->split_plan_valid = false;
   m->pending.valid = false;

@@ -75,6 +75,14 @@ struct Model {
   float *tbl_R = nullptr, *tok_T = nullptr, *tok_Tall = nullptr;
   int *tok_Uall = nullptr, *tok_Pall = nullptr;
   int64_t tok_cap = 0;               // rows of tok_T and ids of u_ids: rows_max * S + 1
+  // The tail gathers max_r U_r rows per rank instead of tok_cap (round 6).  A rank knows an upper bound of its own U on the HOST as soon
+  // as the batch is staged (distinct matchedid values + the mask row: u_bound_host, counted by batch_stage); when the reduce is armed
+  // (rsys_set_grad_sync) the bounds' maximum over the ranks is formed by a one-float all-reduce at the head of the communicator's stream
+  // and copied to pinned memory (h_umax[1], event ev_umax): by the time the tail is enqueued it has been there for a whole backward.
+  int u_bound_host = 0;
+  std::vector<unsigned long long> id_seen;   // batch_stage's bitmap of table rows
+  float* h_umax = nullptr; float* d_umax = nullptr; hipEvent_t ev_umax = nullptr; bool umax_pending = false;
+  int64_t tok_all_rows = 0;          // rows per rank tok_Tall / tok_Uall are sized for
   int tok_all_world = 0;             // ranks tok_Tall / tok_Uall / tok_Pall are sized for
   int gemm_flags = 0;          // OR-ed into GemmParams.flags: 2 while all-reduce kernels may share the CUs with the backward
   int64_t early_reduced = 0;   // elements the last rsys_allreduce_grads found already reduced (tests)
@@ -183,7 +191,7 @@ struct Model {
   hipEvent_t ev_copy_done = nullptr;     // the pending batch's H2D copy (copy_stream)
   hipEvent_t ev_blob_free[2] = {nullptr, nullptr};   // recorded on `stream` when slot i stops being the resident batch: its kernels are all enqueued before
   bool blob_free_valid[2] = {false, false};
-  struct PendingBatch { bool valid = false; BatchDev bd; int rows = 0; bool has_masks = false, has_rope_pos = false;
+  struct PendingBatch { bool valid = false; BatchDev bd; int rows = 0; bool has_masks = false, has_rope_pos = false; int distinct_ids = 0;
                         unsigned char *d_wm = nullptr, *d_rm = nullptr; int* d_rope_pos = nullptr; } pending;
   bool tok_index_valid = false;
   // deterministic mode (rsys_model_set_deterministic): every float sum of the step has a fixed order -- split-K partial tiles go
@@ -288,7 +296,8 @@ bool model_finalize_splittable(const Model* m);
 int model_batch_prefetch(Model* m, const rsys_batch* b);   // stage + copy the NEXT batch beside the running step (replicated table only)
 int model_batch_swap(Model* m);                            // the prefetched batch becomes the resident one
 int model_split_table_enable(Model* m, int on);
-int model_split_table_tail(Model* m, struct rsys_comm* c, hipStream_t cs);   // on cs: gather the ranks' token rows, G[E] = tbl_R + rows
+int model_split_table_arm(Model* m, struct rsys_comm* c);   // at the head of the communicator's stream: the ranks' maximum of distinct ids of their resident batches
+int model_split_table_tail(Model* m, struct rsys_comm* c, hipStream_t cs, int64_t* rows_out);   // on cs: gather the ranks' token rows (*rows_out per rank), G[E] = tbl_R + rows
 int model_finalize_stage(Model* m, int stage /*1: prepare, 2: dWp GEMM*/, int64_t* wp_off, int64_t* wp_n);
 int model_clip(Model* m, float max_norm, float* norm_out);
 int model_set_deterministic(Model* m, int on);

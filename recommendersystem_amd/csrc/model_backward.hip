@@ -481,17 +481,55 @@ int model_split_table_enable(Model* m, int on) {
   return RSYS_OK;
 }
 
-int model_split_table_tail(Model* m, rsys_comm* c, hipStream_t cs) {
+// rows per rank the tail's all-gathers carry: the maximum over the ranks of the batches' distinct-id bounds (model_split_table_arm formed it
+// at the head of the communicator's stream a whole backward ago), at least this rank's exact U, at most the lists' capacity
+int model_split_table_rows(Model* m, int64_t* rows) {
+  int64_t n = m->tok_cap;
+  if (m->umax_pending) {
+    HIP_CHECK(hipEventSynchronize(m->ev_umax));
+    m->umax_pending = false;
+    const int64_t got = (int64_t)m->h_umax[1];
+    ARG_CHECK(got >= m->U && got <= m->tok_cap, "split table reduce: the ranks' maximum of distinct ids is smaller than this rank's own list");
+    n = (got + 63) / 64 * 64;          // (whole 256-byte id blocks per rank)
+    if (n > m->tok_cap) n = m->tok_cap;
+  }
+  *rows = n;
+  return RSYS_OK;
+}
+int model_split_table_arm(Model* m, rsys_comm* c) {
+  if (m->h_umax == nullptr) {
+    HIP_CHECK(hipHostMalloc((void**)&m->h_umax, 64, hipHostMallocDefault));
+    HIP_CHECK(hipMalloc((void**)&m->d_umax, 64));
+    HIP_CHECK(hipEventCreateWithFlags(&m->ev_umax, hipEventDisableTiming));
+  }
+  // (a batch staged before the split reduce was switched on has no count: the lists' capacity then)
+  const int64_t bound = (m->u_bound_host >= 1 && m->u_bound_host <= m->tok_cap) ? m->u_bound_host : m->tok_cap;
+  if (m->umax_pending) HIP_CHECK(hipEventSynchronize(m->ev_umax));   // (an armed step that never reached its tail)
+  m->h_umax[0] = (float)bound;                                         // (< 2^24: exact)
+  HIP_CHECK(hipMemcpyAsync(m->d_umax, m->h_umax, 4, hipMemcpyHostToDevice, c->stream));
+  RC(comm_all_reduce_f32(c, m->d_umax, 1, COMM_MAX, c->stream));
+  HIP_CHECK(hipMemcpyAsync(m->h_umax + 1, m->d_umax, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipEventRecord(m->ev_umax, c->stream));
+  m->umax_pending = true;
+  return RSYS_OK;
+}
+
+int model_split_table_tail(Model* m, rsys_comm* c, hipStream_t cs, int64_t* rows_out) {
   const int W = comm_active(c) ? c->world : 1, D = m->D;
-  const int64_t cap = m->tok_cap;
-  if (m->tok_all_world < W) {
+  int64_t cap = 0;
+  RC(model_split_table_rows(m, &cap));
+  if (rows_out) *rows_out = cap;
+  if (m->tok_all_world < W || m->tok_all_rows < cap) {
     for (void* p : {(void*)m->tok_Tall, (void*)m->tok_Uall, (void*)m->tok_Pall}) if (p) HIP_CHECK(hipFree(p));
     m->tok_Tall = nullptr; m->tok_Uall = nullptr; m->tok_Pall = nullptr;
-    HIP_CHECK(hipMalloc((void**)&m->tok_Tall, (size_t)W * cap * D * 4));
-    HIP_CHECK(hipMalloc((void**)&m->tok_Uall, (size_t)W * cap * 4));
+    const int64_t rows = std::min<int64_t>(m->tok_cap, cap + cap / 8);   // (some room: the next batches' maxima differ by a few percent)
+    HIP_CHECK(hipMalloc((void**)&m->tok_Tall, (size_t)W * rows * D * 4));
+    HIP_CHECK(hipMalloc((void**)&m->tok_Uall, (size_t)W * rows * 4));
     HIP_CHECK(hipMalloc((void**)&m->tok_Pall, (size_t)W * 64));
-    m->tok_all_world = W;
+    m->tok_all_world = W; m->tok_all_rows = rows;
   }
+  // rows [U_r, cap) of a rank's list hold whatever an earlier batch left there: they travel, nobody adds them (the counted add stops at the
+  // rank's own U from its gathered plan)
   RC(comm_all_gather(c, m->tok_T, m->tok_Tall, (size_t)cap * D * 4, cs));
   RC(comm_all_gather(c, m->u_ids, m->tok_Uall, (size_t)cap * 4, cs));
   RC(comm_all_gather(c, m->u_plan, m->tok_Pall, 64, cs));

@@ -53,9 +53,15 @@ class Prefetch:
     ahead (blosc / HDF5 decode and the device calls of the consumer both release the GIL); order and content are the
     dataset's own, an exception in the producer is re-raised in the consumer, leaving the loop early stops the producer."""
 
-    switch_interval = 1e-4    # seconds: interpreter switch interval while the producer thread runs (tools/ab_loader_interval.py)
+    # seconds: interpreter switch interval while the producer thread runs (tools/ab_loader_interval.py).  The interval is a property of the
+    # whole interpreter, so it is changed only between the first batch asked for and the end of the iteration (restored on exhaustion, on
+    # `close()` of the generator and on an exception alike), and never when the embedding application set RSYS_KEEP_SWITCH_INTERVAL=1 or
+    # passes switch_interval=None.
+    switch_interval = 1e-4
 
-    def __init__(self, dataset, depth=16):
+    def __init__(self, dataset, depth=16, switch_interval="default"):
+        if switch_interval != "default":
+            self.switch_interval = switch_interval
         # depth: batches the producer may run ahead.  A shard file is decoded and block-shuffled in one go (~60 ms for 8 batches of
         # cfg-3), so a queue of 3 ran dry at every file boundary; 16 = the reference's 8 workers x prefetch_factor 2 (train.py:162-165)
         self.dataset, self.depth = dataset, max(1, int(depth))
@@ -90,9 +96,11 @@ class Prefetch:
         # The consumer re-takes the interpreter lock after every device call it returns from; with the default 5 ms switch interval
         # a producer busy in numpy / Python code holds it that long and the GPU waits for its next launches (measured: the HDF5-fed
         # loop +4 % over the in-memory loop, gpurun_out/r5f_bench.json).  A short interval hands the lock over within tens of microseconds (1e-4 s: +2.2 %, gpurun_out/r5g_bench_full.json).
+        import os
         import sys
         old_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_interval, self.switch_interval))
+        if self.switch_interval is not None and os.environ.get("RSYS_KEEP_SWITCH_INTERVAL") != "1":
+            sys.setswitchinterval(min(old_interval, self.switch_interval))
         t = threading.Thread(target=produce, daemon=True)
         t.start()
         try:

@@ -225,6 +225,8 @@ def train_epoch(model, dataloader, optimizer, scheduler, task_weights, grad_accu
     # LOSS_RING steps, in order, with the same host arithmetic -- the same floats as the step-by-step read, without a host wait per step.
     deferred = pipelined and hasattr(model, "push_losses")
     parked = 0
+    if deferred:
+        model.drain_losses()                   # steps an earlier epoch parked before it left by an exception are not this epoch's
     it = iter(lockstep_batches(model, dataloader, comm))
     data = next(it, None)
     if data is not None and staged:

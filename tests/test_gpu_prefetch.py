@@ -104,3 +104,37 @@ def test_parked_losses_are_the_step_by_step_ones():
     for (la, wa), (lb, wb) in zip(a, b):
         assert la == lb and wa == wb, (la, lb, wa, wb)
     assert a[0][0] != a[1][0]
+
+
+def test_an_epoch_that_left_by_an_exception_leaves_no_parked_step_to_the_next(tmp_path):
+    """train_epoch parks every step's losses on the device and reads them every LOSS_RING steps; an epoch that leaves by an
+    exception between a push and the drain (here: a batch the prefetch rejects, four steps in) used to hand its parked steps to the NEXT
+    epoch's mean.  Now an epoch starts by emptying the ring: the epoch after the failed one reports exactly what it reports on a fresh
+    model brought to the same state."""
+    import recommendersystem_amd as ra
+    from oracle import synth
+    from recommendersystem_amd.train import ConstantScheduler, LambdaLR, make_task_weights, train_epoch
+    cfg = synth.make_config("hd64", mask_rate=0.2, mask_topk=16, deterministic=True)
+    rows = 2
+    good = [synth.make_batch(cfg, rows, 500 + i) for i in range(4)]
+    bad = {k: np.array(v).copy() for k, v in synth.make_batch(cfg, rows, 600).items()}
+    bad["matchedid"][1] = 10 ** 7
+    second = [synth.make_batch(cfg, rows, 700 + i) for i in range(3)]
+    tw = make_task_weights()
+
+    def run(fail):
+        model = ra.RecommenderModel(cfg, dtype="bf16", max_rows=rows)
+        model.load_state_dict(synth.make_params(cfg, 8, "test"))
+        model.mask_seed = 21
+        opt = ra.create_optimizer(model, cfg)
+        sched = LambdaLR(ConstantScheduler())
+        if fail:
+            with pytest.raises(ra.RsysError):
+                train_epoch(model, good + [bad], opt, sched, tw, 1, None)
+        else:
+            train_epoch(model, good, opt, sched, tw, 1, None)
+        out = train_epoch(model, second, opt, sched, tw, 1, None)
+        model.close()
+        return np.asarray(out, np.float64)
+    a, b = run(False), run(True)
+    assert np.array_equal(a, b), (a, b)

@@ -55,9 +55,10 @@ def _grads(cfg, P, batches, masks, world, split, micro_steps, delay_us=0):
             losses.append(model(batches[r][i], False, masks=masks[r][i]))
         comm.all_reduce_grads(model)
         early = comm.early_reduced(model)
+        sched = comm.grad_schedule(model)
         G = {n: model.grad(n).copy() for n in names}
         model.close(); comm.close()
-        return np.array(losses, np.float64), G, early
+        return np.array(losses, np.float64), G, early, sched
 
     res = _run_ranks(world, rank_fn)
     group.close()
@@ -82,8 +83,18 @@ def test_split_table_reduce_equals_the_dense_all_reduce(world, micro_steps):
     got = _grads(cfg, P, batches, masks, world, True, micro_steps)
     table = "item_embedding.matchedid_embedding.embedding.weight"
     assert table in names
+    # the tail's gathers carry max_r U_r token rows per rank (rounded up to 64), not the lists' capacity rows * S + 1 (round 6): the
+    # schedule's phase-4 entry counts world * rows * (D + 1) gathered floats
+    D, S = cfg["embed_dim"], cfg["max_sequence_length"]
+    distinct = max(len(np.unique(np.asarray(batches[r][-1]["matchedid"]))) + 1 for r in range(world))
     for r in range(world):
-        (la, ga, ea), (lb, gb, eb) = ref[r], got[r]
+        tail = [hi - lo for lo, hi, ph in got[r][3] if ph == 4]
+        assert len(tail) == 1 and tail[0] % (world * (D + 1)) == 0, got[r][3]
+        per_rank = tail[0] // (world * (D + 1))
+        assert per_rank == min(rows * S + 1, (distinct + 63) // 64 * 64), (per_rank, distinct)
+        assert not [1 for lo, hi, ph in ref[r][3] if ph in (3, 4)]
+    for r in range(world):
+        (la, ga, ea, _), (lb, gb, eb, _) = ref[r], got[r]
         assert np.array_equal(la, lb), (r, la, lb)
         assert eb - ea == ga[table].size, (ea, eb, ga[table].size)      # the split path ran: the table left the tail's dense reduce
         for n in names:
