@@ -379,7 +379,10 @@ def test_built_library_has_no_packed_f32_with_a_crossed_low_half(tmp_path):
     objects no v_pk_{mul,fma,add}_f32 may compute its LOW half from the HIGH dword of a source pair (`op_sel:[..1..]`; the broadcast forms
     `op_sel_hi:[..]` alone are fine and stay: 1.5 K of them).  That form, produced by the SLP pass from the RoPE rotations of the
     epilogues, dropped a product on lanes 48-63 about once per 3e5 waves on MI355X (profiles/r4_attn_dq_packed_f32_glitch.log;
-    ISA and hazard-table check: profiles/r5_packed_f32_isa_analysis.md).  Whatever re-creates it -- a flag, a compiler update, an
+    ISA and hazard-table check: profiles/r5_packed_f32_isa_analysis.md).  Round 6 found the cause (profiles/r6_packed_f32_root_cause.md):
+    exactly ONE form -- v_pk_fma_f32 op_sel:[0,1,0], source 1's high dword to both halves -- loses its low-half product on lanes 48-63 while
+    MFMAs of the same wave are still in flight (tools/micro/pk_f32_forms_probe.hip: 851 274 of 2.15e9, every other form 0, the four forms
+    this library contains included).  The test refuses a superset of that form.  Whatever re-creates it -- a flag, a compiler update, an
     ext-vector expression in a new kernel -- fails here before it reaches a GPU."""
     import re
     crossed, packed = [], 0

@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from recommendersystem_amd import _lib, workload
 if os.environ.get('RSYS_LIB_PATH'): _lib.LIB_PATH = os.environ['RSYS_LIB_PATH']
 lib = _lib.lib()
