@@ -431,9 +431,9 @@ static bool attn_kv_pairs(const AttnParams& p);   // the dK/dV launch of this sh
 // kv_pairs: the dK/dV side's slots are PAIRS of kv tiles (attn_bwd_kv32_kernel: 128 keys per workgroup), work = q tiles either tile is visited by
 __global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, int identity, int kv_pairs) {
   extern __shared__ int ocnt[];   // [chunks of 64 slots + 1][34]: slots per (chunk, key), then their exclusive prefixes; last row: totals / bases
-  const int side = blockIdx.y, nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
-  const int n_inner = side == 0 ? (p.H / p.KV / R) * nt : (kv_pairs ? (nt + 1) / 2 : nt);
-  int* out = side == 0 ? p.order_q : p.order_k;
+  const int side = blockIdx.y, nt = (p.T + 63) / 64, n_groups = p.B * p.KV;   // side 2: the forward kernel's (head, q tile PAIR) slots
+  const int n_inner = side == 0 ? (p.H / p.KV / R) * nt : side == 2 ? (p.H / p.KV) * ((nt + 1) / 2) : (kv_pairs ? (nt + 1) / 2 : nt);
+  int* out = side == 0 ? p.order_q : side == 2 ? p.order_q2 : p.order_k;
   if (out == nullptr) return;
   const bool lists = (n_groups & 7) == 0;
   const int ns = lists ? (n_groups >> 3) * n_inner : n_groups * n_inner, xcd = blockIdx.x;
@@ -446,6 +446,10 @@ __global__ __launch_bounds__(256) void attn_order_kernel(AttnParams p, int R, in
     const int group = lists ? (sl / n_inner) * 8 + xcd : sl / n_inner, tile = (sl % n_inner) % nt, b = group / p.KV;
     const int qa = p.q_active != nullptr ? p.q_active[b] : 32;
     if (side == 0) return tile < qa ? __popc(p.qmap[b * nt + tile]) : 0;
+    if (side == 2) {
+      const int t0 = 2 * ((sl % n_inner) % ((nt + 1) / 2)), lim = min(nt, qa);
+      return __popc((t0 < lim ? p.qmap[b * nt + t0] : 0u) | (t0 + 1 < lim ? p.qmap[b * nt + t0 + 1] : 0u));
+    }
     if (kv_pairs) {
       const int t0 = 2 * (sl % n_inner);
       const unsigned int u = p.kmap[b * nt + t0] | (t0 + 1 < nt ? p.kmap[b * nt + t0 + 1] : 0u);
@@ -499,11 +503,11 @@ int launch_attn_tilemap(const AttnParams& p, hipStream_t s) {
     HIP_CHECK(hipMemsetAsync(p.kmap16, 0, bytes * 4, s));
   }
   hipLaunchKernelGGL(attn_tilemap_kernel, dim3((p.T + 63) / 64, p.B), dim3(256), 0, s, p);
-  if (p.order_q != nullptr || p.order_k != nullptr) {
+  if (p.order_q != nullptr || p.order_k != nullptr || p.order_q2 != nullptr) {
     const int R = attn_heads_per_wg(p), nt = (p.T + 63) / 64, n_groups = p.B * p.KV;
     const int ns_max = ((n_groups & 7) == 0 ? (n_groups >> 3) : n_groups) * (p.H / p.KV) * nt;
     // (a list beyond one workgroup's LDS: keep the plain order -- the kernels read an identity permutation)
-    hipLaunchKernelGGL(attn_order_kernel, dim3((n_groups & 7) == 0 ? 8 : 1, 2), dim3(256), (size_t)(std::min((ns_max + 63) / 64, 400) + 1) * 34 * 4, s, p, R, (ns_max + 63) / 64 > 400 ? 1 : 0,
+    hipLaunchKernelGGL(attn_order_kernel, dim3((n_groups & 7) == 0 ? 8 : 1, p.order_q2 != nullptr ? 3 : 2), dim3(256), (size_t)(std::min((ns_max + 63) / 64, 400) + 1) * 34 * 4, s, p, R, (ns_max + 63) / 64 > 400 ? 1 : 0,
                        attn_kv_pairs(p) ? 1 : 0);
   }
   HIP_CHECK(hipGetLastError());
@@ -659,6 +663,16 @@ __device__ __forceinline__ void copy_out_tile_sw(const bf16* Os, bf16* dst, long
     am = wave_max(am);
     if ((t & 63) == 0) f8_amax_add(amax, am);
   }
+}
+// 32 x 32 x 16 products (the 32-token-per-wave kernels: attn_fwd32_kernel, attn_bwd_kv32_kernel; LDS image and fragment maps: see the dK/dV kernel)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ int sw32(int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 pack8f(const f32x16& v, int o) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)v[o + j];
+  return r;
 }
 // ------------------------------------------------------------------------ forward
 // R = query heads per workgroup: the R heads of one kv head's group at the SAME 64 tokens (R = 1: one head).  They share the
@@ -824,6 +838,221 @@ __global__ __launch_bounds__(256, (is_bf16<T>::value && HD <= 64) ? (R == 1 ? 3 
     copy_out_tile<T, HD>(Ks + r * C::TILE, (T*)p.o + (tok0 + qt * 64) * p.ldo + (h0 + r) * HD, p.ldo, qt * 64, p.T, t, p.f8_amax);
 }
 
+
+// ------------------------------------------------------------------------ forward on v_mfma_f32_32x32x16_bf16 (bf16, head_dim 64; round 6)
+// The dK/dV recipe of round 5 (attn_bwd_kv32_kernel) for the forward pass: a wave owns 32 QUERIES (the lanes' l & 31), four waves = 128
+// queries = two q tiles of ONE head per workgroup; every staged K / V tile feeds all of them -- the staging per FLOP of the two-head 64-query
+// kernel above, half its MFMA instructions and fragment reads per FLOP, and one head's accumulators per wave (O 32 + S 32 + Q 16 registers):
+// compiled for FOUR waves per SIMD.
+//   S^T[kv][q] = sum_d K[kv][d] Q[q][d]:  A = K rows from LDS (ds_read_b128: row kv0 + (l & 31), d = 16 s + 8 (l >> 5) ..+7), B = Q from registers
+//   O^T[d][q] += V^T[d][kv] P[kv][q]:     the S accumulator registers 8 s .. 8 s + 7 ARE the B operand of k-step s (keys 16 s + 8 (j >> 2) +
+//   4 (l >> 5) + (j & 3)); A = V^T read transposed from the row-major tile (two ds_read_b64_tr_b16), exactly the dO^T operand of dV in the dK/dV kernel
+// Soft-max: a query's 64 scores of a tile sit in the 32 registers of lanes l and l ^ 32: row maximum and sum are lane-local plus ONE
+// v_permlane32_swap; the accumulators are rescaled only when some query's running maximum moved (wave-uniform test).
+#ifndef ATTN_FWD32_WPS
+#define ATTN_FWD32_WPS 4
+#endif
+__device__ __forceinline__ float pair_rows_max(float v) {   // over lanes l, l ^ 32
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned int)b[0]), __builtin_bit_cast(float, (unsigned int)b[1]));
+}
+__device__ __forceinline__ float pair_rows_sum(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned int)b[0]) + __builtin_bit_cast(float, (unsigned int)b[1]);
+}
+__global__ __launch_bounds__(256, ATTN_FWD32_WPS) void attn_fwd32_kernel(AttnParams p) {
+  constexpr int HD = 64, TB = 64 * 64;   // elements of an unpadded tile
+  using T = bf16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const Kb = smem_raw;                 // [2][64 kv][128 B] swizzled (sw32)
+  unsigned char* const Vb = smem_raw + 2 * TB * 2;    // [2][64 kv][128 B]
+  const int rep = p.H / p.KV, nt = (p.T + 63) / 64, npair = (nt + 1) / 2;
+  int grp, inner;
+  attn_work(p.B * p.KV, rep * npair, p.order_q2, grp, inner);
+  const int b = grp / p.KV, kvh = grp % p.KV, hh = kvh * rep + inner / npair, pr = inner % npair;
+  const int qa = p.q_active != nullptr ? min(p.q_active[b], nt) : nt;   // q tiles >= qa: nobody reads their output
+  if (2 * pr >= qa) return;                                            // (uniform: whole workgroup)
+  const int t = threadIdx.x, l = t & 63, r32 = l & 31, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int qt = 2 * pr + (w >> 1);                   // this wave's q tile (may be inactive: the wave then only stages)
+  const bool tile_ok = qt < qa;
+  const long long tok0 = (long long)b * p.T;
+  const float c2 = rsqrtf((float)HD) * LOG2E;        // scores are handled in log2 units
+  const int q = qt * 64 + 32 * (w & 1) + r32;        // this lane's query
+  const bool qv = tile_ok && q < p.T;
+  bf16x8 qf[4];
+  {
+    const T* qrow = (const T*)p.q + (tok0 + min(q, p.T - 1)) * p.ld + hh * HD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s + 8 * h);
+  }
+  f32x16 O[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const int t0i = b * nt + 2 * pr, t1i = b * nt + min(2 * pr + 1, nt - 1), qti = b * nt + min(qt, nt - 1);
+  const unsigned int bits = (unsigned int)__builtin_amdgcn_readfirstlane((int)(p.qmap[t0i] | (2 * pr + 1 < qa ? p.qmap[t1i] : 0u)));   // kv tiles the workgroup stages
+  const unsigned int fullbits = tile_ok ? (unsigned int)__builtin_amdgcn_readfirstlane((int)p.qmap_full[qti]) : 0u;
+  const unsigned int wbits = tile_ok ? (unsigned int)__builtin_amdgcn_readfirstlane((int)(p.qmap16[qti * 4 + 2 * (w & 1)] | p.qmap16[qti * 4 + 2 * (w & 1) + 1])) : 0u;
+  const at_i32x4 k_rs = at_rsrc((const T*)p.k + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  const at_i32x4 v_rs = at_rsrc((const T*)p.v + tok0 * p.ld + kvh * HD, ((long long)(p.T - 1) * p.ld + HD) * sizeof(T));
+  // the pair bits of this wave's q tile against every kv tile: [nt][64 queries] words (an inactive tile: an empty window, all zero)
+  const at_i32x4 qb_rs = at_rsrc(p.qbits + (long long)qti * nt * 64, tile_ok ? (long long)nt * 64 * 8 : 0);
+  // wave w fills rows 16 w .. 16 w + 15 of each tile with two DMA instructions (8 rows = 1 KB each): per-lane source offsets, fixed
+  int dv_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = 16 * w + 8 * k + (l >> 3), ch = (l & 7) ^ sw32(row);
+    dv_[k] = (int)((row * p.ld + ch * 8) * sizeof(T));
+  }
+  // fragment addresses inside a tile (bytes; lane constants), as in attn_bwd_kv32_kernel:
+  //   row reads: row kv0 + r32, chunk 2 s + h -> slot (2 s) ^ G, G = h ^ sw32(r32)
+  //   transposed reads: row kv0 + 16 s2 + 8 u + 4 h + (i >> 2), columns 32 db + 16 g16 + 4 (i & 3) -> slot L ^ (4 db) ^ u
+  const int G = h ^ sw32(r32);
+  const int i16 = l & 15, g16 = (l >> 4) & 1;
+  const int Lc = (2 * g16 + ((i16 & 3) >> 1)) ^ ((((i16 >> 2) >> 1) & 1) << 2 | (h << 1));
+  int a_row[4], a_tr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a_row[s] = r32 * 128 + (((2 * s) ^ G) << 4);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) a_tr[v] = (4 * h + (i16 >> 2)) * 128 + ((Lc ^ ((v >> 1) << 2) ^ (v & 1)) << 4) + ((i16 & 1) << 3);   // v = 2 db + u
+  const unsigned int lds0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)smem_raw);
+  unsigned long long sqb = 0ull;   // this lane's pair-bit word of the next tile on its way
+  auto stage = [&](int kt, int buf) {
+    const int so = (int)(kt * 64 * p.ld * sizeof(T));
+    const unsigned int kd = lds0 + buf * (TB * 2) + (16 * w) * 128, vd = kd + 2 * TB * 2;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      dma16_asm(k_rs, kd + k * 1024, dv_[k], so);
+      dma16_asm(v_rs, vd + k * 1024, dv_[k], so);
+    }
+    sqb = __builtin_bit_cast(unsigned long long, rsys_at_buffer_load_b64(qb_rs, 8 * (32 * (w & 1) + r32), kt * 512, 0));   // this query's keys of tile kt
+  };
+  int kt = next_bit(bits, 0), cur = 0;
+  unsigned long long wq = 0ull;
+  if (kt < nt) { stage(kt, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wq = sqb; }
+  // the Q fragments' loads are retired here in the compiler's bookkeeping (see dma16 / attn_bwd_kv32_kernel)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+  asm volatile("" : "+v"(wq));
+  __syncthreads();
+  while (kt < nt) {
+    const int nxt = next_bit(bits, kt + 1);
+    if (nxt < nt) stage(nxt, cur ^ 1);   // (the other buffer: every wave left it before the barrier that ended the previous tile)
+    if ((wbits >> kt) & 1u) {            // (a wave whose 32 queries have no allowed key in this tile leaves its state untouched)
+      const unsigned char* Kc = Kb + cur * (TB * 2);
+      const unsigned char* Vc = Vb + cur * (TB * 2);
+      const bool fullt = (fullbits >> kt) & 1u;
+      f32x16 S[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {   // 32 keys at a time: accumulator register r = key 32 kb + 8 (r >> 2) + 4 h + (r & 3)
+        const unsigned int w32 = (unsigned int)(kb ? (wq >> 32) : wq);
+        // the mask enters the score chain as its starting value (0 / -1e30); a 32 x 32 block of which every pair is allowed needs none
+        if (!fullt && __builtin_amdgcn_ballot_w64(w32 != 0xFFFFFFFFu) != 0ull) {
+          const int src = (int)(w32 >> (4 * h));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = __builtin_amdgcn_sbfe(src, 8 * (r >> 2) + (r & 3), 1);
+            S[kb][r] = __builtin_bit_cast(float, __builtin_bit_cast(int, -1e30f) & ~m);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) S[kb] = mfma32(*(const bf16x8*)(Kc + kb * 4096 + a_row[s]), qf[s], S[kb]);   // S^T[kv][q]
+      }
+      float tmax = -1e30f;
+#ifndef ATTN_FWD32_TIMING_NOMAX   // (timing-only builds, tools/: what the row maximum, the exponential and the row sum cost)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, S[kb][r]);
+      tmax = pair_rows_max(tmax);
+#else
+      tmax = 0.25f;
+#endif
+      const float m_new = fmaxf(m_run, tmax * c2);
+      const float mu_old = fmaxf(m_run, -1e20f), mu_new = fmaxf(m_new, -1e20f);
+      const float alpha = fexp2(mu_old - mu_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifdef ATTN_FWD32_TIMING_NOEXP
+          const float pv = fmaf(S[kb][r], c2, -mu_new);
+#else
+          const float pv = fexp2(fmaf(S[kb][r], c2, -mu_new));   // masked entries: exp2(-1.8e29) = 0
+#endif
+          S[kb][r] = pv;
+#ifndef ATTN_FWD32_TIMING_NOSUM
+          psum += pv;
+#endif
+        }
+      psum = pair_rows_sum(psum);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {   // (some query's maximum moved: after the first tiles of a user it rarely does)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {   // k-step = 16 keys: accumulator registers 8 s2 .. 8 s2 + 7
+          const bf16x8 pf = pack8f(S[kb], 8 * s2);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int o = (32 * kb + 16 * s2) * 128;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(Vc + o + a_tr[2 * db]));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS bf16x4*)(Vc + o + 8 * 128 + a_tr[2 * db + 1]));
+            O[db] = mfma32(__builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7), pf, O[db]);   // O^T[d][q] += V^T[d][kv] P[kv][q]
+          }
+        }
+    }
+    if (nxt < nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next tile landed (the barrier publishes it)
+    __syncthreads();
+    wq = sqb;
+    cur ^= 1;
+    kt = nxt;
+  }
+  // epilogue: O as bf16 rows [query][64] through the two K buffers (128 queries x 128 bytes), then row stores.
+  // accumulator register r of block db: d = 32 db + 8 (r >> 2) + 4 h + (r & 3), query = r32 of this wave
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  if (h == 0 && qv) p.lse[((long long)b * p.H + hh) * p.T + q] = (m_run + log2f(l_run)) * (1.f / LOG2E);
+  const int orow = 32 * w + r32;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = 32 * db + 8 * g4 + 4 * h;
+      bf16x4 oo; oo[0] = (bf16)(O[db][4 * g4] * inv); oo[1] = (bf16)(O[db][4 * g4 + 1] * inv); oo[2] = (bf16)(O[db][4 * g4 + 2] * inv); oo[3] = (bf16)(O[db][4 * g4 + 3] * inv);
+      // (chunk slot permuted by the row so that the 8-byte stores of a half-wave spread over the banks; the copy below undoes it)
+      *(bf16x4*)(Kb + orow * 128 + ((((d >> 3) ^ (orow & 7)) << 4) | ((d & 4) << 1))) = oo;
+    }
+  __syncthreads();
+  {
+    float am = 0.f;
+#pragma unroll
+    for (int c = t; c < 128 * 8; c += 256) {   // 16-byte chunks of the 128 rows
+      const int row = c >> 3, ch = c & 7;
+      const int tile = 2 * pr + (row >> 6), tok = tile * 64 + (row & 63);
+      if (tile < qa && tok < p.T) {
+        const uint4 v = *(const uint4*)(Kb + row * 128 + ((ch ^ (row & 7)) << 4));
+        *(uint4*)((T*)p.o + (tok0 + tok) * p.ldo + hh * HD + ch * 8) = v;
+        if (p.f8_amax != nullptr) am = fmaxf(am, chunk_amax<bf16>(v));
+      }
+    }
+    if (p.f8_amax != nullptr) {
+      am = wave_max(am);
+      if (l == 0) f8_amax_add(p.f8_amax, am);
+    }
+  }
+}
+
 // query heads per workgroup of the forward / dQ kernels: the whole group of a kv head when that is 2 (every configuration of
 // H / KV = 2), else 1.
 static bool attn_dma_on() { return sw().attn_dma != 0; }
@@ -842,6 +1071,14 @@ static int attn_fwd_hd(const AttnParams& p, hipStream_t s) {
     set = true;
   }
   if constexpr (is_bf16<T>::value && HD == 64) {
+    if (attn_dma_on() && sw().attn_fwd32 != 0) {   // RSYS_ATTN_FWD32=1 (opt-in): 128 queries of one head per workgroup on 32 x 32 x 16 products
+      static bool set32 = false;
+      if (!set32) { HIP_CHECK(hipFuncSetAttribute((const void*)attn_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 2)); set32 = true; }
+      const int nt = (p.T + 63) / 64;
+      hipLaunchKernelGGL(attn_fwd32_kernel, dim3(((nt + 1) / 2) * p.H * p.B), dim3(256), 4 * 64 * 64 * 2, s, p);
+      HIP_CHECK(hipGetLastError());
+      return RSYS_OK;
+    }
     if (attn_dma_on()) {   // LDS-DMA staging (RSYS_ATTN_DMA=0: the register-staged kernels)
       const size_t sm_dma = 4 * 64 * 64 * 2 + 384 * 4;
       if (attn_heads_per_wg(p) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 2, true>), dim3(((p.T + 63) / 64) * (p.H / 2) * p.B), dim3(256), sm_dma, s, p);
@@ -1229,15 +1466,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_kv_dma_kernel(AttnParams p) {
 // LDS image: unpadded 128-byte rows, 16-byte chunk c of row r in slot c ^ sw32(r), sw32(r) = (r1, r2, r3) as bits (2, 1, 0): with that
 // permutation the 32-row ds_read_b128 fragments (lane groups {0-3, 12-15, 20-27}, ...) and the 4-row x 4-chunk transposed reads of a
 // 32-lane half both touch every bank once (checked against the guide's lane groups; the 16-row kernels' c ^ (r & 7) is 2-way here).
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-__device__ __forceinline__ int sw32(int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1); }
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ bf16x8 pack8f(const f32x16& v, int o) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (bf16)v[o + j];
-  return r;
-}
 static bool attn_kv32_on() { return sw().attn_kv32 != 0; }   // 0 = the 16-key-per-wave kernel
 static bool attn_kv_pairs(const AttnParams& p) {   // (bf16 is the caller's business: the fp32 launches never read order_k's pair form)
   return p.hd == 64 && p.is_bf16 && sw().attn_kv_dma != 0 && attn_dma_on() && attn_kv32_on();

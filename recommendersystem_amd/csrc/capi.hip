@@ -753,12 +753,12 @@ int32_t rsys_op_attention(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_
   p.o = O; p.ldo = (long long)H * hd; p.lse = lse; p.uid = uid; p.tm = tm;
   unsigned int* maps = nullptr; float* delta = nullptr;
   unsigned long long* pairbits = nullptr;
-  HIP_CHECK(hipMalloc((void**)&maps, sizeof(unsigned int) * (12 * B * nt + (size_t)B * (H + KV) * nt)));
+  HIP_CHECK(hipMalloc((void**)&maps, sizeof(unsigned int) * (12 * B * nt + (size_t)B * (2 * H + KV) * nt)));
   HIP_CHECK(hipMalloc((void**)&pairbits, sizeof(unsigned long long) * 2 * (size_t)B * nt * nt * 64));
   HIP_CHECK(hipMalloc((void**)&delta, sizeof(float) * B * H * T));
   p.qmap = maps; p.kmap = maps + B * nt; p.qmap_full = maps + 2 * B * nt; p.kmap_full = maps + 3 * B * nt; p.delta = delta;
   p.qmap16 = maps + 4 * B * nt; p.kmap16 = maps + 8 * B * nt;
-  p.order_q = (int*)(maps + 12 * B * nt); p.order_k = p.order_q + (size_t)B * H * nt;
+  p.order_q = (int*)(maps + 12 * B * nt); p.order_k = p.order_q + (size_t)B * H * nt; p.order_q2 = p.order_k + (size_t)B * KV * nt;
   p.qbits = pairbits; p.kbits = pairbits + (size_t)B * nt * nt * 64;
   p.dO = dO; p.dq = dqkv; p.dk = (unsigned char*)dqkv + (size_t)H * hd * e;
   p.dv = (unsigned char*)dqkv + (size_t)(H + KV) * hd * e; p.ldg = p.ld;

@@ -213,6 +213,9 @@ struct AttnParams {
   // blockIdx -> work mapping: order_q [B * H * ceil(T/64)] for the forward / dQ kernels (work = kv tiles of the q tile), order_k
   // [B * KV * ceil(T/64)] for the dK/dV kernel (work = q tiles of the kv tile).  nullptr: plain order.
   int *order_q, *order_k;
+  // optional: the same for the 128-query forward kernel (attn_fwd32_kernel: slots = (head of the kv group, PAIR of q tiles), work = kv tiles
+  // either tile visits): [B * H * ceil(ceil(T/64) / 2)]
+  int* order_q2;
   // pair bits of every (q tile, kv tile), written by launch_attn_tilemap (the same compares that build the maps) and read by the three
   // kernels instead of comparing keys per score: qbits [B][nt q][nt kv][64 queries]: bit k = the query may see key k of the kv tile;
   // kbits [B][nt kv][nt q][64 keys]: bit q = the key is seen by query q of the q tile (the transposed matrix).  Required.

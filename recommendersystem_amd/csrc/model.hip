@@ -221,7 +221,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
     m->qmap = (unsigned int*)(base + 7 * mb); m->qmap16 = (unsigned int*)(base + 8 * mb);
     m->maps_zero_bytes = (size_t)(7 * mb);
     const int64_t nt = (m->T + 63) / 64;
-    DALLOC(m->attn_order_q, (int64_t)m->rows_max * m->H * nt * 4); DALLOC(m->attn_order_k, (int64_t)m->rows_max * m->KV * nt * 4);
+    DALLOC(m->attn_order_q, (int64_t)m->rows_max * m->H * nt * 4 * 2);   /* second half: the q-tile-pair list (AttnParams::order_q2) */ DALLOC(m->attn_order_k, (int64_t)m->rows_max * m->KV * nt * 4);
     DALLOC(m->attn_qbits, (int64_t)m->rows_max * nt * nt * 64 * 8); DALLOC(m->attn_kbits, (int64_t)m->rows_max * nt * nt * 64 * 8);
   }
   m->la.resize(m->L);
@@ -320,7 +320,7 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       m->kmap_p = (unsigned int*)base; m->kmap_full_p = (unsigned int*)(base + mb); m->qmap_full_p = (unsigned int*)(base + 2 * mb); m->kmap16_p = (unsigned int*)(base + 3 * mb);
       m->qmap_p = (unsigned int*)(base + 7 * mb); m->qmap16_p = (unsigned int*)(base + 8 * mb);
       const int64_t nt = (m->T + 63) / 64;
-      DALLOC(m->attn_order_q_p, (int64_t)m->rows_max * m->H * nt * 4); DALLOC(m->attn_order_k_p, (int64_t)m->rows_max * m->KV * nt * 4);
+      DALLOC(m->attn_order_q_p, (int64_t)m->rows_max * m->H * nt * 4 * 2); DALLOC(m->attn_order_k_p, (int64_t)m->rows_max * m->KV * nt * 4);
       DALLOC(m->attn_qbits_p, (int64_t)m->rows_max * nt * nt * 64 * 8); DALLOC(m->attn_kbits_p, (int64_t)m->rows_max * nt * nt * 64 * 8);
     }
   }

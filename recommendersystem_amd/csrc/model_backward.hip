@@ -165,7 +165,7 @@ int backward_trunk(Model* m) {
   AttnParams ap{};
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
-  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
+  ap.order_q = m->attn_order_q; ap.order_q2 = m->attn_order_q + (int64_t)m->rows_max * m->H * ((m->T + 63) / 64); ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
   ap.rope_cos = m->rope_cos; ap.rope_sin = m->rope_sin; ap.rope_pos = rpos;
   int bucket_top = m->L - 1;
   for (int l = m->L - 1; l >= 0; --l) {
@@ -246,7 +246,7 @@ int backward_trunk(Model* m) {
       AttnParams at = ap;
       at.uid = m->uid_p; at.tm = m->tm_p; at.rope_pos = m->pos_p; at.q_active = m->c_qact;
       at.qmap = m->qmap_p; at.kmap = m->kmap_p; at.qmap_full = m->qmap_full_p; at.kmap_full = m->kmap_full_p; at.qmap16 = m->qmap16_p; at.kmap16 = m->kmap16_p;
-      at.order_q = m->attn_order_q_p; at.order_k = m->attn_order_k_p; at.qbits = m->attn_qbits_p; at.kbits = m->attn_kbits_p;
+      at.order_q = m->attn_order_q_p; at.order_q2 = m->attn_order_q_p + (int64_t)m->rows_max * m->H * ((m->T + 63) / 64); at.order_k = m->attn_order_k_p; at.qbits = m->attn_qbits_p; at.kbits = m->attn_kbits_p;
       RC(launch_attn_bwd<T>(at, s));
     } else {
       RC(launch_attn_bwd<T>(ap, s));

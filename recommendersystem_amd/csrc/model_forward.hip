@@ -173,7 +173,7 @@ int forward_trunk(Model* m) {
   ap.B = rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_t; ap.tm = m->tm_t; ap.qmap = m->qmap; ap.kmap = m->kmap; ap.qmap_full = m->qmap_full; ap.kmap_full = m->kmap_full; ap.qmap16 = m->qmap16; ap.kmap16 = m->kmap16;
   ap.maps_zero_base = m->kmap; ap.maps_zero_bytes = m->maps_zero_bytes;
-  ap.order_q = m->attn_order_q; ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
+  ap.order_q = m->attn_order_q; ap.order_q2 = m->attn_order_q + (int64_t)m->rows_max * m->H * ((m->T + 63) / 64); ap.order_k = m->attn_order_k; ap.qbits = m->attn_qbits; ap.kbits = m->attn_kbits;
   RC(launch_attn_tilemap(ap, s));
   toc(m);
   AttnParams ap_top = ap;   // the last layer under the compact top: selected-first token order, its own tile maps, leading query tiles only
@@ -185,7 +185,7 @@ int forward_trunk(Model* m) {
     ap_top.qmap = m->qmap_p; ap_top.kmap = m->kmap_p; ap_top.qmap_full = m->qmap_full_p; ap_top.kmap_full = m->kmap_full_p;
     ap_top.qmap16 = m->qmap16_p; ap_top.kmap16 = m->kmap16_p;
     ap_top.maps_zero_base = m->kmap_p;
-    ap_top.order_q = m->attn_order_q_p; ap_top.order_k = m->attn_order_k_p; ap_top.qbits = m->attn_qbits_p; ap_top.kbits = m->attn_kbits_p;
+    ap_top.order_q = m->attn_order_q_p; ap_top.order_q2 = m->attn_order_q_p + (int64_t)m->rows_max * m->H * ((m->T + 63) / 64); ap_top.order_k = m->attn_order_k_p; ap_top.qbits = m->attn_qbits_p; ap_top.kbits = m->attn_kbits_p;
     ap_top.q_active = m->c_qact;   // (the launch orders put the query tiles beyond it last)
     RC(launch_attn_tilemap(ap_top, s));
   }
@@ -258,7 +258,7 @@ static int materialise_output_t(Model* m) {
   AttnParams ap{};
   ap.B = m->cur_rows; ap.T = m->T; ap.H = m->H; ap.KV = m->KV; ap.hd = hd; ap.is_bf16 = is_bf16<T>::value ? 1 : 0;
   ap.uid = m->uid_p; ap.tm = m->tm_p; ap.qmap = m->qmap_p; ap.kmap = m->kmap_p; ap.qmap_full = m->qmap_full_p; ap.kmap_full = m->kmap_full_p;
-  ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p; ap.order_q = m->attn_order_q_p; ap.order_k = m->attn_order_k_p; ap.qbits = m->attn_qbits_p; ap.kbits = m->attn_kbits_p;
+  ap.qmap16 = m->qmap16_p; ap.kmap16 = m->kmap16_p; ap.order_q = m->attn_order_q_p; ap.order_q2 = m->attn_order_q_p + (int64_t)m->rows_max * m->H * ((m->T + 63) / 64); ap.order_k = m->attn_order_k_p; ap.qbits = m->attn_qbits_p; ap.kbits = m->attn_kbits_p;
   ap.q = a.qkv; ap.k = AT<T>(a.qkv) + m->H * hd; ap.v = AT<T>(a.qkv) + (m->H + m->KV) * hd; ap.ld = m->Nqkv;
   ap.o = a.O; ap.ldo = D; ap.lse = a.lse;
   RC(launch_attn_fwd<T>(ap, m->stream));

@@ -14,6 +14,7 @@ const Entry kEntries[] = {
     {"RSYS_ATTN_DMA", &Switches::attn_dma, 1},
     {"RSYS_ATTN_KV_DMA", &Switches::attn_kv_dma, 1},
     {"RSYS_ATTN_KV32", &Switches::attn_kv32, 1},
+    {"RSYS_ATTN_FWD32", &Switches::attn_fwd32, 0},
     {"RSYS_GEMM_KERNEL", &Switches::gemm_kernel, -1},
     {"RSYS_GEMM_KERNEL_TN", &Switches::gemm_kernel_tn, -1},
     {"RSYS_GEMM_KERNEL_NT_SPLITK", &Switches::gemm_kernel_nt_splitk, -1},

@@ -11,6 +11,7 @@ struct Switches {
   // ---- kernel choice: both arms live code (the other arm serves other shapes / dtypes, or is the reference side of a bitwise test)
   int attn_dma;               // RSYS_ATTN_DMA=0: bf16 / head_dim 64 on the register-staged attention kernels (every other head size's kernels)
   int attn_kv_dma;            // RSYS_ATTN_KV_DMA=0: dK/dV alone on the register-staged kernel
+  int attn_fwd32;             // RSYS_ATTN_FWD32=1: forward on attn_fwd32_kernel (128 queries of one head per workgroup, 32x32x16 products; measured level with the default 64-query two-head kernel)
   int attn_kv32;              // RSYS_ATTN_KV32=0: dK/dV on the 16-key-per-wave LDS-DMA kernel (the bitwise partner of the register-staged one)
   int gemm_kernel;            // RSYS_GEMM_KERNEL: -1 unset / 0 (shape rule); 1 = the 128x128 register-staged kernel everywhere, 2 = 256x256 LDS-DMA wherever eligible
   int gemm_kernel_tn;         // RSYS_GEMM_KERNEL_TN: -1 unset / 0 (shape rule); 1 = never the K-major LDS-DMA kernels, 2 = both their forms (split-K, store) wherever eligible

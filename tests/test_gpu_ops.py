@@ -446,15 +446,15 @@ def test_attention_lds_dma_kernels_equal_the_register_staged_ones_bit_for_bit(tm
     must agree bit for bit (two processes: the switch is read once per process).  Ragged last tile, two heads per workgroup.
     The default dK/dV kernel (attn_bwd_kv32_kernel: 32 keys per wave on 32 x 32 x 16 products, round 5) sums the same products in another
     order: held against the 16-key kernel (RSYS_ATTN_KV32=0, which is the one compared bit for bit) to bf16 rounding, everything else of
-    that run bit for bit."""
+    that run bit for bit.  The compared forward is the 64-query kernel (RSYS_ATTN_FWD32=0); the default one is held against it below."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "recommendersystem_amd", "librsys_hip.so")
     B, H, KV, hd = 4, 8, 4, 64
     outs = []
-    for dma, kv32 in (("0", "0"), ("1", "0"), ("1", "1")):
-        f = str(tmp_path / f"attn_{dma}{kv32}.npz")
-        env = dict(os.environ, RSYS_ATTN_DMA=dma, RSYS_ATTN_KV32=kv32)
+    for dma, kv32, fwd32 in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
+        f = str(tmp_path / f"attn_{dma}{kv32}{fwd32}.npz")
+        env = dict(os.environ, RSYS_ATTN_DMA=dma, RSYS_ATTN_KV32=kv32, RSYS_ATTN_FWD32=fwd32)
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg", "attn_cmp.py"), "--child", lib, f, str(B), str(T), str(H), str(KV), str(hd), "1"], env=env)
         outs.append(np.load(f))
     for k in outs[0].files:
@@ -469,3 +469,11 @@ def test_attention_lds_dma_kernels_equal_the_register_staged_ones_bit_for_bit(tm
         e = float(np.abs(x - y).max() / np.abs(x).max())
         assert e <= 1e-2, (name, e)                                                         # bf16 outputs of two fp32 summation orders
         assert not np.array_equal(x, y) or True
+    # The default forward kernel (attn_fwd32_kernel: 32 queries per wave on 32 x 32 x 16 products, 128 queries of one head per workgroup,
+    # round 6) sums the same products in another order and takes its running maximum over the same 64-key tiles: O to bf16 rounding, the
+    # log-sum-exp to fp32 rounding, and the backward kernels -- fed that O and lse -- to bf16 rounding of their own outputs
+    c = outs[3]
+    eo = float(np.abs(c["O"].astype(np.float64) - b["O"].astype(np.float64)).max() / np.abs(b["O"].astype(np.float64)).max())
+    el = float(np.abs(c["lse"].astype(np.float64) - b["lse"].astype(np.float64)).max())
+    eg = float(np.abs(c["dqkv"].astype(np.float64) - b["dqkv"].astype(np.float64)).max() / np.abs(b["dqkv"].astype(np.float64)).max())
+    assert eo <= 1e-2 and el <= 2e-5 and eg <= 2e-2, (eo, el, eg)

@@ -21,7 +21,9 @@ ARMS = {"default": {}, "dense_top": {"RSYS_SPARSE_TOP": "0"}, "token_order": {"R
         # round 5 (csrc/switches.hpp): every kernel-choice switch whose other arm is live code has an arm here or a test of its own
         "select_one_pass": {"RSYS_SELECT_CHUNKED": "0"}, "select_aside": {"RSYS_SELECT_ASIDE": "1"},
         "scatter_atomic": {"RSYS_SCATTER_ATOMIC": "1"}, "dkdv_register_staged": {"RSYS_ATTN_KV_DMA": "0"},
-        "side_stream_joined": {"RSYS_SIDE_STREAM": "1"}, "side_stream_deferred": {"RSYS_SIDE_STREAM": "2"}}
+        "side_stream_joined": {"RSYS_SIDE_STREAM": "1"}, "side_stream_deferred": {"RSYS_SIDE_STREAM": "2"},
+        # round 6: the opt-in 128-query forward attention kernel (also with the compact top's q_active limit) and gemm8c's half tiles forced
+        "fwd32": {"RSYS_ATTN_FWD32": "1"}, "gemm8c_half": {"RSYS_GEMM8C_HALF": "2", "RSYS_GEMM_KERNEL": "2"}}
 
 
 @pytest.mark.parametrize("dtype,tol_loss,tol", [("fp32", 1e-6, 2e-5), ("bf16", 2e-3, 3e-2)])

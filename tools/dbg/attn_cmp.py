@@ -26,7 +26,11 @@ uid = np.sort(rng.integers(1, 4, (B, T)), axis=1).astype(np.int32).reshape(-1)
 tm = (rng.integers(1, 3, B * T) * (rng.random(B * T) < 0.2)).astype(np.int32)
 def dev(a):
     p = C.c_void_p(); assert lib.rsys_dev_alloc(C.byref(p), a.nbytes) == 0; lib.rsys_dev_h2d(p, a.ctypes.data, a.nbytes); return p
-cvt = (lambda a: (np.ascontiguousarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint16)) if dtype == 1 else (lambda a: np.ascontiguousarray(a, np.float32))
+def _round_bf16(a):   # round to nearest even, as the device does
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + 0x7FFF)) & 0xFFFF0000).view(np.float32)
+# (RSYS_CMP_ROUND=1: the fp32 run takes the bf16-rounded operands of the bf16 runs -- the exact result of the same inputs)
+cvt = (lambda a: (_round_bf16(a).view(np.uint32) >> 16).astype(np.uint16)) if dtype == 1 else ((lambda a: _round_bf16(a)) if os.environ.get("RSYS_CMP_ROUND") == "1" else (lambda a: np.ascontiguousarray(a, np.float32)))
 back = (lambda u: (u.astype(np.uint32) << 16).view(np.float32)) if dtype == 1 else (lambda u: u)
 et = np.uint16 if dtype == 1 else np.float32
 qkv = dev(cvt(rng.standard_normal((B * T, Nq)))); dO = dev(cvt(rng.standard_normal((B * T, H * hd))))
