@@ -2,6 +2,7 @@
 // (HBM-bound; 16-byte accesses, grid-stride).  transformer.py:273 (clip_grad_norm_)
 // and :285-298 (AdamW, decoupled decay 0.1 on tensors with dim>=2, betas 0.9/0.95).
 #include "kernels.hpp"
+#include "switches.hpp"
 
 namespace rsys {
 
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const float4* g4 = (const float4*)g;
   for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+    const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];   // (nontemporal loads here: +0.1 ms on the step, AdamW re-reads the buffer)
     a0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
     a1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
     a2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
@@ -111,7 +112,7 @@ __device__ __forceinline__ float grad_coef(const float* sumsq, float grad_div, f
   return inv * (c < 1.f ? c : 1.f);
 }
 
-template <typename T>
+template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m, float* v, T* shadow, long long n_decay,
                                                     long long n_total, float lr, float b1, float b2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, const float* sumsq, float grad_div,
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m
   const float coef = grad_coef(sumsq, grad_div, max_norm);
   const long long n4 = n_total >> 2;  // n_decay and n_total are multiples of 4 (the flat layout pads every tensor)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 pv = ((float4*)p)[i], gv = ((float4*)g)[i], mv = ((float4*)m)[i], vv = ((float4*)v)[i];
+    float4 pv, gv, mv, vv;
+    if constexpr (NT) {   // (experiment: every byte is touched once per step and the buffers are 16x the Infinity Cache)
+      typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
+      auto ld = [](const float* q) { const nt_f32x4 t = __builtin_nontemporal_load((const nt_f32x4*)q); return make_float4(t[0], t[1], t[2], t[3]); };
+      pv = ld(p + 4 * i); gv = ld(g + 4 * i); mv = ld(m + 4 * i); vv = ld(v + 4 * i);
+    } else { pv = ((float4*)p)[i]; gv = ((float4*)g)[i]; mv = ((float4*)m)[i]; vv = ((float4*)v)[i]; }
     const float decay = (i * 4 < n_decay) ? (1.f - lr * wd) : 1.f;
     float* pp = (float*)&pv; float* gg = (float*)&gv; float* mm = (float*)&mv; float* vvp = (float*)&vv;
 #pragma unroll
@@ -131,8 +137,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* g, float* m
       float denom = sqrtf(vvp[k]) / bc2_sqrt + eps;
       pp[k] = pk - (lr / bc1) * (mm[k] / denom);
     }
-    ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)v)[i] = vv;
-    if (zero_grad) ((float4*)g)[i] = make_float4(0, 0, 0, 0);
+    if constexpr (NT) {
+      typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
+      auto st = [](float* q, const float4& x) { const nt_f32x4 t = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(t, (nt_f32x4*)q); };
+      st(p + 4 * i, pv); st(m + 4 * i, mv); st(v + 4 * i, vv);
+      if (zero_grad) st(g + 4 * i, make_float4(0, 0, 0, 0));
+    } else {
+      ((float4*)p)[i] = pv; ((float4*)m)[i] = mv; ((float4*)v)[i] = vv;
+      if (zero_grad) ((float4*)g)[i] = make_float4(0, 0, 0, 0);
+    }
     if constexpr (is_bf16<T>::value) {
       if (shadow && !(i * 4 >= sh_skip_lo && i * 4 < sh_skip_hi)) {   // (no bf16 copy where no kernel reads one: the item table E)
         bf16x4 sv; sv[0] = (bf16)pp[0]; sv[1] = (bf16)pp[1]; sv[2] = (bf16)pp[2]; sv[3] = (bf16)pp[3];
@@ -149,7 +162,15 @@ int launch_adamw(float* p, float* g, float* m, float* v, T* shadow, long long n_
   ARG_CHECK(n_decay % 4 == 0 && n_total % 4 == 0 && sh_skip_lo % 4 == 0 && sh_skip_hi % 4 == 0, "adamw: flat sizes must be multiples of 4");
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2s = sqrtf(1.f - powf(b2, (float)step));
-  int grid = (int)std::min<long long>(((n_total >> 2) + 255) / 256, 4096);
+  // Nontemporal loads and stores (round 6): every byte of the four flat buffers is touched once per step and together they are 16 x the
+  // Infinity Cache at cfg-3 -- 0.77 -> 0.66 ms (6.3 TB/s), the step -0.15 ms on a same-box A/B, neutral at cfg-2 (profiles/r6_ab_adamw_nontemporal.log).
+  // RSYS_DEBUG_ADAMW: bit 0 = plain loads / stores (the A/B partner), bit 1 = 8192 workgroups
+  const int mode = sw().debug_adamw;
+  int grid = (int)std::min<long long>(((n_total >> 2) + 255) / 256, (mode & 2) ? 8192 : 4096);
+  if (!(mode & 1))
+    hipLaunchKernelGGL((adamw_kernel<T, true>), dim3(grid), dim3(256), 0, s, p, g, m, v, shadow, n_decay, n_total, lr, b1, b2, eps,
+                       wd, bc1, bc2s, sumsq, grad_div, max_norm, zero_grad, sh_skip_lo, sh_skip_hi);
+  else
   hipLaunchKernelGGL((adamw_kernel<T>), dim3(grid), dim3(256), 0, s, p, g, m, v, shadow, n_decay, n_total, lr, b1, b2, eps,
                      wd, bc1, bc2s, sumsq, grad_div, max_norm, zero_grad, sh_skip_lo, sh_skip_hi);
   HIP_CHECK(hipGetLastError());

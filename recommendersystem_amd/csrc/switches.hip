@@ -41,6 +41,7 @@ const Entry kEntries[] = {
     {"RSYS_DEBUG_F8_CAST_WAVES", &Switches::debug_f8_cast_waves, 4},
     {"RSYS_DEBUG_NORM_BWD_GRID", &Switches::debug_norm_bwd_grid, 1024},
     {"RSYS_DEBUG_NORM_BWD_WAVES", &Switches::debug_norm_bwd_waves, 0},
+    {"RSYS_DEBUG_ADAMW", &Switches::debug_adamw, 0},
 };
 
 Switches g_sw;

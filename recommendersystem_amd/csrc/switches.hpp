@@ -39,6 +39,7 @@ struct Switches {
   int debug_epi;              // RSYS_DEBUG_EPI: rsys_op_gemm only: epilogue class override (99 = none)
   int debug_f8_cast_waves;    // RSYS_DEBUG_F8_CAST_WAVES: waves per workgroup of the fp8 cast kernel (1..4)
   int debug_norm_bwd_grid;    // RSYS_DEBUG_NORM_BWD_GRID: cap of rmsnorm_bwd's waves / 4
+  int debug_adamw;            // RSYS_DEBUG_ADAMW: bit 0 = plain instead of nontemporal loads / stores in AdamW (A/B partner), bit 1 = 8192 workgroups
   int debug_norm_bwd_waves;   // RSYS_DEBUG_NORM_BWD_WAVES: waves per workgroup of rmsnorm_bwd (0 = 16 up to D = 1024, else 4)
 };
 
