@@ -261,8 +261,10 @@ template int launch_rmsnorm_fwd<float>(const float*, const float*, float*, float
 // launch all finish together: with 1024 workgroups of 4 waves that tail was a fixed ~29 us per launch at cfg-2 AND cfg-3 (two-point fit of
 // 45 us for 134 MB and 93 us for 537 MB: the streaming part alone runs at 8.4 TB/s; the grid scan in rmsnorm_bwd_any prices an atomic
 // tail at ~23 ns per workgroup).  The same 16 waves per CU as one workgroup: a quarter of the atomics, same bytes in flight.
+// (a row's three operands are 12 NJ registers per lane: 16 waves per workgroup = 128 registers per lane up to NJ = 2 (D <= 512), 8 waves up to
+// NJ = 4, 4 waves at NJ = 8 -- with 16 waves everywhere the D = 2048 kernel spilled and the production shape's norms ran at half their rate)
 template <typename TG, typename TO, int NJ, bool EXACT>
-__global__ __launch_bounds__(1024) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
+__global__ __launch_bounds__(NJ <= 2 ? 1024 : NJ <= 4 ? 512 : 256) void rmsnorm_bwd_kernel(const TG* __restrict__ g, const float* __restrict__ x,
                                                           const float* __restrict__ scale, const float* __restrict__ rstd,
                                                           const float* resid, float* dx_out, TO* dx_out_t, float* dscale,
                                                           float* part, long long rows, int D, const int* __restrict__ rows_dev,
@@ -368,7 +370,8 @@ static int rmsnorm_bwd_any(const TG* g, const float* x, const float* scale, cons
   // (every workgroup ends with D atomics onto the same D scale gradients: with 4 waves per workgroup, 512-1024 workgroups 1.39-1.45 ms per step
   // at cfg-3, 2048: 1.49, 4096: 1.97, 8192: 3.37.)  RSYS_DEBUG_NORM_BWD_GRID caps the number of WAVES / 4 (the unit of those scans).
   const int grid_cap = sw().debug_norm_bwd_grid;
-  const int wpb = sw().debug_norm_bwd_waves > 0 ? sw().debug_norm_bwd_waves : (D <= 1024 ? 16 : 4);   // waves per workgroup (deterministic mode keeps wpb * D floats in LDS)
+  const int wpb_max = D <= 512 ? 16 : D <= 1024 ? 8 : 4;   // = the kernel's launch bounds for this D
+  const int wpb = sw().debug_norm_bwd_waves > 0 ? std::min(sw().debug_norm_bwd_waves, wpb_max) : wpb_max;   // waves per workgroup: the kernel's launch bounds (deterministic mode keeps wpb * D floats in LDS)
   const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((rows + wpb - 1) / wpb, (long long)grid_cap * 4 / wpb))), block(64 * wpb);
   float* part = det_part((long long)grid.x * D);
 #define RSYS_NORM_BWD(NJ, EX) hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, TO, NJ, EX>), grid, block, (part ? wpb : 1) * D * sizeof(float), s, g, x, scale, \
