@@ -417,6 +417,9 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    if os.environ.get("RSYS_LIB_PATH"):        # same-box A/B of a compile-time variant of the library (tools/); the line then says so
+        from recommendersystem_amd import _lib as _rlib
+        _rlib.LIB_PATH = os.environ["RSYS_LIB_PATH"]
     import recommendersystem_amd as ra
     from recommendersystem_amd import workload as synth   # configurations + synthetic corpus (inputs only)
     from recommendersystem_amd import dist as rdist
@@ -704,6 +707,7 @@ def main():
             "comm": comm_info,
             "replicas_consistent": replicas,   # per-rank parameter checksums equal on every rank (None: one rank, nothing to compare)
             "switches": _lib_switches(),     # RSYS_* switches that differ from the library's defaults ({} = the shipped path)
+            "library": os.environ.get("RSYS_LIB_PATH") or "recommendersystem_amd/librsys_hip.so",
             "config": {"workload": f"{args.config}: train step fwd+bwd+{'allreduce+' if comm is not None else ''}clip+AdamW, D={cfg['embed_dim']} L={cfg['num_layers']} "
                                    f"S={S} V={cfg['vocab_sizes']['0_matchedid'] + cfg['vocab_sizes']['1_matchedid']} M={cfg['metadata_emb_size']} "
                                    f"K={cfg['mask_topk']}", "rows_per_gpu": rows, "global_rows": rows * world,
