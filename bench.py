@@ -25,6 +25,7 @@ HBM_PEAK_GBS = 8000.0
 
 # kernel behind a call-site tag: the library appends "@<kernel>" to every GEMM tag (gemm.hip: gemm_kernel_name)
 KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
+    "4p": "gemm4p_kernel",                                # plain bf16 stores with K >= 8192 on outputs >= 4 tiles wide: four waves of 128 x 128, the K loop one asm statement with named registers (gemm4p.hip)
     "8c": "gemm8c_kernel",                                # 256x256 LDS-DMA, persistent, ONE operand stream across a workgroup's output tiles (gemm8c.hip; one instantiation per epilogue class)
     "8p": "gemm8p_kernel<false, false>",                  # its predecessor: operand requests stop at the end of every output tile (gemm8p.hip; classes without an 8c kernel, RSYS_GEMM8C=0)
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
@@ -38,7 +39,8 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
 }
-KERNEL_LABEL = {"8c": "gemm8c_kernel<epilogue class> (256x256 LDS-DMA, persistent, one operand stream per workgroup, row-major bf16)",
+KERNEL_LABEL = {"4p": "gemm4p_kernel (256x256 LDS-DMA, persistent, four waves of 128x128 with a register-named asm K loop, row-major bf16, plain store)",
+                "8c": "gemm8c_kernel<epilogue class> (256x256 LDS-DMA, persistent, one operand stream per workgroup, row-major bf16)",
                 "8p": "gemm8p_kernel<false, false> (256x256 LDS-DMA, persistent, row-major bf16)", "8s": "gemm8p_kernel<false, true> (256x256 LDS-DMA, row-major bf16, split-K)",
                 "8t": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, split-K)",
                 "8ts": "gemm8p_kernel<true, false> (256x256 LDS-DMA, K-major bf16, one K split, plain fp32 store / accumulate)",

@@ -524,7 +524,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
   if (p.splitk < 1) p.splitk = 1;
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32) {
     const int k = pick_rowmajor_kernel(p);
-    if (k == 2) return gemm8p_forwards_to_8c(p) ? "8c" : "8p";
+    if (k == 2) return gemm8p_forwards_to_8c(p) ? (gemm4p_takes(p) ? "4p" : "8c") : "8p";
   }
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return "8ts";

@@ -372,6 +372,7 @@ bool gemm8c_uses_half(const GemmParams& p, int cus) {
 }
 
 int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
+  if (gemm4p_takes(p0)) return launch_gemm4p(p0, s);
   GemmParams p = p0;
   int cus = 256;
   { static int n = 0; if (n == 0) { int dev = 0, v = 0; n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; } cus = n; }

@@ -144,6 +144,10 @@ int launch_gemm8p(const GemmParams& p, hipStream_t s);
 // tile's first K tile (gemm8c.hip): the epilogue classes of the training step; launch_gemm8p forwards eligible problems
 bool gemm8c_eligible(const GemmParams& p);
 int launch_gemm8c(const GemmParams& p, hipStream_t s);
+// gemm4p.hip: the long-K member of the family (plain bf16 store, whole tiles); launch_gemm8c forwards what gemm4p_takes()
+bool gemm4p_eligible(const GemmParams& p);
+bool gemm4p_takes(const GemmParams& p);
+int launch_gemm4p(const GemmParams& p, hipStream_t s);
 bool gemm8p_forwards_to_8c(const GemmParams& p);   // what launch_gemm8p will do with p (timing tags)
 // the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
 bool gemm8p_tn_eligible(const GemmParams& p);

@@ -156,6 +156,29 @@ def test_gemm_256_tile_kernel(monkeypatch, M, N, K, c_f32, kern):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 384), (2048, 1024, 1408), (16640, 1024, 256), (8192, 2304, 384), (33024, 512, 640)])
+def test_gemm4p_asm_kloop_kernel_matches_gemm8c_bit_for_bit(monkeypatch, M, N, K):
+    """gemm4p.hip (four waves of 128 x 128, the K loop, the hand-over to the workgroup's next tile and the bf16 store as one
+    generated asm statement with named registers), forced wherever it is eligible (RSYS_GEMM4P=2) against gemm8c (=0): the same products in
+    the same order per accumulator, so random outputs agree BIT FOR BIT; exact on asymmetric integer operands.  Shapes: one tile and the
+    shortest K loop the kernel takes (4 K tiles: the peeled pair and one trip); fewer tiles than CUs; an odd count of 128-wide K steps;
+    more tiles than CUs with the shortest K (260 and 258 tiles: the hand-over between two tiles of one workgroup, requests of the next tile
+    in flight behind the stores, twice in a row); a wide and tall output (9 x 32 tiles: the band order of the tile walk)."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    outs = []
+    for mode in ("2", "0"):
+        monkeypatch.setenv("RSYS_GEMM4P", mode)
+        outi, refi = run_gemm(1, M, N, K, False, False, c_f32=False, integer=True, seed=M + N + K)
+        np.testing.assert_array_equal(outi, _bf16_round(refi.astype(np.float32)), err_msg=f"RSYS_GEMM4P={mode}")
+        for rep in range(2):   # (the hand-over is timing dependent: more than one launch)
+            out, ref = run_gemm(1, M, N, K, False, False, c_f32=False, seed=11)
+            outs.append(out)
+    assert np.abs(outs[0] - ref).max() / np.abs(ref).max() < 1e-2
+    for o in outs[1:]:
+        assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32)), (M, N, K)
+    monkeypatch.delenv("RSYS_GEMM4P", raising=False)
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 6208, 4096), (520, 8192, 8192), (2048, 4104, 1024)])
 def test_gemm_rowmajor_splitk_lds_dma_kernel(M, N, K):
     """Row-major operands with split-K fp32 atomics on the LDS-DMA pipeline (gemm8p_kernel<false, true>: the

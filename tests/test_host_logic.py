@@ -492,3 +492,13 @@ def test_environment_is_read_in_one_place():
         assert env in design, env
     for gone in ("RSYS_ATTN_PAIR", "RSYS_ATTN_ORDER", "RSYS_DEBUG_KEEP_PERSISTENT"):
         assert gone not in open(os.path.join(csrc, "switches.hip")).read()
+
+
+def test_generated_asm_of_gemm4p_is_what_its_generator_writes(tmp_path):
+    """recommendersystem_amd/csrc/gemm4p_asm.inc / gemm4p_clobbers.inc (the K loop of gemm4p.hip as one asm statement) are generated files kept in
+    the tree so that the library builds without running a generator: they must be exactly what tools/micro/gen_gemm4p_asm.py writes today."""
+    import subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "gen_gemm4p_asm.py"), str(tmp_path)], check=True, capture_output=True)
+    for name in ("gemm4p_asm.inc", "gemm4p_clobbers.inc"):
+        assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, "recommendersystem_amd", "csrc", name)).read(), name
