@@ -7,7 +7,7 @@ one() {   # name, generator flags...
   local name=$1; shift
   local d=/tmp/gemm4p_$name; mkdir -p $d
   python3 tools/micro/gen_gemm4p_asm.py "$@" $d > /dev/null || exit 1
-  hipcc $FLAGS -DGEMM4P_ASM_INC="\"$d/gemm4p_asm.inc\"" tools/micro/gemm4p.hip -o tools/micro/bin/gemm4p_$name 2>&1 | grep -B2 -A6 "error"
+  hipcc $FLAGS $EXTRA -DGEMM4P_ASM_INC="\"$d/gemm4p_asm.inc\"" tools/micro/gemm4p.hip -o tools/micro/bin/gemm4p_$name 2>&1 | grep -B2 -A6 "error"
 }
 hipcc $FLAGS tools/micro/gemm4p.hip -o tools/micro/bin/gemm4p 2>&1 | grep -B2 -A6 "error" &
 one nomfma --no-mfma &
@@ -16,5 +16,9 @@ one nomfma_bempty --no-mfma --b-empty &
 wait
 one nomfma_pf --no-mfma --pf &
 one pf --pf &
+one deep --deep &
+EXTRA=-DGEMM4P_A_PACKED one nomfma_apacked --no-mfma --a-packed &
+EXTRA=-DGEMM4P_A_PACKED one nomfma_apacked_bempty --no-mfma --a-packed --b-empty &
+one nomfma_deep --no-mfma --deep &
 wait
 ls -la tools/micro/bin

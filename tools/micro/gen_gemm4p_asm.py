@@ -25,6 +25,9 @@ A_EMPTY = "--a-empty" in sys.argv     # timing-only: every A (B) request goes th
 B_EMPTY = "--b-empty" in sys.argv
 PF = "--pf" in sys.argv               # every even K tile also touches, per A row, the 128 bytes BEHIND the ones it requests (one dword per lane into a
                                       # scratch register): the odd K tile's request then hits the L2, and the memory sees 256 contiguous bytes per row and visit
+DEEP = "--deep" in sys.argv           # a barrier and a counted wait in EVERY phase, each region re-requested one phase after its last read: 24 requests
+                                      # (96 KB per CU) in flight at the waits instead of 16 (64 KB), six phases for a request to land instead of five
+A_PACKED = "--a-packed" in sys.argv   # timing-only (with -DGEMM4P_A_PACKED): A read as if stored tile by tile -- a K tile of 256 rows = 32 KB contiguous
 SET = {"Ax": 128, "Ay": 160, "Bx": 192, "By": 224}
 out = []
 
@@ -66,7 +69,7 @@ def advance(kind, count=True):
     """window of `kind` one K tile on; with `count` also the remaining-K-tiles counter and the empty window behind the last K tile"""
     lo, hi, rem, recw, full = ("s88", "s89", "s84", "s62", "0" if A_EMPTY else "%[reca]") if kind == "A" else ("s90", "s91", "s85", "s66", "0" if B_EMPTY else "%[recb]")
     d0, d1 = ("s60", "s61") if kind == "A" else ("s64", "s65")
-    res = [f"s_add_u32 {lo}, {lo}, 128", f"s_addc_u32 {hi}, {hi}, 0", f"s_mov_b32 {d0}, {lo}", f"s_and_b32 {d1}, {hi}, 0xffff"]
+    res = [f"s_add_u32 {lo}, {lo}, {32768 if (A_PACKED and kind == 'A') else 128}", f"s_addc_u32 {hi}, {hi}, 0", f"s_mov_b32 {d0}, {lo}", f"s_and_b32 {d1}, {hi}, 0xffff"]
     if count:
         res += [f"s_sub_i32 {rem}, {rem}, 1", f"s_cmp_gt_i32 {rem}, 0", f"s_cselect_b32 {recw}, {full}, 0"]
     return res
@@ -102,9 +105,17 @@ def phase(ih, jh, aset, bset, pref, dmas, post=(), barrier=True, wait=16, pf=Fal
         emit(line)
 
 
-def ktile(stage, bc, bn, wait13=(16, 16), pf=False):
-    # requests (K tile t + 2, same stage): P1 A h0, P2 B h0 (both read in P3 / P4 of the previous K tile), P3 B h1, P4 A h1 (read in P1 / P2)
+def ktile(stage, bc, bn, wait13=(16, 16), pf=False, deep_waits=(24, 24, 24, 24)):
     st, so = stage, stage ^ 1
+    if DEEP:
+        # requests: P1 B h0 (t + 2; read in P4 of the previous K tile), P2 B h1 (t + 2; read in P1), P3 A h1 (t + 2; read in P2), P4 A h0 of the
+        # OTHER stage (t + 3; read in P3); the B window moves on behind P2, the A window behind P3
+        phase(0, 0, "Ax", bc, ("B", bn, st, 1), ("B", st, 0), wait=deep_waits[0])
+        phase(0, 1, "Ax", bn, ("A", "Ay", st, 1), ("B", st, 1), advance("B"), wait=deep_waits[1])
+        phase(1, 1, "Ay", bn, ("A", "Ax", so, 0), ("A", st, 1), advance("A"), wait=deep_waits[2])
+        phase(1, 0, "Ay", bc, ("B", bn, so, 0), ("A", so, 0), wait=deep_waits[3])
+        return
+    # requests (K tile t + 2, same stage): P1 A h0, P2 B h0 (both read in P3 / P4 of the previous K tile), P3 B h1, P4 A h1 (read in P1 / P2)
     phase(0, 0, "Ax", bc, ("B", bn, st, 1), ("A", st, 0), wait=wait13[0], pf=pf)
     phase(0, 1, "Ax", bn, ("A", "Ay", st, 1), ("B", st, 0), barrier=False)
     phase(1, 1, "Ay", bn, ("A", "Ax", so, 0), ("B", st, 1), wait=wait13[1])
@@ -160,8 +171,17 @@ emit("s_barrier")
 for line in reads("A", "Ax", 0, 0) + reads("B", "Bx", 0, 0):
     emit(line)
 # ---------------------------------------------------------------- K loop: K tiles 0, 1 on prologue data, then pairs
-ktile(0, "Bx", "By", (0, 0), pf=PF)
-ktile(1, "By", "Bx", (0, 16))
+if DEEP:
+    # the request the fourth phase of "K tile -1" would have made: A h0 of K tile 2 into the region just read.  The first wait that guards a
+    # request issued behind the previous tile's stores is P3 of K tile 1 (it reads this one), with the steady state's 24 younger ones
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    request_group("A", 0, 0)
+    ktile(0, "Bx", "By", deep_waits=(0, 0, 0, 0))
+    ktile(1, "By", "Bx", deep_waits=(0, 0, 24, 24))
+else:
+    ktile(0, "Bx", "By", (0, 0), pf=PF)
+    ktile(1, "By", "Bx", (0, 16))
 emit("s_lshr_b32 s86, %[nt], 1")
 emit("s_sub_u32 s86, s86, 1")               # launcher: nt even, >= 4
 emit("1:")
