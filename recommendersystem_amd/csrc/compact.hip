@@ -133,6 +133,28 @@ __global__ void scatter_rows_sel_kernel(const T* __restrict__ src, const int* __
   for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
 }
 
+// The compact top's dO in selected-first order: place p of batch row b (p < 64 q_active[b]: the query tiles the last layer's attention backward visits)
+// <- compact row slot_p[b T + p], or zeros where that place holds no selected token (the ragged end of the last visited tile; every place when the
+// order is the identity).  Places beyond the visited tiles are never read and keep what they held.  One wave per place.
+template <typename T>
+__global__ void scatter_rows_fill_kernel(const T* __restrict__ src, const int* __restrict__ slot_p, const int* __restrict__ q_active, int Tseq, long long places,
+                                         T* dst, long long ld, int D) {
+  const long long place = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int l = threadIdx.x & 63;
+  if (place >= places) return;
+  const int b = (int)(place / Tseq), pp = (int)(place - (long long)b * Tseq);
+  if (pp >= 64 * q_active[b]) return;
+  constexpr int E = 16 / sizeof(T);
+  const int sl = slot_p[place];
+  uint4* d4 = (uint4*)(dst + place * ld);
+  if (sl >= 0) {
+    const uint4* s4 = (const uint4*)(src + (long long)sl * D);
+    for (int c = l; c < D / E; c += 64) d4[c] = s4[c];
+  } else {
+    for (int c = l; c < D / E; c += 64) d4[c] = make_uint4(0, 0, 0, 0);
+  }
+}
+
 // dst rows map[r] <- src rows r, r < n (host count)
 template <typename T>
 __global__ void scatter_rows_map_kernel(const T* __restrict__ src, const int* __restrict__ map, int n, T* dst, long long ld, int D) {
@@ -215,6 +237,16 @@ int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int 
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
+template <typename T>
+int launch_scatter_rows_fill(const T* src, const int* slot_p, const int* q_active, int B, int Tseq, T* dst, long long ld, int D, hipStream_t s) {
+  ARG_CHECK((D * sizeof(T)) % 16 == 0 && (ld * sizeof(T)) % 16 == 0, "scatter_rows_fill: rows must be 16-byte multiples");
+  const long long places = (long long)B * Tseq;
+  hipLaunchKernelGGL((scatter_rows_fill_kernel<T>), dim3((unsigned)((places + 3) / 4)), dim3(256), 0, s, src, slot_p, q_active, Tseq, places, dst, ld, D);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
+}
+template int launch_scatter_rows_fill<bf16>(const bf16*, const int*, const int*, int, int, bf16*, long long, int, hipStream_t);
+template int launch_scatter_rows_fill<float>(const float*, const int*, const int*, int, int, float*, long long, int, hipStream_t);
 template int launch_scatter_rows_sel<bf16>(const bf16*, const int*, const int*, int, bf16*, long long, int, hipStream_t);
 template int launch_scatter_rows_sel<float>(const float*, const int*, const int*, int, float*, long long, int, hipStream_t);
 

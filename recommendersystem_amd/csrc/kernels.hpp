@@ -128,6 +128,8 @@ int launch_selected_first(const unsigned int* bits, const int* pre, int* slot, i
                           int* perm, int* uid_p, int* tm_p, int* pos_p, int* slot_p, int* sel_p, int* q_active, hipStream_t s);
 // dst rows [0, n) <- src rows sel[r]; dst rows [n, n rounded up to 256) <- 0   (n = *n_dev <= cap)
 template <typename T> int launch_gather_rows_sel(const T* src, long long ld, const int* sel, const int* n_dev, int cap, T* dst, int D, hipStream_t s);
+// places [0, 64 q_active[b]) of every batch row <- compact row slot_p[place] or zeros; the other places untouched (compact.hip)
+template <typename T> int launch_scatter_rows_fill(const T* src, const int* slot_p, const int* q_active, int B, int Tseq, T* dst, long long ld, int D, hipStream_t s);
 template <typename T> int launch_scatter_rows_sel(const T* src, const int* sel, const int* n_dev, int cap, T* dst, long long ld, int D, hipStream_t s);
 template <typename T> int launch_scatter_rows_map(const T* src, const int* map, int n, T* dst, long long ld, int D, hipStream_t s);   // dst[map[r]] = src[r]
 // heads: dst[r] = compact[slot[2 idx[r] + parity]] (zeros where -1), r < n; and compact[slot[..]] += src[r] for r < min(n, *npos)
@@ -228,7 +230,7 @@ template <typename T> int launch_attn_bwd(const AttnParams& p, hipStream_t s);
 // ---- optimizer (optim.hip)
 // *out += sum of g[i]^2 in a fixed order (bitwise the same on every rank for the same gradient); part: sumsq_parts() floats of device scratch,
 // reused by consecutive calls on one stream
-int launch_sumsq(const float* g, long long n, float* out /*device scalar, accumulated*/, float* part, hipStream_t s);
+int launch_sumsq(const float* g, long long n, float* out /*device scalar: accumulated, or (overwrite) set*/, float* part, hipStream_t s, bool overwrite = false);
 int sumsq_parts();
 // replica-consistency checksum of the ranges [ranges[2r], ranges[2r+1]) of a flat fp32 buffer: out (device) = {fp64 sum, fp64 sum of squares,
 // low / high 32 bits of a position-weighted wrapping sum of the bit patterns}; part = checksum_scratch_doubles() doubles of device scratch

@@ -309,7 +309,9 @@ int model_create(const rsys_config* cfg, int device, Model** out) {
       DALLOC(m->c_bits, (NT / 32 + 2) * 4); DALLOC(m->c_pre, (NT / 32 + 2) * 4);
       DALLOC(m->c_x, cap * D * 4); DALLOC(m->c_h, cap * D * 4); DALLOC(m->c_xL, cap * D * 4); DALLOC(m->c_rstd2, cap * 4); DALLOC(m->c_rstdf, cap * 4);
       DALLOC(m->c_O, cap * D * e); DALLOC(m->c_hn, cap * D * e); DALLOC(m->c_ab, cap * 2 * m->Ip * e); DALLOC(m->c_g, cap * m->Ip * e); DALLOC(m->c_out, cap * D * e);
-      DALLOC(m->c_gy, cap * D * 4); DALLOC(m->c_gx, cap * D * 4); DALLOC(m->c_dh, cap * D * 4);
+      // c_gy sits 256 bytes behind the 16 loss accumulators: heads() zeroes both with one fill
+      { float* blk = nullptr; DALLOC(blk, 256 + cap * D * 4); m->loss_acc = blk; m->c_gy = blk + 64; m->loss_acc_with_c_gy = true; }
+      DALLOC(m->c_gx, cap * D * 4); DALLOC(m->c_dh, cap * D * 4);
       DALLOC(m->c_dab, cap * 2 * m->Ip * e); DALLOC(m->c_dhn, cap * D * e); DALLOC(m->c_dO, cap * D * e);
       if (m->bf16_mode) { DALLOC(m->c_gx_t, cap * D * 2); DALLOC(m->c_dh_t, cap * D * 2); } else { m->c_gx_t = m->c_gx; m->c_dh_t = m->c_dh; }
       DALLOC(m->c_perm, NT * 4); DALLOC(m->uid_p, NT * 4); DALLOC(m->tm_p, NT * 4); DALLOC(m->pos_p, NT * 4); DALLOC(m->c_slot_p, NT * 4);

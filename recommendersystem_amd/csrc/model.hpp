@@ -243,6 +243,7 @@ struct Model {
   float *c_x = nullptr, *c_h = nullptr, *c_xL = nullptr, *c_rstd2 = nullptr, *c_rstdf = nullptr;
   void *c_O = nullptr, *c_hn = nullptr, *c_ab = nullptr, *c_g = nullptr, *c_out = nullptr;
   float *c_gy = nullptr, *c_gx = nullptr, *c_dh = nullptr;
+  bool loss_acc_with_c_gy = false;   // loss_acc = the 256-byte header of c_gy's allocation (one zero fill for both)
   void *c_gx_t = nullptr, *c_dab = nullptr, *c_dhn = nullptr, *c_dh_t = nullptr, *c_dO = nullptr;
   // ... and the last layer runs on a SELECTED-FIRST token order (inside every batch row the selected tokens, then the others; attention
   // is indifferent to token order): its attention kernels then visit only the leading query tiles c_qact[b] of a row.  c_perm: original

@@ -81,8 +81,9 @@ static int top_tail_compact_bwd(Model* m, bool wt) {
     p.M = cap; p.N = D; p.K = D; p.epi = EPI_STORE; p.m_dev = n;
     RC(gemm<T>(m, "gemm_top_o_dx", p, false, false, !wt));
   }
-  HIP_CHECK(hipMemsetAsync(m->dO, 0, (size_t)NT * D * sizeof(T), s));
-  RC(launch_scatter_rows_sel<T>(AT<T>(m->c_dO), m->c_sel_p, n, cap, AT<T>(m->dO), D, D, s));   // (selected-first order, as the attention backward reads it)
+  // dO in selected-first order, as the attention backward reads it: the selected places from the compact rows, zeros up to the end of the last
+  // query tile the kernels visit (c_qact); nothing is read beyond (round 6: was a 2 NT D-byte zero fill + a scatter)
+  RC(launch_scatter_rows_fill<T>(AT<T>(m->c_dO), m->c_slot_p, m->c_qact, m->cur_rows, m->T, AT<T>(m->dO), D, D, s));
   toc(m);
   return RSYS_OK;
 }

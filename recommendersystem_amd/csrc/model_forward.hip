@@ -464,9 +464,12 @@ int heads(Model* m, int evaluate, const float tw[4]) {
   tic(m, "phase_heads");
   const bool ctop = m->top_is_sparse;   // trunk output and its gradient live in the compact buffers (rows = selected tokens)
   RC(select_join(m));
-  HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
-  if (train && !ctop) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
-  if (train && ctop) HIP_CHECK(hipMemsetAsync(m->c_gy, 0, (size_t)m->ctop_cap * D * 4, s));
+  if (train && ctop && m->loss_acc_with_c_gy) HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 256 + (size_t)m->ctop_cap * D * 4, s));   // (one allocation: model.hip)
+  else {
+    HIP_CHECK(hipMemsetAsync(m->loss_acc, 0, 16 * 4, s));
+    if (train && !ctop) HIP_CHECK(hipMemsetAsync(m->gy, 0, (size_t)NT * D * 4, s));
+    if (train && ctop) HIP_CHECK(hipMemsetAsync(m->c_gy, 0, (size_t)m->ctop_cap * D * 4, s));
+  }
   auto add_rows = [&](const float* src, int ti, int parity) -> int { return head_add_rows(m, src, ti, parity, KB); };
   for (int ti = 0; ti < 4; ++ti) {
     const int medium = ti >> 1, metric = ti & 1;

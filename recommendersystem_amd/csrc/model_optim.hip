@@ -5,14 +5,12 @@ namespace rsys {
 
 // sum of squares of all gradients into m->sumsq.  Row-sharded table: the replicated gradients are identical on every rank
 // (after the all-reduce), the table rows differ: their sum of squares is all-reduced and added.
-static int grad_sumsq(Model* m) {
-  HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, m->stream));
-  if (!m->sharded || !comm_active(m->shard_comm)) return launch_sumsq(m->G, m->n_opt, m->sumsq, m->sumsq_part, m->stream);
+static int grad_sumsq(Model* m) {   // (the first launch of a scalar SETS it: no zero fill in front)
+  if (!m->sharded || !comm_active(m->shard_comm)) return launch_sumsq(m->G, m->n_opt, m->sumsq, m->sumsq_part, m->stream, true);
   const int64_t e0 = m->o_E, e1 = m->o_E + (int64_t)m->TR * m->D;
-  RC(launch_sumsq(m->G, e0, m->sumsq, m->sumsq_part, m->stream));
+  RC(launch_sumsq(m->G, e0, m->sumsq, m->sumsq_part, m->stream, true));
   RC(launch_sumsq(m->G + e1, m->n_opt - e1, m->sumsq, m->sumsq_part, m->stream));
-  HIP_CHECK(hipMemsetAsync(m->sumsq_E, 0, 4, m->stream));
-  RC(launch_sumsq(m->G + e0, e1 - e0, m->sumsq_E, m->sumsq_part, m->stream));
+  RC(launch_sumsq(m->G + e0, e1 - e0, m->sumsq_E, m->sumsq_part, m->stream, true));
   RC(comm_all_reduce_f32(m->shard_comm, m->sumsq_E, 1, COMM_SUM, m->stream));
   return launch_add_scalar(m->sumsq, m->sumsq_E, m->stream);
 }
@@ -105,8 +103,7 @@ int optimizer_step_zero1(Optimizer* o, rsys_comm* c, float lr_factor, float clip
   if (tail > 0) RC(comm_all_reduce_f32(c, m->G + tail_lo, (size_t)tail, COMM_SUM, s));
   const float* ss = nullptr;
   if (clip > 0.f) {
-    HIP_CHECK(hipMemsetAsync(m->sumsq, 0, 4, s));
-    RC(launch_sumsq(m->G + lo, chunk, m->sumsq, m->sumsq_part, s));
+    RC(launch_sumsq(m->G + lo, chunk, m->sumsq, m->sumsq_part, s, true));
     if (last && tail > 0) RC(launch_sumsq(m->G + tail_lo, tail, m->sumsq, m->sumsq_part, s));
     RC(comm_all_reduce_f32(c, m->sumsq, 1, COMM_SUM, s));
     ss = m->sumsq;

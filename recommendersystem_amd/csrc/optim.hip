@@ -33,23 +33,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   const float acc = block_sum((a0 + a1) + (a2 + a3), red);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* out) {
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* out, int overwrite) {
   __shared__ float red[16];
   float a = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
   a = block_sum(a, red);
-  if (threadIdx.x == 0) *out += a;
+  if (threadIdx.x == 0) *out = overwrite ? a : *out + a;
 }
 
 int sumsq_parts() { return 2048; }
-int launch_sumsq(const float* g, long long n, float* out, float* part, hipStream_t s) {
+int launch_sumsq(const float* g, long long n, float* out, float* part, hipStream_t s, bool overwrite) {
   ARG_CHECK(part != nullptr, "sumsq: no partial-sum buffer");
-  if (n <= 0) return RSYS_OK;
+  if (n <= 0) { if (overwrite) HIP_CHECK(hipMemsetAsync(out, 0, 4, s)); return RSYS_OK; }
   ARG_CHECK(((uintptr_t)g % 16) == 0, "sumsq: the range must start on a 16-byte boundary");
   const int grid = (int)std::min<long long>(((n >> 2) + 1023) / 1024 + 1, 2048);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, part);
   HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, part, grid, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, part, grid, out, overwrite ? 1 : 0);
   HIP_CHECK(hipGetLastError());
   return RSYS_OK;
 }
