@@ -35,6 +35,7 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8f": "gemm8p_f8_kernel",                             # --dtype fp8: the persistent pipeline on e4m3 / e5m2 operands (K tiles of 128)
     "8fs": "gemm8p_f8sk_kernel",                          # --dtype fp8: split-K weight gradients on transposed fp8 copies, one product per launch
     "8gf": "gemm8p_group_f8_kernel",                      # --dtype fp8: the same, all layers' products in one grouped launch
+    "8m": "gemm8p_mix_kernel",                            # row-major A x K-major B, split-K atomics over device-side live rows (the tied head's dEw)
     "nt": "gemm_kernelIDF16bLb0ELb0ELb0ELb0E",      # 128x128 register-staged (gemm.hip)
     "nn": "gemm_kernelIDF16bLb0ELb0ELb0ELb1E",
     "tn": "gemm_kernelIDF16bLb0ELb0ELb1ELb1E",
@@ -48,6 +49,7 @@ KERNEL_LABEL = {"4p": "gemm4p_kernel (256x256 LDS-DMA, persistent, four waves of
                 "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
                 "8fs": "gemm8p_f8sk_kernel (256x256 LDS-DMA, fp8 e5m2 x e4m3 on K-contiguous copies, split-K weight gradient)",
                 "8gf": "gemm8p_group_f8_kernel (the fp8 split-K form, grouped weight gradients of all layers)",
+                "8m": "gemm8p_mix_kernel (256x256 LDS-DMA, row-major A x K-major B, split-K atomics over the device-side live rows)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 def _latest_traffic_file():
     """the newest committed PMC summary (profiles/r<round><letter>_pmc_traffic.json, written by tools/prof_round.sh)"""

@@ -44,7 +44,8 @@ int32_t rsys_op_gemm(int32_t dtype, const void* A, const void* B, void* C, int32
                      int32_t splitk);
 /* the same product with the row count taken from device memory, as the head GEMMs over the selected positions do
  * (model.py:501-516: only rows with a positive target weight reach the heads): rows >= *rows_dev are not computed
- * (rows up to the end of the last started tile may be written); row-major A, c_f32 / b_km as above */
+ * (rows up to the end of the last started tile may be written); row-major A, c_f32 / b_km as above; c_f32 == 3: fp32 C ACCUMULATED by
+ * split-K atomics (the tied head's dEw = dlogits . F) */
 int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K,
                           int64_t lda, int64_t ldb, int64_t ldc, int32_t b_km, int32_t c_f32, const int32_t* rows_dev);
 /* K-major operands (A [K][lda >= M], B [K][ldb >= N]), f32 C stored (accumulate = 0) or added to (1), the reduction limited to the first

@@ -664,7 +664,8 @@ int32_t rsys_op_gemm_rows(int32_t dtype, const void* A, const void* B, void* C, 
   ARG_CHECK(rows_dev != nullptr, "rsys_op_gemm_rows: rows_dev is null");
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  p.c_f32 = c_f32; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE; p.m_dev = rows_dev;
+  p.c_f32 = c_f32 != 0; p.splitk = 1; p.alpha = 1.f; p.epi = EPI_STORE; p.m_dev = rows_dev;
+  if (c_f32 == 3) { p.epi = EPI_ATOMIC; p.splitk = 8; }   // the head's dEw form: fp32 C accumulated by split-K atomics
   int rc = dtype == RSYS_DTYPE_BF16 ? launch_gemm<bf16>(p, false, false, false, b_km != 0, nullptr)
                                     : launch_gemm<float>(p, false, false, false, b_km != 0, nullptr);
   if (rc) return rc;

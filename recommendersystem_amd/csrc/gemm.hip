@@ -519,6 +519,18 @@ static bool use_8p_nt_splitk(const GemmParams& p) {
   return t256 >= 32 || (t256 >= 8 && (long long)p.K * t256 >= 32LL * 16384);
 }
 
+// row-major A x K-major B with the atomic epilogue (the tied head's dEw = dlogits . F: a few hundred live rows, K = the vocabulary): the LDS-DMA
+// mixed-layout form when K is long; RSYS_GEMM_KERNEL_MIX: 1 = that rule, 0 = never (the 128x128 kernel), 2 = wherever eligible
+static bool use_8p_mix(const GemmParams& p) {
+  const int mode = sw().gemm_kernel_mix;
+  if (mode == 0 || sw().gemm_kernel == 1) return false;
+  GemmParams q = p; q.K = p.K & ~63;
+  if (!gemm8p_mix_eligible(q)) return false;
+  // measured in the step (profiles/r6_ab_head_dx_mixed_layout.log): cfg-3's dEw (N = 512, ~10^5 K, a few hundred to a thousand live rows) 0.301 -> 0.220 ms
+  // per step; cfg-2's (N = 256: one tile column, three row tiles -- 240 workgroups that each add a 256 KB partial tile atomically) 0.135 -> 0.156: not taken
+  return mode == 2 || (p.K >= 8192 && p.N >= 512);
+}
+
 const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, bool b_f32, bool a_km, bool b_km) {
   GemmParams p = p0;
   if (p.splitk < 1) p.splitk = 1;
@@ -529,6 +541,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return "8ts";
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return "8s";
+  if (bf16_mode && !a_km && b_km && !a_f32 && !b_f32 && use_8p_mix(p)) return "8m";
   return a_km ? "tn" : (b_km ? "nn" : "nt");
 }
 
@@ -562,6 +575,14 @@ int launch_gemm(const GemmParams& p0, bool a_f32, bool b_f32, bool a_km, bool b_
     if (!a_km && !b_km && !a_f32 && !b_f32) {
       const int k = pick_rowmajor_kernel(p);
       if (k == 2) return launch_gemm8p(p, s);
+    }
+    if (!a_km && b_km && !a_f32 && !b_f32 && use_8p_mix(p)) {
+      GemmParams q = p; q.K = p.K & ~63;
+      { const int rc_ = launch_gemm8p_mix(q, s); if (rc_ != RSYS_OK) return rc_; }
+      if ((p.K & 63) == 0) return RSYS_OK;
+      GemmParams t = p;   // the last K % 64 columns of A / rows of B, added by the 128x128 kernel (guarded loads)
+      t.A = (const char*)p.A + (size_t)q.K * 2; t.B = (const char*)p.B + (size_t)q.K * p.ldb * 2; t.K = p.K & 63; t.splitk = 1;
+      return launch_one<CT, false, false, false, true>(t, s);
     }
     if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return launch_gemm8p_tn(p, s);
     if (a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return launch_gemm8p_tn_store(p, s);

@@ -92,6 +92,9 @@ int gemm8p_group_splitk(const GemmGroupPlan* pl);
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s);
 
 // fp8 row-major operands on the persistent 256x256 pipeline (K tiles of 128 elements, v_mfma_f32_16x16x128_f8f6f4); p.f8 set
+// row-major A x K-major B, split-K atomics over device-side live rows (the tied head's dEw); K a multiple of 64
+bool gemm8p_mix_eligible(const GemmParams& p);
+int launch_gemm8p_mix(const GemmParams& p, hipStream_t s);
 bool gemm8p_f8_eligible(const GemmParams& p);
 int launch_gemm8p_f8(const GemmParams& p, hipStream_t s);
 // the same operands, split-K with fp32 atomics (EPI_ATOMIC): the fp8 trunk's weight gradients on K-contiguous (transposed) copies

@@ -95,11 +95,16 @@ __device__ __forceinline__ void dma16_asm(i32x4 rsrc, unsigned int voff, unsigne
 // the two reads together are the lane's 32 k values of ONE v_mfma_f32_16x16x128_f8f6f4 (both operands use the same k order, so
 // which 32 of the 128 a lane group holds does not matter).  The accumulators are multiplied by the descale of the operands'
 // tensor-wise scales before the epilogue (GemmParams::f8_*).
-template <bool KM, bool SK, bool GROUP, int F8 = 0>
+// MIX (K-major form only): A is ROW-major ([M][K], as in the KM = false form: same requests, same LDS image, same fragment reads), B stays
+// K-major -- the tied head's dEw = dlogits . F with F [V][D]: the gradient rows stream K-contiguous, the table is read as it lies.  Both
+// fragment sources hand a lane the same eight k of a 32-wide step, so the two halves combine without a transpose anywhere.
+template <bool KM, bool SK, bool GROUP, int F8 = 0, bool MIX = false>
 __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, const int nblk, const int g_tile, const int g_split) {
   static_assert(!(KM && SK), "the K-major form is always split-K");
   static_assert(!GROUP || KM || SK, "grouped launches exist for the split-K forms");
   static_assert(!F8 || !KM, "fp8 operands are row-major");
+  static_assert(!MIX || (KM && GROUP), "the mixed-layout form is a K-major split-K form whose (tile, split) comes from its kernel");
+  constexpr bool KMA = KM && !MIX, KMB = KM;   // layout of each operand
   constexpr bool PERSIST = !KM && !SK;
   constexpr int KE = F8 ? 128 : T8_BK;     // elements per K tile
   constexpr int ES = F8 ? 1 : 2;           // bytes per element
@@ -172,17 +177,18 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   auto tile_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    if constexpr (!KM) {
+    if constexpr (!KMA || !KMB) {
       const int lr = (w * 2 + j) * 8 + (l >> 3);
       const int c = (l & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int grow = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), p.M - 1);   // clamped rows are never stored
         const int gcol = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), p.N - 1);
-        aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * (16 / ES)) * ES);
-        boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * (16 / ES)) * ES);
+        if constexpr (!KMA) aoff[j][h] = (unsigned int)(((long long)grow * p.lda + c * (16 / ES)) * ES);
+        if constexpr (!KMB) boff[j][h] = (unsigned int)(((long long)gcol * p.ldb + c * (16 / ES)) * ES);
       }
-    } else {
+    }
+    if constexpr (KMA || KMB) {
       // K-major: piece (w*2+j) = k rows (w*2+j)*4 + [0,4) of the half-tile, 256 B = eight 16-column blocks per row;
       // lane l -> row + (l>>4), 16-byte chunk l&15.  Block mb of row k is stored at block mb ^ f(k),
       // f(k) = ((k>>3)&1)<<2 | (k&3): the eight rows one half-wave of a transposed read touches land on distinct banks.
@@ -193,8 +199,8 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
       for (int h = 0; h < 2; ++h) {
         const int ma = min(m0 + (mb >> 2) * 128 + h * 64 + (mb & 3) * 16 + half * 8, p.M - 8);   // (clamped columns are never added)
         const int nb = min(n0 + (mb >> 1) * 64 + h * 32 + (mb & 1) * 16 + half * 8, p.N - 8);
-        aoff[j][h] = (unsigned int)(((long long)krow * p.lda + ma) * 2);
-        boff[j][h] = (unsigned int)(((long long)krow * p.ldb + nb) * 2);
+        if constexpr (KMA) aoff[j][h] = (unsigned int)(((long long)krow * p.lda + ma) * 2);
+        if constexpr (KMB) boff[j][h] = (unsigned int)(((long long)krow * p.ldb + nb) * 2);
       }
     }
   }
@@ -203,15 +209,15 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   // Running operand windows (wave-uniform, SGPRs): a_cur / b_cur = base of K tile kt, a_rem / b_rem = bytes from there
   // to the end of the operand (K-major only: rows past K read as zeros, so the K tail of the last split needs no guard).
   // The K loop advances them with two scalar adds per operand instead of rebuilding 64-bit products per DMA.
-  const long long stepA = KM ? (long long)T8_BK * p.lda * 2 : (long long)T8_BK * 2;
-  const long long stepB = KM ? (long long)T8_BK * p.ldb * 2 : (long long)T8_BK * 2;
+  const long long stepA = KMA ? (long long)T8_BK * p.lda * 2 : (long long)T8_BK * 2;
+  const long long stepB = KMB ? (long long)T8_BK * p.ldb * 2 : (long long)T8_BK * 2;
   const char* a_cur = (const char*)p.A + (long long)kt0 * stepA;
   const char* b_cur = (const char*)p.B + (long long)kt0 * stepB;
-  long long a_rem = KM ? (long long)keff * p.lda * 2 - (long long)kt0 * stepA : 0;
-  long long b_rem = KM ? (long long)keff * p.ldb * 2 - (long long)kt0 * stepB : 0;
-  auto window = [&](const char* cur, long long rem, long long step, int d) __attribute__((always_inline)) -> i32x4 {
+  long long a_rem = KMA ? (long long)keff * p.lda * 2 - (long long)kt0 * stepA : 0;
+  long long b_rem = KMB ? (long long)keff * p.ldb * 2 - (long long)kt0 * stepB : 0;
+  auto window = [&](auto KMX, const char* cur, long long rem, long long step, int d) __attribute__((always_inline)) -> i32x4 {
     i32x4 r = make_rsrc(cur + d * step);
-    if constexpr (KM) {
+    if constexpr (decltype(KMX)::value) {
       const long long left = rem - d * step;
       r[2] = __builtin_amdgcn_readfirstlane((int)(unsigned int)(left <= 0 ? 0 : (left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left)));
     }
@@ -222,7 +228,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   [[maybe_unused]] const unsigned int dma_lds = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)(LDS_AS unsigned char*)dma_base);
   auto stage_a = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
-    const i32x4 rs = window(a_cur, a_rem, stepA, d);
+    const i32x4 rs = window(std::integral_constant<bool, KMA>{}, a_cur, a_rem, stepA, d);
     if constexpr (KM) {
       const unsigned int at = (unsigned int)__builtin_amdgcn_readfirstlane((int)(dma_lds + bo + h * 16384));
       dma16_asm(rs, aoff[0][h], at);
@@ -234,7 +240,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   };
   auto stage_b = [&](int bo, auto H, int d) {
     constexpr int h = decltype(H)::value;
-    const i32x4 rs = window(b_cur, b_rem, stepB, d);
+    const i32x4 rs = window(std::integral_constant<bool, KMB>{}, b_cur, b_rem, stepB, d);
     if constexpr (KM) {
       const unsigned int at = (unsigned int)__builtin_amdgcn_readfirstlane((int)(dma_lds + bo + 32768 + h * 16384));
       dma16_asm(rs, boff[0][h], at);
@@ -277,7 +283,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   auto read_a = [&](int bo, int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (!KM) {
+      if constexpr (!KMA) {
         af[i][0] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd0);
         af[i][1] = *(const bf16x8*)(smem + bo + h * 16384 + i * 2048 + a_rd1);
       } else {
@@ -289,7 +295,7 @@ __device__ __forceinline__ void gemm8p_body(const GemmParams& p, const int bid, 
   auto read_b = [&](bf16x8(&bf)[2][2], int bo, int h) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if constexpr (!KM) {
+      if constexpr (!KMB) {
         bf[j][0] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd0);
         bf[j][1] = *(const bf16x8*)(smem + bo + h * 16384 + j * 2048 + b_rd1);
       } else {
@@ -605,6 +611,24 @@ __global__ __launch_bounds__(512) void gemm8p_group_kernel(const GemmParams* __r
   gemm8p_body<true, false, true>(p, blockIdx.x, gridDim.x, (int)(wk & 0xFFFFu), (int)((wk >> 16) & 0xFFu));
 }
 
+// Mixed layouts (gemm8p_body's MIX): C[M][N] += A[M][K] (row-major) . B[K][N] (K-major), split-K with fp32 atomics, over the rows the device says are
+// live (*m_dev: the tied head's dEw = dlogits . F over the selected positions).  The grid is fixed (the launcher does not know the row count); the
+// kernel deals (tile, K split) pairs itself: XCD x owns the splits x, x + 8, ..., as many per XCD as its workgroups can take at once, the tiles of one
+// split side by side (they share the split's K-major rows through that XCD's L2); more tiles than workgroups per XCD: a workgroup takes several pairs.
+__global__ __launch_bounds__(512) void gemm8p_mix_kernel(GemmParams p) {
+  const int rows = p.m_dev != nullptr ? __builtin_amdgcn_readfirstlane(max(min(*p.m_dev, p.M), 0)) : p.M;
+  const int ntiles = ((rows + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
+  if (ntiles == 0) return;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int S = max(1, G / ntiles);
+  GemmParams q = p;
+  q.M = rows; q.m_dev = nullptr; q.splitk = 8 * S;
+  for (int i = local; i < ntiles * S; i += G) {
+    if (i != local) __syncthreads();   // (the previous pair's epilogue staged through the LDS the next prologue fills)
+    gemm8p_body<true, false, true, 0, true>(q, blockIdx.x, gridDim.x, i % ntiles, xcd + 8 * (i / ntiles));
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ grouped launch plan
@@ -839,6 +863,25 @@ int launch_gemm8p_nt_splitk(const GemmParams& p0, hipStream_t s) {
   hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());
   return gemm_slab_end(p, s);
+}
+
+// row-major A, K-major B, split-K atomics (gemm8p_mix_kernel); the caller passes K as a multiple of 64 (a row-major operand has no zero-filled
+// K tail: gemm.hip adds the last K % 64 columns with the 128x128 kernel)
+bool gemm8p_mix_eligible(const GemmParams& p) {
+  if (p.epi != EPI_ATOMIC || !p.c_f32 || p.k_dev != nullptr || p.slab != nullptr || p.f8 != 0) return false;
+  if (p.K < 16 * T8_BK || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.N % 8 != 0 || p.N < 8 || p.M < 1) return false;
+  if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32)) return false;                                  // row-major A: 32-bit row offsets
+  if ((unsigned long long)64 * p.ldb * 2 + (unsigned long long)p.N * 2 >= (1ull << 31)) return false;      // K-major B: a K tile's window
+  if ((unsigned long long)p.K * p.ldb * 2 >= (1ull << 40)) return false;
+  return true;
+}
+static int cu_count();
+int launch_gemm8p_mix(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  ARG_CHECK(p.K % T8_BK == 0, "gemm8p_mix: K must be a multiple of 64 (the caller splits the tail off)");
+  hipLaunchKernelGGL(gemm8p_mix_kernel, dim3(8 * std::max(1, cu_count() / 8)), dim3(512), 0, s, p);
+  HIP_CHECK(hipGetLastError());
+  return RSYS_OK;
 }
 
 // at most one workgroup per CU (128 KB of LDS each): the kernel walks the remaining tiles itself

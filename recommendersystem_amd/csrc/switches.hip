@@ -18,6 +18,7 @@ const Entry kEntries[] = {
     {"RSYS_GEMM_KERNEL", &Switches::gemm_kernel, -1},
     {"RSYS_GEMM_KERNEL_TN", &Switches::gemm_kernel_tn, -1},
     {"RSYS_GEMM_KERNEL_NT_SPLITK", &Switches::gemm_kernel_nt_splitk, -1},
+    {"RSYS_GEMM_KERNEL_MIX", &Switches::gemm_kernel_mix, 1},
     {"RSYS_GEMM8C_HALF", &Switches::gemm8c_half, 1},
     {"RSYS_GEMM4P", &Switches::gemm4p, 1},
     {"RSYS_GEMM8C", &Switches::gemm8c, 1},

@@ -16,6 +16,7 @@ struct Switches {
   int gemm_kernel;            // RSYS_GEMM_KERNEL: -1 unset / 0 (shape rule); 1 = the 128x128 register-staged kernel everywhere, 2 = 256x256 LDS-DMA wherever eligible
   int gemm_kernel_tn;         // RSYS_GEMM_KERNEL_TN: -1 unset / 0 (shape rule); 1 = never the K-major LDS-DMA kernels, 2 = both their forms (split-K, store) wherever eligible
   int gemm_kernel_nt_splitk;  // RSYS_GEMM_KERNEL_NT_SPLITK: -1 unset (shape rule); 0 off; 2 force
+  int gemm_kernel_mix;        // RSYS_GEMM_KERNEL_MIX: 1 = row-major A x K-major B atomic products with K >= 8192 and N >= 512 on the mixed-layout LDS-DMA kernel (gemm8p_mix_kernel); 0 = never; 2 = wherever eligible
   int gemm8c_half;            // RSYS_GEMM8C_HALF: 1 = 128x256 output tiles for outputs with fewer 256x256 tiles than CUs; 0 = never; 2 = wherever the class has the kernel
   int gemm4p;                 // RSYS_GEMM4P: 1 = plain bf16 stores with K >= 8192 on outputs >= 4 tiles wide on the four-wave register-named K loop (gemm4p.hip); 0 = never; 2 = wherever eligible
   int gemm8c;                 // RSYS_GEMM8C=0: row-major 256x256 products on gemm8p.hip (per-tile operand requests) instead of gemm8c.hip

@@ -188,6 +188,44 @@ def test_gemm_rowmajor_splitk_lds_dma_kernel(M, N, K):
     np.testing.assert_array_equal(out, ref.astype(np.float32))
 
 
+@pytest.mark.parametrize("rows", [0, 1, 300, 1300, 2048, 9000])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 4096 + 40), (4096, 264, 8192), (8704, 256, 1024)])
+def test_gemm_mixed_layout_splitk_kernel(monkeypatch, rows, M, N, K):
+    """gemm8p_mix_kernel (round 6): row-major A [M][K] x K-major B [K][N], fp32 C accumulated by split-K atomics, over the first *rows_dev
+    rows -- the tied head's dEw = dlogits . F (model.py:153-170 backward: a few hundred live rows against the whole vocabulary).  Forced
+    (RSYS_GEMM_KERNEL_MIX=2) and switched off (=0: the 128x128 kernel): exact on asymmetric integer data; a K that is no multiple of 64
+    (the row-major operand's tail goes through the 128x128 kernel), ragged N, more row tiles than a workgroup per XCD can take at once
+    (8704 rows = 34 tiles: a workgroup walks several (tile, split) pairs), row counts of 0, 1, inside a tile, beyond M; C starts from a
+    non-zero value (accumulation); rows from the end of the last started 128-row tile on keep it (rows between the count and that end may
+    hold anything: the documented contract of a device-side row count, the heads never read them)."""
+    from recommendersystem_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(rows + M + N)
+    A = rng.integers(-2, 3, (M, K)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    A[:, 0] = np.arange(M) % 5 - 2; B[1, :] = np.arange(N) % 7 - 3
+    lda = (K + 7) // 8 * 8; ldb = (N + 7) // 8 * 8
+    Ap = np.zeros((M, lda), np.float32); Ap[:, :K] = A
+    Bp = np.zeros((K, ldb), np.float32); Bp[:, :N] = B
+    live = min(rows, M)
+    want = np.full((M, N), 3.0, np.float32)
+    want[:live] += (A[:live].astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+    for mode in ("2", "0"):
+        monkeypatch.setenv("RSYS_GEMM_KERNEL_MIX", mode)
+        dA = _to_dev(lib, _pack(Ap, True)); dB = _to_dev(lib, _pack(Bp, True))
+        dC = _to_dev(lib, np.full((M, N), 3.0, np.float32))
+        dR = _to_dev(lib, np.array([rows], np.int32))
+        rc = lib.rsys_op_gemm_rows(1, dA, dB, dC, M, N, K, lda, ldb, N, 1, 3, dR)
+        assert rc == 0, _lib.last_error()
+        out = np.empty((M, N), np.float32)
+        assert lib.rsys_dev_d2h(out.ctypes.data, dC, out.nbytes) == 0
+        for p in (dA, dB, dC, dR):
+            lib.rsys_dev_free(p)
+        np.testing.assert_array_equal(out[:live], want[:live], err_msg=f"RSYS_GEMM_KERNEL_MIX={mode} rows={rows}")
+        end = (live + 127) // 128 * 128
+        np.testing.assert_array_equal(out[end:], want[end:], err_msg=f"RSYS_GEMM_KERNEL_MIX={mode} rows={rows}: rows behind the last started tile")
+    monkeypatch.delenv("RSYS_GEMM_KERNEL_MIX", raising=False)
+
+
 @pytest.mark.parametrize("rows", [0, 1, 256, 300, 717, 1280, 2048, 5000])
 @pytest.mark.parametrize("kern", ["1", "2", "2p"])
 def test_gemm_device_side_row_count(monkeypatch, rows, kern):
