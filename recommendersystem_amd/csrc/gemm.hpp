@@ -54,7 +54,7 @@ struct GemmParams {
   float* slab; long long slab_floats;
   int flags;        // bit 0: timing experiment (no allowance for pending stores); bit 1: 256x256 kernel with one workgroup
                     // per tile instead of its persistent grid (used while RCCL kernels share the CUs, see model.hip);
-                    // bit 2: start-stagger experiment; bits 3-6: gemm8c walks the tiles in bands of that many tile rows (set by its launcher); bit 7: EPI_ATOMIC row-major product on the 256x256 split-K kernel whatever its tile count
+                    // bit 2: start-stagger experiment; bits 3-6: gemm8c walks the tiles in bands of that many tile rows (set by its launcher); bit 7: EPI_ATOMIC row-major product on the 256x256 split-K kernel whatever its tile count; bit 8: gemm8c walks its tile rows from the last to the first (the caller's A was written just before, front to back)
   // fp8 operands (launch_gemm8p_f8, the fp8 trunk of f8.hip): f8 = 1: A is e4m3, 2: A is e5m2; B is always e4m3.  lda / ldb / K
   // count 1-byte elements.  The fp32 accumulators are multiplied by a descale 1 / (scale_A scale_B) before the epilogue:
   int f8;

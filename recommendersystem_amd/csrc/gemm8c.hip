@@ -100,6 +100,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
   // XCD's L2 where a row-major run of a wide output shares 1 + 32 (launcher: outputs more than eight tiles wide)
   const int band_rows = (p.flags >> 3) & 15;
   const bool patch = band_rows != 0;
+  const bool rev = (p.flags & 256) != 0 && !patch;   // flags bit 8: the run walks the tile ROWS from the last to the first (row-major order otherwise unchanged)
   const int tiles_m_all = ntiles / tiles_n;
   auto tile_pos = [&](C8Tile& x) __attribute__((always_inline)) {
     if (x.t >= ntiles) return;   // (past the end: never dereferenced)
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     auto tile_inc = [&](C8Tile& x) __attribute__((always_inline)) {
       x.t += tile_step;
       if (patch) { tile_pos(x); return; }
+      if (rev) { if (x.t < ntiles) { const int r = x.t / tiles_n; x.tm = tiles_m_all - 1 - r; x.tn = x.t - r * tiles_n; } return; }
       x.tm += step_m; x.tn += step_n;
       if (x.tn >= tiles_n) { x.tn -= tiles_n; ++x.tm; }
     };
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(512) void gemm8c_kernel(GemmParams p) {
     };
     C8Tile tile{tile_first, tile_first / tiles_n, tile_first % tiles_n};
     if (patch) tile_pos(tile);
+    if (rev) tile.tm = tiles_m_all - 1 - tile.tm;
     while (tile.t < tile_end && tile_full(tile) != WANT) tile_inc(tile);
     if (tile.t >= tile_end) return;
     // The request stream runs two K tiles ahead of the MFMAs.  cs = window of K tile g + 2, cn = of g + 1; nx = the first K tile
@@ -374,6 +377,7 @@ bool gemm8c_uses_half(const GemmParams& p, int cus) {
 int launch_gemm8c(const GemmParams& p0, hipStream_t s) {
   if (gemm4p_takes(p0)) return launch_gemm4p(p0, s);
   GemmParams p = p0;
+  { const int mode = sw().gemm_reverse; if (mode == 2) p.flags |= 256; else if (mode == 0) p.flags &= ~256; }   // (bit 8: tile rows walked from the last to the first)
   int cus = 256;
   { static int n = 0; if (n == 0) { int dev = 0, v = 0; n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; } cus = n; }
   const bool half = gemm8c_uses_half(p, cus);

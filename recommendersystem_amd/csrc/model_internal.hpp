@@ -114,6 +114,11 @@ static int gemm(Model* m, const char* tag, GemmParams p, bool a_f32, bool a_km, 
     p.splitk = pick_splitk(p.M, p.N, (p.k_dev != nullptr && p.k_expect > 0) ? std::min(p.K, p.k_expect) : p.K, is_bf16<T>::value ? 64 : 32);
   if (p.splitk == 0) p.splitk = 1;
   p.flags |= m->gemm_flags;
+  // A consumer that reads a large activation the previous kernel has just written walks its tile rows from the LAST to the first: the rows written
+  // last are still in the Infinity Cache, a forward walk meets only the evicted ones (w2_fwd reads h behind w13_fwd's 553 MB of output, w13_dx reads
+  // dab behind w2_dx; measured per call site, profiles/r6_ab_reverse_tile_rows.log: -1.7 % and -2.4 %, nothing at the other sites).  launch_gemm8c
+  // honours the bit by RSYS_GEMM_REVERSE.
+  if (strcmp(tag, "gemm_w2_fwd") == 0 || strcmp(tag, "gemm_w13_dx") == 0) p.flags |= 256;
   if (m->deterministic && p.epi == EPI_ATOMIC) RC(det_slab_for(m, gemm_slab_need<T>(p, a_f32, false, a_km, b_km), p));
   if (m->timer.enabled) tic(m, (std::string(tag) + "@" + gemm_kernel_name(p, is_bf16<T>::value, a_f32, false, a_km, b_km)).c_str(), 2.0 * p.M * p.N * (double)p.K);
   int rc = launch_gemm<T>(p, a_f32, false, a_km, b_km, m->stream);

@@ -22,6 +22,7 @@ const Entry kEntries[] = {
     {"RSYS_GEMM8C_HALF", &Switches::gemm8c_half, 1},
     {"RSYS_GEMM4P", &Switches::gemm4p, 1},
     {"RSYS_GEMM8C", &Switches::gemm8c, 1},
+    {"RSYS_GEMM_REVERSE", &Switches::gemm_reverse, 1},
     {"RSYS_GEMM_PATCH", &Switches::gemm_patch, 1},
     {"RSYS_TABLE_TAIL", &Switches::table_tail, 1},
     {"RSYS_DW_GROUP", &Switches::dw_group, 1},

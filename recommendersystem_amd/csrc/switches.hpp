@@ -20,6 +20,7 @@ struct Switches {
   int gemm8c_half;            // RSYS_GEMM8C_HALF: 1 = 128x256 output tiles for outputs with fewer 256x256 tiles than CUs; 0 = never; 2 = wherever the class has the kernel
   int gemm4p;                 // RSYS_GEMM4P: 1 = plain bf16 stores with K >= 8192 on outputs >= 4 tiles wide on the four-wave register-named K loop (gemm4p.hip); 0 = never; 2 = wherever eligible
   int gemm8c;                 // RSYS_GEMM8C=0: row-major 256x256 products on gemm8p.hip (per-tile operand requests) instead of gemm8c.hip
+  int gemm_reverse;           // RSYS_GEMM_REVERSE: 1 = the consumers of a just-written large activation (w2_fwd, w13_dx) walk their tile rows from the last to the first; 0 = never; 2 = every gemm8c launch
   int gemm_patch;             // RSYS_GEMM_PATCH: 1 = band order of the output tiles for wide and tall outputs; 0 = row-major everywhere; 2 = bands everywhere
   int table_tail;             // RSYS_TABLE_TAIL=0: the fused item table in ONE launch (its last persistent round on a fraction of the CUs) instead of main launch + split-K tail
   int dw_group;               // RSYS_DW_GROUP=0: one weight-gradient launch per product instead of the grouped launch

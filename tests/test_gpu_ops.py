@@ -108,6 +108,26 @@ def test_gemm_band_order_of_the_output_tiles_changes_no_bit(monkeypatch):
     monkeypatch.delenv("RSYS_GEMM_PATCH", raising=False)
 
 
+def test_gemm_reverse_walk_of_the_tile_rows_changes_no_bit(monkeypatch):
+    """gemm8c walks its tile rows from the last to the first where the caller says its A operand was written just before, front to back (w2_fwd,
+    w13_dx: the rows written last are still in the Infinity Cache; GemmParams::flags bit 8, RSYS_GEMM_REVERSE).  Like the band order it only
+    assigns tiles to workgroups: forced on every launch (=2) and switched off (=0) the outputs agree bit for bit -- ragged edges, more tiles
+    than CUs, the HALF form (128-row tiles), fp32 and bf16 outputs; exact on integer operands either way."""
+    monkeypatch.setenv("RSYS_GEMM_KERNEL", "2")
+    for (M, N, K, c_f32, half) in [(1100, 520, 192, False, "0"), (33000, 512, 256, False, "0"), (16640, 768, 128, True, "0"), (9000, 264, 192, False, "2")]:
+        monkeypatch.setenv("RSYS_GEMM8C_HALF", half)
+        outs = []
+        for mode in ("0", "2"):
+            monkeypatch.setenv("RSYS_GEMM_REVERSE", mode)
+            out, ref = run_gemm(1, M, N, K, False, False, c_f32=c_f32, integer=False, seed=M + K)
+            outs.append(out)
+            outi, refi = run_gemm(1, M, N, K, False, False, c_f32=True, integer=True, seed=N)
+            np.testing.assert_array_equal(outi, refi.astype(np.float32), err_msg=f"{mode} {M} {N} {K}")
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (M, N, K)
+    for k in ("RSYS_GEMM_REVERSE", "RSYS_GEMM8C_HALF"):
+        monkeypatch.delenv(k, raising=False)
+
+
 @pytest.mark.parametrize("dtype,tol", [(0, 2e-5), (1, 2e-2)])
 @pytest.mark.parametrize("a_km,b_km", LAYOUTS)
 def test_gemm_random(dtype, tol, a_km, b_km):
