@@ -42,5 +42,50 @@ for (M, N, K) in [(2048, 5632, 32768), (4096, 2048, 65536), (11264, 2048, 16384)
         n += 1
         if not np.array_equal(out, ref.astype(np.float32)):
             bad += 1; print("MISMATCH 8t long", M, N, K, rep, int((out != ref.astype(np.float32)).sum()))
+# round 6: gemm4p (the hand-over between two tiles of a workgroup rests on vmcnt's 6-bit range and on in-order retirement behind 64 stores; whole
+# tiles only), gemm8c's HALF form and its reverse walk of the tile rows, the mixed-layout split-K kernel of the head's dEw
+for k in ("RSYS_GEMM_KERNEL_TN",):
+    os.environ.pop(k, None)
+os.environ.update({"RSYS_GEMM_KERNEL": "2", "RSYS_GEMM8C": "1", "RSYS_GEMM4P": "2"})
+for _ in range(28):
+    M = 256 * int(rng.choice([1, 2, 5, 33, 64, 65, 130, 257])); N = 256 * int(rng.choice([1, 2, 3, 4, 9])); K = 128 * int(rng.choice([2, 3, 4, 5, 11, 22]))
+    for rep in range(3):
+        out, ref = T.run_gemm(1, M, N, K, False, False, c_f32=False, integer=True, seed=M + N + K + rep)
+        n += 1
+        if not np.array_equal(out, T._bf16_round(ref.astype(np.float32))):
+            bad += 1; print("MISMATCH 4p", M, N, K, rep, int((out != T._bf16_round(ref.astype(np.float32))).sum()))
+os.environ.update({"RSYS_GEMM4P": "0", "RSYS_GEMM8C_HALF": "2", "RSYS_GEMM_REVERSE": "2"})
+for _ in range(16):
+    M = int(rng.choice([256, 1000, 3000, 16384, 20000, 33000])); N = int(rng.choice([256, 512, 264, 776, 1408])); K = int(rng.choice([128, 192, 256, 576, 1408]))
+    for rep in range(2):
+        out, ref = T.run_gemm(1, M, N, K, False, False, c_f32=False, integer=True, seed=M + N + K + rep)
+        n += 1
+        if not np.array_equal(out, T._bf16_round(ref.astype(np.float32))):
+            bad += 1; print("MISMATCH 8c half + reverse", M, N, K, rep)
+for k in ("RSYS_GEMM4P", "RSYS_GEMM8C_HALF", "RSYS_GEMM_REVERSE", "RSYS_GEMM_KERNEL"):
+    os.environ.pop(k, None)
+os.environ["RSYS_GEMM_KERNEL_MIX"] = "2"
+from recommendersystem_amd import _lib
+lib = _lib.lib()
+for _ in range(16):
+    M = int(rng.choice([512, 2048, 4096, 8704])); N = int(rng.choice([256, 512, 264, 1024])); K = int(rng.choice([1024, 4096 + 40, 8192, 20001]))
+    rows = int(rng.choice([1, 300, 1300, 2600, 9000]))
+    A = rng.integers(-2, 3, (M, K)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    lda = (K + 7) // 8 * 8; ldb = (N + 7) // 8 * 8
+    Ap = np.zeros((M, lda), np.float32); Ap[:, :K] = A
+    Bp = np.zeros((K, ldb), np.float32); Bp[:, :N] = B
+    live = min(rows, M)
+    want = (A[:live].astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+    dA = T._to_dev(lib, T._pack(Ap, True)); dB = T._to_dev(lib, T._pack(Bp, True))
+    for rep in range(2):
+        dC = T._to_dev(lib, np.zeros((M, N), np.float32)); dR = T._to_dev(lib, np.array([rows], np.int32))
+        assert lib.rsys_op_gemm_rows(1, dA, dB, dC, M, N, K, lda, ldb, N, 1, 3, dR) == 0, _lib.last_error()
+        out = np.empty((M, N), np.float32)
+        assert lib.rsys_dev_d2h(out.ctypes.data, dC, out.nbytes) == 0
+        lib.rsys_dev_free(dC); lib.rsys_dev_free(dR)
+        n += 1
+        if not np.array_equal(out[:live], want):
+            bad += 1; print("MISMATCH 8m", M, N, K, rows, rep, int((out[:live] != want).sum()))
+    lib.rsys_dev_free(dA); lib.rsys_dev_free(dB)
 print(f"screened {n} GEMMs, {bad} mismatches")
 sys.exit(1 if bad else 0)
