@@ -28,6 +28,10 @@ PF = "--pf" in sys.argv               # every even K tile also touches, per A ro
 DEEP = "--deep" in sys.argv           # a barrier and a counted wait in EVERY phase, each region re-requested one phase after its last read: 24 requests
                                       # (96 KB per CU) in flight at the waits instead of 16 (64 KB), six phases for a request to land instead of five
 A_PACKED = "--a-packed" in sys.argv   # timing-only (with -DGEMM4P_A_PACKED): A read as if stored tile by tile -- a K tile of 256 rows = 32 KB contiguous
+DMA_AT = (11, 15, 19, 23)             # behind which MFMAs of a phase (1 .. 32) its four requests are issued; --dma-at=a,b,c,d: measurement
+for _a in sys.argv[1:]:
+    if _a.startswith("--dma-at="):
+        DMA_AT = tuple(int(x) for x in _a.split("=")[1].split(","))
 SET = {"Ax": 128, "Ay": 160, "Bx": 192, "By": 224}
 out = []
 
@@ -89,16 +93,16 @@ def phase(ih, jh, aset, bset, pref, dmas, post=(), barrier=True, wait=16, pf=Fal
         for j in range(4):
             for kk in range(2):
                 n += 1
-                if n in (11, 15, 19, 23):
-                    emit(dm[(n - 11) // 4][0])          # s_add_u32 m0: the MFMA below is its wait state in front of the DMA
+                if n in DMA_AT:
+                    emit(dm[DMA_AT.index(n)][0])        # s_add_u32 m0: the MFMA below is its wait state in front of the DMA
                 if NO_MFMA:
                     emit("s_nop 0")
                 else:
                     emit(f"v_mfma_f32_16x16x32_bf16 {acc(4 * ih + i, 4 * jh + j)}, {frag(bset, j, kk)}, {frag(aset, i, kk)}, {acc(4 * ih + i, 4 * jh + j)}")
                 if n <= 8:
                     emit(rd[n - 1])
-                elif n in (11, 15, 19, 23):
-                    emit(dm[(n - 11) // 4][2])
+                elif n in DMA_AT:
+                    emit(dm[DMA_AT.index(n)][2])
                 elif n == 26 and pf:
                     emit("buffer_load_dword v119, %[vpf], s[60:63], 0 offen offset:128")
     for line in post:
