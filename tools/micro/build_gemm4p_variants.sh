@@ -17,6 +17,7 @@ wait
 one nomfma_pf --no-mfma --pf &
 one pf --pf &
 one deep --deep &
+one nt_store --nt-store &
 one dma_late --dma-at=29,30,31,32 &
 one dma_spread --dma-at=10,17,24,31 &
 EXTRA=-DGEMM4P_A_PACKED one nomfma_apacked --no-mfma --a-packed &

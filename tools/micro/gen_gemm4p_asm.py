@@ -32,6 +32,7 @@ DMA_AT = (11, 15, 19, 23)             # behind which MFMAs of a phase (1 .. 32) 
 for _a in sys.argv[1:]:
     if _a.startswith("--dma-at="):
         DMA_AT = tuple(int(x) for x in _a.split("=")[1].split(","))
+NT_STORE = "--nt-store" in sys.argv   # measurement: the output tile stored with the non-temporal policy (what the vendor's kernel for this class does: "NTD")
 SET = {"Ax": 128, "Ay": 160, "Bx": 192, "By": 224}
 out = []
 
@@ -217,7 +218,7 @@ for i in range(8):
             emit(f"v_accvgpr_read_b32 v{t + k}, a{r + k}")
         emit(f"v_cvt_pk_bf16_f32 v{t + 4}, v{t}, v{t + 1}")
         emit(f"v_cvt_pk_bf16_f32 v{t + 5}, v{t + 2}, v{t + 3}")
-        emit(f"buffer_store_dwordx2 v[{t + 4}:{t + 5}], %[vc], %[cdesc], s{68 + i} offen offset:{j * 32}")
+        emit(f"buffer_store_dwordx2 v[{t + 4}:{t + 5}], %[vc], %[cdesc], s{68 + i} offen offset:{j * 32}" + (" nt" if NT_STORE else ""))
 emit("s_bitcmp1_b32 %[flags], 1")
 emit("s_cbranch_scc1 5f")
 emit("s_waitcnt vmcnt(0)")                  # last tile of the run

@@ -34,6 +34,14 @@ if [ "$1" = dma ]; then
   done
   exit 0
 fi
+if [ "$1" = nt ]; then
+  for shape in "65536 512 2816" "65536 512 1408" "65536 512 1024" "65536 1024 512" "8192 8192 8192"; do
+    for b in gemm4p gemm4p_nt_store; do
+      timeout -k 10 120 $GRAFT_REPO_ROOT/tools/micro/bin/$b 5 $shape | sed "s/^/$b: /" || exit 1
+    done
+  done
+  exit 0
+fi
 if [ "$1" = packed ]; then
   for shape in "32768 512 2816" "65536 512 2816" "131072 512 2816" "65536 512 1024"; do
     for b in gemm4p_nomfma gemm4p_nomfma_apacked gemm4p_nomfma_bempty gemm4p_nomfma_apacked_bempty; do
