@@ -31,6 +31,8 @@ KERNEL_SYMBOL = {   # substring of the kernel's name in rocprofv3 output
     "8s": "gemm8p_kernel<false, true>",                   # the same pipeline, row-major operands + split-K atomics
     "8t": "gemm8p_kernel<true, false>",                   # the same pipeline, K-major operands + split-K atomics
     "8ts": "gemm8p_kernel<true, false>",                  # the same kernel, one K split, fp32 output stored / accumulated (the tied head's table gradient)
+    "4k": "gemm4k_kernel",                                # K-major operands + split-K atomics on four waves of 128 x 128 with a register-named asm loop (gemm4k.hip)
+    "4kg": "gemm4k_group_kernel",                         # the same loop, all layers' weight gradients in one grouped launch
     "8g": "gemm8p_group_kernel",                          # the K-major pipeline, all layers' weight gradients in one grouped launch
     "8f": "gemm8p_f8_kernel",                             # --dtype fp8: the persistent pipeline on e4m3 / e5m2 operands (K tiles of 128)
     "8fs": "gemm8p_f8sk_kernel",                          # --dtype fp8: split-K weight gradients on transposed fp8 copies, one product per launch
@@ -49,6 +51,8 @@ KERNEL_LABEL = {"4p": "gemm4p_kernel (256x256 LDS-DMA, persistent, four waves of
                 "8f": "gemm8p_f8_kernel (256x256 LDS-DMA, persistent, row-major fp8 operands: e4m3 x e4m3 forward, e5m2 x e4m3 dx)",
                 "8fs": "gemm8p_f8sk_kernel (256x256 LDS-DMA, fp8 e5m2 x e4m3 on K-contiguous copies, split-K weight gradient)",
                 "8gf": "gemm8p_group_f8_kernel (the fp8 split-K form, grouped weight gradients of all layers)",
+                "4k": "gemm4k_kernel (256x256 LDS-DMA, K-major bf16, split-K, four waves of 128x128 with a register-named asm loop)",
+                "4kg": "gemm4k_group_kernel (the same loop, grouped weight gradients of all layers)",
                 "8m": "gemm8p_mix_kernel (256x256 LDS-DMA, row-major A x K-major B, split-K atomics over the device-side live rows)",
                 "nt": "gemm_kernel<bf16,NT>", "nn": "gemm_kernel<bf16,NN>", "tn": "gemm_kernel<bf16,TN>"}
 def _latest_traffic_file():

@@ -538,7 +538,7 @@ const char* gemm_kernel_name(const GemmParams& p0, bool bf16_mode, bool a_f32, b
     const int k = pick_rowmajor_kernel(p);
     if (k == 2) return gemm8p_forwards_to_8c(p) ? (gemm4p_takes(p) ? "4p" : "8c") : "8p";
   }
-  if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) return "8t";
+  if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn(p)) { GemmParams q = p; q.splitk = 8; return gemm4k_eligible(q) ? "4k" : "8t"; }
   if (bf16_mode && a_km && b_km && !a_f32 && !b_f32 && use_8p_tn_store(p)) return "8ts";
   if (bf16_mode && !a_km && !b_km && !a_f32 && !b_f32 && use_8p_nt_splitk(p)) return "8s";
   if (bf16_mode && !a_km && b_km && !a_f32 && !b_f32 && use_8p_mix(p)) return "8m";

@@ -88,6 +88,7 @@ bool gemm8p_group_eligible(const GemmParams& p);   // (p.f8 set: the fp8 split-K
 int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out, bool ordered = false);   // ordered: split-K partial tiles to slabs, summed in index order (deterministic mode)
 void gemm8p_group_plan_destroy(GemmGroupPlan* pl);
 double gemm8p_group_flops(const GemmGroupPlan* pl);
+bool gemm8p_group_on_4k(const GemmGroupPlan* pl);
 int gemm8p_group_splitk(const GemmGroupPlan* pl);
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s);
 

@@ -637,6 +637,7 @@ struct GemmGroupPlan {
   const GemmParams* d_probs = nullptr; const int* d_off = nullptr; const unsigned int* d_work = nullptr;
   int grid = 0, n = 0, splitk = 1;
   bool f8 = false;
+  bool asm4k = false;           // every product can run on gemm4k.hip (bf16, atomic, no slab): launch_gemm8p_group takes its kernel for the same work lists
   double flops = 0.0;
   // ordered (deterministic) form: every product's K splits store their partial tiles into its own slab [split][M][N] (all of them in
   // one allocation, cleared per launch) and one batched kernel adds the splits in index order into C afterwards
@@ -756,16 +757,20 @@ int gemm8p_group_plan_create(const GemmParams* probs, int n, GemmGroupPlan** out
   ok = ok && hipMemcpy((void*)pl->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { hipFree(pl->dev); if (slab_all) hipFree(slab_all); delete pl; set_error("grouped GEMM: plan upload failed"); return RSYS_ERR_HIP; }
   pl->grid = 8 * longest; pl->n = n; pl->splitk = best_s; pl->flops = flops; pl->f8 = f8;
+  pl->asm4k = !f8;
+  for (int i = 0; i < n && pl->asm4k; ++i) pl->asm4k = gemm4k_eligible(hp[i]);
   *out = pl;
   return RSYS_OK;
 }
 void gemm8p_group_plan_destroy(GemmGroupPlan* pl) { if (pl) { if (pl->dev) hipFree(pl->dev); if (pl->slab_all) hipFree(pl->slab_all); delete pl; } }
 double gemm8p_group_flops(const GemmGroupPlan* pl) { return pl->flops; }
+bool gemm8p_group_on_4k(const GemmGroupPlan* pl) { return pl->asm4k && !pl->f8 && sw().gemm4k != 0; }   // (the launch goes to gemm4k.hip: its tag says so)
 int gemm8p_group_splitk(const GemmGroupPlan* pl) { return pl->splitk; }
 int launch_gemm8p_group(const GemmGroupPlan* pl, hipStream_t s) {
   if (pl->grid <= 0) return RSYS_OK;
   if (pl->slab_all) HIP_CHECK(hipMemsetAsync(pl->slab_all, 0, pl->slab_bytes, s));   // (K splits without work leave their part untouched)
   if (pl->f8) hipLaunchKernelGGL(gemm8p_group_f8_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
+  else if (pl->asm4k && sw().gemm4k != 0) return launch_gemm4k_group(pl->d_probs, pl->d_off, pl->d_work, pl->grid, s);
   else hipLaunchKernelGGL(gemm8p_group_kernel, dim3(pl->grid), dim3(512), 0, s, pl->d_probs, pl->d_off, pl->d_work);
   HIP_CHECK(hipGetLastError());
   if (pl->slab_all) {
@@ -841,6 +846,7 @@ int launch_gemm8p_tn(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   const int tiles = ((p.M + T8_BM - 1) / T8_BM) * ((p.N + T8_BN - 1) / T8_BN);
   p.splitk = gemm8p_splits(p, true);
+  if (gemm4k_eligible(p)) return launch_gemm4k(p, tiles * p.splitk, s);   // (no slab: the four-wave register-named loop, same grid and work mapping)
   { const int rc_ = gemm_slab_begin(p, s); if (rc_ != RSYS_OK) return rc_; }
   hipLaunchKernelGGL(gemm8p_kernel<true>, dim3(tiles * p.splitk), dim3(512), 0, s, p);
   HIP_CHECK(hipGetLastError());

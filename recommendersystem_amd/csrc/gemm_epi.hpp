@@ -148,6 +148,10 @@ int launch_gemm8c(const GemmParams& p, hipStream_t s);
 bool gemm4p_eligible(const GemmParams& p);
 bool gemm4p_takes(const GemmParams& p);
 int launch_gemm4p(const GemmParams& p, hipStream_t s);
+// gemm4k.hip: the K-major split-K member of the four-wave loops (weight gradients); grids and work lists are gemm8p's
+bool gemm4k_eligible(const GemmParams& p);
+int launch_gemm4k(const GemmParams& p, int grid, hipStream_t s);
+int launch_gemm4k_group(const GemmParams* d_probs, const int* d_off, const unsigned int* d_work, int grid, hipStream_t s);
 bool gemm8p_forwards_to_8c(const GemmParams& p);   // what launch_gemm8p will do with p (timing tags)
 // the same pipeline for K-major bf16 operands with split-K fp32 atomics (weight gradients); picks its own K split
 bool gemm8p_tn_eligible(const GemmParams& p);

@@ -124,7 +124,7 @@ static int grouped_weight_grads(Model* m, int l_lo, int l_hi) {
     RC(gemm8p_group_plan_create(ps.data(), (int)ps.size(), &pl, ordered));
     it = m->dw_plans.emplace(key, pl).first;
   }
-  if (m->timer.enabled) tic(m, f8 ? "gemm_dw_group@8gf" : "gemm_dw_group@8g", gemm8p_group_flops(it->second));
+  if (m->timer.enabled) tic(m, f8 ? "gemm_dw_group@8gf" : (gemm8p_group_on_4k(it->second) ? "gemm_dw_group@4kg" : "gemm_dw_group@8g"), gemm8p_group_flops(it->second));
   int rc = launch_gemm8p_group(it->second, m->stream);
   toc(m);
   if (rc == RSYS_OK && f8) rc = f8_dw_round_accum(m, l_lo, l_hi);

@@ -21,6 +21,7 @@ const Entry kEntries[] = {
     {"RSYS_GEMM_KERNEL_MIX", &Switches::gemm_kernel_mix, 1},
     {"RSYS_GEMM8C_HALF", &Switches::gemm8c_half, 1},
     {"RSYS_GEMM4P", &Switches::gemm4p, 1},
+    {"RSYS_GEMM4K", &Switches::gemm4k, 1},
     {"RSYS_GEMM8C", &Switches::gemm8c, 1},
     {"RSYS_GEMM_REVERSE", &Switches::gemm_reverse, 1},
     {"RSYS_GEMM_PATCH", &Switches::gemm_patch, 1},

@@ -19,6 +19,7 @@ struct Switches {
   int gemm_kernel_mix;        // RSYS_GEMM_KERNEL_MIX: 1 = row-major A x K-major B atomic products with K >= 8192 and N >= 512 on the mixed-layout LDS-DMA kernel (gemm8p_mix_kernel); 0 = never; 2 = wherever eligible
   int gemm8c_half;            // RSYS_GEMM8C_HALF: 1 = 128x256 output tiles for outputs with fewer 256x256 tiles than CUs; 0 = never; 2 = wherever the class has the kernel
   int gemm4p;                 // RSYS_GEMM4P: 1 = plain bf16 stores with K >= 8192 on outputs >= 4 tiles wide on the four-wave register-named K loop (gemm4p.hip); 0 = never; 2 = wherever eligible
+  int gemm4k;                 // RSYS_GEMM4K=0: K-major split-K products (weight gradients) on gemm8p's eight-wave kernels instead of the four-wave register-named loop (gemm4k.hip)
   int gemm8c;                 // RSYS_GEMM8C=0: row-major 256x256 products on gemm8p.hip (per-tile operand requests) instead of gemm8c.hip
   int gemm_reverse;           // RSYS_GEMM_REVERSE: 1 = the consumers of a just-written large activation (w2_fwd, w13_dx) walk their tile rows from the last to the first; 0 = never; 2 = every gemm8c launch
   int gemm_patch;             // RSYS_GEMM_PATCH: 1 = band order of the output tiles for wide and tall outputs; 0 = row-major everywhere; 2 = bands everywhere

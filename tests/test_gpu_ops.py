@@ -282,11 +282,15 @@ def test_gemm_device_side_row_count(monkeypatch, rows, kern):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 4096), (512, 1408, 8192), (1024, 512, 4160), (520, 264, 1000), (64, 72, 640),
                                    (256, 512, 1216), (264, 256, 1408), (512, 512, 65536),    # (K splits of 3 / 1 K tiles ... and of 128)
                                    (512, 2568, 2048), (768, 5632, 1024)])                       # (11 / 22 tile columns: banded tile order)
-def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K):
+@pytest.mark.parametrize("kern", ["4k", "8t"])
+def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K, kern):
     """K-major operands (weight-gradient shape, K = tokens) on the LDS-DMA pipeline with ds_read_b64_tr_b16 fragments
-    and split-K fp32 atomics (gemm8p_kernel<true>), forced: exact on asymmetric integer data, ragged M / N / K (the K tail
-    is zero-filled by the buffer descriptor), and agreement with the 128x128 kernel on random data."""
+    and split-K fp32 atomics, forced -- gemm4k.hip (four waves of 128 x 128, prologue / K loop / atomic epilogue one generated asm statement
+    with named registers: the default since round 6) and gemm8p_kernel<true> (eight waves, HIP; RSYS_GEMM4K=0: deterministic launches and the
+    store forms stay on it): exact on asymmetric integer data, ragged M / N / K (the K tail and an odd K-tile count
+    are zero-filled by the buffer descriptor), and agreement with the 128x128 kernel on random data."""
     monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "2")
+    monkeypatch.setenv("RSYS_GEMM4K", "1" if kern == "4k" else "0")
     out, ref = run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, integer=True, seed=M + N + K)
     np.testing.assert_array_equal(out, ref.astype(np.float32))
     out_r, ref_r = run_gemm(1, M, N, K, True, True, c_f32=True, splitk=2, seed=11)

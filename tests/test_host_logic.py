@@ -494,11 +494,13 @@ def test_environment_is_read_in_one_place():
         assert gone not in open(os.path.join(csrc, "switches.hip")).read()
 
 
-def test_generated_asm_of_gemm4p_is_what_its_generator_writes(tmp_path):
-    """recommendersystem_amd/csrc/gemm4p_asm.inc / gemm4p_clobbers.inc (the K loop of gemm4p.hip as one asm statement) are generated files kept in
-    the tree so that the library builds without running a generator: they must be exactly what tools/micro/gen_gemm4p_asm.py writes today."""
+def test_generated_asm_of_gemm4p_and_gemm4k_is_what_the_generators_write(tmp_path):
+    """recommendersystem_amd/csrc/gemm4p_asm.inc / gemm4k_asm.inc (+ their clobber lists: the loops of gemm4p.hip and gemm4k.hip as one asm statement each)
+    are generated files kept in the tree so that the library builds without running a generator: they must be exactly what
+    tools/micro/gen_gemm4p_asm.py / gen_gemm4k_asm.py write today."""
     import subprocess, sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "gen_gemm4p_asm.py"), str(tmp_path)], check=True, capture_output=True)
-    for name in ("gemm4p_asm.inc", "gemm4p_clobbers.inc"):
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "gen_gemm4k_asm.py"), str(tmp_path)], check=True, capture_output=True)
+    for name in ("gemm4p_asm.inc", "gemm4p_clobbers.inc", "gemm4k_asm.inc", "gemm4k_clobbers.inc"):
         assert open(os.path.join(str(tmp_path), name)).read() == open(os.path.join(ROOT, "recommendersystem_amd", "csrc", name)).read(), name
