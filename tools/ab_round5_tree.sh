@@ -3,7 +3,7 @@
 # the default workload (cfg-3) and cfg-2, alternating, un-instrumented step time
 R=$GRAFT_REPO_ROOT
 FLAGS="--steps 40 --warmup 8 --no-kernel-timing --no-cpu-baseline --no-train-loop --no-extra-legs --no-live-pmc"
-for cfg in cfg3 cfg2; do
+for cfg in ${AB_CONFIGS:-cfg3 cfg2}; do
   for rep in 1 2 3; do
     for tree in r5 r6; do
       if [ $tree = r5 ]; then D=$R/tools/micro/bin/r5tree; else D=$R; fi
