@@ -300,6 +300,39 @@ def test_gemm_kmajor_lds_dma_kernel(monkeypatch, M, N, K, kern):
     assert np.abs(out_r - out_1).max() / np.abs(ref_r).max() < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1536, 8192 - 24), (1024, 512, 4096 + 1), (520, 264, 2048 - 63), (512, 512, 1000), (2816, 512, 16384 + 40), (512, 512, 6000)])
+@pytest.mark.parametrize("kern", ["4k", "8t"])
+def test_gemm_kmajor_splitk_stops_at_k(monkeypatch, M, N, K, kern):
+    """The split-K atomic K-major kernels with a K that is no multiple of 64: the operands are followed in memory by 64 rows of poison (1e30) -- what a K-major
+    activation buffer holds behind the live tokens -- and the last K tile's window must end at row K, not at the tile's end: a row read past K shows as 1e60-scale
+    sums or NaN.  gemm4k.hip counts the BYTES left in a workgroup's K range (its windows end inside the last K tile); gemm8p_kernel<true> (RSYS_GEMM4K=0)
+    likewise.  Exact on integer data; C starts from non-zero values (accumulation)."""
+    from recommendersystem_amd import _lib
+    lib = _lib.lib()
+    monkeypatch.setenv("RSYS_GEMM_KERNEL_TN", "2")
+    monkeypatch.setenv("RSYS_GEMM4K", "1" if kern == "4k" else "0")
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-2, 3, (K, M)).astype(np.float32); B = rng.integers(-2, 3, (K, N)).astype(np.float32)
+    A[:, 0] = np.arange(K) % 5 - 2; B[0, :] = np.arange(N) % 7 - 3
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    pad = lambda n: (n + 7) // 8 * 8
+    lda, ldb, ldc = pad(M), pad(N), pad(N)
+    As = np.full((K + 64, lda), 1e30, np.float32); As[:K] = 0; As[:K, :M] = A
+    Bs = np.full((K + 64, ldb), -1e30, np.float32); Bs[:K] = 0; Bs[:K, :N] = B
+    C0 = rng.integers(-5, 6, (M, ldc)).astype(np.float32)
+    dA = _to_dev(lib, _pack(As, True)); dB = _to_dev(lib, _pack(Bs, True)); dC = _to_dev(lib, C0)
+    rc = lib.rsys_op_gemm(1, dA, dB, dC, M, N, K, lda, ldb, ldc, 1, 1, 0, 1, 2)
+    assert rc == 0, _lib.last_error()
+    out = np.empty((M, ldc), np.float32)
+    assert lib.rsys_dev_d2h(out.ctypes.data, dC, out.nbytes) == 0
+    for ptr in (dA, dB, dC):
+        lib.rsys_dev_free(ptr)
+    np.testing.assert_array_equal(out[:, :N], (ref + C0[:, :N]).astype(np.float32))
+    np.testing.assert_array_equal(out[:, N:], C0[:, N:])          # padding columns untouched
+    for k in ("RSYS_GEMM_KERNEL_TN", "RSYS_GEMM4K"):
+        monkeypatch.delenv(k, raising=False)
+
+
 @pytest.mark.parametrize("M,N,K,live", [(768, 512, 704, 333), (1024, 256, 192, 64), (520, 264, 320, 1), (512, 512, 256, 0), (2048, 512, 4096, 4096)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_gemm_kmajor_store_form_with_device_side_k_limit(monkeypatch, M, N, K, live, accumulate):

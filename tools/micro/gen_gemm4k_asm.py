@@ -14,7 +14,7 @@ requests (region read a phase ago, K tile two ahead) behind four later ones.
 Epilogue: each wave passes its 128 x 128 block through a private LDS patch, 32 rows at a time ([32][132] f32), so that every atomic wave instruction
 adds 256 contiguous bytes (the full-rate shape); rows past M fall outside the output descriptor, columns past N are EXEC-masked.
 Registers: a[0:255] accumulators; v[128:255] fragment sets A_x, A_y, B_x, B_y (epilogue: temporaries); v[104:119] fragment read addresses
-(operand x block x stage); s[60:67] descriptors, s[68:83] scalar row offsets, s[84:87] byte counters / trip count, s[88:91] windows, s[92:95] epilogue.
+(operand x block x stage); v[96:103] request offsets (rotating); s[60:67] descriptors, s[68:83] scalar row offsets, s[84:87] byte counters / trip count, s[88:91] windows, s[92:95] epilogue.
     python tools/micro/gen_gemm4k_asm.py [outdir]   (default: recommendersystem_amd/csrc; the committed copies are compared by tests/test_host_logic.py)
 """
 import os
@@ -39,13 +39,20 @@ def acc(i, j):
     return f"a[{r}:{r + 3}]"
 
 
+_tmp = [0]
+
+
 def dma(kind, stage, h, j):
+    """one LDS-DMA request.  The 4 j rows and the half's columns are added to the per-lane offset (a rotating scratch register) rather than passed as the
+    instruction's scalar offset: the windows here end INSIDE a K tile (a K that is no multiple of 64), and this way the cut does not depend on how the range
+    check treats the scalar offset.  (Both forms pass test_gemm_kmajor_splitk_stops_at_k on gfx950 and run at the same speed: the check does cover it.)"""
     region = (0 if kind == "A" else 2) + h
     imm = stage * 65536 + region * 16384 + j * 1024
     desc = "s[60:63]" if kind == "A" else "s[64:67]"
     soff = (68 if kind == "A" else 76) + 4 * h + j
     voff = f"%[v{kind.lower()}{j >> 1}]"
-    return [f"s_add_u32 m0, %[dmalds], {imm}", "s_nop 0", f"buffer_load_dwordx4 {voff}, {desc}, s{soff} offen lds"]
+    t = 96 + _tmp[0]; _tmp[0] = (_tmp[0] + 1) % 8
+    return [f"s_add_u32 m0, %[dmalds], {imm}", f"v_add_u32 v{t}, s{soff}, {voff}", f"buffer_load_dwordx4 v{t}, {desc}, 0 offen lds"]
 
 
 def reads(kind, setname, stage, h):
@@ -82,7 +89,8 @@ def phase(ih, jh, aset, bset, pref, dmas, post=(), barrier=True):
             for kk in range(2):
                 n += 1
                 if n in DMA_AT:
-                    emit(dm[DMA_AT.index(n)][0])
+                    emit(dm[DMA_AT.index(n)][0])        # m0 and the request's vector offset: the MFMA below is the wait state in front of the request
+                    emit(dm[DMA_AT.index(n)][1])
                 if NO_MFMA:
                     emit("s_nop 0")
                 else:
@@ -186,6 +194,6 @@ with open(os.path.join(here, "gemm4k_asm.inc"), "w") as f:
         f.write(f'"{l}\\n\\t"\n')
 with open(os.path.join(here, "gemm4k_clobbers.inc"), "w") as f:
     f.write("// generated by tools/micro/gen_gemm4k_asm.py -- do not edit\n")
-    regs = [f"v{r}" for r in range(104, 120)] + [f"v{r}" for r in range(128, 256)] + [f"a{r}" for r in range(256)] + [f"s{r}" for r in range(60, 94)]
+    regs = [f"v{r}" for r in range(96, 120)] + [f"v{r}" for r in range(128, 256)] + [f"a{r}" for r in range(256)] + [f"s{r}" for r in range(60, 94)]
     f.write(", ".join(f'"{r}"' for r in regs) + "\n")
 print(len(out), "asm lines")
