@@ -23,7 +23,12 @@ ARMS = {"default": {}, "dense_top": {"RSYS_SPARSE_TOP": "0"}, "token_order": {"R
         "scatter_atomic": {"RSYS_SCATTER_ATOMIC": "1"}, "dkdv_register_staged": {"RSYS_ATTN_KV_DMA": "0"},
         "side_stream_joined": {"RSYS_SIDE_STREAM": "1"}, "side_stream_deferred": {"RSYS_SIDE_STREAM": "2"},
         # round 6: the opt-in 128-query forward attention kernel (also with the compact top's q_active limit) and gemm8c's half tiles forced
-        "fwd32": {"RSYS_ATTN_FWD32": "1"}, "gemm8c_half": {"RSYS_GEMM8C_HALF": "2", "RSYS_GEMM_KERNEL": "2"}}
+        "fwd32": {"RSYS_ATTN_FWD32": "1"}, "gemm8c_half": {"RSYS_GEMM8C_HALF": "2", "RSYS_GEMM_KERNEL": "2"},
+        # round 6, late: the four-wave register-named loops forced on (row-major plain stores, every eligible shape) / off (weight gradients back on the
+        # eight-wave kernels), the mixed-layout dEw kernel forced, the reverse walk of the tile rows on every gemm8c launch
+        "gemm4p_forced": {"RSYS_GEMM4P": "2", "RSYS_GEMM_KERNEL": "2"}, "gemm4k_off": {"RSYS_GEMM4K": "0", "RSYS_GEMM_KERNEL_TN": "2"},
+        "gemm4k_forced_tn": {"RSYS_GEMM_KERNEL_TN": "2"}, "gemm_mix_forced": {"RSYS_GEMM_KERNEL_MIX": "2"},
+        "reverse_everywhere": {"RSYS_GEMM_REVERSE": "2", "RSYS_GEMM_KERNEL": "2"}}
 
 
 @pytest.mark.parametrize("dtype,tol_loss,tol", [("fp32", 1e-6, 2e-5), ("bf16", 2e-3, 3e-2)])
